@@ -1,0 +1,33 @@
+/* pc_oracle.h -- C interface of the CPU restatement (TEST INFRASTRUCTURE ONLY; see pc_oracle.c). */
+#ifndef PC_ORACLE_H
+#define PC_ORACLE_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct {
+    int read_start, read_end, adapter_start, adapter_end, score;
+    int aligned_matches, aligned_len, full_matches, full_len;
+    int path_len;
+    int failed; /* 1 => reference prints read_start == -1 (empty input) */
+} pc_oracle_result;
+
+/* returns 0 on success, -1 on allocation failure, -2 for gap_open == gap_extend (linear-gap
+   recurrence of the reference is not restated) */
+int pc_oracle_align_raw(const char *read, int n, const char *adapter, int m,
+                        int match, int mismatch, int gap_open, int gap_extend,
+                        pc_oracle_result *res);
+int pc_oracle_format(const pc_oracle_result *r, char *buf, size_t buflen);
+char *pc_oracle_adapterAlignment(const char *readSeq, const char *adapterSeq, int matchScore,
+                                 int mismatchScore, int gapOpenScore, int gapExtensionScore);
+void pc_oracle_free(char *p);
+int pc_oracle_align_many(const char *read_arena, const int64_t *read_off, const int32_t *read_len,
+                         const char *adapter_arena, const int64_t *ad_off, const int32_t *ad_len,
+                         int64_t npairs, int match, int mismatch, int gap_open, int gap_extend,
+                         int32_t *out9);
+#ifdef __cplusplus
+}
+#endif
+#endif

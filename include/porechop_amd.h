@@ -1,0 +1,121 @@
+/*
+ * porechop_amd.h -- C ABI of the MI355X-native adapter-alignment core (libporechop_amd.so,
+ * also installable as Porechop's porechop/cpp_functions.so).
+ *
+ * Plain pointers and sizes only; no torch / HIP types.  Every entry point runs on the GPU:
+ * there is NO CPU fallback anywhere behind this header (a missing device is an error).
+ *
+ * Part 1 is the reference's own FFI surface, kept bit-for-bit so that the unchanged
+ * porechop/cpp_function_wrappers.py binds it.  Part 2 is the batch surface the reference does
+ * not have (its API is one pair per call); it is what makes a GPU worthwhile.
+ */
+#ifndef PORECHOP_AMD_H
+#define PORECHOP_AMD_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------------------------------
+ * Part 1 -- drop-in replacements for the reference exports
+ * ------------------------------------------------------------------------------------------ */
+
+/* Replaces  porechop/include/adapter_align.h:12-16 / porechop/src/adapter_align.cpp:11-31
+ * (bound by porechop/cpp_function_wrappers.py:27-33 with restype c_void_p).
+ * Inputs are borrowed NUL-terminated ASCII strings.  Returns a malloc()ed C string
+ *   "readStart,readEnd,adapterStart,adapterEnd,rawScore,alignedRegion%id,fullAdapter%id"
+ * formatted exactly like porechop/src/alignment.cpp:113-121 ("%d" ints, "%f" doubles;
+ * "-1,..." when either sequence is empty).  Served from the prefetch memo (Part 2) when the
+ * pair was prefetched, otherwise by a single-pair GPU launch.  Never throws; on an
+ * unsupported scoring scheme or a device error it prints to stderr and returns NULL. */
+char *adapterAlignment(char *readSeq, char *adapterSeq, int matchScore, int mismatchScore,
+                       int gapOpenScore, int gapExtensionScore);
+
+/* Replaces porechop/src/adapter_align.cpp:34-36 (cpp_function_wrappers.py:38-39): free(). */
+void freeCString(char *p);
+
+/* ------------------------------------------------------------------------------------------
+ * Part 2 -- batch API
+ * ------------------------------------------------------------------------------------------ */
+
+typedef struct pc_ctx pc_ctx;
+
+enum {
+    PC_OK = 0,
+    PC_ERR_NO_DEVICE = -1,          /* no HIP device / HIP call failed */
+    PC_ERR_UNSUPPORTED_SCORES = -2, /* scheme outside the exact int16 path (see pc_scores_supported) */
+    PC_ERR_BAD_ARG = -3,
+    PC_ERR_ADAPTER_TOO_LONG = -4,   /* adapter longer than PC_MAX_ADAPTER */
+    PC_ERR_INTERNAL = -5            /* a kernel reported an inconsistency (never expected) */
+};
+
+#define PC_MAX_ADAPTER 128
+#define PC_RESULT_INTS 8   /* readStart, readEnd, adapterStart, adapterEnd, rawScore,
+                              matches, alignedRegionLength, fullAdapterLength.
+                              identities are (100.0*matches)/length in double, as the reference
+                              computes them (alignment.cpp:81-82,89-90); matches is the same
+                              count for both.  Empty read or adapter: {-1,0,-1,0,INT_MIN,0,0,0}. */
+
+/* scan modes */
+#define PC_MODE_AUTO 0      /* by window length */
+#define PC_MODE_TRACE 1     /* one pass, full trace (end windows) */
+#define PC_MODE_TWO_PASS 2  /* score-only pass + bounded traced window (whole reads) */
+
+const char *pc_version(void);
+const char *pc_strerror(int code);
+
+/* 1 if (match, mismatch, gap_open, gap_extend) is handled exactly by the GPU path for adapters
+ * up to max_adapter_len bases; 0 otherwise (gap_open == gap_extend, non-negative gap scores,
+ * match <= mismatch, or magnitudes that overflow the int16 lanes). */
+int pc_scores_supported(int match, int mismatch, int gap_open, int gap_extend, int max_adapter_len);
+
+/* device < 0: current device.  The context owns its stream-ordered scratch buffers. */
+int pc_create(pc_ctx **ctx, int device);
+void pc_destroy(pc_ctx *ctx);
+
+int pc_set_scores(pc_ctx *ctx, int match, int mismatch, int gap_open, int gap_extend);
+
+/* Upload the adapter panel (the strings of porechop/adapters.py ADAPTERS start/end sequences
+ * or any other): adapter index i in the calls below refers to seqs[i]. */
+int pc_set_adapters(pc_ctx *ctx, const char *const *seqs, int nadapters);
+
+/* Host-buffer batch: pair p aligns window  read_arena[win_off[p] .. win_off[p]+win_len[p])
+ * against adapter adapter_idx[p]; results out[p*PC_RESULT_INTS ...].  Pairs may come in any
+ * order; the library groups them.  Blocking. */
+int pc_align_batch_host(pc_ctx *ctx, const char *read_arena, int64_t arena_bytes,
+                        const int64_t *win_off, const int32_t *win_len, const int32_t *adapter_idx,
+                        int64_t npairs, int mode, int32_t *out);
+
+/* Device-buffer batch (inputs already resident in HBM; nothing crosses PCIe but the small job
+ * table).  d_* are device pointers.  Pairs are grouped into jobs of one adapter each: job k
+ * covers pairs [job_start[k], job_start[k+1]) and aligns them against job_adapter[k].
+ * max_len is an upper bound on every win_len (checked on the device).  The arena must be
+ * readable 8 bytes past its last window.  Asynchronous on `stream` (a hipStream_t, or NULL
+ * for the context's own stream); call pc_sync() before reading d_out. */
+int pc_scan_device(pc_ctx *ctx, const void *d_arena, const int64_t *d_win_off,
+                   const int32_t *d_win_len, int64_t npairs, const int32_t *job_adapter,
+                   const int64_t *job_start, int njobs, int max_len, int mode, int32_t *d_out,
+                   void *stream);
+
+/* Waits for `stream` (or the context stream) and returns PC_ERR_INTERNAL if any kernel since the
+ * last pc_sync reported an inconsistency. */
+int pc_sync(pc_ctx *ctx, void *stream);
+
+/* Format one result record exactly as the reference prints it; buf must hold >= 160 bytes. */
+int pc_format_result(const int32_t *rec, char *buf, size_t buflen);
+
+/* Prefetch memo for the per-call symbol: compute these pairs on the GPU now and remember the
+ * answers, keyed by (window bytes, adapter bytes, scores), so that later adapterAlignment()
+ * calls with the same arguments are lookups.  Uses the process-wide default context. */
+int pc_prefetch(const char *read_arena, int64_t arena_bytes, const int64_t *win_off,
+                const int32_t *win_len, const char *const *adapters, const int32_t *adapter_idx,
+                int64_t npairs, int match, int mismatch, int gap_open, int gap_extend);
+void pc_memo_clear(void);
+/* hits, misses (single-pair launches), entries */
+void pc_memo_stats(int64_t *hits, int64_t *misses, int64_t *entries);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PORECHOP_AMD_H */

@@ -1,0 +1,77 @@
+"""ctypes binding of libporechop_amd.so (the C ABI of include/porechop_amd.h).
+
+The library is built in-tree by porechop_amd/csrc/Makefile (``__graft_entry__.build()``);
+it is never pip-installed, so the GPU box loads exactly the .so that sits in this directory.
+"""
+import ctypes
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libporechop_amd.so")
+
+# every symbol include/porechop_amd.h declares (tests check the list against the header)
+EXPORTS = [
+    "adapterAlignment", "freeCString",
+    "pc_version", "pc_strerror", "pc_scores_supported", "pc_create", "pc_destroy",
+    "pc_set_scores", "pc_set_adapters", "pc_align_batch_host", "pc_scan_device", "pc_sync",
+    "pc_format_result", "pc_prefetch", "pc_memo_clear", "pc_memo_stats",
+]
+
+
+class LibraryMissing(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load_library():
+    """Load (once) and type the shared library.  No fallback: a missing build is an error."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise LibraryMissing(
+            "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C porechop_amd/csrc`). porechop_amd has no CPU fallback." % LIB_PATH)
+    L = ctypes.CDLL(LIB_PATH)
+    c_int, c_i64, c_vp, c_cp = ctypes.c_int, ctypes.c_int64, ctypes.c_void_p, ctypes.c_char_p
+    L.adapterAlignment.argtypes = [c_cp, c_cp, c_int, c_int, c_int, c_int]
+    L.adapterAlignment.restype = c_vp
+    L.freeCString.argtypes = [c_vp]
+    L.freeCString.restype = None
+    L.pc_version.restype = c_cp
+    L.pc_strerror.argtypes = [c_int]
+    L.pc_strerror.restype = c_cp
+    L.pc_scores_supported.argtypes = [c_int] * 5
+    L.pc_scores_supported.restype = c_int
+    L.pc_create.argtypes = [ctypes.POINTER(c_vp), c_int]
+    L.pc_create.restype = c_int
+    L.pc_destroy.argtypes = [c_vp]
+    L.pc_destroy.restype = None
+    L.pc_set_scores.argtypes = [c_vp, c_int, c_int, c_int, c_int]
+    L.pc_set_scores.restype = c_int
+    L.pc_set_adapters.argtypes = [c_vp, ctypes.POINTER(c_cp), c_int]
+    L.pc_set_adapters.restype = c_int
+    L.pc_align_batch_host.argtypes = [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_int, c_vp]
+    L.pc_align_batch_host.restype = c_int
+    L.pc_scan_device.argtypes = [c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp]
+    L.pc_scan_device.restype = c_int
+    L.pc_sync.argtypes = [c_vp, c_vp]
+    L.pc_sync.restype = c_int
+    L.pc_format_result.argtypes = [c_vp, c_cp, ctypes.c_size_t]
+    L.pc_format_result.restype = c_int
+    L.pc_prefetch.argtypes = [c_vp, c_i64, c_vp, c_vp, ctypes.POINTER(c_cp), c_vp, c_i64, c_int, c_int, c_int, c_int]
+    L.pc_prefetch.restype = c_int
+    L.pc_memo_clear.argtypes = []
+    L.pc_memo_clear.restype = None
+    L.pc_memo_stats.argtypes = [ctypes.POINTER(c_i64)] * 3
+    L.pc_memo_stats.restype = None
+    _lib = L
+    return L
+
+
+def check(rc, what="porechop_amd"):
+    if rc != 0:
+        L = load_library()
+        raise RuntimeError("%s failed: %s (%d)" % (what, L.pc_strerror(rc).decode(), rc))

@@ -1,0 +1,117 @@
+"""Batch interface over the C ABI: many (window, adapter) pairs per call.
+
+Host arrays are numpy; device-resident inputs are torch tensors (PyTorch is used only to own
+HBM buffers and streams -- the compute is the HIP library).
+"""
+import ctypes
+
+import numpy as np
+
+from ._lib import check, load_library
+
+RESULT_INTS = 8      # readStart, readEnd, adapterStart, adapterEnd, rawScore, matches, alignedLen, fullLen
+MODE_AUTO, MODE_TRACE, MODE_TWO_PASS = 0, 1, 2
+DEFAULT_SCORES = (3, -6, -5, -2)   # porechop/porechop.py:145
+INT_MIN = -2147483648
+
+
+def format_result(rec):
+    """One 8-int record -> the reference's 7-field string (formatted by the C side, i.e. by the
+    same libc printf the reference uses through std::to_string)."""
+    lib = load_library()
+    arr = (ctypes.c_int32 * RESULT_INTS)(*[int(x) for x in rec])
+    buf = ctypes.create_string_buffer(160)
+    lib.pc_format_result(arr, buf, 160)
+    return buf.value.decode()
+
+
+def records_to_fields(recs):
+    """[n,8] int32 -> what porechop/nanopore_read.py:476-491 (align_adapter) derives per call:
+    full_adapter_identity, aligned_identity (float64), read_start, read_end (= field1 + 1)."""
+    recs = np.asarray(recs)
+    failed = recs[:, 0] == -1
+    with np.errstate(divide="ignore", invalid="ignore"):
+        m = recs[:, 5].astype(np.float64)
+        aligned = 100.0 * m / recs[:, 6].astype(np.float64)
+        full = 100.0 * m / recs[:, 7].astype(np.float64)
+    read_start = recs[:, 0].copy()
+    read_end = recs[:, 1] + 1
+    full[failed] = 0.0
+    aligned[failed] = 0.0
+    read_end[failed] = 0
+    return full, aligned, read_start, read_end
+
+
+class Aligner:
+    """One GPU context: a scoring scheme + an adapter panel + scratch buffers."""
+
+    def __init__(self, adapters, scores=DEFAULT_SCORES, device=-1):
+        self.lib = load_library()
+        self._ctx = ctypes.c_void_p()
+        check(self.lib.pc_create(ctypes.byref(self._ctx), device), "pc_create")
+        self.scores = tuple(int(s) for s in scores)
+        check(self.lib.pc_set_scores(self._ctx, *self.scores), "pc_set_scores")
+        self.adapters = [a if isinstance(a, bytes) else a.encode() for a in adapters]
+        arr = (ctypes.c_char_p * max(1, len(self.adapters)))(*self.adapters)
+        check(self.lib.pc_set_adapters(self._ctx, arr, len(self.adapters)), "pc_set_adapters")
+
+    def close(self):
+        if self._ctx:
+            self.lib.pc_destroy(self._ctx)
+            self._ctx = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- host buffers ------------------------------------------------------------------
+    def align_host(self, arena, win_off, win_len, adapter_idx, mode=MODE_AUTO):
+        """arena: bytes / uint8 array; win_off int64[n]; win_len int32[n]; adapter_idx int32[n]
+        -> int32 [n, 8]"""
+        arena = np.frombuffer(arena, dtype=np.uint8) if isinstance(arena, (bytes, bytearray)) \
+            else np.ascontiguousarray(arena, dtype=np.uint8)
+        win_off = np.ascontiguousarray(win_off, dtype=np.int64)
+        win_len = np.ascontiguousarray(win_len, dtype=np.int32)
+        adapter_idx = np.ascontiguousarray(adapter_idx, dtype=np.int32)
+        n = win_off.shape[0]
+        out = np.zeros((n, RESULT_INTS), dtype=np.int32)
+        check(self.lib.pc_align_batch_host(self._ctx, arena.ctypes.data, arena.size, win_off.ctypes.data,
+                                           win_len.ctypes.data, adapter_idx.ctypes.data, n, mode,
+                                           out.ctypes.data), "pc_align_batch_host")
+        return out
+
+    def align_pairs(self, pairs, mode=MODE_AUTO):
+        """pairs: iterable of (read_str, adapter_index) -> int32 [n, 8]"""
+        offs, lens, idx, chunks, pos = [], [], [], [], 0
+        for rd, ai in pairs:
+            b = rd if isinstance(rd, bytes) else rd.encode()
+            offs.append(pos)
+            lens.append(len(b))
+            idx.append(ai)
+            chunks.append(b)
+            pos += len(b)
+        return self.align_host(b"".join(chunks), offs, lens, idx, mode)
+
+    # ---- device buffers (torch tensors on the GPU) --------------------------------------
+    def scan_device(self, arena, win_off, win_len, job_adapter, job_start, max_len, out,
+                    mode=MODE_AUTO, stream=None):
+        """arena uint8[*], win_off int64[n], win_len int32[n], out int32[n,8]: CUDA(HIP) tensors.
+        job_adapter int32[k], job_start int64[k+1]: host numpy.  Asynchronous; call sync()."""
+        import torch
+        assert arena.is_cuda and win_off.is_cuda and win_len.is_cuda and out.is_cuda
+        assert win_off.dtype == torch.int64 and win_len.dtype == torch.int32 and out.dtype == torch.int32
+        job_adapter = np.ascontiguousarray(job_adapter, dtype=np.int32)
+        job_start = np.ascontiguousarray(job_start, dtype=np.int64)
+        n = win_off.shape[0]
+        s = stream if stream is not None else torch.cuda.current_stream().cuda_stream
+        check(self.lib.pc_scan_device(self._ctx, arena.data_ptr(), win_off.data_ptr(), win_len.data_ptr(), n,
+                                      job_adapter.ctypes.data, job_start.ctypes.data, len(job_adapter),
+                                      int(max_len), mode, out.data_ptr(), ctypes.c_void_p(s)),
+              "pc_scan_device")
+
+    def sync(self, stream=None):
+        import torch
+        s = stream if stream is not None else torch.cuda.current_stream().cuda_stream
+        check(self.lib.pc_sync(self._ctx, ctypes.c_void_p(s)), "pc_sync")

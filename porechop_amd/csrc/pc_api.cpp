@@ -1,0 +1,674 @@
+// pc_api.cpp -- host side of the C ABI declared in include/porechop_amd.h.
+//
+// Everything here is plumbing around the kernels in pc_kernels.hip: device buffers, grouping
+// pairs into single-adapter tiles, launch order of the two-pass whole-read scan, result
+// formatting (porechop/src/alignment.cpp:113-121) and the prefetch memo that turns the
+// reference's one-pair-per-call symbol (porechop/src/adapter_align.cpp:11) into a lookup.
+// There is deliberately no CPU implementation of the alignment in this library.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <climits>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/porechop_amd.h"
+#include "pc_bounds.h"
+#include "pc_kernels.h"
+
+#define PC_VERSION "porechop_amd 0.1 (gfx950)"
+
+namespace {
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes)
+    {
+        if (bytes <= cap) return PC_OK;
+        if (p) { if (hipFree(p) != hipSuccess) return PC_ERR_NO_DEVICE; p = nullptr; cap = 0; }
+        size_t want = bytes + bytes / 4 + 256;
+        if (hipMalloc(&p, want) != hipSuccess) {
+            fprintf(stderr, "porechop_amd: hipMalloc(%zu) failed\n", want);
+            return PC_ERR_NO_DEVICE;
+        }
+        cap = want;
+        return PC_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <typename T> T *as() const { return (T *)p; }
+};
+
+struct Group {            // tiles that run in one launch
+    int rows;             // 0: generic kernel
+    int gen_max_rows;     // generic: largest adapter in the group
+    bool pad;
+    bool two_pass;
+    size_t tile_begin, tile_count;
+    int max_window;       // for two-pass groups: slab columns needed by the traced window
+};
+
+}  // namespace
+
+struct pc_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int ncu = 256;
+    int match = 3, mismatch = -6, gap_open = -5, gap_extend = -2;
+    std::vector<std::string> adapters;
+    std::vector<int> ad_len, ad_window;
+    bool panel_dirty = true;
+    DevBuf d_ad_codes, d_ad_len, d_ad_window;
+    DevBuf d_tiles, d_slab, d_k1, d_woff2, d_wlen2, d_col0, d_ntot, d_frow, d_fscore, d_err;
+    // host-API staging
+    DevBuf d_arena, d_woff, d_wlen, d_out;
+    // cached job table (bench loops repeat the same one: skip the re-upload)
+    std::vector<pck::Tile> tiles;
+    std::vector<Group> groups;
+    std::vector<int32_t> last_job_adapter;
+    std::vector<int64_t> last_job_start;
+    int last_max_len = -1, last_mode = -1;
+    bool tiles_uploaded = false;
+    std::mutex mu;
+};
+
+namespace {
+
+int dna5(unsigned char c)
+{
+    switch (c) {
+        case 'A': case 'a': return 0;
+        case 'C': case 'c': return 1;
+        case 'G': case 'g': return 2;
+        case 'T': case 't': case 'U': case 'u': return 3;
+        default: return 4;
+    }
+}
+
+#define HIP_TRY(x)                                                                              \
+    do {                                                                                        \
+        hipError_t e_ = (x);                                                                    \
+        if (e_ != hipSuccess) {                                                                 \
+            fprintf(stderr, "porechop_amd: %s failed: %s\n", #x, hipGetErrorString(e_));        \
+            return PC_ERR_NO_DEVICE;                                                            \
+        }                                                                                       \
+    } while (0)
+
+int upload_panel(pc_ctx *c)
+{
+    if (!c->panel_dirty) return PC_OK;
+    const int n = (int)c->adapters.size();
+    std::vector<uint32_t> codes((size_t)std::max(n, 1) * pcb::MAX_ADAPTER, 5u);
+    c->ad_len.assign(std::max(n, 1), 0);
+    c->ad_window.assign(std::max(n, 1), 0);
+    int maxm = 1;
+    for (int i = 0; i < n; ++i) {
+        const std::string &s = c->adapters[i];
+        if ((int)s.size() > pcb::MAX_ADAPTER) return PC_ERR_ADAPTER_TOO_LONG;
+        c->ad_len[i] = (int)s.size();
+        maxm = std::max(maxm, (int)s.size());
+        for (size_t k = 0; k < s.size(); ++k) codes[(size_t)i * pcb::MAX_ADAPTER + k] = (uint32_t)dna5((unsigned char)s[k]);
+    }
+    if (!pcb::scores_supported(c->match, c->mismatch, c->gap_open, c->gap_extend, maxm))
+        return PC_ERR_UNSUPPORTED_SCORES;
+    for (int i = 0; i < n; ++i) {
+        pcb::Bounds b;
+        if (!pcb::compute_bounds(c->match, c->mismatch, c->gap_open, c->gap_extend, std::max(1, c->ad_len[i]), b))
+            return PC_ERR_UNSUPPORTED_SCORES;
+        c->ad_window[i] = b.window;
+    }
+    // stream-ordered: earlier launches may still read the old tables
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    int rc;
+    if ((rc = c->d_ad_codes.ensure(codes.size() * 4)) || (rc = c->d_ad_len.ensure(c->ad_len.size() * 4)) ||
+        (rc = c->d_ad_window.ensure(c->ad_window.size() * 4)))
+        return rc;
+    HIP_TRY(hipMemcpy(c->d_ad_codes.p, codes.data(), codes.size() * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->d_ad_len.p, c->ad_len.data(), c->ad_len.size() * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->d_ad_window.p, c->ad_window.data(), c->ad_window.size() * 4, hipMemcpyHostToDevice));
+    c->panel_dirty = false;
+    c->tiles_uploaded = false;
+    c->last_max_len = -1;
+    return PC_OK;
+}
+
+// Build (or reuse) the tile table for a job list.
+int build_tiles(pc_ctx *c, const int32_t *job_adapter, const int64_t *job_start, int njobs, int max_len, int mode)
+{
+    const bool same = c->tiles_uploaded && c->last_max_len == max_len && c->last_mode == mode &&
+                      (int)c->last_job_adapter.size() == njobs &&
+                      std::equal(job_adapter, job_adapter + njobs, c->last_job_adapter.begin()) &&
+                      std::equal(job_start, job_start + njobs + 1, c->last_job_start.begin());
+    if (same) return PC_OK;
+
+    std::map<std::pair<int, int>, std::vector<pck::Tile>> by_group;   // (rows*2+pad, two_pass) -> tiles
+    std::map<std::pair<int, int>, int> group_window;
+    for (int k = 0; k < njobs; ++k) {
+        const int ad = job_adapter[k];
+        if (ad < 0 || ad >= (int)c->adapters.size()) return PC_ERR_BAD_ARG;
+        const int m = c->ad_len[ad];
+        bool pad = false;
+        if (m <= 0) return PC_ERR_BAD_ARG;
+        if (m > pcb::MAX_ADAPTER) return PC_ERR_ADAPTER_TOO_LONG;
+        const int rows = pck::pick_rows(m, &pad);     // 0 => generic LDS-state kernel
+        const int window = c->ad_window[ad];
+        bool two = (mode == PC_MODE_TWO_PASS) || (mode == PC_MODE_AUTO && max_len > 2 * window + 64);
+        auto key = std::make_pair(rows * 2 + (pad ? 1 : 0), two ? 1 : 0);
+        auto &v = by_group[key];
+        group_window[key] = std::max(group_window[key], window);
+        for (int64_t s = job_start[k]; s < job_start[k + 1]; s += 128) {
+            pck::Tile t;
+            t.pair_base = s;
+            t.count = (int32_t)std::min<int64_t>(128, job_start[k + 1] - s);
+            t.adapter_lo = ad; t.adapter_hi = ad; t.rows = rows ? rows : m;
+            v.push_back(t);
+        }
+    }
+    c->tiles.clear();
+    c->groups.clear();
+    for (auto &kv : by_group) {
+        Group g;
+        g.rows = kv.first.first / 2; g.pad = (kv.first.first & 1) != 0; g.two_pass = kv.first.second != 0;
+        g.tile_begin = c->tiles.size(); g.tile_count = kv.second.size();
+        g.max_window = group_window[kv.first];
+        g.gen_max_rows = 1;
+        for (const pck::Tile &t : kv.second) g.gen_max_rows = std::max(g.gen_max_rows, (int)t.rows);
+        c->tiles.insert(c->tiles.end(), kv.second.begin(), kv.second.end());
+        c->groups.push_back(g);
+    }
+    // the previous table may still be in use by launches in flight
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    int rc = c->d_tiles.ensure(std::max<size_t>(1, c->tiles.size()) * sizeof(pck::Tile));
+    if (rc) return rc;
+    if (!c->tiles.empty())
+        HIP_TRY(hipMemcpy(c->d_tiles.p, c->tiles.data(), c->tiles.size() * sizeof(pck::Tile), hipMemcpyHostToDevice));
+    c->last_job_adapter.assign(job_adapter, job_adapter + njobs);
+    c->last_job_start.assign(job_start, job_start + njobs + 1);
+    c->last_max_len = max_len; c->last_mode = mode;
+    c->tiles_uploaded = true;
+    return PC_OK;
+}
+
+int grid_for(const pc_ctx *c, const Group &g, size_t ntiles, int slab_cols, size_t *slab_stride_dwords)
+{
+    const int rows = g.rows ? g.rows : g.gen_max_rows;
+    // resident waves per SIMD: by register footprint (2 packed VGPRs per row + ~48) for the
+    // register variants, by LDS (8 B per row per lane) for the generic one
+    int per_simd = g.rows ? 512 / (2 * rows + 48) : (int)((160 * 1024) / ((size_t)rows * 520 + 1024)) / 4;
+    per_simd = std::max(1, std::min(8, per_simd));
+    int64_t grid = (int64_t)c->ncu * 4 * per_simd;
+    const size_t stride = (size_t)std::max(1, slab_cols) * pck::trace_words_per_col(rows) * 64;
+    const size_t budget = (size_t)6 << 30;    // keep the trace scratch under 6 GiB
+    while (grid > 1 && (size_t)grid * stride * 4 > budget) grid /= 2;
+    grid = std::min<int64_t>(grid, (int64_t)ntiles);
+    if (slab_stride_dwords) *slab_stride_dwords = stride;
+    return (int)std::max<int64_t>(1, grid);
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *pc_version(void) { return PC_VERSION; }
+
+const char *pc_strerror(int code)
+{
+    switch (code) {
+        case PC_OK: return "ok";
+        case PC_ERR_NO_DEVICE: return "no usable HIP device / HIP runtime error";
+        case PC_ERR_UNSUPPORTED_SCORES: return "scoring scheme outside the exact GPU path";
+        case PC_ERR_BAD_ARG: return "bad argument";
+        case PC_ERR_ADAPTER_TOO_LONG: return "adapter longer than PC_MAX_ADAPTER";
+        case PC_ERR_INTERNAL: return "kernel reported an internal inconsistency";
+        default: return "unknown error";
+    }
+}
+
+int pc_scores_supported(int match, int mismatch, int gap_open, int gap_extend, int max_adapter_len)
+{
+    if (max_adapter_len > pcb::MAX_ADAPTER) return 0;
+    return pcb::scores_supported(match, mismatch, gap_open, gap_extend, std::max(1, max_adapter_len)) ? 1 : 0;
+}
+
+int pc_create(pc_ctx **out, int device)
+{
+    if (!out) return PC_ERR_BAD_ARG;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        fprintf(stderr, "porechop_amd: no HIP device visible -- this library has no CPU path\n");
+        return PC_ERR_NO_DEVICE;
+    }
+    if (device < 0) { if (hipGetDevice(&device) != hipSuccess) return PC_ERR_NO_DEVICE; }
+    if (device >= ndev) return PC_ERR_BAD_ARG;
+    HIP_TRY(hipSetDevice(device));
+    pc_ctx *c = new pc_ctx();
+    c->device = device;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->ncu = prop.multiProcessorCount;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return PC_ERR_NO_DEVICE; }
+    if (c->d_err.ensure(256) != PC_OK || hipMemset(c->d_err.p, 0, 256) != hipSuccess) { delete c; return PC_ERR_NO_DEVICE; }
+    *out = c;
+    return PC_OK;
+}
+
+void pc_destroy(pc_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    DevBuf *bufs[] = {&c->d_ad_codes, &c->d_ad_len, &c->d_ad_window, &c->d_tiles, &c->d_slab, &c->d_k1, &c->d_woff2,
+                      &c->d_wlen2, &c->d_col0, &c->d_ntot, &c->d_frow, &c->d_fscore, &c->d_err, &c->d_arena,
+                      &c->d_woff, &c->d_wlen, &c->d_out};
+    for (DevBuf *b : bufs) b->release();
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int pc_set_scores(pc_ctx *c, int match, int mismatch, int gap_open, int gap_extend)
+{
+    if (!c) return PC_ERR_BAD_ARG;
+    if (!pcb::scores_supported(match, mismatch, gap_open, gap_extend, 1)) return PC_ERR_UNSUPPORTED_SCORES;
+    if (match != c->match || mismatch != c->mismatch || gap_open != c->gap_open || gap_extend != c->gap_extend) {
+        c->match = match; c->mismatch = mismatch; c->gap_open = gap_open; c->gap_extend = gap_extend;
+        c->panel_dirty = true;
+    }
+    return PC_OK;
+}
+
+int pc_set_adapters(pc_ctx *c, const char *const *seqs, int n)
+{
+    if (!c || n < 0 || (n > 0 && !seqs)) return PC_ERR_BAD_ARG;
+    std::vector<std::string> v;
+    for (int i = 0; i < n; ++i) {
+        if (!seqs[i]) return PC_ERR_BAD_ARG;
+        v.emplace_back(seqs[i]);
+        if (v.back().size() > (size_t)pcb::MAX_ADAPTER) return PC_ERR_ADAPTER_TOO_LONG;
+    }
+    c->adapters.swap(v);
+    c->panel_dirty = true;
+    (void)hipSetDevice(c->device);
+    return upload_panel(c);
+}
+
+int pc_scan_device(pc_ctx *c, const void *d_arena, const int64_t *d_win_off, const int32_t *d_win_len,
+                   int64_t npairs, const int32_t *job_adapter, const int64_t *job_start, int njobs,
+                   int max_len, int mode, int32_t *d_out, void *stream_v)
+{
+    if (!c || npairs < 0 || njobs < 0 || max_len < 0) return PC_ERR_BAD_ARG;
+    if (npairs == 0 || njobs == 0) return PC_OK;
+    if (!d_arena || !d_win_off || !d_win_len || !job_adapter || !job_start || !d_out) return PC_ERR_BAD_ARG;
+    (void)hipSetDevice(c->device);
+    int rc = upload_panel(c);
+    if (rc) return rc;
+    if ((rc = build_tiles(c, job_adapter, job_start, njobs, max_len, mode))) return rc;
+    hipStream_t stream = stream_v ? (hipStream_t)stream_v : c->stream;
+
+    // scratch sizing over all groups
+    size_t slab_bytes = 0;
+    bool any_two = false;
+    for (const Group &g : c->groups) {
+        size_t stride;
+        const int cols = g.two_pass ? g.max_window + 1 : max_len;
+        const int grid = grid_for(c, g, g.tile_count, cols, &stride);
+        slab_bytes = std::max(slab_bytes, (size_t)grid * stride * 4);
+        any_two |= g.two_pass;
+    }
+    if ((rc = c->d_slab.ensure(slab_bytes + 256))) return rc;
+    if (any_two) {
+        const size_t n = (size_t)npairs;
+        if ((rc = c->d_k1.ensure(n * 16)) || (rc = c->d_woff2.ensure(n * 8)) || (rc = c->d_wlen2.ensure(n * 4)) ||
+            (rc = c->d_col0.ensure(n * 4)) || (rc = c->d_ntot.ensure(n * 4)) || (rc = c->d_frow.ensure(n * 4)) ||
+            (rc = c->d_fscore.ensure(n * 4)))
+            return rc;
+    }
+
+    for (const Group &g : c->groups) {
+        pck::ScanArgs a;
+        memset(&a, 0, sizeof(a));
+        a.arena = (const uint8_t *)d_arena;
+        a.ad_codes = c->d_ad_codes.as<uint32_t>();
+        a.ad_len = c->d_ad_len.as<int32_t>();
+        a.tiles = c->d_tiles.as<pck::Tile>() + g.tile_begin;
+        a.ntiles = (int32_t)g.tile_count;
+        a.match = c->match; a.mismatch = c->mismatch; a.gap_open = c->gap_open; a.gap_extend = c->gap_extend;
+        a.err = c->d_err.as<uint32_t>();
+        a.slab = c->d_slab.as<uint32_t>();
+        a.gen_max_rows = g.gen_max_rows;
+        size_t stride;
+        if (!g.two_pass) {
+            a.win_off = d_win_off; a.win_len = d_win_len;
+            a.out = d_out;
+            a.slab_cols = max_len;
+            const int grid = grid_for(c, g, g.tile_count, max_len, &stride);
+            a.slab_stride = (int64_t)stride;
+            if ((rc = pck::launch_trace(a, g.rows, g.pad, grid, stream))) return PC_ERR_NO_DEVICE;
+        } else {
+            // pass 1: score only, whole window
+            a.win_off = d_win_off; a.win_len = d_win_len;
+            a.out = c->d_k1.as<int32_t>();
+            a.slab = nullptr; a.slab_cols = 0; a.slab_stride = 0;
+            int grid = grid_for(c, g, g.tile_count, 1, nullptr);
+            if ((rc = pck::launch_score(a, g.rows, g.pad, grid, stream))) return PC_ERR_NO_DEVICE;
+            // plan the bounded windows
+            pck::PlanArgs pl;
+            memset(&pl, 0, sizeof(pl));
+            pl.win_off = d_win_off; pl.win_len = d_win_len; pl.k1 = c->d_k1.as<int32_t>();
+            pl.win_off2 = c->d_woff2.as<int64_t>(); pl.win_len2 = c->d_wlen2.as<int32_t>();
+            pl.col02 = c->d_col0.as<int32_t>(); pl.ntot2 = c->d_ntot.as<int32_t>();
+            pl.force_row2 = c->d_frow.as<int32_t>(); pl.force_score2 = c->d_fscore.as<int32_t>();
+            pl.tiles = a.tiles; pl.ntiles = a.ntiles;
+            pl.ad_window = c->d_ad_window.as<int32_t>();
+            if ((rc = pck::launch_plan(pl, stream))) return PC_ERR_NO_DEVICE;
+            // pass 2: traced window ending at the max cell
+            a.win_off = pl.win_off2; a.win_len = pl.win_len2; a.col0 = pl.col02; a.n_total = pl.ntot2;
+            a.force_row = pl.force_row2; a.force_score = pl.force_score2;
+            a.out = d_out;
+            a.slab = c->d_slab.as<uint32_t>();
+            a.slab_cols = g.max_window + 1;
+            grid = grid_for(c, g, g.tile_count, a.slab_cols, &stride);
+            a.slab_stride = (int64_t)stride;
+            if ((rc = pck::launch_trace(a, g.rows, g.pad, grid, stream))) return PC_ERR_NO_DEVICE;
+        }
+    }
+    return PC_OK;
+}
+
+int pc_sync(pc_ctx *c, void *stream_v)
+{
+    if (!c) return PC_ERR_BAD_ARG;
+    (void)hipSetDevice(c->device);
+    hipStream_t stream = stream_v ? (hipStream_t)stream_v : c->stream;
+    HIP_TRY(hipStreamSynchronize(stream));
+    uint32_t err = 0;
+    HIP_TRY(hipMemcpy(&err, c->d_err.p, 4, hipMemcpyDeviceToHost));
+    if (err) {
+        (void)hipMemset(c->d_err.p, 0, 4);
+        fprintf(stderr, "porechop_amd: %u alignment(s) reported an internal inconsistency\n", err);
+        return PC_ERR_INTERNAL;
+    }
+    return PC_OK;
+}
+
+int pc_align_batch_host(pc_ctx *c, const char *read_arena, int64_t arena_bytes, const int64_t *win_off,
+                        const int32_t *win_len, const int32_t *adapter_idx, int64_t npairs, int mode, int32_t *out)
+{
+    if (!c || npairs < 0 || arena_bytes < 0) return PC_ERR_BAD_ARG;
+    if (npairs == 0) return PC_OK;
+    if (!read_arena || !win_off || !win_len || !adapter_idx || !out) return PC_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    (void)hipSetDevice(c->device);
+    int rc = upload_panel(c);
+    if (rc) return rc;
+    const int nad = (int)c->adapters.size();
+
+    // empties are answered here exactly as the reference reports them (alignment.cpp:9-21):
+    // only field 0 (-1) and the score (INT_MIN, dp_algorithm_impl.h:1540-1541) are defined
+    struct Key { int ad; int cls; int len; int64_t idx; };
+    std::vector<Key> keys;
+    keys.reserve((size_t)npairs);
+    for (int64_t p = 0; p < npairs; ++p) {
+        const int ad = adapter_idx[p];
+        if (ad < 0 || ad >= nad || win_len[p] < 0 || win_off[p] < 0 || win_off[p] + win_len[p] > arena_bytes) return PC_ERR_BAD_ARG;
+        int32_t *o = out + p * PC_RESULT_INTS;
+        if (win_len[p] == 0 || c->ad_len[ad] == 0) {
+            o[0] = -1; o[1] = 0; o[2] = -1; o[3] = 0; o[4] = INT_MIN; o[5] = 0; o[6] = 0; o[7] = 0;
+            continue;
+        }
+        const int window = c->ad_window[ad];
+        const bool two = (mode == PC_MODE_TWO_PASS) || (mode == PC_MODE_AUTO && win_len[p] > 2 * window + 64);
+        keys.push_back({ad, two ? 1 : 0, win_len[p], p});
+    }
+    if (keys.empty()) return PC_OK;
+    // group by (class, adapter); inside a job longest windows first so tiles are length-balanced
+    std::sort(keys.begin(), keys.end(), [](const Key &a, const Key &b) {
+        if (a.cls != b.cls) return a.cls < b.cls;
+        if (a.ad != b.ad) return a.ad < b.ad;
+        if (a.len != b.len) return a.len > b.len;
+        return a.idx < b.idx;
+    });
+    const size_t n = keys.size();
+    std::vector<int64_t> s_off(n);
+    std::vector<int32_t> s_len(n);
+    for (size_t i = 0; i < n; ++i) { s_off[i] = win_off[keys[i].idx]; s_len[i] = keys[i].len; }
+
+    if ((rc = c->d_arena.ensure((size_t)arena_bytes + 64)) || (rc = c->d_woff.ensure(n * 8)) ||
+        (rc = c->d_wlen.ensure(n * 4)) || (rc = c->d_out.ensure(n * PC_RESULT_INTS * 4)))
+        return rc;
+    HIP_TRY(hipMemcpyAsync(c->d_arena.p, read_arena, (size_t)arena_bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemsetAsync((char *)c->d_arena.p + arena_bytes, 'N', 64, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->d_woff.p, s_off.data(), n * 8, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->d_wlen.p, s_len.data(), n * 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+
+    // one pc_scan_device call per class (their max_len differ by orders of magnitude)
+    size_t i0 = 0;
+    while (i0 < n) {
+        size_t i1 = i0;
+        while (i1 < n && keys[i1].cls == keys[i0].cls) ++i1;
+        std::vector<int32_t> job_ad;
+        std::vector<int64_t> job_start;
+        int max_len = 0;
+        for (size_t i = i0; i < i1; ++i) {
+            if (i == i0 || keys[i].ad != keys[i - 1].ad) { job_ad.push_back(keys[i].ad); job_start.push_back((int64_t)(i - i0)); }
+            max_len = std::max(max_len, keys[i].len);
+        }
+        job_start.push_back((int64_t)(i1 - i0));
+        rc = pc_scan_device(c, c->d_arena.p, c->d_woff.as<int64_t>() + i0, c->d_wlen.as<int32_t>() + i0,
+                            (int64_t)(i1 - i0), job_ad.data(), job_start.data(), (int)job_ad.size(), max_len,
+                            keys[i0].cls ? PC_MODE_TWO_PASS : PC_MODE_TRACE,
+                            c->d_out.as<int32_t>() + i0 * PC_RESULT_INTS, c->stream);
+        if (rc) return rc;
+        // the tile cache is keyed by the job table; descriptors differ per class, so drain here
+        if ((rc = pc_sync(c, c->stream))) return rc;
+        i0 = i1;
+    }
+    std::vector<int32_t> tmp(n * PC_RESULT_INTS);
+    HIP_TRY(hipMemcpy(tmp.data(), c->d_out.p, tmp.size() * 4, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < n; ++i)
+        memcpy(out + keys[i].idx * PC_RESULT_INTS, tmp.data() + i * PC_RESULT_INTS, PC_RESULT_INTS * 4);
+    return PC_OK;
+}
+
+int pc_format_result(const int32_t *r, char *buf, size_t buflen)
+{
+    if (!r || !buf) return PC_ERR_BAD_ARG;
+    if (r[0] == -1 && r[4] == INT_MIN) {
+        // the reference leaves fields 1,3,5,6 uninitialised here; Porechop only tests field 0
+        return snprintf(buf, buflen, "-1,0,-1,0,%d,0.000000,0.000000", INT_MIN);
+    }
+    // (100.0 * count) / length in double, evaluated at run time like alignment.cpp:81-82,89-90,
+    // so a zero-length overlap prints this platform's 0.0/0.0 ("-nan" on x86-64 glibc)
+    volatile double m = (double)r[5], al = (double)r[6], fl = (double)r[7];
+    const double pa = 100.0 * m / al;
+    const double pf = 100.0 * m / fl;
+    return snprintf(buf, buflen, "%d,%d,%d,%d,%d,%f,%f", r[0], r[1], r[2], r[3], r[4], pa, pf);
+}
+
+// ---------------------------------------------------------------------------------------------
+// process-wide default context + prefetch memo behind the reference's per-call symbol
+// ---------------------------------------------------------------------------------------------
+}  // extern "C"
+
+namespace {
+
+struct MemoKey {
+    uint64_t h1, h2;
+    bool operator==(const MemoKey &o) const { return h1 == o.h1 && h2 == o.h2; }
+};
+struct MemoHash { size_t operator()(const MemoKey &k) const { return (size_t)(k.h1 ^ (k.h2 * 0x9E3779B97F4A7C15ull)); } };
+struct MemoVal { int32_t r[PC_RESULT_INTS]; };
+
+inline uint64_t mix64(uint64_t x) { x ^= x >> 33; x *= 0xff51afd7ed558ccdull; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull; x ^= x >> 33; return x; }
+
+MemoKey make_key(const char *rd, size_t n, const char *ad, size_t m, int a, int b, int o, int e)
+{
+    // two independent 64-bit hashes over (len, read bytes, adapter bytes, scores)
+    uint64_t h1 = 0xcbf29ce484222325ull ^ n, h2 = 0x9ae16a3b2f90404full + m;
+    auto feed = [&](const unsigned char *p, size_t len) {
+        size_t i = 0;
+        for (; i + 8 <= len; i += 8) {
+            uint64_t w; memcpy(&w, p + i, 8);
+            h1 = (h1 ^ w) * 0x100000001b3ull; h1 ^= h1 >> 29;
+            h2 = mix64(h2 + w * 0x9E3779B97F4A7C15ull);
+        }
+        uint64_t w = 0; memcpy(&w, p + i, len - i);
+        w |= (uint64_t)(len - i) << 56;
+        h1 = (h1 ^ w) * 0x100000001b3ull; h1 ^= h1 >> 29;
+        h2 = mix64(h2 + w * 0x9E3779B97F4A7C15ull);
+    };
+    feed((const unsigned char *)rd, n);
+    feed((const unsigned char *)ad, m);
+    const uint64_t sc = ((uint64_t)(uint16_t)a << 48) | ((uint64_t)(uint16_t)b << 32) | ((uint64_t)(uint16_t)o << 16) | (uint16_t)e;
+    h1 = mix64(h1 ^ sc); h2 = mix64(h2 + sc);
+    return {h1, h2};
+}
+
+struct Global {
+    std::mutex mu;
+    pc_ctx *ctx = nullptr;
+    std::unordered_map<std::string, int> ad_index;
+    std::vector<std::string> ad_list;
+    std::unordered_map<MemoKey, MemoVal, MemoHash> memo;
+    int64_t hits = 0, misses = 0;
+};
+Global &G() { static Global g; return g; }
+
+// with G().mu held
+int default_ctx(int a, int b, int o, int e, pc_ctx **out)
+{
+    Global &g = G();
+    if (!g.ctx) { int rc = pc_create(&g.ctx, -1); if (rc) return rc; }
+    int rc = pc_set_scores(g.ctx, a, b, o, e);
+    if (rc) return rc;
+    *out = g.ctx;
+    return PC_OK;
+}
+
+int intern_adapters(const char *const *seqs, int n, std::vector<int> &idx)
+{
+    Global &g = G();
+    bool grew = false;
+    idx.resize(n);
+    for (int i = 0; i < n; ++i) {
+        std::string s(seqs[i]);
+        if (s.size() > (size_t)PC_MAX_ADAPTER) return PC_ERR_ADAPTER_TOO_LONG;
+        auto it = g.ad_index.find(s);
+        if (it == g.ad_index.end()) { it = g.ad_index.emplace(s, (int)g.ad_list.size()).first; g.ad_list.push_back(s); grew = true; }
+        idx[i] = it->second;
+    }
+    if (grew || g.ctx->adapters.size() != g.ad_list.size()) {
+        std::vector<const char *> ptrs;
+        for (auto &s : g.ad_list) ptrs.push_back(s.c_str());
+        return pc_set_adapters(g.ctx, ptrs.data(), (int)ptrs.size());
+    }
+    return PC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pc_prefetch(const char *read_arena, int64_t arena_bytes, const int64_t *win_off, const int32_t *win_len,
+                const char *const *adapters, const int32_t *adapter_idx, int64_t npairs, int match, int mismatch,
+                int gap_open, int gap_extend)
+{
+    if (npairs <= 0) return PC_OK;
+    if (!read_arena || !win_off || !win_len || !adapters || !adapter_idx) return PC_ERR_BAD_ARG;
+    Global &g = G();
+    std::lock_guard<std::mutex> lk(g.mu);
+    pc_ctx *c;
+    int rc = default_ctx(match, mismatch, gap_open, gap_extend, &c);
+    if (rc) return rc;
+    int nad = 0;
+    for (int64_t p = 0; p < npairs; ++p) nad = std::max(nad, adapter_idx[p] + 1);
+    std::vector<int> gidx;
+    if ((rc = intern_adapters(adapters, nad, gidx))) return rc;
+    // skip what is already known
+    std::vector<int64_t> todo;
+    std::vector<MemoKey> keys((size_t)npairs);
+    for (int64_t p = 0; p < npairs; ++p) {
+        const char *ad = adapters[adapter_idx[p]];
+        keys[p] = make_key(read_arena + win_off[p], (size_t)win_len[p], ad, strlen(ad), match, mismatch, gap_open, gap_extend);
+        if (g.memo.find(keys[p]) == g.memo.end()) todo.push_back(p);
+    }
+    if (todo.empty()) return PC_OK;
+    std::vector<int64_t> off(todo.size());
+    std::vector<int32_t> len(todo.size()), aidx(todo.size());
+    for (size_t i = 0; i < todo.size(); ++i) { off[i] = win_off[todo[i]]; len[i] = win_len[todo[i]]; aidx[i] = gidx[adapter_idx[todo[i]]]; }
+    std::vector<int32_t> res(todo.size() * PC_RESULT_INTS);
+    rc = pc_align_batch_host(c, read_arena, arena_bytes, off.data(), len.data(), aidx.data(), (int64_t)todo.size(), PC_MODE_AUTO, res.data());
+    if (rc) return rc;
+    for (size_t i = 0; i < todo.size(); ++i) {
+        MemoVal v; memcpy(v.r, res.data() + i * PC_RESULT_INTS, sizeof(v.r));
+        g.memo[keys[todo[i]]] = v;
+    }
+    return PC_OK;
+}
+
+void pc_memo_clear(void)
+{
+    Global &g = G();
+    std::lock_guard<std::mutex> lk(g.mu);
+    g.memo.clear(); g.hits = g.misses = 0;
+}
+
+void pc_memo_stats(int64_t *hits, int64_t *misses, int64_t *entries)
+{
+    Global &g = G();
+    std::lock_guard<std::mutex> lk(g.mu);
+    if (hits) *hits = g.hits;
+    if (misses) *misses = g.misses;
+    if (entries) *entries = (int64_t)g.memo.size();
+}
+
+char *adapterAlignment(char *readSeq, char *adapterSeq, int matchScore, int mismatchScore, int gapOpenScore,
+                       int gapExtensionScore)
+{
+    if (!readSeq || !adapterSeq) return nullptr;
+    const size_t n = strlen(readSeq), m = strlen(adapterSeq);
+    int32_t rec[PC_RESULT_INTS];
+    Global &g = G();
+    {
+        std::lock_guard<std::mutex> lk(g.mu);
+        const MemoKey key = make_key(readSeq, n, adapterSeq, m, matchScore, mismatchScore, gapOpenScore, gapExtensionScore);
+        auto it = g.memo.find(key);
+        if (it != g.memo.end()) {
+            ++g.hits;
+            memcpy(rec, it->second.r, sizeof(rec));
+        } else {
+            ++g.misses;
+            if (n == 0 || m == 0) {
+                rec[0] = -1; rec[1] = 0; rec[2] = -1; rec[3] = 0; rec[4] = INT_MIN; rec[5] = rec[6] = rec[7] = 0;
+            } else {
+                pc_ctx *c;
+                int rc = default_ctx(matchScore, mismatchScore, gapOpenScore, gapExtensionScore, &c);
+                std::vector<int> gidx;
+                const char *ads[1] = {adapterSeq};
+                if (!rc) rc = intern_adapters(ads, 1, gidx);
+                const int64_t off = 0; const int32_t len = (int32_t)n, aidx = rc ? 0 : gidx[0];
+                if (!rc) rc = pc_align_batch_host(c, readSeq, (int64_t)n, &off, &len, &aidx, 1, PC_MODE_AUTO, rec);
+                if (rc) {
+                    fprintf(stderr, "porechop_amd: adapterAlignment failed: %s (scores %d,%d,%d,%d)\n", pc_strerror(rc),
+                            matchScore, mismatchScore, gapOpenScore, gapExtensionScore);
+                    return nullptr;
+                }
+            }
+            MemoVal v; memcpy(v.r, rec, sizeof(rec));
+            g.memo[key] = v;
+        }
+    }
+    char *buf = (char *)malloc(160);
+    if (!buf) return nullptr;
+    pc_format_result(rec, buf, 160);
+    return buf;
+}
+
+void freeCString(char *p) { free(p); }
+
+}  // extern "C"

@@ -1,0 +1,66 @@
+// pc_bounds.h -- score-scheme preconditions and the exact window bound of the two-pass scan.
+//
+// The reference allocates a full (|read|+1) x (|adapter|+1) trace matrix
+// (seqan/align/dp_algorithm_impl.h:1547-1569).  For whole-read ("middle") scans this library
+// instead (1) runs a score-only forward pass that finds the reference's max cell (I,J), then
+// (2) recomputes with trace only columns [J - window, J].  That is exact, not heuristic:
+//
+//  * trace span W.  The traced path is an optimal path with score = best >= 0 (the cell
+//    (m,0)=0 is always tracked).  Every gap character costs at least g = min(|open|,|ext|),
+//    at most m diagonals earn at most `match` each, so #read-gap columns <= match*m/g and the
+//    path touches at most  W = m + floor(match*m/g)  read columns left of J.
+//
+//  * warm-up span SPAN.  Column c of the window DP is started from a state every entry of
+//    which is the score of a real path (row-0 free start followed by a vertical gap), so all
+//    window values are <= the true ones, and equal as soon as the true optimum for that cell
+//    is reached by a path starting inside the window.  Any path spanning s read columns
+//    scores <= match*m - g*(s - m); every cell state has a trivial in-column alternative
+//    scoring >= -(2|open| + (m-1)|ext|).  Hence paths with
+//        s > m + (match*m + 2|open| + (m-1)|ext|)/g
+//    are never optimal and all three states of every cell are exact from column
+//    c + SPAN on,  SPAN = m + floor((match*m + 2|open| + (m-1)|ext|)/g) + 1.
+//
+//  * trace bits of column k depend on columns k-1 and k, so  window = W + SPAN + 1.
+//
+// Preconditions (checked, not assumed): match > 0, match > mismatch, open < 0, ext < 0,
+// open != ext (the reference dispatches open == ext to a different, linear-gap recurrence,
+// seqan/align/global_alignment_unbanded.h:217-220), and every DP value must fit the packed
+// int16 lanes the kernels compute in.
+#pragma once
+#include <stdint.h>
+
+namespace pcb {
+
+constexpr int MAX_ADAPTER = 128;     // rows the kernels can keep in registers
+constexpr int NEG16 = -16384;        // "-infinity" of the int16 lanes; never wins a max
+
+struct Bounds {
+    int W;        // columns the traced path can span left of J
+    int SPAN;     // warm-up columns before values are exact
+    int window;   // W + SPAN + 1
+};
+
+inline bool scores_supported(int match, int mismatch, int gap_open, int gap_extend, int max_m)
+{
+    if (!(match > 0 && match > mismatch && gap_open < 0 && gap_extend < 0)) return false;
+    if (gap_open == gap_extend) return false;
+    const long D = (long)match - mismatch;
+    if (6 * D > 16000) return false;                         // spaced base codes 0..5*D in u16
+    if ((long)match * max_m > 8000) return false;            // upper range of M
+    if (2L * -gap_open + (long)max_m * -gap_extend > 8000) return false;   // lower range of M,H,V
+    if (-mismatch > 8000 || -gap_open > 8000 || -gap_extend > 8000) return false;
+    return true;
+}
+
+inline bool compute_bounds(int match, int mismatch, int gap_open, int gap_extend, int m, Bounds &b)
+{
+    if (!scores_supported(match, mismatch, gap_open, gap_extend, m > 0 ? m : 1)) return false;
+    const int go = -gap_open, ge = -gap_extend;
+    const int g = go < ge ? go : ge;
+    b.W = m + (match * m) / g;
+    b.SPAN = m + (match * m + 2 * go + (m - 1) * ge) / g + 1;
+    b.window = b.W + b.SPAN + 1;
+    return true;
+}
+
+}  // namespace pcb

@@ -1,0 +1,75 @@
+// pc_kernels.h -- argument structures shared by the HIP kernels and the host-side C ABI.
+#pragma once
+#include <stdint.h>
+
+namespace pck {
+
+// One tile = one wavefront's worth of work: up to 128 (window, adapter) pairs.  Lanes 0..63
+// carry pair  pair_base + lane  in the LOW int16 half of every packed register and pair
+// pair_base + 64 + lane  in the HIGH half.  All low-half pairs of a tile share adapter_lo,
+// all high-half pairs share adapter_hi.
+struct Tile {
+    int64_t pair_base;
+    int32_t count;        // 1..128 valid pairs
+    int32_t adapter_lo;
+    int32_t adapter_hi;
+    int32_t rows;         // register rows R this tile must run with (>= both adapter lengths)
+};
+
+struct ScanArgs {
+    const uint8_t *arena;        // read bytes, 1 B/base, as delivered by the caller
+    const int64_t *win_off;      // [npairs] byte offset of the window's first column
+    const int32_t *win_len;      // [npairs] columns to run
+    const int32_t *col0;         // [npairs] global column of the window start   (null => 0)
+    const int32_t *n_total;      // [npairs] whole read length                   (null => win_len)
+    const int32_t *force_row;    // [npairs] end cell row (1..m) at the window's last column (null => scout)
+    const int32_t *force_score;  // [npairs] score the forced cell must reproduce (null => unchecked)
+    const uint32_t *ad_codes;    // [nadapters][128] Dna5 codes 0..4
+    const int32_t *ad_len;       // [nadapters]
+    const Tile *tiles;
+    int32_t ntiles;
+    int32_t *out;                // trace kernels: 8 x int32 per pair; score kernels: 4 x int32 per pair
+    uint32_t *slab;              // trace scratch: [grid][slab_cols][NW][64] dwords
+    int64_t slab_stride;         // dwords per block
+    int32_t slab_cols;
+    int32_t match, mismatch, gap_open, gap_extend;
+    uint32_t *err;               // err[0] += 1 on any internal inconsistency (reported loudly by the host)
+    uint32_t one2, two2, sixteen2;   // packed constants kept opaque to the compiler (set by the launcher)
+    int32_t gen_max_rows;            // generic (LDS-state) variant: largest tile.rows in the launch
+};
+
+// pass-2 planner: from the score-only pass's (score, I, J) build the bounded windows
+struct PlanArgs {
+    const int64_t *win_off; const int32_t *win_len;     // the whole-read scan descriptors
+    const int32_t *k1;                                  // [npairs][4] score, I, J, 0
+    int64_t *win_off2; int32_t *win_len2; int32_t *col02; int32_t *ntot2; int32_t *force_row2; int32_t *force_score2;
+    const Tile *tiles; int32_t ntiles;                  // same tiles as the score pass
+    const int32_t *ad_window;                           // [nadapters] W+SPAN+1 for that adapter length
+};
+
+constexpr int TRACE_OUT_INTS = 8;
+constexpr int SCORE_OUT_INTS = 4;
+
+// rows-in-registers variants that are instantiated.
+//  exact : adapter fills all R rows (no padding rows, adapter codes in SGPRs) -- the fast path
+//  padded: any adapter length <= R (top padding rows; per-row constants via LDS broadcast)
+static const int kExactRows[] = {22, 24, 28, 32};
+static const int kPaddedRows[] = {16, 24, 32, 40, 56};
+constexpr int kMaxRows = 56;
+
+// -> rows, *pad; 0 = no register variant fits: use the generic LDS-state kernel (rows = m at run time)
+inline int pick_rows(int m, bool *pad)
+{
+    for (int r : kExactRows) if (r == m) { *pad = false; return r; }
+    for (int r : kPaddedRows) if (r >= m) { *pad = true; return r; }
+    *pad = true;
+    return 0;
+}
+
+// launchers (pc_kernels.hip); stream is a hipStream_t passed as void*
+int launch_trace(const ScanArgs &a, int rows, bool pad, int grid, void *stream);
+int launch_score(const ScanArgs &a, int rows, bool pad, int grid, void *stream);
+int launch_plan(const PlanArgs &a, void *stream);
+int trace_words_per_col(int rows);   // NW
+
+}  // namespace pck

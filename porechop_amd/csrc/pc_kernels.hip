@@ -1,0 +1,472 @@
+// pc_kernels.hip -- the adapter-alignment hot path as hand-written HIP for gfx950 (CDNA4).
+//
+// What is computed is exactly the reference's path:
+//   Gotoh affine-gap DP with all four end gaps free, SeqAn's tie-breaking
+//   (seqan/align/dp_formula_affine.h:456-495), its max search over last row / last column
+//   (dp_scout.h:165-179), its traceback (dp_traceback_impl.h:376-552) and Porechop's
+//   ScoredAlignment digest (porechop/src/alignment.cpp:6-111).
+// How it is computed is MI355X-first and shares nothing with the reference's structure:
+//
+//   * inter-pair SIMD: one LANE owns two (window, adapter) pairs, packed in the low/high int16
+//     halves of every VGPR, so a wavefront advances 128 independent alignments with zero
+//     cross-lane traffic, no ramp-up/down and every lane busy (adapters are 22..50 rows, so an
+//     anti-diagonal-per-wave mapping would idle most of a 64-wide wave);
+//   * the whole DP column (M+open and H per adapter row) lives in VGPRs, rows fully unrolled;
+//     the adapter is uniform per half-wave, so its bases are SGPR (or LDS-broadcast) operands;
+//   * all cell arithmetic is v_pk_*_i16 (2 cells per VALU op): 11 ops per cell pair for the
+//     score recurrence, +12 for the 4 trace bits in the tracing variant;
+//   * the 4-bit trace is written to a per-wave slab with fully coalesced 256-B stores and read
+//     back only along the path; whole-read scans never store trace for the whole read: a
+//     score-only pass finds the end cell, a bounded window is re-run with trace (pc_bounds.h);
+//   * read bytes are consumed as delivered (1 B/base ASCII); byte -> Dna5 code is a 512-B LDS
+//     table lookup per column.
+//
+// No MFMA: this is integer max-plus DP, not a contraction.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "pc_bounds.h"
+#include "pc_kernels.h"
+#include "pc_walk.h"
+
+namespace pck {
+
+typedef uint32_t u32;
+
+// ---- packed int16 primitives.  Plain ext-vector C++ compiles 1:1 to v_pk_*_i16/u16 on gfx950.
+// The trace-bit idiom min_u16(x - y, 1) must use an OPAQUE 1 (a kernel argument): with a literal
+// hipcc rewrites it into v_cmp/v_cndmask/v_perm chains that cost 2.5x more.
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ s16x2 SV(u32 x) { return __builtin_bit_cast(s16x2, x); }
+__device__ __forceinline__ u16x2 UV(u32 x) { return __builtin_bit_cast(u16x2, x); }
+__device__ __forceinline__ u32 WV(s16x2 x) { return __builtin_bit_cast(u32, x); }
+__device__ __forceinline__ u32 WV(u16x2 x) { return __builtin_bit_cast(u32, x); }
+__device__ __forceinline__ u32 pk_add(u32 a, u32 b) { return WV(SV(a) + SV(b)); }
+__device__ __forceinline__ u32 pk_sub(u32 a, u32 b) { return WV(SV(a) - SV(b)); }
+__device__ __forceinline__ u32 pk_max(u32 a, u32 b) { return WV(__builtin_elementwise_max(SV(a), SV(b))); }
+__device__ __forceinline__ u32 pk_minu(u32 a, u32 b) { return WV(__builtin_elementwise_min(UV(a), UV(b))); }
+__device__ __forceinline__ u32 pk_madu(u32 a, u32 k, u32 c) { return WV(UV(a) * UV(k) + UV(c)); }
+
+__device__ __forceinline__ u32 pack2(int v) { return ((u32)v & 0xFFFFu) | ((u32)v << 16); }
+__device__ __forceinline__ int lo16(u32 x) { return (int)(short)(x & 0xFFFFu); }
+__device__ __forceinline__ int hi16(u32 x) { return (int)(short)(x >> 16); }
+
+__device__ __forceinline__ int dna5_code(int c) {
+    // seqan/basic/alphabet_residue_tabs.h:113-140
+    c &= 0xFF;
+    if (c == 'A' || c == 'a') return 0;
+    if (c == 'C' || c == 'c') return 1;
+    if (c == 'G' || c == 'g') return 2;
+    if (c == 'T' || c == 't' || c == 'U' || c == 'u') return 3;
+    return 4;
+}
+
+typedef u32 u32_unaligned __attribute__((aligned(1)));
+__device__ __forceinline__ u32 load_u32_unaligned(const uint8_t *p) {
+    // gfx9 global loads are byte-addressable at any alignment (SH_MEM_CONFIG unaligned mode)
+    return *(const u32_unaligned *)p;
+}
+
+
+// Scout state of one packed half
+struct Best { int score, I, J, tie; };
+
+// ---------------------------------------------------------------------------------------------
+// One DP column for both halves of every lane.
+//   T[r] = M[r][j-1] + open      U[r] = H[r][j-1]          (packed lo/hi int16)
+//   h2   = spaced Dna5 codes of the two reads' bases at this column
+//   per-row adapter constants: spaced code vc, and the min-constant dm (D=match-mismatch for a
+//   real adapter row, `match` for a padding row above the adapter: padding rows then
+//   reproduce row 0 exactly -- M stays 0, V re-opens -- see DESIGN.md "top padding")
+//   PAD=false: both adapters fill all R rows, dm is the uniform D and vc lives in SGPRs.
+//   PAD=true : (vc, dm) come from an LDS broadcast read per row.
+// The row loop is software-pipelined by hand: the 6 ops of row r+2 that do not depend on the
+// vertical chain are issued between the 5 chain ops of row r, so dependent v_pk ops are never
+// adjacent (gfx950 needs a wait state between them) and one wave alone keeps the VALU busy.
+// ---------------------------------------------------------------------------------------------
+struct KConst { u32 A2, AO2, E2, O2, NEG2, D2, ONE2, TWO2, SIXTEEN2; };
+
+template <int R, bool PAD, bool TRACE>
+__device__ __forceinline__ void column_step(u32 (&T)[R], u32 (&U)[R], u32 h2,
+                                            const u32 (&vcs)[PAD ? 1 : R], const uint2 *lds_const,
+                                            const KConst &k, u32 (&trw)[(R + 3) / 4], u32 &last_tie01)  // NOLINT
+{
+    constexpr int K = 2;                    // pipeline depth (rows ahead)
+    u32 dd[R], Hh[R], b0s[TRACE ? R : 1];   // only a window of K+1 entries is ever live
+    u32 dq = k.A2;                          // M[-1][j-1] + match = match
+    auto ind = [&](int r) {
+        u32 vc, dm;
+        if constexpr (PAD) {
+            asm volatile("" : "+s"(lds_const));     // pin this LDS-broadcast read to its row
+            const uint2 c = lds_const[r]; vc = c.x; dm = c.y;
+        }
+        else { vc = vcs[r]; dm = k.D2; }
+        const u32 y = pk_sub(h2, vc);
+        const u32 Hx = pk_add(U[r], k.E2);
+        const u32 z = pk_minu(y, dm);
+        const u32 Hs = pk_max(Hx, T[r]);
+        dd[r] = pk_sub(dq, z);
+        dq = pk_add(T[r], k.AO2);           // diagonal term of row r+1, from the OLD T[r]
+        Hh[r] = Hs;
+        if constexpr (TRACE) b0s[r] = pk_minu(pk_sub(Hs, Hx), k.ONE2);   // HOPEN
+    };
+#pragma clang loop unroll(full)
+    for (int r = 0; r < K && r < R; ++r) ind(r);
+    u32 Tup = k.O2, Vprev = k.NEG2, acc = 0;
+#pragma clang loop unroll(full)
+    for (int r = 0; r < R; ++r) {
+        if (r + K < R) {
+            // data-dependence fence: row r+K's independent ops may not start before the vertical
+            // chain has reached row r (keeps live ranges to a K+1 row window at every level of
+            // the compiler, which a sched_barrier alone does not)
+            asm volatile("" : "+v"(U[r + K]), "+v"(Vprev));
+            ind(r + K);
+        }
+        const u32 Vx = pk_add(Vprev, k.E2);
+        const u32 Vs = pk_max(Vx, Tup);
+        const u32 g = pk_max(Hh[r], Vs);
+        const u32 Mn = pk_max(dd[r], g);
+        const u32 Tn = pk_add(Mn, k.O2);
+        if constexpr (TRACE) {
+            const u32 b1 = pk_minu(pk_sub(Vs, Vx), k.ONE2);      // VOPEN
+            const u32 b2 = pk_minu(pk_sub(g, Vs), k.ONE2);       // FROMH
+            const u32 b3 = pk_minu(pk_sub(Mn, dd[r]), k.ONE2);   // NOTDIAG
+            u32 nib = pk_madu(b3, k.TWO2, b2);
+            nib = pk_madu(nib, k.TWO2, b1);
+            nib = pk_madu(nib, k.TWO2, b0s[r]);
+            acc = pk_madu(acc, k.SIXTEEN2, nib);
+            if ((r & 3) == 3 || r == R - 1) { trw[r >> 2] = acc; acc = 0; }
+        }
+        if (r == R - 1) last_tie01 = pk_minu(dd[r] ^ g, k.ONE2);   // 0 where d == max(H,V)
+        T[r] = Tn; U[r] = Hh[r];
+        Tup = Tn; Vprev = Vs;
+        if constexpr (TRACE) {
+            // same kind of fence for the trace bits: they must retire inside this row's window
+            // instead of being sunk below the whole column (which keeps 6 values per row alive)
+            if ((r & 3) == 3 || r == R - 1) asm volatile("" : "+v"(trw[r >> 2]), "+v"(Tup));
+            else asm volatile("" : "+v"(acc), "+v"(Tup));
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// The scan kernel.  TRACE=true : full alignment (trace slab, traceback, digest) -> 8 ints/pair
+//                   TRACE=false: score-only forward pass -> (score, I, J) per pair
+// R > 0 : DP column in VGPRs, R rows fully unrolled (the fast path; PAD as in column_step).
+// R == 0: "generic" variant for adapters longer than the register variants: the column lives in
+//         LDS ([row][lane], conflict-free), rows = tile.rows at run time, rolled row loop.
+// One wavefront per block; blocks stride over tiles.
+// ---------------------------------------------------------------------------------------------
+template <int R, bool PAD, bool TRACE>
+__global__ __launch_bounds__(64) void scan_kernel(ScanArgs a)
+{
+    constexpr bool GEN = (R == 0);
+    constexpr int RS = GEN ? 1 : R;          // static array extent
+    __shared__ uint16_t lut[256];
+    __shared__ uint2 lds_const_s[RS];        // per-row (spaced code, min-constant), packed lo|hi
+    __shared__ uint2 lds_fin_s[RS * 64];     // last-column scratch [row][lane]
+    extern __shared__ __attribute__((aligned(16))) uint2 dyn_lds[];   // GEN: consts + column state
+    uint2 *lds_const = GEN ? dyn_lds : lds_const_s;
+    uint2 *lds_fin = GEN ? dyn_lds + a.gen_max_rows : lds_fin_s;     // GEN: the column state itself
+
+    const int lane = threadIdx.x;
+    const int D = a.match - a.mismatch;
+    for (int c = lane; c < 256; c += 64) lut[c] = (uint16_t)(dna5_code(c) * D);
+
+    KConst k;
+    k.A2 = pack2(a.match); k.AO2 = pack2(a.match - a.gap_open); k.E2 = pack2(a.gap_extend);
+    k.O2 = pack2(a.gap_open); k.NEG2 = pack2(pcb::NEG16); k.D2 = pack2(D);
+    k.ONE2 = a.one2; k.TWO2 = a.two2; k.SIXTEEN2 = a.sixteen2;   // opaque on purpose
+    const u32 NEG2 = k.NEG2;
+    u32 *slab = TRACE ? a.slab + (int64_t)blockIdx.x * a.slab_stride : nullptr;
+
+    for (int t = blockIdx.x; t < a.ntiles; t += gridDim.x) {
+        const Tile tile = a.tiles[t];
+        const int rows = GEN ? tile.rows : R;
+        const int NW = (rows + 3) >> 2;      // trace dwords per column per lane
+        const int m_lo = a.ad_len[tile.adapter_lo];
+        const int m_hi = a.ad_len[tile.adapter_hi];
+        const u32 *codes_lo = a.ad_codes + (int64_t)tile.adapter_lo * pcb::MAX_ADAPTER;
+        const u32 *codes_hi = a.ad_codes + (int64_t)tile.adapter_hi * pcb::MAX_ADAPTER;
+        const int pad_lo = rows - m_lo, pad_hi = rows - m_hi;     // top padding rows of each half
+        if (pad_lo < 0 || pad_hi < 0 || (GEN && rows > a.gen_max_rows)) {   // host bug
+            if (lane == 0) atomicAdd(a.err, 1u);
+            continue;
+        }
+
+        // ---- per-row adapter constants -> LDS (-> SGPRs for the exact variants) -----------
+        __syncthreads();
+        for (int r = lane; r < rows; r += 64) {
+            const int il = r - pad_lo, ih = r - pad_hi;
+            const u32 rl = codes_lo[il >= 0 ? il : 0], rh = codes_hi[ih >= 0 ? ih : 0];
+            const u32 cl = il >= 0 ? rl * (u32)D : 6u * (u32)D;
+            const u32 ch = ih >= 0 ? rh * (u32)D : 6u * (u32)D;
+            const u32 dl = il >= 0 ? (u32)D : (u32)a.match;
+            const u32 dh = ih >= 0 ? (u32)D : (u32)a.match;
+            lds_const[r] = make_uint2(cl | (ch << 16), dl | (dh << 16));
+        }
+        __syncthreads();
+        u32 vcs[(PAD || GEN) ? 1 : RS];
+        if constexpr (!PAD && !GEN) {
+            if (pad_lo != 0 || pad_hi != 0) { if (lane == 0) atomicAdd(a.err, 1u); continue; }   // host bug
+#pragma clang loop unroll(full)
+            for (int r = 0; r < R; ++r) vcs[r] = __builtin_amdgcn_readfirstlane(lds_const[r].x);
+        } else {
+            vcs[0] = 0;
+        }
+
+        // ---- this lane's two pairs -----------------------------------------------------
+        const int64_t p_lo = tile.pair_base + lane, p_hi = tile.pair_base + 64 + lane;
+        const bool have_lo = lane < tile.count, have_hi = 64 + lane < tile.count;
+        const uint8_t *w_lo = a.arena + (have_lo ? a.win_off[p_lo] : 0);
+        const uint8_t *w_hi = a.arena + (have_hi ? a.win_off[p_hi] : 0);
+        const int n_lo = have_lo ? a.win_len[p_lo] : 0;
+        const int n_hi = have_hi ? a.win_len[p_hi] : 0;
+        const int c0_lo = (have_lo && a.col0) ? a.col0[p_lo] : 0;
+        const int c0_hi = (have_hi && a.col0) ? a.col0[p_hi] : 0;
+        const int fr_lo = (have_lo && a.force_row) ? a.force_row[p_lo] : -1;   // adapter row or -1
+        const int fr_hi = (have_hi && a.force_row) ? a.force_row[p_hi] : -1;
+
+        // ---- column 0 state --------------------------------------------------------------
+        // scout start: M=0 everywhere (free leading gaps).  interior start (window not at the
+        // read's column 0): every state is a real lower-bound path, row-0 start + vertical gap:
+        // M = open + (i-1)*ext for adapter row i>=1, i.e. T = M + open.
+        u32 T[RS], U[RS];
+        auto init_T = [&](int r) -> u32 {
+            const int vl = (c0_lo > 0 && r >= pad_lo) ? 2 * a.gap_open + (r - pad_lo) * a.gap_extend : a.gap_open;
+            const int vh = (c0_hi > 0 && r >= pad_hi) ? 2 * a.gap_open + (r - pad_hi) * a.gap_extend : a.gap_open;
+            return ((u32)vl & 0xFFFFu) | ((u32)vh << 16);
+        };
+        if constexpr (GEN) {
+#pragma unroll 1
+            for (int r = 0; r < rows; ++r) lds_fin[r * 64 + lane] = make_uint2(init_T(r), NEG2);
+            T[0] = 0; U[0] = 0;
+        } else {
+#pragma clang loop unroll(full)
+            for (int r = 0; r < R; ++r) { T[r] = init_T(r); U[r] = NEG2; }
+        }
+        Best b_lo = {0, m_lo, 0, 0}, b_hi = {0, m_hi, 0, 0};
+
+        int nmax = n_lo > n_hi ? n_lo : n_hi;
+#pragma unroll
+        for (int s = 32; s >= 1; s >>= 1) { const int o = __shfl_xor(nmax, s); nmax = o > nmax ? o : nmax; }
+        if (TRACE && nmax > a.slab_cols) {   // host sized the slab from a wrong bound: refuse
+            if (lane == 0) atomicAdd(a.err, 1u);
+            nmax = 0;
+        }
+
+        // last-column scan of one row (tracked cells visited top to bottom, strict '>',
+        // dp_scout.h:165-179; a forced end cell just records that row)
+        auto scan_row = [&](int r, int j, u32 Tn, u32 t01, bool fin_lo, bool fin_hi) {
+            const int il = r - pad_lo + 1, ih = r - pad_hi + 1;
+            const int cl = lo16(Tn) - a.gap_open, ch = hi16(Tn) - a.gap_open;
+            if (fin_lo && il >= 1 && (fr_lo >= 0 ? (il == fr_lo) : (cl > b_lo.score))) {
+                b_lo.score = cl; b_lo.I = il; b_lo.J = j; b_lo.tie = !(t01 & 0xFFFFu);
+            }
+            if (fin_hi && ih >= 1 && (fr_hi >= 0 ? (ih == fr_hi) : (ch > b_hi.score))) {
+                b_hi.score = ch; b_hi.I = ih; b_hi.J = j; b_hi.tie = !(t01 >> 16);
+            }
+        };
+
+        u32 cur_lo = 0, cur_hi = 0;
+        for (int j = 1; j <= nmax; ++j) {
+            if (((j - 1) & 3) == 0) {
+                // next 4 bases of each stream; finished streams re-read their last dword
+                const int kl = (j - 1 < n_lo) ? j - 1 : (n_lo > 0 ? ((n_lo - 1) & ~3) : 0);
+                const int kh = (j - 1 < n_hi) ? j - 1 : (n_hi > 0 ? ((n_hi - 1) & ~3) : 0);
+                cur_lo = load_u32_unaligned(w_lo + kl);
+                cur_hi = load_u32_unaligned(w_hi + kh);
+            }
+            const u32 h2 = (u32)lut[cur_lo & 0xFF] | ((u32)lut[cur_hi & 0xFF] << 16);
+            cur_lo >>= 8; cur_hi >>= 8;
+
+            u32 tie01 = 0, Tlast = 0;
+            const bool fin_lo = (j == n_lo), fin_hi = (j == n_hi);
+            const bool any_fin = __any(fin_lo || fin_hi);
+            u32 *trace_dst = TRACE ? slab + ((int64_t)(j - 1) * NW) * 64 + lane : nullptr;
+
+            if constexpr (GEN) {
+                // ---- rolled column over the LDS-resident state --------------------------
+                u32 dq = k.A2, Tup = k.O2, Vprev = k.NEG2, acc = 0;
+#pragma unroll 2
+                for (int r = 0; r < rows; ++r) {
+                    const uint2 old = lds_fin[r * 64 + lane];      // (T, U) of column j-1
+                    const uint2 c = lds_const[r];
+                    const u32 z = pk_minu(pk_sub(h2, c.x), c.y);
+                    const u32 d = pk_sub(dq, z);
+                    const u32 Hx = pk_add(old.y, k.E2);
+                    const u32 Hs = pk_max(Hx, old.x);
+                    const u32 Vx = pk_add(Vprev, k.E2);
+                    const u32 Vs = pk_max(Vx, Tup);
+                    const u32 g = pk_max(Hs, Vs);
+                    const u32 Mn = pk_max(d, g);
+                    const u32 Tn = pk_add(Mn, k.O2);
+                    const u32 t01 = pk_minu(d ^ g, k.ONE2);
+                    if constexpr (TRACE) {
+                        const u32 b0 = pk_minu(pk_sub(Hs, Hx), k.ONE2);
+                        const u32 b1 = pk_minu(pk_sub(Vs, Vx), k.ONE2);
+                        const u32 b2 = pk_minu(pk_sub(g, Vs), k.ONE2);
+                        const u32 b3 = pk_minu(pk_sub(Mn, d), k.ONE2);
+                        u32 nib = pk_madu(b3, k.TWO2, b2);
+                        nib = pk_madu(nib, k.TWO2, b1);
+                        nib = pk_madu(nib, k.TWO2, b0);
+                        acc = pk_madu(acc, k.SIXTEEN2, nib);
+                        if ((r & 3) == 3 || r == rows - 1) { trace_dst[(r >> 2) * 64] = acc; acc = 0; }
+                    }
+                    if (any_fin) scan_row(r, j, Tn, t01, fin_lo, fin_hi);
+                    lds_fin[r * 64 + lane] = make_uint2(Tn, Hs);
+                    dq = pk_add(old.x, k.AO2); Tup = Tn; Vprev = Vs;
+                    tie01 = t01; Tlast = Tn;
+                }
+            } else {
+                if (any_fin) {
+                    // some pair reaches its last column: keep the previous column for the scan below
+#pragma clang loop unroll(full)
+                    for (int r = 0; r < R; ++r) lds_fin[r * 64 + lane] = make_uint2(T[r], U[r]);
+                }
+                u32 trw[(RS + 3) / 4];
+                column_step<RS, PAD, TRACE>(T, U, h2, vcs, lds_const, k, trw, tie01);
+                Tlast = T[RS - 1];
+                if constexpr (TRACE) {
+#pragma unroll
+                    for (int w = 0; w < (RS + 3) / 4; ++w) trace_dst[w * 64] = trw[w];
+                }
+                if (any_fin) {
+                    // Rare, so it is a rolled re-run of the column from the saved state (same
+                    // packed arithmetic) that also yields the d == max(H,V) flag of every row.
+                    u32 dq = k.A2, Tup = k.O2, Vprev = k.NEG2;
+#pragma unroll 1
+                    for (int r = 0; r < R; ++r) {
+                        const uint2 old = lds_fin[r * 64 + lane];
+                        const uint2 c = lds_const[r];
+                        const u32 z = pk_minu(pk_sub(h2, c.x), c.y);
+                        const u32 d = pk_sub(dq, z);
+                        const u32 Hs = pk_max(pk_add(old.y, k.E2), old.x);
+                        const u32 Vs = pk_max(pk_add(Vprev, k.E2), Tup);
+                        const u32 g = pk_max(Hs, Vs);
+                        const u32 Tn = pk_add(pk_max(d, g), k.O2);
+                        const u32 t01 = pk_minu(d ^ g, k.ONE2);
+                        dq = pk_add(old.x, k.AO2); Tup = Tn; Vprev = Vs;
+                        scan_row(r, j, Tn, t01, fin_lo, fin_hi);
+                    }
+                }
+            }
+            // last adapter row of columns 1..n-1 (bottom register row for both halves)
+            {
+                const int cl = lo16(Tlast) - a.gap_open, ch = hi16(Tlast) - a.gap_open;
+                if (j < n_lo && fr_lo < 0 && cl > b_lo.score) { b_lo.score = cl; b_lo.I = m_lo; b_lo.J = j; b_lo.tie = !(tie01 & 0xFFFFu); }
+                if (j < n_hi && fr_hi < 0 && ch > b_hi.score) { b_hi.score = ch; b_hi.I = m_hi; b_hi.J = j; b_hi.tie = !(tie01 >> 16); }
+            }
+        }
+
+        // ---- results -----------------------------------------------------------------
+        if constexpr (!TRACE) {
+            if (have_lo) { int4 o = {b_lo.score, b_lo.I, b_lo.J, 0}; *(int4 *)(a.out + p_lo * SCORE_OUT_INTS) = o; }
+            if (have_hi) { int4 o = {b_hi.score, b_hi.I, b_hi.J, 0}; *(int4 *)(a.out + p_hi * SCORE_OUT_INTS) = o; }
+        } else {
+#pragma unroll 1
+            for (int hf = 0; hf < 2; ++hf) {
+                const bool have = hf ? have_hi : have_lo;
+                if (!have) continue;
+                const Best b = hf ? b_hi : b_lo;
+                const int m = hf ? m_hi : m_lo, pad = hf ? pad_hi : pad_lo;
+                const int c0 = hf ? c0_hi : c0_lo;
+                const int64_t p = hf ? p_hi : p_lo;
+                const uint8_t *w = hf ? w_hi : w_lo;
+                const u32 *codes = hf ? codes_hi : codes_lo;
+                const int nt = a.n_total ? a.n_total[p] : (hf ? n_hi : n_lo);
+                auto nibf = [&](int col, int row) -> int {
+                    const int r = pad + row - 1;
+                    const int wq = r >> 2;
+                    const int rows_in_group = (rows - 4 * wq) < 4 ? (rows - 4 * wq) : 4;
+                    const int pos = rows_in_group - 1 - (r & 3);
+                    const u32 dw = slab[((int64_t)(col - 1) * NW + wq) * 64 + lane];
+                    return (int)((dw >> (16 * hf + 4 * pos)) & 0xFu);
+                };
+                auto eqf = [&](int col, int row) -> bool {
+                    return dna5_code(w[col - 1]) == (int)codes[row - 1];
+                };
+                int tie_fix = 0;
+                if (b.J > 0 && b.I > 0) {
+                    const int nb = nibf(b.J, b.I);
+                    if ((nb & pcw::NIB_NOTDIAG) || b.tie) tie_fix = (nb & pcw::NIB_FROMH) ? 2 : 1;
+                }
+                pcw::Digest dg;
+                int err = pcw::walk(nibf, eqf, b.I, b.J, m, c0, nt, b.score, tie_fix, dg);
+                if (a.force_score && a.force_score[p] != b.score) err = 1;
+                if (err) atomicAdd(a.err, 1u);
+                int4 o0 = {dg.read_start, dg.read_end, dg.adapter_start, dg.adapter_end};
+                int4 o1 = {dg.score, dg.matches, dg.aligned_len, dg.full_len};
+                int4 *op = (int4 *)(a.out + p * TRACE_OUT_INTS);
+                op[0] = o0; op[1] = o1;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Planner between the two passes of a whole-read scan: bounded window ending at the max cell.
+// ---------------------------------------------------------------------------------------------
+__global__ void plan_kernel(PlanArgs a)
+{
+    const Tile tile = a.tiles[blockIdx.x];
+    const int i = threadIdx.x;
+    if (i >= tile.count) return;
+    const int64_t p = tile.pair_base + i;
+    const int score = a.k1[p * 4 + 0], I = a.k1[p * 4 + 1], J = a.k1[p * 4 + 2];
+    const int window = a.ad_window[i < 64 ? tile.adapter_lo : tile.adapter_hi];
+    int c0 = J - window;
+    if (c0 < 0) c0 = 0;
+    a.win_off2[p] = a.win_off[p] + c0;
+    a.win_len2[p] = J - c0;
+    a.col02[p] = c0;
+    a.ntot2[p] = a.win_len[p];
+    a.force_row2[p] = I;
+    a.force_score2[p] = score;
+}
+
+int trace_words_per_col(int rows) { return (rows + 3) / 4; }
+
+template <bool TRACE>
+static int launch_scan(const ScanArgs &a0, int rows, bool pad, int grid, void *stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    ScanArgs a = a0;
+    a.one2 = 0x00010001u; a.two2 = 0x00020002u; a.sixteen2 = 0x00100010u;
+#define PC_EXACT(RR) case RR: hipLaunchKernelGGL((scan_kernel<RR, false, TRACE>), dim3(grid), dim3(64), 0, s, a); break;
+#define PC_PADDED(RR) case RR: hipLaunchKernelGGL((scan_kernel<RR, true, TRACE>), dim3(grid), dim3(64), 0, s, a); break;
+    if (rows == 0) {
+        // generic: dynamic LDS = per-row constants + the DP column of 64 lanes
+        const size_t lds = (size_t)a.gen_max_rows * 8 + (size_t)a.gen_max_rows * 64 * 8;
+        if (hipFuncSetAttribute((const void *)scan_kernel<0, true, TRACE>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds) != hipSuccess)
+            return -2;
+        hipLaunchKernelGGL((scan_kernel<0, true, TRACE>), dim3(grid), dim3(64), lds, s, a);
+    } else if (!pad) {
+        switch (rows) {
+            PC_EXACT(22) PC_EXACT(24) PC_EXACT(28) PC_EXACT(32)
+            default: return -1;
+        }
+    } else {
+        switch (rows) {
+            PC_PADDED(16) PC_PADDED(24) PC_PADDED(32) PC_PADDED(40) PC_PADDED(56)
+            default: return -1;
+        }
+    }
+#undef PC_EXACT
+#undef PC_PADDED
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+int launch_trace(const ScanArgs &a, int rows, bool pad, int grid, void *stream) { return launch_scan<true>(a, rows, pad, grid, stream); }
+int launch_score(const ScanArgs &a, int rows, bool pad, int grid, void *stream) { return launch_scan<false>(a, rows, pad, grid, stream); }
+
+int launch_plan(const PlanArgs &a, void *stream)
+{
+    if (a.ntiles <= 0) return 0;
+    hipLaunchKernelGGL(plan_kernel, dim3((unsigned)a.ntiles), dim3(128), 0, (hipStream_t)stream, a);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+}  // namespace pck

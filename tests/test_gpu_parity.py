@@ -1,0 +1,149 @@
+"""GPU parity tests: every call goes through the C ABI (include/porechop_amd.h) and is compared
+bit-exactly -- ints and the printed identity decimals -- with
+  * the committed goldens minted from the compiled reference (tests/golden/), and
+  * the CPU oracle (oracle/pc_oracle.c) on seeded inputs.
+"""
+import random
+
+import numpy as np
+import pytest
+
+from tests.golden_io import comparable, load_synthetic
+from tests.pairgen import SCHEMES, random_case
+
+pytestmark = pytest.mark.gpu
+
+MAX_GPU_ADAPTER = 128
+
+
+@pytest.fixture(scope="module")
+def pa():
+    import porechop_amd
+    return porechop_amd
+
+
+def run_batch(pa, cases, scores, mode=0):
+    """cases: list of (read, adapter) strings -> list of 7-field strings via the batch C ABI."""
+    ads, idx = [], {}
+    pairs = []
+    for rd, ad in cases:
+        if ad not in idx:
+            idx[ad] = len(ads)
+            ads.append(ad)
+        pairs.append((rd, idx[ad]))
+    al = pa.Aligner(ads, scores)
+    recs = al.align_pairs(pairs, mode)
+    al.close()
+    return [pa.format_result(r) for r in recs]
+
+
+def test_known_answer_vectors_per_call(pa):
+    # SURVEY.md section 8a, through the reference-shaped per-call symbol
+    kav = [
+        ("ACGTACGTAC", "ACGT", "0,3,0,3,12,100.000000,100.000000"),
+        ("TTTTACGTTTTT", "ACGT", "4,7,0,3,12,100.000000,100.000000"),
+        ("ACGT", "TTACGTTT", "0,3,2,5,12,100.000000,50.000000"),
+        ("GTTT", "ACGT", "0,1,2,3,6,100.000000,50.000000"),
+        ("TTAC", "ACGT", "2,3,0,1,6,100.000000,50.000000"),
+        ("NNNNNNNN", "ACGT", "0,0,4,3,0,-nan,0.000000"),
+        ("ACNNGT", "ACNNGT", "0,5,0,5,18,100.000000,100.000000"),
+        ("AC--GT", "ACGT", "0,5,0,3,5,66.666667,66.666667"),
+        ("ACXXGT", "ACNNGT", "0,5,0,5,18,100.000000,100.000000"),
+        ("A", "C", "0,0,1,0,0,-nan,0.000000"),
+        ("A", "ACGT", "0,0,0,0,3,100.000000,25.000000"),
+        ("TTTTACGAACGTTTTT", "ACGTACGT", "4,11,0,7,15,87.500000,87.500000"),
+        ("TTTTACGTTACGTTTTT", "ACGTACGT", "4,12,0,7,19,88.888889,88.888889"),
+        ("AAAAAAAAAA", "CCCC", "0,0,4,3,0,-nan,0.000000"),
+    ]
+    for rd, ad, want in kav:
+        assert pa.adapter_alignment(rd, ad, [3, -6, -5, -2]) == want, (rd, ad)
+    assert pa.adapter_alignment("", "ACGT", [3, -6, -5, -2]).split(",")[0] == "-1"
+    assert pa.adapter_alignment("ACGT", "", [3, -6, -5, -2]).split(",")[0] == "-1"
+
+
+def test_recorded_reference_calls(pa, goldens):
+    """All 25 680 distinct adapter_alignment calls the reference CLI makes on its bundled
+    fixtures (end windows, whole-read middle scans incl. masked reads, 2 scoring schemes)."""
+    S = goldens["strings"]
+    by_scheme = {}
+    for ri, ai, sc, res in goldens["calls"]:
+        by_scheme.setdefault(tuple(sc), []).append((S[ri], S[ai], res))
+    total = 0
+    for sc, items in by_scheme.items():
+        got = run_batch(pa, [(r, a) for r, a, _ in items], sc)
+        bad = [(len(r), a, want, g) for (r, a, want), g in zip(items, got) if comparable(g) != comparable(want)]
+        assert not bad, (sc, len(bad), bad[:5])
+        total += len(items)
+    assert total == len(goldens["calls"])
+
+
+def test_synthetic_goldens_all_schemes(pa):
+    by_scheme = {}
+    for rd, ad, sc, res in load_synthetic():
+        by_scheme.setdefault(tuple(sc), []).append((rd, ad, res))
+    for sc, items in by_scheme.items():
+        got = run_batch(pa, [(r, a) for r, a, _ in items], sc)
+        bad = [(r, a, want, g) for (r, a, want), g in zip(items, got) if comparable(g) != comparable(want)]
+        assert not bad, (sc, len(bad), bad[:5])
+
+
+def test_random_end_windows_vs_oracle(pa, oracle):
+    rng = random.Random(424242)
+    for sc in SCHEMES:
+        cases = [random_case(rng) for _ in range(6000)]
+        got = run_batch(pa, cases, sc)
+        bad = []
+        for (rd, ad), g in zip(cases, got):
+            want = oracle.adapter_alignment(rd, ad, sc)
+            if comparable(g) != comparable(want):
+                bad.append((rd, ad, want, g))
+        assert not bad, (sc, len(bad), bad[:3])
+
+
+def test_whole_read_two_pass_vs_oracle(pa, oracle):
+    """Middle-scan shape: whole reads (2-12 kb) x short adapters; the GPU runs the score-only pass
+    + bounded traced window, the oracle the full matrix."""
+    rng = random.Random(99)
+    cases = []
+    for _ in range(300):
+        n = rng.choice([700, 2000, 5000, 8000, 12000])
+        m = rng.choice([22, 24, 28, 28, 33, 50])
+        cases.append(random_case(rng, n=n, m=m, alphabet=rng.choice(["ACGT", "ACGT", "ACGT-", "ACGTN"])))
+    got = run_batch(pa, cases, (3, -6, -5, -2))
+    bad = [(len(rd), ad, g) for (rd, ad), g in zip(cases, got) if g != oracle.adapter_alignment(rd, ad)]
+    assert not bad, (len(bad), bad[:3])
+
+
+def test_modes_agree(pa):
+    """The same pairs through the one-pass traced kernel and through the two-pass scan."""
+    rng = random.Random(5)
+    cases = [random_case(rng, n=rng.choice([300, 900, 1500]), m=rng.choice([22, 24, 28, 40])) for _ in range(400)]
+    a = run_batch(pa, cases, (3, -6, -5, -2), mode=pa.MODE_TRACE)
+    b = run_batch(pa, cases, (3, -6, -5, -2), mode=pa.MODE_TWO_PASS)
+    assert a == b
+
+
+def test_ragged_and_unaligned_windows(pa, oracle):
+    """Windows at every byte alignment, lengths 1..160, adapters 1..56, sharing one arena."""
+    rng = random.Random(17)
+    arena = "".join(rng.choice("ACGT") for _ in range(5000))
+    ads = ["".join(rng.choice("ACGT") for _ in range(m)) for m in (1, 2, 7, 16, 22, 23, 24, 28, 31, 32, 33, 40, 50, 56)]
+    al = pa.Aligner(ads)
+    offs, lens, idx = [], [], []
+    for k in range(4000):
+        n = rng.randint(1, 160)
+        o = rng.randint(0, len(arena) - n)
+        offs.append(o); lens.append(n); idx.append(rng.randrange(len(ads)))
+    recs = al.align_host(arena.encode(), offs, lens, idx)
+    al.close()
+    for o, n, i, r in zip(offs, lens, idx, recs):
+        assert pa.format_result(r) == oracle.adapter_alignment(arena[o:o + n], ads[i]), (o, n, ads[i])
+
+
+def test_unsupported_scores_fail_loudly(pa):
+    with pytest.raises(RuntimeError):
+        pa.Aligner(["ACGT"], scores=(3, -6, -5, -5))      # linear gaps: different reference recurrence
+    with pytest.raises(RuntimeError):
+        pa.Aligner(["ACGT"], scores=(3, -6, 5, -2))       # positive gap score
+    with pytest.raises(RuntimeError):
+        pa.adapter_alignment("ACGT", "ACGT", [3, -6, -5, -5])

@@ -102,6 +102,15 @@ int pc_scan_device(pc_ctx *ctx, const void *d_arena, const int64_t *d_win_off,
  * last pc_sync reported an inconsistency. */
 int pc_sync(pc_ctx *ctx, void *stream);
 
+/* Kernel timing hooks (bench.py roofline leg): when enabled, every kernel launch made by
+ * pc_scan_device is bracketed by HIP events on the launch stream.  pc_get_timing waits for the
+ * stream, then returns per kernel kind (0 = score-only scan, 1 = window planner, 2 = traced scan)
+ * the summed duration in milliseconds, the number of launches and the number of pairs they
+ * covered, and resets the accumulators.  Each array holds PC_KERNEL_KINDS entries. */
+#define PC_KERNEL_KINDS 3
+int pc_set_timing(pc_ctx *ctx, int enabled);
+int pc_get_timing(pc_ctx *ctx, void *stream, double *ms, int64_t *launches, int64_t *pairs);
+
 /* Format one result record exactly as the reference prints it; buf must hold >= 160 bytes. */
 int pc_format_result(const int32_t *rec, char *buf, size_t buflen);
 

@@ -111,6 +111,19 @@ class Aligner:
                                       int(max_len), mode, out.data_ptr(), ctypes.c_void_p(s)),
               "pc_scan_device")
 
+    def set_timing(self, enabled=True):
+        check(self.lib.pc_set_timing(self._ctx, 1 if enabled else 0), "pc_set_timing")
+
+    def get_timing(self, stream=None):
+        """-> dict kind -> (ms, launches, pairs) for kinds 'score', 'plan', 'trace' since the last call."""
+        import torch
+        s = stream if stream is not None else torch.cuda.current_stream().cuda_stream
+        ms = (ctypes.c_double * 3)()
+        ln = (ctypes.c_int64 * 3)()
+        pr = (ctypes.c_int64 * 3)()
+        check(self.lib.pc_get_timing(self._ctx, ctypes.c_void_p(s), ms, ln, pr), "pc_get_timing")
+        return {k: (ms[i], ln[i], pr[i]) for i, k in enumerate(("score", "plan", "trace"))}
+
     def sync(self, stream=None):
         import torch
         s = stream if stream is not None else torch.cuda.current_stream().cuda_stream

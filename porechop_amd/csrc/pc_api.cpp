@@ -76,6 +76,10 @@ struct pc_ctx {
     int last_max_len = -1, last_mode = -1;
     bool tiles_uploaded = false;
     std::mutex mu;
+    // optional per-launch HIP-event timing (pc_set_timing / pc_get_timing)
+    bool timing = false;
+    struct Timed { hipEvent_t e0, e1; int kind; int64_t pairs; };
+    std::vector<Timed> timed;
 };
 
 namespace {
@@ -194,6 +198,18 @@ int build_tiles(pc_ctx *c, const int32_t *job_adapter, const int64_t *job_start,
     c->tiles_uploaded = true;
     return PC_OK;
 }
+
+struct ScopedTimer {
+    pc_ctx *c; hipStream_t s; bool on; pc_ctx::Timed t;
+    ScopedTimer(pc_ctx *c_, hipStream_t s_, int kind, int64_t pairs) : c(c_), s(s_), on(c_->timing)
+    {
+        if (!on) return;
+        t.kind = kind; t.pairs = pairs;
+        if (hipEventCreate(&t.e0) != hipSuccess || hipEventCreate(&t.e1) != hipSuccess) { on = false; return; }
+        (void)hipEventRecord(t.e0, s);
+    }
+    ~ScopedTimer() { if (on) { (void)hipEventRecord(t.e1, s); c->timed.push_back(t); } }
+};
 
 int grid_for(const pc_ctx *c, const Group &g, size_t ntiles, int slab_cols, size_t *slab_stride_dwords)
 {
@@ -347,14 +363,22 @@ int pc_scan_device(pc_ctx *c, const void *d_arena, const int64_t *d_win_off, con
             a.slab_cols = max_len;
             const int grid = grid_for(c, g, g.tile_count, max_len, &stride);
             a.slab_stride = (int64_t)stride;
+            int64_t np = 0;
+            for (size_t i = 0; i < g.tile_count; ++i) np += c->tiles[g.tile_begin + i].count;
+            ScopedTimer tm(c, stream, 2, np);
             if ((rc = pck::launch_trace(a, g.rows, g.pad, grid, stream))) return PC_ERR_NO_DEVICE;
         } else {
+            int64_t np = 0;
+            for (size_t i = 0; i < g.tile_count; ++i) np += c->tiles[g.tile_begin + i].count;
             // pass 1: score only, whole window
             a.win_off = d_win_off; a.win_len = d_win_len;
             a.out = c->d_k1.as<int32_t>();
             a.slab = nullptr; a.slab_cols = 0; a.slab_stride = 0;
             int grid = grid_for(c, g, g.tile_count, 1, nullptr);
-            if ((rc = pck::launch_score(a, g.rows, g.pad, grid, stream))) return PC_ERR_NO_DEVICE;
+            {
+                ScopedTimer tm(c, stream, 0, np);
+                if ((rc = pck::launch_score(a, g.rows, g.pad, grid, stream))) return PC_ERR_NO_DEVICE;
+            }
             // plan the bounded windows
             pck::PlanArgs pl;
             memset(&pl, 0, sizeof(pl));
@@ -364,7 +388,10 @@ int pc_scan_device(pc_ctx *c, const void *d_arena, const int64_t *d_win_off, con
             pl.force_row2 = c->d_frow.as<int32_t>(); pl.force_score2 = c->d_fscore.as<int32_t>();
             pl.tiles = a.tiles; pl.ntiles = a.ntiles;
             pl.ad_window = c->d_ad_window.as<int32_t>();
-            if ((rc = pck::launch_plan(pl, stream))) return PC_ERR_NO_DEVICE;
+            {
+                ScopedTimer tm(c, stream, 1, np);
+                if ((rc = pck::launch_plan(pl, stream))) return PC_ERR_NO_DEVICE;
+            }
             // pass 2: traced window ending at the max cell
             a.win_off = pl.win_off2; a.win_len = pl.win_len2; a.col0 = pl.col02; a.n_total = pl.ntot2;
             a.force_row = pl.force_row2; a.force_score = pl.force_score2;
@@ -373,9 +400,35 @@ int pc_scan_device(pc_ctx *c, const void *d_arena, const int64_t *d_win_off, con
             a.slab_cols = g.max_window + 1;
             grid = grid_for(c, g, g.tile_count, a.slab_cols, &stride);
             a.slab_stride = (int64_t)stride;
-            if ((rc = pck::launch_trace(a, g.rows, g.pad, grid, stream))) return PC_ERR_NO_DEVICE;
+            {
+                ScopedTimer tm(c, stream, 2, np);
+                if ((rc = pck::launch_trace(a, g.rows, g.pad, grid, stream))) return PC_ERR_NO_DEVICE;
+            }
         }
     }
+    return PC_OK;
+}
+
+int pc_set_timing(pc_ctx *c, int enabled)
+{
+    if (!c) return PC_ERR_BAD_ARG;
+    c->timing = enabled != 0;
+    return PC_OK;
+}
+
+int pc_get_timing(pc_ctx *c, void *stream_v, double *ms, int64_t *launches, int64_t *pairs)
+{
+    if (!c || !ms || !launches || !pairs) return PC_ERR_BAD_ARG;
+    (void)hipSetDevice(c->device);
+    hipStream_t stream = stream_v ? (hipStream_t)stream_v : c->stream;
+    HIP_TRY(hipStreamSynchronize(stream));
+    for (int k = 0; k < PC_KERNEL_KINDS; ++k) { ms[k] = 0.0; launches[k] = 0; pairs[k] = 0; }
+    for (auto &t : c->timed) {
+        float f = 0.f;
+        if (hipEventElapsedTime(&f, t.e0, t.e1) == hipSuccess) { ms[t.kind] += f; launches[t.kind] += 1; pairs[t.kind] += t.pairs; }
+        (void)hipEventDestroy(t.e0); (void)hipEventDestroy(t.e1);
+    }
+    c->timed.clear();
     return PC_OK;
 }
 

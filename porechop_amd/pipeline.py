@@ -1,0 +1,321 @@
+"""Batched form of Porechop's three adapter-search phases, driving the GPU library.
+
+This is the host-side mirror of the CALLERS of the hot path, batched so that the GPU sees
+millions of (window, adapter) pairs per launch instead of one pair per ctypes call:
+
+  phase A  porechop/porechop.py:286-327   find_matching_adapter_sets (+ nanopore_read.py:149-164)
+  phase B  porechop/porechop.py:438-514   find_adapters_at_read_ends (+ nanopore_read.py:166-208)
+  phase C  porechop/porechop.py:533-595   find_adapters_in_read_middles (+ nanopore_read.py:210-243)
+
+Every decision (thresholds, trim arithmetic, the sequential mask-and-realign loop of phase C) is
+the reference's, evaluated with torch tensor ops on the device from the integer records the
+kernels return; the alignments themselves only ever come from the C ABI (no CPU path).
+PyTorch is plumbing here: it owns the HBM buffers and the stream.
+"""
+from dataclasses import dataclass, field
+from typing import List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from .batch import MODE_TRACE, MODE_TWO_PASS, Aligner, RESULT_INTS
+
+
+@dataclass
+class AdapterSet:
+    """Mirror of porechop/adapters.py:18-52 (name + optional (name, seq) start / end)."""
+    name: str
+    start: Optional[Tuple[str, str]] = None
+    end: Optional[Tuple[str, str]] = None
+
+
+@dataclass
+class ScanParams:
+    # defaults of porechop/porechop.py:138-185
+    end_size: int = 150
+    min_trim_size: int = 4
+    extra_end_trim: int = 2
+    end_threshold: float = 75.0
+    middle_threshold: float = 90.0
+    adapter_threshold: float = 90.0
+    check_reads: int = 10000
+    scores: Tuple[int, int, int, int] = (3, -6, -5, -2)
+
+
+@dataclass
+class DeviceReads:
+    """Reads resident in HBM: one byte per base as delivered (upper-cased ASCII), read r at
+    arena[off[r] : off[r] + length[r]].  The arena must have >= 8 readable bytes after the last
+    read (the kernels fetch bases a dword at a time)."""
+    arena: torch.Tensor    # uint8 [bytes]
+    off: torch.Tensor      # int64 [R]
+    length: torch.Tensor   # int32 [R]
+
+    @property
+    def n(self):
+        return int(self.off.shape[0])
+
+
+@dataclass
+class MiddleHits:
+    read: torch.Tensor       # int64 [H]   read index
+    adapter: torch.Tensor    # int32 [H]   index into Pipeline.middle_adapters
+    start: torch.Tensor      # int32 [H]   read_start in trimmed-read coordinates
+    end: torch.Tensor        # int32 [H]   read_end (exclusive)
+    identity: torch.Tensor   # float64 [H] full-adapter identity
+    rounds: int = 0
+    alignments: int = 0
+
+
+def _identities(rec):
+    """float64 (full, partial) exactly as nanopore_read.py:476-491 parses them: the C side prints
+    (100.0*matches)/len with %f and Python float()s it back; comparing the unrounded doubles with
+    the thresholds is equivalent only if no value lies within 5e-7 of a threshold without being
+    equal to it -- identities are ratios of small integers (len <= a few hundred), whose distance
+    from a threshold such as 75.0 or 90.0 is either 0 or >= 100/len^2 >> 5e-7."""
+    m = rec[:, 5].to(torch.float64)
+    partial = 100.0 * m / rec[:, 6].to(torch.float64)
+    full = 100.0 * m / rec[:, 7].to(torch.float64)
+    # the %f round trip: round to 6 decimals (what float(str) sees)
+    partial = torch.round(partial * 1e6) / 1e6
+    full = torch.round(full * 1e6) / 1e6
+    return full, partial
+
+
+class Pipeline:
+    def __init__(self, sets: List[AdapterSet], params: ScanParams = None, device=None):
+        self.sets = list(sets)
+        self.p = params or ScanParams()
+        self.device = torch.device(device if device is not None else "cuda")
+        # one adapter table for everything (deduplicated sequences)
+        self.seq_index = {}
+        seqs = []
+        for s in self.sets:
+            for side in (s.start, s.end):
+                if side is not None and side[1] not in self.seq_index:
+                    self.seq_index[side[1]] = len(seqs)
+                    seqs.append(side[1])
+        self.seqs = seqs
+        dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self.aligner = Aligner(seqs, self.p.scores, device=dev_index)
+        self.stats = {"pairs_end": 0, "pairs_middle": 0, "cells_end": 0, "cells_middle": 0}
+
+    # ------------------------------------------------------------------------------------------
+    def _end_windows(self, reads: DeviceReads, idx: Optional[torch.Tensor], side: str):
+        """seq[:end_size] / seq[-end_size:] as (offset, length) windows (nanopore_read.py:155,160)."""
+        off = reads.off if idx is None else reads.off[idx]
+        ln = reads.length if idx is None else reads.length[idx]
+        wl = torch.clamp(ln, max=self.p.end_size)
+        if side == "start":
+            return off, wl
+        return off + (ln - wl).to(torch.int64), wl
+
+    def _scan_jobs(self, arena, jobs, mode, max_len):
+        """jobs: list of (adapter_index, win_off int64[n], win_len int32[n]) -> list of [n,8] views."""
+        woff = torch.cat([j[1] for j in jobs])
+        wlen = torch.cat([j[2] for j in jobs]).to(torch.int32)
+        starts = np.zeros(len(jobs) + 1, dtype=np.int64)
+        for k, j in enumerate(jobs):
+            starts[k + 1] = starts[k] + j[1].shape[0]
+        out = torch.empty((int(starts[-1]), RESULT_INTS), dtype=torch.int32, device=self.device)
+        if starts[-1] > 0:
+            self.aligner.scan_device(arena, woff, wlen, np.array([j[0] for j in jobs], dtype=np.int32),
+                                     starts, max_len, out, mode)
+        return [out[int(starts[k]):int(starts[k + 1])] for k in range(len(jobs))]
+
+    # ------------------------------------------------------------------------------------------
+    def phase_a(self, reads: DeviceReads, check_idx: Optional[torch.Tensor] = None):
+        """-> (best_start[S], best_end[S]) float64 on device: the max full-adapter identity of every
+        set's start / end sequence over the check reads.  This table is the only cross-read
+        reduction in Porechop (nanopore_read.py:159,164); a multi-GPU run all-reduces it (MAX)."""
+        S = len(self.sets)
+        best_start = torch.zeros(S, dtype=torch.float64, device=self.device)
+        best_end = torch.zeros(S, dtype=torch.float64, device=self.device)
+        n = reads.n if check_idx is None else int(check_idx.shape[0])
+        if n == 0:
+            return best_start, best_end
+        so, sl = self._end_windows(reads, check_idx, "start")
+        eo, el = self._end_windows(reads, check_idx, "end")
+        jobs, where = [], []
+        for si, s in enumerate(self.sets):
+            if "(full sequence)" in s.name:       # porechop.py:296
+                continue
+            if s.start is not None:
+                jobs.append((self.seq_index[s.start[1]], so, sl)); where.append((si, 0))
+            if s.end is not None:
+                jobs.append((self.seq_index[s.end[1]], eo, el)); where.append((si, 1))
+        outs = self._scan_jobs(reads.arena, jobs, MODE_TRACE, self.p.end_size)
+        for (si, side), rec in zip(where, outs):
+            full, _ = _identities(rec)
+            full = torch.where(rec[:, 0] == -1, torch.zeros_like(full), full)
+            v = full.max()
+            if side == 0:
+                best_start[si] = torch.maximum(best_start[si], v)
+            else:
+                best_end[si] = torch.maximum(best_end[si], v)
+        self.stats["pairs_end"] += sum(int(j[1].shape[0]) for j in jobs)
+        return best_start, best_end
+
+    def matching_sets(self, best_start, best_end):
+        """porechop.py:327: sets whose best start-or-end score reaches --adapter_threshold."""
+        best = torch.maximum(best_start, best_end).cpu().numpy()
+        return [i for i, s in enumerate(self.sets)
+                if "(full sequence)" not in s.name and best[i] >= self.p.adapter_threshold]
+
+    # ------------------------------------------------------------------------------------------
+    def phase_b(self, reads: DeviceReads, matching: List[int]):
+        """-> (start_trim[R], end_trim[R]) int32: nanopore_read.py:166-208 for every read."""
+        R = reads.n
+        p = self.p
+        start_trim = torch.zeros(R, dtype=torch.int32, device=self.device)
+        end_trim = torch.zeros(R, dtype=torch.int32, device=self.device)
+        so, sl = self._end_windows(reads, None, "start")
+        eo, el = self._end_windows(reads, None, "end")
+        jobs, where = [], []
+        for si in matching:
+            s = self.sets[si]
+            if s.start is not None:
+                jobs.append((self.seq_index[s.start[1]], so, sl)); where.append(0)
+            if s.end is not None:
+                jobs.append((self.seq_index[s.end[1]], eo, el)); where.append(1)
+        if not jobs:
+            return start_trim, end_trim
+        outs = self._scan_jobs(reads.arena, jobs, MODE_TRACE, p.end_size)
+        for side, rec in zip(where, outs):
+            _, partial = _identities(rec)
+            ok = rec[:, 0] != -1
+            rs = rec[:, 0]
+            re = rec[:, 1] + 1
+            if side == 0:
+                cond = ok & (partial > p.end_threshold) & (re != p.end_size) & ((re - rs) >= p.min_trim_size)
+                start_trim = torch.where(cond, torch.maximum(start_trim, re + p.extra_end_trim), start_trim)
+            else:
+                cond = ok & (partial > p.end_threshold) & (rs != 0) & ((re - rs) >= p.min_trim_size)
+                end_trim = torch.where(cond, torch.maximum(end_trim, (p.end_size - rs) + p.extra_end_trim), end_trim)
+        self.stats["pairs_end"] += sum(int(j[1].shape[0]) for j in jobs)
+        return start_trim, end_trim
+
+    # ------------------------------------------------------------------------------------------
+    def middle_adapter_list(self, matching: List[int]):
+        """porechop.py:541-548: start sequence of every matching set, plus its end sequence when
+        that differs from its own start sequence (duplicates across sets are kept, as there)."""
+        ads = []
+        for si in matching:
+            s = self.sets[si]
+            if s.start is not None:
+                ads.append(s.start)
+            if s.end is not None and (s.start is None or s.end[1] != s.start[1]):
+                ads.append(s.end)
+        return ads
+
+    def phase_c(self, reads: DeviceReads, start_trim, end_trim, matching: List[int]) -> MiddleHits:
+        """nanopore_read.py:210-243 for every read: adapters in order, and for each adapter keep
+        re-aligning against the progressively masked read while the hit reaches --middle_threshold.
+
+        Round 0 aligns every adapter against every (unmasked) trimmed read in one go.  That is
+        exact for a read up to and including its first hit; only reads with a hit ("dirty", ~1 %)
+        get a private masked copy and continue one alignment per round until they run out of
+        adapters -- same sequence of alignments as the reference's nested loops."""
+        p = self.p
+        dev = self.device
+        ads = self.middle_adapter_list(matching)
+        self.middle_adapters = ads
+        A = len(ads)
+        empty = MiddleHits(*(torch.empty(0, dtype=dt, device=dev) for dt in
+                             (torch.int64, torch.int32, torch.int32, torch.int32, torch.float64)))
+        R = reads.n
+        if A == 0 or R == 0:
+            return empty
+        # masked_seq = seq[start_trim : len - end_trim] with Python slice semantics (nanopore_read.py:56-62)
+        ln = reads.length.to(torch.int64)
+        s_pos = torch.clamp(start_trim.to(torch.int64), max=ln)
+        e_pos = ln - end_trim.to(torch.int64)
+        e_pos = torch.where(e_pos < 0, torch.clamp(ln + e_pos, min=0), e_pos)
+        untouched = (start_trim == 0) & (end_trim == 0)
+        s_pos = torch.where(untouched, torch.zeros_like(s_pos), s_pos)
+        e_pos = torch.where(untouched, ln, e_pos)
+        tlen = torch.clamp(e_pos - s_pos, min=0).to(torch.int32)
+        toff = reads.off + s_pos
+        live = torch.nonzero(tlen > 0).flatten()
+        if live.numel() == 0:
+            return empty
+        loff, llen = toff[live], tlen[live]
+        max_len = int(llen.max().item())
+        aidx = [self.seq_index[a[1]] for a in ads]
+
+        # ---- round 0: all adapters x all reads, unmasked -------------------------------------
+        outs = self._scan_jobs(reads.arena, [(ai, loff, llen) for ai in aidx], MODE_TWO_PASS, max_len)
+        n_align = A * int(live.numel())
+        self.stats["pairs_middle"] += n_align
+        fulls = []
+        for rec in outs:
+            full, _ = _identities(rec)
+            fulls.append(torch.where(rec[:, 0] == -1, torch.zeros_like(full), full))
+        fulls = torch.stack(fulls)                                   # [A, L]
+        hit0 = fulls >= p.middle_threshold
+        any_hit = hit0.any(dim=0)
+        first = torch.where(any_hit, hit0.to(torch.int32).argmax(dim=0), torch.full_like(any_hit, A, dtype=torch.int64))
+        d_sel = torch.nonzero(any_hit).flatten()                     # dirty reads (indices into live)
+        H_read, H_ad, H_s, H_e, H_id = [], [], [], [], []
+        rounds = 0
+        if d_sel.numel() > 0:
+            Dn = int(d_sel.numel())
+            cur = first[d_sel].clone()                               # adapter each dirty read is at
+            recs0 = torch.stack(outs)                                # [A, L, 8]
+            rec = recs0[cur, d_sel]                                  # the first hit of each
+            # private, maskable copies of the dirty reads: [Dn, stride]
+            dlen = llen[d_sel]
+            stride = (int(dlen.max().item()) + 8 + 15) // 16 * 16
+            col = torch.arange(stride, device=dev, dtype=torch.int64)
+            src = loff[d_sel][:, None] + torch.clamp(col[None, :], max=(dlen.to(torch.int64) - 1)[:, None])
+            dirty = reads.arena[src]
+            dirty[col[None, :] >= dlen[:, None]] = ord("N")
+            d_off = torch.arange(Dn, device=dev, dtype=torch.int64) * stride
+            active = torch.ones(Dn, dtype=torch.bool, device=dev)
+            full_d = fulls[cur, d_sel]
+            while True:
+                # consume the alignment just made for every active dirty read
+                ishit = active & (full_d >= p.middle_threshold) & (rec[:, 0] != -1)
+                hsel = torch.nonzero(ishit).flatten()
+                if hsel.numel() > 0:
+                    rs = rec[hsel, 0]
+                    re = rec[hsel, 1] + 1
+                    H_read.append(live[d_sel[hsel]]); H_ad.append(cur[hsel].to(torch.int32))
+                    H_s.append(rs); H_e.append(re); H_id.append(full_d[hsel])
+                    m = (col[None, :] >= rs[:, None]) & (col[None, :] < re[:, None])
+                    rows = dirty[hsel]
+                    rows[m] = ord("-")                               # masked_seq[rs:re] = '-' * (re - rs)
+                    dirty[hsel] = rows
+                cur = torch.where(active & ~ishit, cur + 1, cur)     # no hit: next adapter
+                active = active & (cur < A)
+                act = torch.nonzero(active).flatten()
+                if act.numel() == 0:
+                    break
+                rounds += 1
+                # one alignment per active dirty read, grouped by the adapter it is at
+                cur_h = cur[act].cpu().numpy()
+                order = np.argsort(cur_h, kind="stable")
+                act_sorted = act[torch.from_numpy(order).to(dev)]
+                cur_sorted = cur_h[order]
+                jobs = []
+                for a in np.unique(cur_sorted):
+                    sel = act_sorted[torch.from_numpy(np.nonzero(cur_sorted == a)[0]).to(dev)]
+                    jobs.append((aidx[int(a)], d_off[sel], dlen[sel], sel))
+                outs_r = self._scan_jobs(dirty.view(-1), [(j[0], j[1], j[2]) for j in jobs], MODE_TWO_PASS,
+                                         int(dlen.max().item()))
+                n_align += int(act.numel())
+                self.stats["pairs_middle"] += int(act.numel())
+                rec = rec.clone()
+                full_d = full_d.clone()
+                for j, o in zip(jobs, outs_r):
+                    f, _ = _identities(o)
+                    rec[j[3]] = o
+                    full_d[j[3]] = torch.where(o[:, 0] == -1, torch.zeros_like(f), f)
+        if not H_read:
+            empty.rounds, empty.alignments = rounds, n_align
+            return empty
+        return MiddleHits(torch.cat(H_read), torch.cat(H_ad), torch.cat(H_s), torch.cat(H_e), torch.cat(H_id),
+                          rounds, n_align)
+
+    def close(self):
+        self.aligner.close()

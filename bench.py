@@ -53,46 +53,39 @@ def one_step(pl, reads, n_check, world):
     return matching, st, et, hits
 
 
-def cpu_baseline(reads, pl, matching, seconds, threads):
-    """Phases B + C of the same reads, sequential per-read logic (tests/ref_pipeline.py) on the
-    host cores.  Bounded: stops taking reads after ~`seconds` of wall time."""
-    from concurrent.futures import ThreadPoolExecutor
-    from oracle.oracle import Oracle, Reference, REF_SO
-    from tests import ref_pipeline
+def cpu_baseline(reads, pl, matching, seconds, workers):
+    """Phases B + C of the same reads, the reference's sequential per-read logic
+    (tests/ref_pipeline.py), on all host cores: one spawned worker PROCESS per core (Porechop's own
+    --threads pool is GIL-bound, README.md:355-359; processes are its fair upper bound).
+    Bounded: the sample is sized from a probe so the leg takes ~`seconds`."""
+    import multiprocessing as mp
+    from dataclasses import asdict
+    from oracle.oracle import REF_SO
+    from tests.cpu_worker import run_chunk
 
-    if os.path.isfile(REF_SO):
-        backend, kind = Reference(), "reference"
-    else:
-        backend, kind = Oracle(), "port"
-    fn = backend.adapter_alignment
-    p = pl.p
-    n_pull = min(reads.n, 4096)
+    kind = "reference" if os.path.isfile(REF_SO) else "port"
+    n_pull = min(reads.n, 16384)
     ln = int(reads.length[0].item())
     host = reads.arena[: n_pull * ln].cpu().numpy().tobytes().decode("ascii")
     seqs = [host[i * ln:(i + 1) * ln] for i in range(n_pull)]
-    adapters = pl.middle_adapter_list(matching)
-
-    def work(seq):
-        st, et = ref_pipeline.phase_b(fn, seq, pl.sets, matching, p)
-        ref_pipeline.phase_c(fn, seq, st, et, adapters, p)
-        return 1
-
-    # probe, then size the sample for ~`seconds`
-    t0 = time.perf_counter()
-    for s in seqs[:8]:
-        work(s)
-    per_read = (time.perf_counter() - t0) / 8
-    n = int(max(threads * 4, min(n_pull, seconds * threads / max(per_read, 1e-6))))
-    n = min(n, n_pull)
-    t0 = time.perf_counter()
-    with ThreadPoolExecutor(threads) as ex:
-        done = sum(ex.map(work, seqs[:n], chunksize=max(1, n // (threads * 8))))
-    dt = time.perf_counter() - t0
-    return {"value": done / dt, "unit": "reads/s", "cores": threads, "kind": kind,
-            "sample": "%d of the benchmark's reads (%d bp each), phases B+C, %d Python threads "
-                      "over the %s (GIL released inside the C call), %.1f s"
-                      % (done, ln, threads, "compiled reference oracle/_ref/cpp_functions.so"
-                         if kind == "reference" else "oracle port oracle/pc_oracle.c", dt)}
+    sets = [(s.name, s.start, s.end) for s in pl.sets]
+    params = asdict(pl.p)
+    _, t_probe = run_chunk((seqs[:4], sets, matching, params, True))
+    per_read = t_probe / 4
+    n = int(min(n_pull, max(workers * 2, seconds * workers / max(per_read, 1e-6))))
+    per = max(1, n // workers)
+    chunks = [seqs[i:i + per] for i in range(0, n, per)]
+    ctx = mp.get_context("spawn")
+    with ctx.Pool(workers) as pool:
+        pool.map(run_chunk, [(c[:1], sets, matching, params, True) for c in chunks])   # start-up + import, untimed
+        t0 = time.perf_counter()
+        res = pool.map(run_chunk, [(c, sets, matching, params, True) for c in chunks])
+        dt = time.perf_counter() - t0
+    done = sum(r[0] for r in res)
+    return {"value": done / dt, "unit": "reads/s", "cores": workers, "kind": kind,
+            "sample": "%d of the benchmark's reads (%d bp each), phases B+C, %d worker processes over the %s, %.1f s wall"
+                      % (done, ln, workers, "compiled reference oracle/_ref/cpp_functions.so" if kind == "reference"
+                         else "oracle port oracle/pc_oracle.c", dt)}
 
 
 def main():

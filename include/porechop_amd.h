@@ -57,6 +57,11 @@ enum {
                               computes them (alignment.cpp:81-82,89-90); matches is the same
                               count for both.  Empty read or adapter: {-1,0,-1,0,INT_MIN,0,0,0}. */
 
+/* `stream` arguments are hipStream_t handles passed as void*: NULL is HIP's default (null)
+ * stream -- what torch.cuda.current_stream().cuda_stream is unless the caller changed it --
+ * and PC_STREAM_CONTEXT selects the context's own non-blocking stream. */
+#define PC_STREAM_CONTEXT ((void *)(intptr_t)-1)
+
 /* scan modes */
 #define PC_MODE_AUTO 0      /* by window length */
 #define PC_MODE_TRACE 1     /* one pass, full trace (end windows) */
@@ -91,15 +96,15 @@ int pc_align_batch_host(pc_ctx *ctx, const char *read_arena, int64_t arena_bytes
  * table).  d_* are device pointers.  Pairs are grouped into jobs of one adapter each: job k
  * covers pairs [job_start[k], job_start[k+1]) and aligns them against job_adapter[k].
  * max_len is an upper bound on every win_len (checked on the device).  The arena must be
- * readable 8 bytes past its last window.  Asynchronous on `stream` (a hipStream_t, or NULL
- * for the context's own stream); call pc_sync() before reading d_out. */
+ * readable 8 bytes past its last window.  Asynchronous on `stream`; call pc_sync() (or
+ * otherwise order your reads after it on the same stream) before reading d_out. */
 int pc_scan_device(pc_ctx *ctx, const void *d_arena, const int64_t *d_win_off,
                    const int32_t *d_win_len, int64_t npairs, const int32_t *job_adapter,
                    const int64_t *job_start, int njobs, int max_len, int mode, int32_t *d_out,
                    void *stream);
 
-/* Waits for `stream` (or the context stream) and returns PC_ERR_INTERNAL if any kernel since the
- * last pc_sync reported an inconsistency. */
+/* Waits for `stream` and returns PC_ERR_INTERNAL if any kernel since the last pc_sync reported
+ * an inconsistency. */
 int pc_sync(pc_ctx *ctx, void *stream);
 
 /* Kernel timing hooks (bench.py roofline leg): when enabled, every kernel launch made by

@@ -30,6 +30,15 @@ def load_library():
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch ships its own copy of the HIP runtime (torch/lib/libamdhip64.so, same SONAME as the
+    # system one).  Whichever copy is loaded first is the one a later NEEDED "libamdhip64.so.7"
+    # binds to, but torch itself asks for it by file name and would load a SECOND runtime if ours
+    # came first -- two runtimes in one process share neither streams nor devices.  So when torch
+    # is available it goes first; without torch (plain Porechop drop-in) the system runtime is used.
+    try:
+        import torch  # noqa: F401
+    except Exception:  # pragma: no cover - torch-less deployments
+        pass
     if not os.path.isfile(LIB_PATH):
         raise LibraryMissing(
             "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "

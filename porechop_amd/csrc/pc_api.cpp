@@ -323,7 +323,7 @@ int pc_scan_device(pc_ctx *c, const void *d_arena, const int64_t *d_win_off, con
     int rc = upload_panel(c);
     if (rc) return rc;
     if ((rc = build_tiles(c, job_adapter, job_start, njobs, max_len, mode))) return rc;
-    hipStream_t stream = stream_v ? (hipStream_t)stream_v : c->stream;
+    hipStream_t stream = (stream_v == PC_STREAM_CONTEXT) ? c->stream : (hipStream_t)stream_v;
 
     // scratch sizing over all groups
     size_t slab_bytes = 0;
@@ -420,7 +420,7 @@ int pc_get_timing(pc_ctx *c, void *stream_v, double *ms, int64_t *launches, int6
 {
     if (!c || !ms || !launches || !pairs) return PC_ERR_BAD_ARG;
     (void)hipSetDevice(c->device);
-    hipStream_t stream = stream_v ? (hipStream_t)stream_v : c->stream;
+    hipStream_t stream = (stream_v == PC_STREAM_CONTEXT) ? c->stream : (hipStream_t)stream_v;
     HIP_TRY(hipStreamSynchronize(stream));
     for (int k = 0; k < PC_KERNEL_KINDS; ++k) { ms[k] = 0.0; launches[k] = 0; pairs[k] = 0; }
     for (auto &t : c->timed) {
@@ -436,7 +436,7 @@ int pc_sync(pc_ctx *c, void *stream_v)
 {
     if (!c) return PC_ERR_BAD_ARG;
     (void)hipSetDevice(c->device);
-    hipStream_t stream = stream_v ? (hipStream_t)stream_v : c->stream;
+    hipStream_t stream = (stream_v == PC_STREAM_CONTEXT) ? c->stream : (hipStream_t)stream_v;
     HIP_TRY(hipStreamSynchronize(stream));
     uint32_t err = 0;
     HIP_TRY(hipMemcpy(&err, c->d_err.p, 4, hipMemcpyDeviceToHost));

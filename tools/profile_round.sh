@@ -1,0 +1,26 @@
+#!/bin/bash
+# Collect the rocprofv3 evidence for one round on the GPU box (run through gpurun):
+#   1. --kernel-trace --stats of the bench (smaller batch so the trace stays small)
+#   2. FETCH_SIZE and WRITE_SIZE in their own passes (never together with trace domains)
+# Only the summaries are kept under gpurun_out/prof_<tag>/ ; copy them into profiles/ afterwards.
+TAG=${1:-r01}
+READS=${2:-400000}
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out/prof_$TAG
+rm -rf $OUT; mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+CMD="python $ROOT/bench.py --reads $READS --steps 2 --warmup 1 --cpu-seconds 0"
+W=/tmp/prof_work; rm -rf $W; mkdir -p $W
+rocprofv3 --kernel-trace --stats --output-format csv -d $W/trace -o trace -- $CMD > $OUT/bench_trace.log 2>&1
+find $W/trace -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats.csv \;
+# per-dispatch durations of our kernels only (start/end timestamps -> ns)
+KT=$(find $W/trace -name "*kernel_trace.csv" | head -1)
+if [ -n "$KT" ]; then head -1 $KT > $OUT/kernel_trace_scan.csv; grep -E "scan_kernel|plan_kernel" $KT >> $OUT/kernel_trace_scan.csv; fi
+for C in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $C --output-format csv -d $W/$C -o pmc -- $CMD > $OUT/bench_$C.log 2>&1
+  CC=$(find $W/$C -name "*counter_collection.csv" | head -1)
+  if [ -n "$CC" ]; then head -1 $CC > $OUT/pmc_$C.csv; grep -E "scan_kernel|plan_kernel" $CC >> $OUT/pmc_$C.csv; fi
+done
+for f in $OUT/bench_*.log; do tail -1 $f > $f.json; grep -v "^W2\|^I2\|^E2" $f | tail -5 > $f.tail; rm $f; done
+ls -la $OUT; du -sh $OUT
+head -12 $OUT/kernel_stats.csv

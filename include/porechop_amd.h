@@ -93,15 +93,18 @@ int pc_align_batch_host(pc_ctx *ctx, const char *read_arena, int64_t arena_bytes
                         int64_t npairs, int mode, int32_t *out);
 
 /* Device-buffer batch (inputs already resident in HBM; nothing crosses PCIe but the small job
- * table).  d_* are device pointers.  Pairs are grouped into jobs of one adapter each: job k
- * covers pairs [job_start[k], job_start[k+1]) and aligns them against job_adapter[k].
- * max_len is an upper bound on every win_len (checked on the device).  The arena must be
- * readable 8 bytes past its last window.  Asynchronous on `stream`; call pc_sync() (or
- * otherwise order your reads after it on the same stream) before reading d_out. */
+ * table).  d_* are device pointers.  d_win_off/d_win_len describe `nwindows` windows; job k scans
+ * windows [job_start[k], job_start[k+1]) against adapter job_adapter[k] and -- when job_adapter_b
+ * is non-NULL and job_adapter_b[k] >= 0 -- also against that second adapter IN THE SAME PASS (each
+ * window is then read from HBM once for both).  Results, PC_RESULT_INTS each, are written in job
+ * order: for job k first its n_k records for job_adapter[k], then (if any) its n_k records for
+ * job_adapter_b[k].  max_len is an upper bound on every win_len (checked on the device).  The
+ * arena must be readable 8 bytes past its last window.  Asynchronous on `stream`; call pc_sync()
+ * (or otherwise order your reads after it on the same stream) before reading d_out. */
 int pc_scan_device(pc_ctx *ctx, const void *d_arena, const int64_t *d_win_off,
-                   const int32_t *d_win_len, int64_t npairs, const int32_t *job_adapter,
-                   const int64_t *job_start, int njobs, int max_len, int mode, int32_t *d_out,
-                   void *stream);
+                   const int32_t *d_win_len, int64_t nwindows, const int32_t *job_adapter,
+                   const int32_t *job_adapter_b, const int64_t *job_start, int njobs, int max_len,
+                   int mode, int32_t *d_out, void *stream);
 
 /* Waits for `stream` and returns PC_ERR_INTERNAL if any kernel since the last pc_sync reported
  * an inconsistency. */

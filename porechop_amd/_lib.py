@@ -64,7 +64,7 @@ def load_library():
     L.pc_set_adapters.restype = c_int
     L.pc_align_batch_host.argtypes = [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_int, c_vp]
     L.pc_align_batch_host.restype = c_int
-    L.pc_scan_device.argtypes = [c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp]
+    L.pc_scan_device.argtypes = [c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp]
     L.pc_scan_device.restype = c_int
     L.pc_sync.argtypes = [c_vp, c_vp]
     L.pc_sync.restype = c_int

@@ -96,18 +96,24 @@ class Aligner:
 
     # ---- device buffers (torch tensors on the GPU) --------------------------------------
     def scan_device(self, arena, win_off, win_len, job_adapter, job_start, max_len, out,
-                    mode=MODE_AUTO, stream=None):
-        """arena uint8[*], win_off int64[n], win_len int32[n], out int32[n,8]: CUDA(HIP) tensors.
-        job_adapter int32[k], job_start int64[k+1]: host numpy.  Asynchronous; call sync()."""
+                    mode=MODE_AUTO, stream=None, job_adapter_b=None):
+        """arena uint8[*], win_off int64[n], win_len int32[n]: CUDA(HIP) tensors describing n windows.
+        job_adapter int32[k], job_start int64[k+1] (window ranges), optional job_adapter_b int32[k]
+        (-1 = none): host numpy.  out int32[total,8] with total = sum n_k * (1 or 2), job order,
+        adapter A's records before adapter B's.  Asynchronous; call sync()."""
         import torch
         assert arena.is_cuda and win_off.is_cuda and win_len.is_cuda and out.is_cuda
         assert win_off.dtype == torch.int64 and win_len.dtype == torch.int32 and out.dtype == torch.int32
         job_adapter = np.ascontiguousarray(job_adapter, dtype=np.int32)
         job_start = np.ascontiguousarray(job_start, dtype=np.int64)
+        jb = None
+        if job_adapter_b is not None:
+            jb = np.ascontiguousarray(job_adapter_b, dtype=np.int32)
         n = win_off.shape[0]
         s = stream if stream is not None else torch.cuda.current_stream().cuda_stream
         check(self.lib.pc_scan_device(self._ctx, arena.data_ptr(), win_off.data_ptr(), win_len.data_ptr(), n,
-                                      job_adapter.ctypes.data, job_start.ctypes.data, len(job_adapter),
+                                      job_adapter.ctypes.data, jb.ctypes.data if jb is not None else None,
+                                      job_start.ctypes.data, len(job_adapter),
                                       int(max_len), mode, out.data_ptr(), ctypes.c_void_p(s)),
               "pc_scan_device")
 

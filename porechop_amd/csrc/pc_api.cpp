@@ -65,13 +65,13 @@ struct pc_ctx {
     std::vector<int> ad_len, ad_window;
     bool panel_dirty = true;
     DevBuf d_ad_codes, d_ad_len, d_ad_window;
-    DevBuf d_tiles, d_slab, d_k1, d_woff2, d_wlen2, d_col0, d_ntot, d_frow, d_fscore, d_err;
+    DevBuf d_tiles, d_slab, d_fin, d_k1, d_woff2, d_wlen2, d_col0, d_ntot, d_frow, d_fscore, d_err;
     // host-API staging
     DevBuf d_arena, d_woff, d_wlen, d_out;
     // cached job table (bench loops repeat the same one: skip the re-upload)
     std::vector<pck::Tile> tiles;
     std::vector<Group> groups;
-    std::vector<int32_t> last_job_adapter;
+    std::vector<int32_t> last_job_adapter, last_job_adapter_b;
     std::vector<int64_t> last_job_start;
     int last_max_len = -1, last_mode = -1;
     bool tiles_uploaded = false;
@@ -142,36 +142,65 @@ int upload_panel(pc_ctx *c)
     return PC_OK;
 }
 
-// Build (or reuse) the tile table for a job list.
-int build_tiles(pc_ctx *c, const int32_t *job_adapter, const int64_t *job_start, int njobs, int max_len, int mode)
+// Build (or reuse) the tile table for a job list.  Job k scans windows [job_start[k], job_start[k+1])
+// against adapter job_adapter[k] and, when job_adapter_b[k] >= 0, ALSO against that second adapter in
+// the same pass (both halves of a lane then read the same window: one read stream instead of two).
+// Outputs: out_start(k) = sum over k' < k of n_k' * (1 or 2); adapter A's records first, then B's.
+int build_tiles(pc_ctx *c, const int32_t *job_adapter, const int32_t *job_adapter_b, const int64_t *job_start,
+                int njobs, int max_len, int mode, int64_t *total_out)
 {
+    std::vector<int32_t> jb(njobs, -1);
+    if (job_adapter_b) jb.assign(job_adapter_b, job_adapter_b + njobs);
+    int64_t tot = 0;
+    for (int k = 0; k < njobs; ++k) tot += (job_start[k + 1] - job_start[k]) * (jb[k] >= 0 ? 2 : 1);
+    if (total_out) *total_out = tot;
     const bool same = c->tiles_uploaded && c->last_max_len == max_len && c->last_mode == mode &&
                       (int)c->last_job_adapter.size() == njobs &&
                       std::equal(job_adapter, job_adapter + njobs, c->last_job_adapter.begin()) &&
+                      jb == c->last_job_adapter_b &&
                       std::equal(job_start, job_start + njobs + 1, c->last_job_start.begin());
     if (same) return PC_OK;
 
     std::map<std::pair<int, int>, std::vector<pck::Tile>> by_group;   // (rows*2+pad, two_pass) -> tiles
     std::map<std::pair<int, int>, int> group_window;
+    int64_t out_pos = 0;
     for (int k = 0; k < njobs; ++k) {
-        const int ad = job_adapter[k];
-        if (ad < 0 || ad >= (int)c->adapters.size()) return PC_ERR_BAD_ARG;
-        const int m = c->ad_len[ad];
+        const int ad = job_adapter[k], adb = jb[k];
+        const int nad = (int)c->adapters.size();
+        if (ad < 0 || ad >= nad || adb >= nad) return PC_ERR_BAD_ARG;
+        const int m = c->ad_len[ad], mb = adb >= 0 ? c->ad_len[adb] : m;
+        if (m <= 0 || mb <= 0) return PC_ERR_BAD_ARG;
+        if (m > pcb::MAX_ADAPTER || mb > pcb::MAX_ADAPTER) return PC_ERR_ADAPTER_TOO_LONG;
         bool pad = false;
-        if (m <= 0) return PC_ERR_BAD_ARG;
-        if (m > pcb::MAX_ADAPTER) return PC_ERR_ADAPTER_TOO_LONG;
-        const int rows = pck::pick_rows(m, &pad);     // 0 => generic LDS-state kernel
-        const int window = c->ad_window[ad];
+        const int rows = pck::pick_rows(m, mb, &pad);     // 0 => generic LDS-state kernel
+        const int window = std::max(c->ad_window[ad], adb >= 0 ? c->ad_window[adb] : 0);
         bool two = (mode == PC_MODE_TWO_PASS) || (mode == PC_MODE_AUTO && max_len > 2 * window + 64);
         auto key = std::make_pair(rows * 2 + (pad ? 1 : 0), two ? 1 : 0);
         auto &v = by_group[key];
         group_window[key] = std::max(group_window[key], window);
-        for (int64_t s = job_start[k]; s < job_start[k + 1]; s += 128) {
-            pck::Tile t;
-            t.pair_base = s;
-            t.count = (int32_t)std::min<int64_t>(128, job_start[k + 1] - s);
-            t.adapter_lo = ad; t.adapter_hi = ad; t.rows = rows ? rows : m;
-            v.push_back(t);
+        const int64_t ws = job_start[k], n = job_start[k + 1] - job_start[k];
+        if (n < 0) return PC_ERR_BAD_ARG;
+        if (adb >= 0) {
+            for (int64_t s = 0; s < n; s += 64) {
+                pck::Tile t;
+                t.win_lo = ws + s; t.win_hi = ws + s;
+                t.out_lo = out_pos + s; t.out_hi = out_pos + n + s;
+                t.count_lo = t.count_hi = (int32_t)std::min<int64_t>(64, n - s);
+                t.adapter_lo = ad; t.adapter_hi = adb; t.rows = rows ? rows : std::max(m, mb); t.pad_ = 0;
+                v.push_back(t);
+            }
+            out_pos += 2 * n;
+        } else {
+            for (int64_t s = 0; s < n; s += 128) {
+                pck::Tile t;
+                t.win_lo = ws + s; t.win_hi = ws + s + 64;
+                t.out_lo = out_pos + s; t.out_hi = out_pos + s + 64;
+                t.count_lo = (int32_t)std::min<int64_t>(64, n - s);
+                t.count_hi = (int32_t)std::max<int64_t>(0, std::min<int64_t>(64, n - s - 64));
+                t.adapter_lo = ad; t.adapter_hi = ad; t.rows = rows ? rows : m; t.pad_ = 0;
+                v.push_back(t);
+            }
+            out_pos += n;
         }
     }
     c->tiles.clear();
@@ -187,12 +216,13 @@ int build_tiles(pc_ctx *c, const int32_t *job_adapter, const int64_t *job_start,
         c->groups.push_back(g);
     }
     // the previous table may still be in use by launches in flight
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipDeviceSynchronize());
     int rc = c->d_tiles.ensure(std::max<size_t>(1, c->tiles.size()) * sizeof(pck::Tile));
     if (rc) return rc;
     if (!c->tiles.empty())
         HIP_TRY(hipMemcpy(c->d_tiles.p, c->tiles.data(), c->tiles.size() * sizeof(pck::Tile), hipMemcpyHostToDevice));
     c->last_job_adapter.assign(job_adapter, job_adapter + njobs);
+    c->last_job_adapter_b = jb;
     c->last_job_start.assign(job_start, job_start + njobs + 1);
     c->last_max_len = max_len; c->last_mode = mode;
     c->tiles_uploaded = true;
@@ -278,7 +308,7 @@ void pc_destroy(pc_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    DevBuf *bufs[] = {&c->d_ad_codes, &c->d_ad_len, &c->d_ad_window, &c->d_tiles, &c->d_slab, &c->d_k1, &c->d_woff2,
+    DevBuf *bufs[] = {&c->d_ad_codes, &c->d_ad_len, &c->d_ad_window, &c->d_tiles, &c->d_slab, &c->d_fin, &c->d_k1, &c->d_woff2,
                       &c->d_wlen2, &c->d_col0, &c->d_ntot, &c->d_frow, &c->d_fscore, &c->d_err, &c->d_arena,
                       &c->d_woff, &c->d_wlen, &c->d_out};
     for (DevBuf *b : bufs) b->release();
@@ -313,29 +343,33 @@ int pc_set_adapters(pc_ctx *c, const char *const *seqs, int n)
 }
 
 int pc_scan_device(pc_ctx *c, const void *d_arena, const int64_t *d_win_off, const int32_t *d_win_len,
-                   int64_t npairs, const int32_t *job_adapter, const int64_t *job_start, int njobs,
-                   int max_len, int mode, int32_t *d_out, void *stream_v)
+                   int64_t nwindows, const int32_t *job_adapter, const int32_t *job_adapter_b,
+                   const int64_t *job_start, int njobs, int max_len, int mode, int32_t *d_out, void *stream_v)
 {
-    if (!c || npairs < 0 || njobs < 0 || max_len < 0) return PC_ERR_BAD_ARG;
-    if (npairs == 0 || njobs == 0) return PC_OK;
+    if (!c || nwindows < 0 || njobs < 0 || max_len < 0) return PC_ERR_BAD_ARG;
+    if (nwindows == 0 || njobs == 0) return PC_OK;
     if (!d_arena || !d_win_off || !d_win_len || !job_adapter || !job_start || !d_out) return PC_ERR_BAD_ARG;
+    if (job_start[0] < 0 || job_start[njobs] > nwindows) return PC_ERR_BAD_ARG;
     (void)hipSetDevice(c->device);
     int rc = upload_panel(c);
     if (rc) return rc;
-    if ((rc = build_tiles(c, job_adapter, job_start, njobs, max_len, mode))) return rc;
+    int64_t npairs = 0;
+    if ((rc = build_tiles(c, job_adapter, job_adapter_b, job_start, njobs, max_len, mode, &npairs))) return rc;
     hipStream_t stream = (stream_v == PC_STREAM_CONTEXT) ? c->stream : (hipStream_t)stream_v;
 
     // scratch sizing over all groups
-    size_t slab_bytes = 0;
+    size_t slab_bytes = 0, fin_bytes = 0;
     bool any_two = false;
     for (const Group &g : c->groups) {
         size_t stride;
         const int cols = g.two_pass ? g.max_window + 1 : max_len;
         const int grid = grid_for(c, g, g.tile_count, cols, &stride);
         slab_bytes = std::max(slab_bytes, (size_t)grid * stride * 4);
+        const int grid1 = grid_for(c, g, g.tile_count, 1, nullptr);
+        fin_bytes = std::max(fin_bytes, (size_t)std::max(grid, grid1) * std::max(1, g.rows) * 64 * 8);
         any_two |= g.two_pass;
     }
-    if ((rc = c->d_slab.ensure(slab_bytes + 256))) return rc;
+    if ((rc = c->d_slab.ensure(slab_bytes + 256)) || (rc = c->d_fin.ensure(fin_bytes + 256))) return rc;
     if (any_two) {
         const size_t n = (size_t)npairs;
         if ((rc = c->d_k1.ensure(n * 16)) || (rc = c->d_woff2.ensure(n * 8)) || (rc = c->d_wlen2.ensure(n * 4)) ||
@@ -356,6 +390,8 @@ int pc_scan_device(pc_ctx *c, const void *d_arena, const int64_t *d_win_off, con
         a.err = c->d_err.as<uint32_t>();
         a.slab = c->d_slab.as<uint32_t>();
         a.gen_max_rows = g.gen_max_rows;
+        a.fin_scratch = c->d_fin.as<uint32_t>();
+        a.win_by_out = 0;
         size_t stride;
         if (!g.two_pass) {
             a.win_off = d_win_off; a.win_len = d_win_len;
@@ -364,12 +400,12 @@ int pc_scan_device(pc_ctx *c, const void *d_arena, const int64_t *d_win_off, con
             const int grid = grid_for(c, g, g.tile_count, max_len, &stride);
             a.slab_stride = (int64_t)stride;
             int64_t np = 0;
-            for (size_t i = 0; i < g.tile_count; ++i) np += c->tiles[g.tile_begin + i].count;
+            for (size_t i = 0; i < g.tile_count; ++i) np += c->tiles[g.tile_begin + i].count_lo + c->tiles[g.tile_begin + i].count_hi;
             ScopedTimer tm(c, stream, 2, np);
             if ((rc = pck::launch_trace(a, g.rows, g.pad, grid, stream))) return PC_ERR_NO_DEVICE;
         } else {
             int64_t np = 0;
-            for (size_t i = 0; i < g.tile_count; ++i) np += c->tiles[g.tile_begin + i].count;
+            for (size_t i = 0; i < g.tile_count; ++i) np += c->tiles[g.tile_begin + i].count_lo + c->tiles[g.tile_begin + i].count_hi;
             // pass 1: score only, whole window
             a.win_off = d_win_off; a.win_len = d_win_len;
             a.out = c->d_k1.as<int32_t>();
@@ -394,6 +430,7 @@ int pc_scan_device(pc_ctx *c, const void *d_arena, const int64_t *d_win_off, con
             }
             // pass 2: traced window ending at the max cell
             a.win_off = pl.win_off2; a.win_len = pl.win_len2; a.col0 = pl.col02; a.n_total = pl.ntot2;
+            a.win_by_out = 1;
             a.force_row = pl.force_row2; a.force_score = pl.force_score2;
             a.out = d_out;
             a.slab = c->d_slab.as<uint32_t>();
@@ -513,7 +550,7 @@ int pc_align_batch_host(pc_ctx *c, const char *read_arena, int64_t arena_bytes, 
         }
         job_start.push_back((int64_t)(i1 - i0));
         rc = pc_scan_device(c, c->d_arena.p, c->d_woff.as<int64_t>() + i0, c->d_wlen.as<int32_t>() + i0,
-                            (int64_t)(i1 - i0), job_ad.data(), job_start.data(), (int)job_ad.size(), max_len,
+                            (int64_t)(i1 - i0), job_ad.data(), nullptr, job_start.data(), (int)job_ad.size(), max_len,
                             keys[i0].cls ? PC_MODE_TWO_PASS : PC_MODE_TRACE,
                             c->d_out.as<int32_t>() + i0 * PC_RESULT_INTS, c->stream);
         if (rc) return rc;

@@ -9,17 +9,21 @@ namespace pck {
 // pair_base + 64 + lane  in the HIGH half.  All low-half pairs of a tile share adapter_lo,
 // all high-half pairs share adapter_hi.
 struct Tile {
-    int64_t pair_base;
-    int32_t count;        // 1..128 valid pairs
-    int32_t adapter_lo;
-    int32_t adapter_hi;
-    int32_t rows;         // register rows R this tile must run with (>= both adapter lengths)
+    int64_t win_lo, win_hi;      // first WINDOW index of the low / high half (64 consecutive each);
+                                 // win_lo == win_hi: both halves scan the same windows with two
+                                 // different adapters (one read stream instead of two)
+    int64_t out_lo, out_hi;      // first OUTPUT (pair) index of each half
+    int32_t count_lo, count_hi;  // valid lanes of each half (0..64)
+    int32_t adapter_lo, adapter_hi;
+    int32_t rows;                // register rows R this tile must run with (>= both adapter lengths)
+    int32_t pad_;
 };
 
 struct ScanArgs {
     const uint8_t *arena;        // read bytes, 1 B/base, as delivered by the caller
-    const int64_t *win_off;      // [npairs] byte offset of the window's first column
-    const int32_t *win_len;      // [npairs] columns to run
+    const int64_t *win_off;      // [nwindows] byte offset of the window's first column
+    const int32_t *win_len;      // [nwindows] columns to run
+    int32_t win_by_out;          // 1: the window arrays are indexed by OUTPUT index (pass-2 windows)
     const int32_t *col0;         // [npairs] global column of the window start   (null => 0)
     const int32_t *n_total;      // [npairs] whole read length                   (null => win_len)
     const int32_t *force_row;    // [npairs] end cell row (1..m) at the window's last column (null => scout)
@@ -36,6 +40,7 @@ struct ScanArgs {
     uint32_t *err;               // err[0] += 1 on any internal inconsistency (reported loudly by the host)
     uint32_t one2, two2, sixteen2;   // packed constants kept opaque to the compiler (set by the launcher)
     int32_t gen_max_rows;            // generic (LDS-state) variant: largest tile.rows in the launch
+    uint32_t *fin_scratch;           // [grid][rows*64*2] dwords: previous column kept for the last-column scan
 };
 
 // pass-2 planner: from the score-only pass's (score, I, J) build the bounded windows
@@ -54,13 +59,16 @@ constexpr int SCORE_OUT_INTS = 4;
 //  exact : adapter fills all R rows (no padding rows, adapter codes in SGPRs) -- the fast path
 //  padded: any adapter length <= R (top padding rows; per-row constants via LDS broadcast)
 static const int kExactRows[] = {22, 24, 28, 32};
-static const int kPaddedRows[] = {16, 24, 32, 40, 56};
+static const int kPaddedRows[] = {16, 24, 28, 32, 36, 40, 48, 56};
 constexpr int kMaxRows = 56;
 
-// -> rows, *pad; 0 = no register variant fits: use the generic LDS-state kernel (rows = m at run time)
-inline int pick_rows(int m, bool *pad)
+// m_lo/m_hi: adapter lengths of the two halves.  -> rows, *pad; 0 = no register variant fits: use
+// the generic LDS-state kernel (rows = max length at run time)
+inline int pick_rows(int m_lo, int m_hi, bool *pad)
 {
-    for (int r : kExactRows) if (r == m) { *pad = false; return r; }
+    const int m = m_lo > m_hi ? m_lo : m_hi;
+    if (m_lo == m_hi)
+        for (int r : kExactRows) if (r == m) { *pad = false; return r; }
     for (int r : kPaddedRows) if (r >= m) { *pad = true; return r; }
     *pad = true;
     return 0;

@@ -87,28 +87,41 @@ struct Best { int score, I, J, tie; };
 // ---------------------------------------------------------------------------------------------
 struct KConst { u32 A2, AO2, E2, O2, NEG2, D2, ONE2, TWO2, SIXTEEN2; };
 
+// where the per-row adapter constants live
+enum ConstMode { CONST_EXACT = 0,   // no padding rows: code in SGPRs, min-constant is the uniform D
+                 CONST_REGS = 1,    // padded, R <= 40: code in VGPRs (uniform value), min-constant in SGPRs
+                 CONST_LDS = 2 };   // padded, larger R: (code, min-constant) by LDS broadcast read per row
+template <int R, bool PAD> struct Cfg {
+    static constexpr int kMode = !PAD ? CONST_EXACT : (R <= 40 ? CONST_REGS : CONST_LDS);
+    static constexpr int kNS = (kMode == CONST_LDS) ? 1 : R;                        // SGPR array extent
+    static constexpr int kNV = (kMode == CONST_REGS) ? R : 1;                       // VGPR array extent
+};
+
 template <int R, bool PAD, bool TRACE>
 __device__ __forceinline__ void column_step(u32 (&T)[R], u32 (&U)[R], u32 h2,
-                                            const u32 (&vcs)[PAD ? 1 : R], const uint2 *lds_const,
-                                            const KConst &k, u32 (&trw)[(R + 3) / 4], u32 &last_tie01)  // NOLINT
+                                            const u32 (&cs)[Cfg<R, PAD>::kNS], const u32 (&cv)[Cfg<R, PAD>::kNV],
+                                            const uint2 *lds_const, const KConst &k,
+                                            u32 (&trw)[(R + 3) / 4], u32 &last_tie01)
 {
+    constexpr int MODE = Cfg<R, PAD>::kMode;
     constexpr int K = 2;                    // pipeline depth (rows ahead)
-    u32 dd[R], Hh[R], b0s[TRACE ? R : 1];   // only a window of K+1 entries is ever live
+    u32 dd[R], Hh[R], dh[R], b0s[TRACE ? R : 1];   // only a window of K+1 entries is ever live
     u32 dq = k.A2;                          // M[-1][j-1] + match = match
     auto ind = [&](int r) {
         u32 vc, dm;
-        if constexpr (PAD) {
+        if constexpr (MODE == CONST_LDS) {
             asm volatile("" : "+s"(lds_const));     // pin this LDS-broadcast read to its row
             const uint2 c = lds_const[r]; vc = c.x; dm = c.y;
-        }
-        else { vc = vcs[r]; dm = k.D2; }
+        } else if constexpr (MODE == CONST_REGS) { vc = cv[r]; dm = cs[r]; }
+        else { vc = cs[r]; dm = k.D2; }
         const u32 y = pk_sub(h2, vc);
         const u32 Hx = pk_add(U[r], k.E2);
         const u32 z = pk_minu(y, dm);
         const u32 Hs = pk_max(Hx, T[r]);
-        dd[r] = pk_sub(dq, z);
+        const u32 d = pk_sub(dq, z);
         dq = pk_add(T[r], k.AO2);           // diagonal term of row r+1, from the OLD T[r]
-        Hh[r] = Hs;
+        dd[r] = d; Hh[r] = Hs;
+        dh[r] = pk_max(d, Hs);              // off the vertical chain: M = max(max(d,H), V)
         if constexpr (TRACE) b0s[r] = pk_minu(pk_sub(Hs, Hx), k.ONE2);   // HOPEN
     };
 #pragma clang loop unroll(full)
@@ -120,15 +133,16 @@ __device__ __forceinline__ void column_step(u32 (&T)[R], u32 (&U)[R], u32 h2,
             // data-dependence fence: row r+K's independent ops may not start before the vertical
             // chain has reached row r (keeps live ranges to a K+1 row window at every level of
             // the compiler, which a sched_barrier alone does not)
-            asm volatile("" : "+v"(U[r + K]), "+v"(Vprev));
+            asm volatile("" : "+v"(U[r + K]), "+v"(T[r + K]), "+v"(Vprev));
             ind(r + K);
         }
+        // the vertical chain: 3 dependent ops per row (Vs, M, T')
         const u32 Vx = pk_add(Vprev, k.E2);
         const u32 Vs = pk_max(Vx, Tup);
-        const u32 g = pk_max(Hh[r], Vs);
-        const u32 Mn = pk_max(dd[r], g);
+        const u32 Mn = pk_max(dh[r], Vs);
         const u32 Tn = pk_add(Mn, k.O2);
         if constexpr (TRACE) {
+            const u32 g = pk_max(Hh[r], Vs);
             const u32 b1 = pk_minu(pk_sub(Vs, Vx), k.ONE2);      // VOPEN
             const u32 b2 = pk_minu(pk_sub(g, Vs), k.ONE2);       // FROMH
             const u32 b3 = pk_minu(pk_sub(Mn, dd[r]), k.ONE2);   // NOTDIAG
@@ -137,8 +151,10 @@ __device__ __forceinline__ void column_step(u32 (&T)[R], u32 (&U)[R], u32 h2,
             nib = pk_madu(nib, k.TWO2, b0s[r]);
             acc = pk_madu(acc, k.SIXTEEN2, nib);
             if ((r & 3) == 3 || r == R - 1) { trw[r >> 2] = acc; acc = 0; }
+            if (r == R - 1) last_tie01 = pk_minu(dd[r] ^ g, k.ONE2);   // 0 where d == max(H,V)
+        } else {
+            if (r == R - 1) last_tie01 = pk_minu(dd[r] ^ pk_max(Hh[r], Vs), k.ONE2);
         }
-        if (r == R - 1) last_tie01 = pk_minu(dd[r] ^ g, k.ONE2);   // 0 where d == max(H,V)
         T[r] = Tn; U[r] = Hh[r];
         Tup = Tn; Vprev = Vs;
         if constexpr (TRACE) {
@@ -165,10 +181,11 @@ __global__ __launch_bounds__(64) void scan_kernel(ScanArgs a)
     constexpr int RS = GEN ? 1 : R;          // static array extent
     __shared__ uint16_t lut[256];
     __shared__ uint2 lds_const_s[RS];        // per-row (spaced code, min-constant), packed lo|hi
-    __shared__ uint2 lds_fin_s[RS * 64];     // last-column scratch [row][lane]
     extern __shared__ __attribute__((aligned(16))) uint2 dyn_lds[];   // GEN: consts + column state
     uint2 *lds_const = GEN ? dyn_lds : lds_const_s;
-    uint2 *lds_fin = GEN ? dyn_lds + a.gen_max_rows : lds_fin_s;     // GEN: the column state itself
+    uint2 *lds_col = dyn_lds + a.gen_max_rows;                        // GEN only: the DP column [row][lane]
+    // previous column kept for the (rare) last-column scan of the register variants: global scratch
+    uint2 *fin = GEN ? nullptr : (uint2 *)a.fin_scratch + (int64_t)blockIdx.x * RS * 64;
 
     const int lane = threadIdx.x;
     const int D = a.match - a.mismatch;
@@ -207,22 +224,31 @@ __global__ __launch_bounds__(64) void scan_kernel(ScanArgs a)
             lds_const[r] = make_uint2(cl | (ch << 16), dl | (dh << 16));
         }
         __syncthreads();
-        u32 vcs[(PAD || GEN) ? 1 : RS];
-        if constexpr (!PAD && !GEN) {
+        constexpr int MODE = GEN ? (int)CONST_LDS : Cfg<RS, PAD>::kMode;
+        u32 cs[GEN ? 1 : Cfg<RS, PAD>::kNS], cv[GEN ? 1 : Cfg<RS, PAD>::kNV];
+        cs[0] = 0; cv[0] = 0;
+        if constexpr (MODE == CONST_EXACT) {
             if (pad_lo != 0 || pad_hi != 0) { if (lane == 0) atomicAdd(a.err, 1u); continue; }   // host bug
 #pragma clang loop unroll(full)
-            for (int r = 0; r < R; ++r) vcs[r] = __builtin_amdgcn_readfirstlane(lds_const[r].x);
-        } else {
-            vcs[0] = 0;
+            for (int r = 0; r < RS; ++r) cs[r] = __builtin_amdgcn_readfirstlane(lds_const[r].x);
+        } else if constexpr (MODE == CONST_REGS) {
+#pragma clang loop unroll(full)
+            for (int r = 0; r < RS; ++r) {
+                const uint2 c = lds_const[r];
+                cv[r] = c.x; cs[r] = __builtin_amdgcn_readfirstlane(c.y);
+            }
         }
 
         // ---- this lane's two pairs -----------------------------------------------------
-        const int64_t p_lo = tile.pair_base + lane, p_hi = tile.pair_base + 64 + lane;
-        const bool have_lo = lane < tile.count, have_hi = 64 + lane < tile.count;
-        const uint8_t *w_lo = a.arena + (have_lo ? a.win_off[p_lo] : 0);
-        const uint8_t *w_hi = a.arena + (have_hi ? a.win_off[p_hi] : 0);
-        const int n_lo = have_lo ? a.win_len[p_lo] : 0;
-        const int n_hi = have_hi ? a.win_len[p_hi] : 0;
+        const int64_t p_lo = tile.out_lo + lane, p_hi = tile.out_hi + lane;            // output slots
+        const int64_t wi_lo = a.win_by_out ? p_lo : tile.win_lo + lane;                  // window slots
+        const int64_t wi_hi = a.win_by_out ? p_hi : tile.win_hi + lane;
+        const bool have_lo = lane < tile.count_lo, have_hi = lane < tile.count_hi;
+        const bool one_stream = !a.win_by_out && tile.win_lo == tile.win_hi;             // same windows, two adapters
+        const uint8_t *w_lo = a.arena + (have_lo ? a.win_off[wi_lo] : 0);
+        const uint8_t *w_hi = a.arena + (have_hi ? a.win_off[wi_hi] : 0);
+        const int n_lo = have_lo ? a.win_len[wi_lo] : 0;
+        const int n_hi = have_hi ? a.win_len[wi_hi] : 0;
         const int c0_lo = (have_lo && a.col0) ? a.col0[p_lo] : 0;
         const int c0_hi = (have_hi && a.col0) ? a.col0[p_hi] : 0;
         const int fr_lo = (have_lo && a.force_row) ? a.force_row[p_lo] : -1;   // adapter row or -1
@@ -240,7 +266,7 @@ __global__ __launch_bounds__(64) void scan_kernel(ScanArgs a)
         };
         if constexpr (GEN) {
 #pragma unroll 1
-            for (int r = 0; r < rows; ++r) lds_fin[r * 64 + lane] = make_uint2(init_T(r), NEG2);
+            for (int r = 0; r < rows; ++r) lds_col[r * 64 + lane] = make_uint2(init_T(r), NEG2);
             T[0] = 0; U[0] = 0;
         } else {
 #pragma clang loop unroll(full)
@@ -274,12 +300,21 @@ __global__ __launch_bounds__(64) void scan_kernel(ScanArgs a)
             if (((j - 1) & 3) == 0) {
                 // next 4 bases of each stream; finished streams re-read their last dword
                 const int kl = (j - 1 < n_lo) ? j - 1 : (n_lo > 0 ? ((n_lo - 1) & ~3) : 0);
-                const int kh = (j - 1 < n_hi) ? j - 1 : (n_hi > 0 ? ((n_hi - 1) & ~3) : 0);
                 cur_lo = load_u32_unaligned(w_lo + kl);
-                cur_hi = load_u32_unaligned(w_hi + kh);
+                if (!one_stream) {
+                    const int kh = (j - 1 < n_hi) ? j - 1 : (n_hi > 0 ? ((n_hi - 1) & ~3) : 0);
+                    cur_hi = load_u32_unaligned(w_hi + kh);
+                }
             }
-            const u32 h2 = (u32)lut[cur_lo & 0xFF] | ((u32)lut[cur_hi & 0xFF] << 16);
-            cur_lo >>= 8; cur_hi >>= 8;
+            u32 h2;
+            if (one_stream) {
+                const u32 c = lut[cur_lo & 0xFF];
+                h2 = c | (c << 16);
+            } else {
+                h2 = (u32)lut[cur_lo & 0xFF] | ((u32)lut[cur_hi & 0xFF] << 16);
+                cur_hi >>= 8;
+            }
+            cur_lo >>= 8;
 
             u32 tie01 = 0, Tlast = 0;
             const bool fin_lo = (j == n_lo), fin_hi = (j == n_hi);
@@ -291,7 +326,7 @@ __global__ __launch_bounds__(64) void scan_kernel(ScanArgs a)
                 u32 dq = k.A2, Tup = k.O2, Vprev = k.NEG2, acc = 0;
 #pragma unroll 2
                 for (int r = 0; r < rows; ++r) {
-                    const uint2 old = lds_fin[r * 64 + lane];      // (T, U) of column j-1
+                    const uint2 old = lds_col[r * 64 + lane];      // (T, U) of column j-1
                     const uint2 c = lds_const[r];
                     const u32 z = pk_minu(pk_sub(h2, c.x), c.y);
                     const u32 d = pk_sub(dq, z);
@@ -315,7 +350,7 @@ __global__ __launch_bounds__(64) void scan_kernel(ScanArgs a)
                         if ((r & 3) == 3 || r == rows - 1) { trace_dst[(r >> 2) * 64] = acc; acc = 0; }
                     }
                     if (any_fin) scan_row(r, j, Tn, t01, fin_lo, fin_hi);
-                    lds_fin[r * 64 + lane] = make_uint2(Tn, Hs);
+                    lds_col[r * 64 + lane] = make_uint2(Tn, Hs);
                     dq = pk_add(old.x, k.AO2); Tup = Tn; Vprev = Vs;
                     tie01 = t01; Tlast = Tn;
                 }
@@ -323,10 +358,10 @@ __global__ __launch_bounds__(64) void scan_kernel(ScanArgs a)
                 if (any_fin) {
                     // some pair reaches its last column: keep the previous column for the scan below
 #pragma clang loop unroll(full)
-                    for (int r = 0; r < R; ++r) lds_fin[r * 64 + lane] = make_uint2(T[r], U[r]);
+                    for (int r = 0; r < R; ++r) fin[r * 64 + lane] = make_uint2(T[r], U[r]);
                 }
                 u32 trw[(RS + 3) / 4];
-                column_step<RS, PAD, TRACE>(T, U, h2, vcs, lds_const, k, trw, tie01);
+                column_step<RS, PAD, TRACE>(T, U, h2, cs, cv, lds_const, k, trw, tie01);
                 Tlast = T[RS - 1];
                 if constexpr (TRACE) {
 #pragma unroll
@@ -338,7 +373,7 @@ __global__ __launch_bounds__(64) void scan_kernel(ScanArgs a)
                     u32 dq = k.A2, Tup = k.O2, Vprev = k.NEG2;
 #pragma unroll 1
                     for (int r = 0; r < R; ++r) {
-                        const uint2 old = lds_fin[r * 64 + lane];
+                        const uint2 old = fin[r * 64 + lane];
                         const uint2 c = lds_const[r];
                         const u32 z = pk_minu(pk_sub(h2, c.x), c.y);
                         const u32 d = pk_sub(dq, z);
@@ -411,17 +446,18 @@ __global__ __launch_bounds__(64) void scan_kernel(ScanArgs a)
 __global__ void plan_kernel(PlanArgs a)
 {
     const Tile tile = a.tiles[blockIdx.x];
-    const int i = threadIdx.x;
-    if (i >= tile.count) return;
-    const int64_t p = tile.pair_base + i;
+    const int i = threadIdx.x & 63, hi = threadIdx.x >> 6;
+    if (i >= (hi ? tile.count_hi : tile.count_lo)) return;
+    const int64_t p = (hi ? tile.out_hi : tile.out_lo) + i;      // pair (output) slot
+    const int64_t w = (hi ? tile.win_hi : tile.win_lo) + i;      // its whole-read window
     const int score = a.k1[p * 4 + 0], I = a.k1[p * 4 + 1], J = a.k1[p * 4 + 2];
-    const int window = a.ad_window[i < 64 ? tile.adapter_lo : tile.adapter_hi];
+    const int window = a.ad_window[hi ? tile.adapter_hi : tile.adapter_lo];
     int c0 = J - window;
     if (c0 < 0) c0 = 0;
-    a.win_off2[p] = a.win_off[p] + c0;
+    a.win_off2[p] = a.win_off[w] + c0;
     a.win_len2[p] = J - c0;
     a.col02[p] = c0;
-    a.ntot2[p] = a.win_len[p];
+    a.ntot2[p] = a.win_len[w];
     a.force_row2[p] = I;
     a.force_score2[p] = score;
 }
@@ -450,7 +486,7 @@ static int launch_scan(const ScanArgs &a0, int rows, bool pad, int grid, void *s
         }
     } else {
         switch (rows) {
-            PC_PADDED(16) PC_PADDED(24) PC_PADDED(32) PC_PADDED(40) PC_PADDED(56)
+            PC_PADDED(16) PC_PADDED(24) PC_PADDED(28) PC_PADDED(32) PC_PADDED(36) PC_PADDED(40) PC_PADDED(48) PC_PADDED(56)
             default: return -1;
         }
     }

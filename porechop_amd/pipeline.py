@@ -111,17 +111,42 @@ class Pipeline:
         return off + (ln - wl).to(torch.int64), wl
 
     def _scan_jobs(self, arena, jobs, mode, max_len):
-        """jobs: list of (adapter_index, win_off int64[n], win_len int32[n]) -> list of [n,8] views."""
-        woff = torch.cat([j[1] for j in jobs])
-        wlen = torch.cat([j[2] for j in jobs]).to(torch.int32)
-        starts = np.zeros(len(jobs) + 1, dtype=np.int64)
+        """jobs: list of (adapter_index, win_off int64[n], win_len int32[n]) -> list of [n,8] views.
+
+        Jobs that scan the very same windows (same tensors) are fused two adapters at a time
+        (similar lengths together), so each window is streamed from HBM once per adapter PAIR."""
+        groups = {}
         for k, j in enumerate(jobs):
-            starts[k + 1] = starts[k] + j[1].shape[0]
-        out = torch.empty((int(starts[-1]), RESULT_INTS), dtype=torch.int32, device=self.device)
+            groups.setdefault((id(j[1]), id(j[2])), []).append(k)
+        fused = []                      # (job index a, job index b or None)
+        for ks in groups.values():
+            ks = sorted(ks, key=lambda k: -len(self.seqs[jobs[k][0]]))
+            for i in range(0, len(ks) - 1, 2):
+                fused.append((ks[i], ks[i + 1]))
+            if len(ks) % 2:
+                fused.append((ks[-1], None))
+        woff = torch.cat([jobs[a][1] for a, _ in fused])
+        wlen = torch.cat([jobs[a][2] for a, _ in fused]).to(torch.int32)
+        starts = np.zeros(len(fused) + 1, dtype=np.int64)
+        ostarts = np.zeros(len(fused) + 1, dtype=np.int64)
+        for k, (a, b) in enumerate(fused):
+            n = jobs[a][1].shape[0]
+            starts[k + 1] = starts[k] + n
+            ostarts[k + 1] = ostarts[k] + n * (2 if b is not None else 1)
+        out = torch.empty((int(ostarts[-1]), RESULT_INTS), dtype=torch.int32, device=self.device)
         if starts[-1] > 0:
-            self.aligner.scan_device(arena, woff, wlen, np.array([j[0] for j in jobs], dtype=np.int32),
-                                     starts, max_len, out, mode)
-        return [out[int(starts[k]):int(starts[k + 1])] for k in range(len(jobs))]
+            self.aligner.scan_device(arena, woff, wlen, np.array([jobs[a][0] for a, _ in fused], dtype=np.int32),
+                                     starts, max_len, out, mode,
+                                     job_adapter_b=np.array([jobs[b][0] if b is not None else -1 for _, b in fused],
+                                                            dtype=np.int32))
+        res = [None] * len(jobs)
+        for k, (a, b) in enumerate(fused):
+            n = jobs[a][1].shape[0]
+            o = int(ostarts[k])
+            res[a] = out[o:o + n]
+            if b is not None:
+                res[b] = out[o + n:o + 2 * n]
+        return res
 
     # ------------------------------------------------------------------------------------------
     def phase_a(self, reads: DeviceReads, check_idx: Optional[torch.Tensor] = None):

@@ -62,9 +62,9 @@ struct pc_ctx {
     int ncu = 256;
     int match = 3, mismatch = -6, gap_open = -5, gap_extend = -2;
     std::vector<std::string> adapters;
-    std::vector<int> ad_len, ad_window;
+    std::vector<int> ad_len, ad_window, ad_span;
     bool panel_dirty = true;
-    DevBuf d_ad_codes, d_ad_len, d_ad_window;
+    DevBuf d_ad_codes, d_ad_len, d_ad_window, d_ad_span;
     DevBuf d_tiles, d_slab, d_fin, d_k1, d_woff2, d_wlen2, d_col0, d_ntot, d_frow, d_fscore, d_err;
     // host-API staging
     DevBuf d_arena, d_woff, d_wlen, d_out;
@@ -111,6 +111,7 @@ int upload_panel(pc_ctx *c)
     std::vector<uint32_t> codes((size_t)std::max(n, 1) * pcb::MAX_ADAPTER, 5u);
     c->ad_len.assign(std::max(n, 1), 0);
     c->ad_window.assign(std::max(n, 1), 0);
+    c->ad_span.assign(std::max(n, 1), 0);
     int maxm = 1;
     for (int i = 0; i < n; ++i) {
         const std::string &s = c->adapters[i];
@@ -126,16 +127,18 @@ int upload_panel(pc_ctx *c)
         if (!pcb::compute_bounds(c->match, c->mismatch, c->gap_open, c->gap_extend, std::max(1, c->ad_len[i]), b))
             return PC_ERR_UNSUPPORTED_SCORES;
         c->ad_window[i] = b.window;
+        c->ad_span[i] = b.SPAN;
     }
     // stream-ordered: earlier launches may still read the old tables
     HIP_TRY(hipStreamSynchronize(c->stream));
     int rc;
     if ((rc = c->d_ad_codes.ensure(codes.size() * 4)) || (rc = c->d_ad_len.ensure(c->ad_len.size() * 4)) ||
-        (rc = c->d_ad_window.ensure(c->ad_window.size() * 4)))
+        (rc = c->d_ad_window.ensure(c->ad_window.size() * 4)) || (rc = c->d_ad_span.ensure(c->ad_span.size() * 4)))
         return rc;
     HIP_TRY(hipMemcpy(c->d_ad_codes.p, codes.data(), codes.size() * 4, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(c->d_ad_len.p, c->ad_len.data(), c->ad_len.size() * 4, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(c->d_ad_window.p, c->ad_window.data(), c->ad_window.size() * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->d_ad_span.p, c->ad_span.data(), c->ad_span.size() * 4, hipMemcpyHostToDevice));
     c->panel_dirty = false;
     c->tiles_uploaded = false;
     c->last_max_len = -1;
@@ -229,6 +232,8 @@ int build_tiles(pc_ctx *c, const int32_t *job_adapter, const int32_t *job_adapte
     return PC_OK;
 }
 
+constexpr int kMaxChunks = 16;
+
 struct ScopedTimer {
     pc_ctx *c; hipStream_t s; bool on; pc_ctx::Timed t;
     ScopedTimer(pc_ctx *c_, hipStream_t s_, int kind, int64_t pairs) : c(c_), s(s_), on(c_->timing)
@@ -308,7 +313,7 @@ void pc_destroy(pc_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    DevBuf *bufs[] = {&c->d_ad_codes, &c->d_ad_len, &c->d_ad_window, &c->d_tiles, &c->d_slab, &c->d_fin, &c->d_k1, &c->d_woff2,
+    DevBuf *bufs[] = {&c->d_ad_codes, &c->d_ad_len, &c->d_ad_window, &c->d_ad_span, &c->d_tiles, &c->d_slab, &c->d_fin, &c->d_k1, &c->d_woff2,
                       &c->d_wlen2, &c->d_col0, &c->d_ntot, &c->d_frow, &c->d_fscore, &c->d_err, &c->d_arena,
                       &c->d_woff, &c->d_wlen, &c->d_out};
     for (DevBuf *b : bufs) b->release();
@@ -372,7 +377,7 @@ int pc_scan_device(pc_ctx *c, const void *d_arena, const int64_t *d_win_off, con
     if ((rc = c->d_slab.ensure(slab_bytes + 256)) || (rc = c->d_fin.ensure(fin_bytes + 256))) return rc;
     if (any_two) {
         const size_t n = (size_t)npairs;
-        if ((rc = c->d_k1.ensure(n * 16)) || (rc = c->d_woff2.ensure(n * 8)) || (rc = c->d_wlen2.ensure(n * 4)) ||
+        if ((rc = c->d_k1.ensure(n * 16 * kMaxChunks)) || (rc = c->d_woff2.ensure(n * 8)) || (rc = c->d_wlen2.ensure(n * 4)) ||
             (rc = c->d_col0.ensure(n * 4)) || (rc = c->d_ntot.ensure(n * 4)) || (rc = c->d_frow.ensure(n * 4)) ||
             (rc = c->d_fscore.ensure(n * 4)))
             return rc;
@@ -410,7 +415,19 @@ int pc_scan_device(pc_ctx *c, const void *d_arena, const int64_t *d_win_off, con
             a.win_off = d_win_off; a.win_len = d_win_len;
             a.out = c->d_k1.as<int32_t>();
             a.slab = nullptr; a.slab_cols = 0; a.slab_stride = 0;
-            int grid = grid_for(c, g, g.tile_count, 1, nullptr);
+            // too few tiles to fill the chip (small batches, mask-and-realign rounds): cut the
+            // windows into column chunks, each warmed up by SPAN columns (exact, see pc_bounds.h)
+            const int capacity = grid_for(c, g, (size_t)1 << 30, 1, nullptr);
+            int chunks = 1;
+            if ((int64_t)g.tile_count * 2 <= capacity) {
+                chunks = (int)std::min<int64_t>(kMaxChunks, capacity / (int64_t)g.tile_count);
+                const int min_len = 4 * g.max_window;          // keep the warm-up overhead under ~15 %
+                chunks = std::max(1, std::min(chunks, max_len / std::max(1, min_len)));
+            }
+            a.chunks = chunks;
+            a.chunk_len = (max_len + chunks - 1) / chunks;
+            a.ad_span = c->d_ad_span.as<int32_t>();
+            int grid = grid_for(c, g, g.tile_count * (size_t)chunks, 1, nullptr);
             {
                 ScopedTimer tm(c, stream, 0, np);
                 if ((rc = pck::launch_score(a, g.rows, g.pad, grid, stream))) return PC_ERR_NO_DEVICE;
@@ -422,7 +439,8 @@ int pc_scan_device(pc_ctx *c, const void *d_arena, const int64_t *d_win_off, con
             pl.win_off2 = c->d_woff2.as<int64_t>(); pl.win_len2 = c->d_wlen2.as<int32_t>();
             pl.col02 = c->d_col0.as<int32_t>(); pl.ntot2 = c->d_ntot.as<int32_t>();
             pl.force_row2 = c->d_frow.as<int32_t>(); pl.force_score2 = c->d_fscore.as<int32_t>();
-            pl.tiles = a.tiles; pl.ntiles = a.ntiles;
+            pl.tiles = a.tiles; pl.ntiles = a.ntiles; pl.chunks = chunks;
+            a.chunks = 1;
             pl.ad_window = c->d_ad_window.as<int32_t>();
             {
                 ScopedTimer tm(c, stream, 1, np);

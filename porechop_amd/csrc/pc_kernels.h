@@ -41,6 +41,8 @@ struct ScanArgs {
     uint32_t one2, two2, sixteen2;   // packed constants kept opaque to the compiler (set by the launcher)
     int32_t gen_max_rows;            // generic (LDS-state) variant: largest tile.rows in the launch
     uint32_t *fin_scratch;           // [grid][rows*64*2] dwords: previous column kept for the last-column scan
+    int32_t chunks, chunk_len;       // score-only pass: column chunks per tile (1 = whole window) and their length
+    const int32_t *ad_span;          // [nadapters] warm-up columns (SPAN) for chunked passes
 };
 
 // pass-2 planner: from the score-only pass's (score, I, J) build the bounded windows
@@ -49,6 +51,7 @@ struct PlanArgs {
     const int32_t *k1;                                  // [npairs][4] score, I, J, 0
     int64_t *win_off2; int32_t *win_len2; int32_t *col02; int32_t *ntot2; int32_t *force_row2; int32_t *force_score2;
     const Tile *tiles; int32_t ntiles;                  // same tiles as the score pass
+    int32_t chunks;                                     // chunk results per pair in k1 (>= 1)
     const int32_t *ad_window;                           // [nadapters] W+SPAN+1 for that adapter length
 };
 
@@ -59,7 +62,7 @@ constexpr int SCORE_OUT_INTS = 4;
 //  exact : adapter fills all R rows (no padding rows, adapter codes in SGPRs) -- the fast path
 //  padded: any adapter length <= R (top padding rows; per-row constants via LDS broadcast)
 static const int kExactRows[] = {22, 24, 28, 32};
-static const int kPaddedRows[] = {16, 24, 28, 32, 36, 40, 48, 56};
+static const int kPaddedRows[] = {16, 20, 24, 26, 28, 30, 32, 34, 36, 38, 40, 48, 56};
 constexpr int kMaxRows = 56;
 
 // m_lo/m_hi: adapter lengths of the two halves.  -> rows, *pad; 0 = no register variant fits: use

@@ -198,7 +198,13 @@ __global__ __launch_bounds__(64) void scan_kernel(ScanArgs a)
     const u32 NEG2 = k.NEG2;
     u32 *slab = TRACE ? a.slab + (int64_t)blockIdx.x * a.slab_stride : nullptr;
 
-    for (int t = blockIdx.x; t < a.ntiles; t += gridDim.x) {
+    // score-only whole-read passes may be cut into `chunks` column chunks per tile (virtual
+    // tiles) when real tiles are too few to fill the chip: chunk c tracks the last-row cells of
+    // columns (c*L, (c+1)*L] after a warm-up of SPAN columns that makes its values exact
+    // (pc_bounds.h); the planner kernel then merges the per-chunk maxima in visiting order.
+    const int nchunks = (!TRACE && a.chunks > 1) ? a.chunks : 1;
+    for (int vt = blockIdx.x; vt < a.ntiles * nchunks; vt += gridDim.x) {
+        const int t = vt / nchunks, chunk = vt - t * nchunks;
         const Tile tile = a.tiles[t];
         const int rows = GEN ? tile.rows : R;
         const int NW = (rows + 3) >> 2;      // trace dwords per column per lane
@@ -247,10 +253,24 @@ __global__ __launch_bounds__(64) void scan_kernel(ScanArgs a)
         const bool one_stream = !a.win_by_out && tile.win_lo == tile.win_hi;             // same windows, two adapters
         const uint8_t *w_lo = a.arena + (have_lo ? a.win_off[wi_lo] : 0);
         const uint8_t *w_hi = a.arena + (have_hi ? a.win_off[wi_hi] : 0);
-        const int n_lo = have_lo ? a.win_len[wi_lo] : 0;
-        const int n_hi = have_hi ? a.win_len[wi_hi] : 0;
-        const int c0_lo = (have_lo && a.col0) ? a.col0[p_lo] : 0;
-        const int c0_hi = (have_hi && a.col0) ? a.col0[p_hi] : 0;
+        int n_lo = have_lo ? a.win_len[wi_lo] : 0;
+        int n_hi = have_hi ? a.win_len[wi_hi] : 0;
+        int c0_lo = (have_lo && a.col0) ? a.col0[p_lo] : 0;
+        int c0_hi = (have_hi && a.col0) ? a.col0[p_hi] : 0;
+        // chunked pass: [tf+1 .. n] are the tracked local columns, tail = this chunk ends the read
+        int tf_lo = 0, tf_hi = 0;
+        bool tail_lo = true, tail_hi = true;
+        if (nchunks > 1) {
+            const int L = a.chunk_len, start = chunk * L;
+            auto cut = [&](int nfull, int span, const uint8_t *&w, int &n, int &c0, int &tf, bool &tail) {
+                if (start >= nfull) { n = 0; c0 = 0; tf = 0; tail = false; return; }   // empty chunk
+                c0 = start - span > 0 ? start - span : 0;
+                const int end = start + L < nfull ? start + L : nfull;
+                w += c0; n = end - c0; tf = start - c0; tail = (end == nfull);
+            };
+            cut(n_lo, a.ad_span[tile.adapter_lo], w_lo, n_lo, c0_lo, tf_lo, tail_lo);
+            cut(n_hi, a.ad_span[tile.adapter_hi], w_hi, n_hi, c0_hi, tf_hi, tail_hi);
+        }
         const int fr_lo = (have_lo && a.force_row) ? a.force_row[p_lo] : -1;   // adapter row or -1
         const int fr_hi = (have_hi && a.force_row) ? a.force_row[p_hi] : -1;
 
@@ -273,6 +293,7 @@ __global__ __launch_bounds__(64) void scan_kernel(ScanArgs a)
             for (int r = 0; r < R; ++r) { T[r] = init_T(r); U[r] = NEG2; }
         }
         Best b_lo = {0, m_lo, 0, 0}, b_hi = {0, m_hi, 0, 0};
+        if (chunk > 0) { b_lo.score = -32768; b_lo.J = -1; b_hi.score = -32768; b_hi.J = -1; }   // (m,0) belongs to chunk 0
 
         int nmax = n_lo > n_hi ? n_lo : n_hi;
 #pragma unroll
@@ -317,7 +338,7 @@ __global__ __launch_bounds__(64) void scan_kernel(ScanArgs a)
             cur_lo >>= 8;
 
             u32 tie01 = 0, Tlast = 0;
-            const bool fin_lo = (j == n_lo), fin_hi = (j == n_hi);
+            const bool fin_lo = (j == n_lo) && tail_lo, fin_hi = (j == n_hi) && tail_hi;
             const bool any_fin = __any(fin_lo || fin_hi);
             u32 *trace_dst = TRACE ? slab + ((int64_t)(j - 1) * NW) * 64 + lane : nullptr;
 
@@ -357,8 +378,10 @@ __global__ __launch_bounds__(64) void scan_kernel(ScanArgs a)
             } else {
                 if (any_fin) {
                     // some pair reaches its last column: keep the previous column for the scan below
+                    if (fin_lo || fin_hi) {
 #pragma clang loop unroll(full)
-                    for (int r = 0; r < R; ++r) fin[r * 64 + lane] = make_uint2(T[r], U[r]);
+                        for (int r = 0; r < R; ++r) fin[r * 64 + lane] = make_uint2(T[r], U[r]);
+                    }
                 }
                 u32 trw[(RS + 3) / 4];
                 column_step<RS, PAD, TRACE>(T, U, h2, cs, cv, lds_const, k, trw, tie01);
@@ -373,7 +396,7 @@ __global__ __launch_bounds__(64) void scan_kernel(ScanArgs a)
                     u32 dq = k.A2, Tup = k.O2, Vprev = k.NEG2;
 #pragma unroll 1
                     for (int r = 0; r < R; ++r) {
-                        const uint2 old = fin[r * 64 + lane];
+                        const uint2 old = (fin_lo || fin_hi) ? fin[r * 64 + lane] : make_uint2(0u, 0u);
                         const uint2 c = lds_const[r];
                         const u32 z = pk_minu(pk_sub(h2, c.x), c.y);
                         const u32 d = pk_sub(dq, z);
@@ -390,15 +413,18 @@ __global__ __launch_bounds__(64) void scan_kernel(ScanArgs a)
             // last adapter row of columns 1..n-1 (bottom register row for both halves)
             {
                 const int cl = lo16(Tlast) - a.gap_open, ch = hi16(Tlast) - a.gap_open;
-                if (j < n_lo && fr_lo < 0 && cl > b_lo.score) { b_lo.score = cl; b_lo.I = m_lo; b_lo.J = j; b_lo.tie = !(tie01 & 0xFFFFu); }
-                if (j < n_hi && fr_hi < 0 && ch > b_hi.score) { b_hi.score = ch; b_hi.I = m_hi; b_hi.J = j; b_hi.tie = !(tie01 >> 16); }
+                const bool tr_lo = j > tf_lo && (tail_lo ? j < n_lo : j <= n_lo);
+                const bool tr_hi = j > tf_hi && (tail_hi ? j < n_hi : j <= n_hi);
+                if (tr_lo && fr_lo < 0 && cl > b_lo.score) { b_lo.score = cl; b_lo.I = m_lo; b_lo.J = j; b_lo.tie = !(tie01 & 0xFFFFu); }
+                if (tr_hi && fr_hi < 0 && ch > b_hi.score) { b_hi.score = ch; b_hi.I = m_hi; b_hi.J = j; b_hi.tie = !(tie01 >> 16); }
             }
         }
 
         // ---- results -----------------------------------------------------------------
         if constexpr (!TRACE) {
-            if (have_lo) { int4 o = {b_lo.score, b_lo.I, b_lo.J, 0}; *(int4 *)(a.out + p_lo * SCORE_OUT_INTS) = o; }
-            if (have_hi) { int4 o = {b_hi.score, b_hi.I, b_hi.J, 0}; *(int4 *)(a.out + p_hi * SCORE_OUT_INTS) = o; }
+            // J is reported in whole-window columns; chunk results go to [pair][chunk]
+            if (have_lo) { int4 o = {b_lo.score, b_lo.I, b_lo.J + c0_lo, 0}; *(int4 *)(a.out + (p_lo * nchunks + chunk) * SCORE_OUT_INTS) = o; }
+            if (have_hi) { int4 o = {b_hi.score, b_hi.I, b_hi.J + c0_hi, 0}; *(int4 *)(a.out + (p_hi * nchunks + chunk) * SCORE_OUT_INTS) = o; }
         } else {
 #pragma unroll 1
             for (int hf = 0; hf < 2; ++hf) {
@@ -450,7 +476,13 @@ __global__ void plan_kernel(PlanArgs a)
     if (i >= (hi ? tile.count_hi : tile.count_lo)) return;
     const int64_t p = (hi ? tile.out_hi : tile.out_lo) + i;      // pair (output) slot
     const int64_t w = (hi ? tile.win_hi : tile.win_lo) + i;      // its whole-read window
-    const int score = a.k1[p * 4 + 0], I = a.k1[p * 4 + 1], J = a.k1[p * 4 + 2];
+    // merge the per-chunk maxima in the reference's visiting order (strict '>', earlier chunk wins)
+    const int nch = a.chunks > 1 ? a.chunks : 1;
+    int score = a.k1[(p * nch) * 4 + 0], I = a.k1[(p * nch) * 4 + 1], J = a.k1[(p * nch) * 4 + 2];
+    for (int c = 1; c < nch; ++c) {
+        const int sc = a.k1[(p * nch + c) * 4 + 0];
+        if (sc > score) { score = sc; I = a.k1[(p * nch + c) * 4 + 1]; J = a.k1[(p * nch + c) * 4 + 2]; }
+    }
     const int window = a.ad_window[hi ? tile.adapter_hi : tile.adapter_lo];
     int c0 = J - window;
     if (c0 < 0) c0 = 0;
@@ -486,7 +518,8 @@ static int launch_scan(const ScanArgs &a0, int rows, bool pad, int grid, void *s
         }
     } else {
         switch (rows) {
-            PC_PADDED(16) PC_PADDED(24) PC_PADDED(28) PC_PADDED(32) PC_PADDED(36) PC_PADDED(40) PC_PADDED(48) PC_PADDED(56)
+            PC_PADDED(16) PC_PADDED(20) PC_PADDED(24) PC_PADDED(26) PC_PADDED(28) PC_PADDED(30) PC_PADDED(32) PC_PADDED(34)
+            PC_PADDED(36) PC_PADDED(38) PC_PADDED(40) PC_PADDED(48) PC_PADDED(56)
             default: return -1;
         }
     }

@@ -38,15 +38,31 @@ def load_panel_sets():
                        tuple(a["end"]) if a["end"] else None) for a in panel]
 
 
+def host_cores():
+    """Cores this process may really use: affinity mask and cgroup CPU quota, not os.cpu_count()."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
 def one_step(pl, reads, n_check, world):
     """The hot path over one resident batch.  Returns (matching, start_trim, end_trim, hits)."""
+    from porechop_amd.distributed import reduce_presence
     check = None if n_check >= reads.n else torch.arange(n_check, device=reads.off.device)
     best_s, best_e = pl.phase_a(reads, check)
-    if world > 1:
-        # adapter-set presence is the one cross-read reduction (porechop.py:327): 119 x 2 maxima
-        table = torch.stack([best_s, best_e])
-        dist.all_reduce(table, op=dist.ReduceOp.MAX)
-        best_s, best_e = table[0], table[1]
+    # adapter-set presence is the one cross-read reduction (porechop.py:327): 119 x 2 maxima, MAX
+    # all-reduce over RCCL (a no-op at world size 1)
+    best_s, best_e = reduce_presence(best_s, best_e)
     matching = pl.matching_sets(best_s, best_e)
     st, et = pl.phase_b(reads, matching)
     hits = pl.phase_c(reads, st, et, matching)
@@ -188,7 +204,7 @@ def main():
         }
         if args.cpu_seconds > 0 and world >= 1:
             try:
-                out["cpu_baseline"] = cpu_baseline(reads, pl, matching, args.cpu_seconds, os.cpu_count() or 1)
+                out["cpu_baseline"] = cpu_baseline(reads, pl, matching, args.cpu_seconds, host_cores())
                 out["config"]["speedup_vs_cpu_baseline"] = reads_per_s / out["cpu_baseline"]["value"]
             except Exception as e:   # the baseline leg must never break the bench line
                 out["cpu_baseline"] = {"value": None, "unit": "reads/s", "cores": 0, "kind": "port",

@@ -370,7 +370,7 @@ int pc_scan_device(pc_ctx *c, const void *d_arena, const int64_t *d_win_off, con
         const int cols = g.two_pass ? g.max_window + 1 : max_len;
         const int grid = grid_for(c, g, g.tile_count, cols, &stride);
         slab_bytes = std::max(slab_bytes, (size_t)grid * stride * 4);
-        const int grid1 = grid_for(c, g, g.tile_count, 1, nullptr);
+        const int grid1 = grid_for(c, g, g.tile_count * (size_t)kMaxChunks, 1, nullptr);   // chunked score pass
         fin_bytes = std::max(fin_bytes, (size_t)std::max(grid, grid1) * std::max(1, g.rows) * 64 * 8);
         any_two |= g.two_pass;
     }

@@ -268,8 +268,11 @@ __global__ __launch_bounds__(64) void scan_kernel(ScanArgs a)
                 const int end = start + L < nfull ? start + L : nfull;
                 w += c0; n = end - c0; tf = start - c0; tail = (end == nfull);
             };
-            cut(n_lo, a.ad_span[tile.adapter_lo], w_lo, n_lo, c0_lo, tf_lo, tail_lo);
-            cut(n_hi, a.ad_span[tile.adapter_hi], w_hi, n_hi, c0_hi, tf_hi, tail_hi);
+            // a longer warm-up is still exact: halves sharing one read stream must share it
+            int sp_lo = a.ad_span[tile.adapter_lo], sp_hi = a.ad_span[tile.adapter_hi];
+            if (one_stream) sp_lo = sp_hi = (sp_lo > sp_hi ? sp_lo : sp_hi);
+            cut(n_lo, sp_lo, w_lo, n_lo, c0_lo, tf_lo, tail_lo);
+            cut(n_hi, sp_hi, w_hi, n_hi, c0_hi, tf_hi, tail_hi);
         }
         const int fr_lo = (have_lo && a.force_row) ? a.force_row[p_lo] : -1;   // adapter row or -1
         const int fr_hi = (have_hi && a.force_row) ? a.force_row[p_hi] : -1;

@@ -1,0 +1,46 @@
+"""Multi-GPU layout of the path: reads are sharded over ranks (one process per GPU), every
+alignment depends on exactly one read, so phases B and C need no exchange at all.  The single
+cross-read reduction in Porechop is the adapter-set presence table of phase A -- the max
+full-adapter identity per set and side over the check reads (nanopore_read.py:159,164), consumed
+at porechop.py:327 -- which is all-reduced with MAX (RCCL on GPUs, gloo in the CPU tests)."""
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(n_items, world, rank):
+    """Contiguous, order-preserving shard [lo, hi) of rank `rank` (sizes differ by at most 1)."""
+    base, rem = divmod(n_items, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def check_read_share(check_reads, world, rank):
+    """Porechop checks the FIRST `check_reads` reads of the input (porechop.py:224-273).  With the
+    input sharded contiguously, rank r holds global reads [lo_r, hi_r); its share of the check set is
+    the overlap with [0, check_reads).  Returns how many of the rank's leading reads to check."""
+    def share(n_local_lo, n_local_hi):
+        return max(0, min(n_local_hi, check_reads) - n_local_lo)
+    return share
+
+
+def reduce_presence(best_start, best_end, group=None):
+    """MAX all-reduce of the [S] + [S] presence tables (in place on a stacked copy)."""
+    table = torch.stack([best_start, best_end])
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(table, op=dist.ReduceOp.MAX, group=group)
+    return table[0], table[1]
+
+
+def gather_in_order(local, group=None):
+    """Concatenate per-rank 1-D/2-D tensors in rank order (= read order for contiguous shards)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return local
+    world = dist.get_world_size(group)
+    sizes = [torch.zeros(1, dtype=torch.int64, device=local.device) for _ in range(world)]
+    dist.all_gather(sizes, torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device), group=group)
+    mx = int(max(int(s.item()) for s in sizes))
+    pad = torch.zeros((mx,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[: local.shape[0]] = local
+    parts = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(parts, pad, group=group)
+    return torch.cat([p[: int(s.item())] for p, s in zip(parts, sizes)])

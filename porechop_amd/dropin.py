@@ -1,0 +1,190 @@
+"""Drop the GPU core under an UNCHANGED Porechop: batch what its three phase drivers are about
+to ask, one pair at a time, through ``adapter_alignment``.
+
+    import porechop.porechop as pp          # the reference package, unmodified
+    import porechop_amd.dropin as dropin
+    dropin.install(pp)
+    pp.main()
+
+``install`` replaces ``porechop.nanopore_read.adapter_alignment`` (the name ``align_adapter``
+resolves at call time, porechop/nanopore_read.py:476-477) by a memoising function and wraps
+
+    find_matching_adapter_sets      porechop/porechop.py:286-327   (phase A)
+    find_adapters_at_read_ends      porechop/porechop.py:438-514   (phase B)
+    find_adapters_in_read_middles   porechop/porechop.py:533-595   (phase C)
+
+so that, before the original function runs, every (window, adapter) pair it will request has
+been aligned in a few large GPU batches and sits in the memo.  Phase C's mask-and-realign loop
+(nanopore_read.py:210-243) is replayed here on the memoised results to discover which further
+alignments the reference will ask for; those are batched round by round.  The original
+functions then run untouched and only ever hit the memo (``stats()['misses'] == 0``).
+
+The backend is any object with ``align(pairs, scores) -> list[str]`` (pairs = [(read, adapter)]);
+the default is the GPU library.  There is no CPU backend in this package; tests inject the oracle.
+"""
+import functools
+
+
+class GpuBackend:
+    """(read, adapter) string pairs -> the reference's 7-field strings, through the C ABI."""
+
+    def __init__(self):
+        self._aligners = {}
+
+    def align(self, pairs, scores):
+        from .batch import Aligner, format_result
+        if not pairs:
+            return []
+        ads, idx = [], {}
+        items = []
+        for rd, ad in pairs:
+            if ad not in idx:
+                idx[ad] = len(ads)
+                ads.append(ad)
+            items.append((rd, idx[ad]))
+        al = Aligner(ads, tuple(scores))
+        try:
+            recs = al.align_pairs(items)
+        finally:
+            al.close()
+        return [format_result(r) for r in recs]
+
+
+class _State:
+    def __init__(self, backend):
+        self.backend = backend
+        self.memo = {}
+        self.hits = 0
+        self.misses = 0
+        self.batched = 0
+
+    def prefetch(self, pairs, scores):
+        key_scores = tuple(scores)
+        todo, seen = [], set()
+        for rd, ad in pairs:
+            k = (rd, ad, key_scores)
+            if k not in self.memo and k not in seen:
+                seen.add(k)
+                todo.append((rd, ad))
+        if not todo:
+            return
+        out = self.backend.align(todo, key_scores)
+        self.batched += len(todo)
+        for (rd, ad), res in zip(todo, out):
+            self.memo[(rd, ad, key_scores)] = res
+
+    def lookup(self, read_sequence, adapter_sequence, scoring_scheme_vals):
+        k = (read_sequence, adapter_sequence, tuple(scoring_scheme_vals))
+        r = self.memo.get(k)
+        if r is not None:
+            self.hits += 1
+            return r
+        self.misses += 1
+        r = self.backend.align([(read_sequence, adapter_sequence)], tuple(scoring_scheme_vals))[0]
+        self.memo[k] = r
+        return r
+
+
+_state = None
+
+
+def stats():
+    return {"hits": _state.hits, "misses": _state.misses, "batched": _state.batched,
+            "entries": len(_state.memo)} if _state else {}
+
+
+def _parse(result):
+    # porechop/nanopore_read.py:476-491 (align_adapter)
+    parts = result.split(',')
+    read_start = int(parts[0])
+    if read_start == -1:
+        return 0.0, 0.0, -1, 0
+    return float(parts[6]), float(parts[5]), read_start, int(parts[1]) + 1
+
+
+def install(pp, backend=None):
+    """pp: the imported (unchanged) ``porechop.porechop`` module.  Returns the state object."""
+    global _state
+    import importlib
+    nr = importlib.import_module(pp.__name__.rsplit('.', 1)[0] + '.nanopore_read')
+    st = _State(backend if backend is not None else GpuBackend())
+    _state = st
+    nr.adapter_alignment = st.lookup
+
+    orig_a = pp.find_matching_adapter_sets
+    orig_b = pp.find_adapters_at_read_ends
+    orig_c = pp.find_adapters_in_read_middles
+
+    @functools.wraps(orig_a)
+    def find_matching_adapter_sets(check_reads, verbosity, end_size, scoring_scheme_vals, *args, **kw):
+        pairs = []
+        search = [a for a in pp.ADAPTERS if '(full sequence)' not in a.name]      # porechop.py:296
+        for read in check_reads:
+            start, end = read.seq[:end_size], read.seq[-end_size:]                # nanopore_read.py:155,160
+            for s in search:
+                if s.start_sequence:
+                    pairs.append((start, s.start_sequence[1]))
+                if s.end_sequence:
+                    pairs.append((end, s.end_sequence[1]))
+        st.prefetch(pairs, scoring_scheme_vals)
+        return orig_a(check_reads, verbosity, end_size, scoring_scheme_vals, *args, **kw)
+
+    @functools.wraps(orig_b)
+    def find_adapters_at_read_ends(reads, matching_sets, verbosity, end_size, extra_trim_size, end_threshold,
+                                   scoring_scheme_vals, *args, **kw):
+        pairs = []
+        for read in reads:
+            start, end = read.seq[:end_size], read.seq[-end_size:]                # nanopore_read.py:174,196
+            for s in matching_sets:
+                if s.start_sequence:
+                    pairs.append((start, s.start_sequence[1]))
+                if s.end_sequence:
+                    pairs.append((end, s.end_sequence[1]))
+        st.prefetch(pairs, scoring_scheme_vals)
+        return orig_b(reads, matching_sets, verbosity, end_size, extra_trim_size, end_threshold,
+                      scoring_scheme_vals, *args, **kw)
+
+    @functools.wraps(orig_c)
+    def find_adapters_in_read_middles(reads, matching_sets, verbosity, middle_threshold, extra_trim_good_side,
+                                      extra_trim_bad_side, scoring_scheme_vals, *args, **kw):
+        adapters = []                                                             # porechop.py:541-548
+        for ms in matching_sets:
+            if ms.start_sequence:
+                adapters.append(ms.start_sequence[1])
+            if ms.end_sequence:
+                if (not ms.start_sequence) or ms.end_sequence[1] != ms.start_sequence[1]:
+                    adapters.append(ms.end_sequence[1])
+        key_scores = tuple(scoring_scheme_vals)
+        seqs = [r.get_seq_with_start_end_adapters_trimmed() for r in reads]       # nanopore_read.py:216
+        # round 0: every adapter against every unmasked trimmed read
+        st.prefetch([(s, a) for s in seqs for a in adapters], scoring_scheme_vals)
+        # replay nanopore_read.py:217-243 on the memo to learn what else will be asked
+        active = []                       # [masked_seq, adapter index] of reads still in the loop
+        for s in seqs:
+            active.append([s, 0])
+        while active:
+            need, nxt = [], []
+            for item in active:
+                masked, ai = item
+                while ai < len(adapters):
+                    res = st.memo.get((masked, adapters[ai], key_scores))
+                    if res is None:
+                        need.append((masked, adapters[ai]))
+                        break
+                    full, _, rs, re = _parse(res)
+                    if full >= middle_threshold:
+                        masked = masked[:rs] + '-' * (re - rs) + masked[re:]
+                    else:
+                        ai += 1
+                item[0], item[1] = masked, ai
+                if ai < len(adapters):
+                    nxt.append(item)
+            st.prefetch(need, scoring_scheme_vals)
+            active = nxt
+        return orig_c(reads, matching_sets, verbosity, middle_threshold, extra_trim_good_side,
+                      extra_trim_bad_side, scoring_scheme_vals, *args, **kw)
+
+    pp.find_matching_adapter_sets = find_matching_adapter_sets
+    pp.find_adapters_at_read_ends = find_adapters_at_read_ends
+    pp.find_adapters_in_read_middles = find_adapters_in_read_middles
+    return st

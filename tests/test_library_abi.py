@@ -16,6 +16,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def declared_symbols():
     hdr = open(os.path.join(REPO, "include", "porechop_amd.h")).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    hdr = "\n".join(l for l in hdr.split("\n") if not l.lstrip().startswith("#"))
     names = re.findall(r"\b([A-Za-z_][A-Za-z0-9_]*)\s*\([^;{]*\)\s*;", hdr)
     return sorted(set(names))
 

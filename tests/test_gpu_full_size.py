@@ -1,0 +1,109 @@
+"""BASELINE-size runs (the bench's own workload, 1 M x 8 kb reads with 1 % chimeras), checked through
+properties that do not need the oracle to run the whole set:
+  * a random sample of reads goes through the reference's sequential logic driven by the oracle and
+    must agree on trims and middle hits;
+  * determinism: a second pass over the same resident batch reproduces every output bit;
+  * chunked vs whole-window score pass: the same reads scanned as a small batch (which triggers the
+    column-chunked pass) and as part of the big batch (which does not) give identical records;
+  * planted structure: ~90 % start trims, ~50 % end trims, middle-hit reads ~ the chimera fraction.
+Also the end-trim-only shape of BASELINE configs[1] at 100 k reads."""
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from tests import ref_pipeline
+from tests.golden_io import load_panel
+
+pytestmark = pytest.mark.gpu
+
+
+def panel_sets():
+    from porechop_amd.pipeline import AdapterSet
+    return [AdapterSet(a["name"], tuple(a["start"]) if a["start"] else None, tuple(a["end"]) if a["end"] else None)
+            for a in load_panel()]
+
+
+def run_all(pl, reads, n_check):
+    check = torch.arange(n_check, device="cuda")
+    bs, be = pl.phase_a(reads, check)
+    matching = pl.matching_sets(bs, be)
+    st, et = pl.phase_b(reads, matching)
+    hits = pl.phase_c(reads, st, et, matching)
+    pl.aligner.sync()
+    return matching, st, et, hits
+
+
+def host_seq(reads, r):
+    o, n = int(reads.off[r]), int(reads.length[r])
+    return reads.arena[o:o + n].cpu().numpy().tobytes().decode()
+
+
+@pytest.mark.parametrize("n_reads,chimera", [(1_000_000, 0.01)])
+def test_config4_full_size_properties(oracle, n_reads, chimera):
+    from porechop_amd.pipeline import Pipeline, ScanParams, DeviceReads
+    from porechop_amd.synth import make_reads
+    p = ScanParams()
+    pl = Pipeline(panel_sets(), p)
+    reads = make_reads(n_reads, 8000, seed=3, start_frac=0.9, end_frac=0.5, chimera_frac=chimera)
+    matching, st, et, hits = run_all(pl, reads, p.check_reads)
+    names = [pl.sets[i].name for i in matching]
+    assert "SQK-NSK007" in names
+
+    # planted structure
+    assert 0.85 < float((st > 0).float().mean()) < 0.95
+    assert 0.42 < float((et > 0).float().mean()) < 0.58
+    hit_reads = torch.unique(hits.read).numel()
+    assert 0.6 * chimera * n_reads < hit_reads < 1.4 * chimera * n_reads
+
+    # determinism (same resident inputs -> same bits)
+    matching2, st2, et2, hits2 = run_all(pl, reads, p.check_reads)
+    assert matching2 == matching and torch.equal(st, st2) and torch.equal(et, et2)
+    for a, b in ((hits.read, hits2.read), (hits.adapter, hits2.adapter), (hits.start, hits2.start), (hits.end, hits2.end)):
+        assert torch.equal(a, b)
+
+    # a sample through the reference's sequential logic (oracle-driven), incl. reads with middle hits
+    rng = random.Random(11)
+    sample = rng.sample(range(n_reads), 24) + [int(x) for x in torch.unique(hits.read)[:24].cpu()]
+    got = {}
+    for r, a, s, e in zip(hits.read.cpu().tolist(), hits.adapter.cpu().tolist(), hits.start.cpu().tolist(), hits.end.cpu().tolist()):
+        got.setdefault(r, []).append((a, s, e))
+    stl, etl = st.cpu().tolist(), et.cpu().tolist()
+    for r in sample:
+        seq = host_seq(reads, r)
+        assert (stl[r], etl[r]) == ref_pipeline.phase_b(oracle.adapter_alignment, seq, pl.sets, matching, p), r
+        want = [(a, s, e) for a, s, e, _ in ref_pipeline.phase_c(oracle.adapter_alignment, seq, stl[r], etl[r], pl.middle_adapters, p)]
+        assert got.get(r, []) == want, r
+
+    # the same reads as a small batch: the score pass is cut into column chunks there
+    sub = torch.tensor(sorted(set(sample)), device="cuda")
+    small = DeviceReads(reads.arena, reads.off[sub], reads.length[sub])
+    st_s, et_s = pl.phase_b(small, matching)
+    hits_s = pl.phase_c(small, st_s, et_s, matching)
+    pl.aligner.sync()
+    assert torch.equal(st_s, st[sub]) and torch.equal(et_s, et[sub])
+    got_s = {}
+    for r, a, s, e in zip(hits_s.read.cpu().tolist(), hits_s.adapter.cpu().tolist(), hits_s.start.cpu().tolist(), hits_s.end.cpu().tolist()):
+        got_s.setdefault(int(sub[r]), []).append((a, s, e))
+    assert got_s == {r: v for r, v in got.items() if r in set(sub.cpu().tolist())}
+    pl.close()
+
+
+def test_config2_end_trim_only_100k(oracle):
+    """BASELINE configs[1]: 100 k reads, end trim only (--no_split): phases A + B."""
+    from porechop_amd.pipeline import Pipeline, ScanParams
+    from porechop_amd.synth import make_reads
+    p = ScanParams()
+    pl = Pipeline(panel_sets(), p)
+    reads = make_reads(100_000, 8000, seed=1, start_frac=0.9, end_frac=0.5, chimera_frac=0.0)
+    bs, be = pl.phase_a(reads, torch.arange(p.check_reads, device="cuda"))
+    matching = pl.matching_sets(bs, be)
+    st, et = pl.phase_b(reads, matching)
+    pl.aligner.sync()
+    assert "SQK-NSK007" in [pl.sets[i].name for i in matching]
+    stl, etl = st.cpu().tolist(), et.cpu().tolist()
+    rng = random.Random(5)
+    for r in rng.sample(range(100_000), 64):
+        assert (stl[r], etl[r]) == ref_pipeline.phase_b(oracle.adapter_alignment, host_seq(reads, r), pl.sets, matching, p), r
+    pl.close()

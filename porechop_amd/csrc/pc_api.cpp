@@ -20,6 +20,7 @@
 
 #include "../../include/porechop_amd.h"
 #include "pc_bounds.h"
+#include "pc_jit.h"
 #include "pc_kernels.h"
 
 #define PC_VERSION "porechop_amd 0.1 (gfx950)"
@@ -429,8 +430,38 @@ int pc_scan_device(pc_ctx *c, const void *d_arena, const int64_t *d_win_off, con
             a.ad_span = c->d_ad_span.as<int32_t>();
             int grid = grid_for(c, g, g.tile_count * (size_t)chunks, 1, nullptr);
             {
+                // tiles of one job (= one adapter pair) are contiguous: a run-time specialised
+                // kernel per pair when hiprtc can provide one, the generic kernel otherwise
                 ScopedTimer tm(c, stream, 0, np);
-                if ((rc = pck::launch_score(a, g.rows, g.pad, grid, stream))) return PC_ERR_NO_DEVICE;
+                size_t i = 0;
+                while (i < g.tile_count) {
+                    const pck::Tile &t0 = c->tiles[g.tile_begin + i];
+                    size_t e = i + 1;
+                    while (e < g.tile_count && c->tiles[g.tile_begin + e].adapter_lo == t0.adapter_lo &&
+                           c->tiles[g.tile_begin + e].adapter_hi == t0.adapter_hi)
+                        ++e;
+                    pcj::Spec *sp = g.rows ? pcj::get(c->device, c->adapters[t0.adapter_lo], c->adapters[t0.adapter_hi],
+                                                      c->match, c->mismatch, c->gap_open, c->gap_extend)
+                                           : nullptr;
+                    const int sub_grid = (int)std::min<size_t>((size_t)grid, (e - i) * (size_t)chunks);
+                    if (sp) {
+                        pcj::SpecArgs sa;
+                        memset(&sa, 0, sizeof(sa));
+                        sa.arena = a.arena; sa.win_off = a.win_off; sa.win_len = a.win_len;
+                        sa.tiles = a.tiles + i; sa.ntiles = (int32_t)(e - i);
+                        sa.out = a.out; sa.fin_scratch = c->d_fin.p;
+                        sa.gap_open = c->gap_open; sa.gap_extend = c->gap_extend;
+                        sa.chunks = chunks; sa.chunk_len = a.chunk_len;
+                        sa.span = std::max(c->ad_span[t0.adapter_lo], c->ad_span[t0.adapter_hi]);
+                        sa.err = a.err;
+                        if (pcj::launch(sp, sa, sub_grid, stream)) return PC_ERR_NO_DEVICE;
+                    } else {
+                        pck::ScanArgs b = a;
+                        b.tiles = a.tiles + i; b.ntiles = (int32_t)(e - i);
+                        if ((rc = pck::launch_score(b, g.rows, g.pad, sub_grid, stream))) return PC_ERR_NO_DEVICE;
+                    }
+                    i = e;
+                }
             }
             // plan the bounded windows
             pck::PlanArgs pl;

@@ -1,0 +1,187 @@
+// pc_jit.cpp -- run-time specialisation of the score-only scan kernel for one adapter pair.
+//
+// hiprtc is loaded with dlopen (no link-time dependency); if it is missing, or a compile fails,
+// pcj::get() returns null and the caller keeps using the ahead-of-time generic kernels -- still
+// the GPU, only 11 instead of 8 packed ops per cell pair.  PC_DISABLE_JIT=1 forces that path.
+#include "pc_jit.h"
+
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "pc_jit_source.h"
+
+namespace pcj {
+
+namespace {
+
+typedef struct _hiprtcProgram *hiprtcProgram;
+typedef int hiprtcResult;
+struct Rtc {
+    void *lib = nullptr;
+    hiprtcResult (*CreateProgram)(hiprtcProgram *, const char *, const char *, int, const char *const *, const char *const *) = nullptr;
+    hiprtcResult (*CompileProgram)(hiprtcProgram, int, const char *const *) = nullptr;
+    hiprtcResult (*GetProgramLogSize)(hiprtcProgram, size_t *) = nullptr;
+    hiprtcResult (*GetProgramLog)(hiprtcProgram, char *) = nullptr;
+    hiprtcResult (*GetCodeSize)(hiprtcProgram, size_t *) = nullptr;
+    hiprtcResult (*GetCode)(hiprtcProgram, char *) = nullptr;
+    hiprtcResult (*DestroyProgram)(hiprtcProgram *) = nullptr;
+    bool ok = false;
+};
+
+Rtc &rtc()
+{
+    static Rtc r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char *names[] = {"libhiprtc.so.7", "libhiprtc.so", "libhiprtc.so.6"};
+        for (const char *n : names) { r.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL); if (r.lib) break; }
+        if (!r.lib) return;
+#define PC_SYM(field, sym) *(void **)(&r.field) = dlsym(r.lib, sym); if (!r.field) return;
+        PC_SYM(CreateProgram, "hiprtcCreateProgram")
+        PC_SYM(CompileProgram, "hiprtcCompileProgram")
+        PC_SYM(GetProgramLogSize, "hiprtcGetProgramLogSize")
+        PC_SYM(GetProgramLog, "hiprtcGetProgramLog")
+        PC_SYM(GetCodeSize, "hiprtcGetCodeSize")
+        PC_SYM(GetCode, "hiprtcGetCode")
+        PC_SYM(DestroyProgram, "hiprtcDestroyProgram")
+#undef PC_SYM
+        r.ok = true;
+    });
+    return r;
+}
+
+int dna5(unsigned char c)
+{
+    switch (c) {
+        case 'A': case 'a': return 0;
+        case 'C': case 'c': return 1;
+        case 'G': case 'g': return 2;
+        case 'T': case 't': case 'U': case 'u': return 3;
+        default: return 4;
+    }
+}
+
+std::mutex g_mu;
+std::map<std::string, Spec *> g_cache;   // key -> spec (null = failed, do not retry)
+
+}  // namespace
+
+bool disabled()
+{
+    const char *e = getenv("PC_DISABLE_JIT");
+    return e && *e && *e != '0';
+}
+
+Spec *get(int device, const std::string &ad_lo, const std::string &ad_hi, int match, int mismatch, int gap_open,
+          int gap_extend)
+{
+    if (disabled()) return nullptr;
+    const int m_lo = (int)ad_lo.size(), m_hi = (int)ad_hi.size();
+    const int R = m_lo > m_hi ? m_lo : m_hi;
+    if (R < 2 || R > 48) return nullptr;    // register budget of the specialised kernel
+    char keybuf[64];
+    snprintf(keybuf, sizeof keybuf, "|%d|%d,%d,%d,%d", device, match, mismatch, gap_open, gap_extend);
+    const std::string key = ad_lo + "|" + ad_hi + keybuf;
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto it = g_cache.find(key);
+    if (it != g_cache.end()) return it->second;
+    g_cache[key] = nullptr;
+    Rtc &r = rtc();
+    if (!r.ok) {
+        static bool told = false;
+        if (!told) { fprintf(stderr, "porechop_amd: hiprtc not available, using the generic scan kernels\n"); told = true; }
+        return nullptr;
+    }
+    // letters per register row of each half (bottom-aligned): 0..4 = Dna5 code, 5 = padding row
+    std::vector<int> lo(R, 5), hi(R, 5);
+    for (int i = 0; i < m_lo; ++i) lo[R - m_lo + i] = dna5((unsigned char)ad_lo[i]);
+    for (int i = 0; i < m_hi; ++i) hi[R - m_hi + i] = dna5((unsigned char)ad_hi[i]);
+    std::vector<int> combos;             // distinct lo*6+hi
+    std::vector<int> combo_of_row(R);
+    for (int row = 0; row < R; ++row) {
+        const int c = lo[row] * 6 + hi[row];
+        int k = -1;
+        for (size_t i = 0; i < combos.size(); ++i) if (combos[i] == c) k = (int)i;
+        if (k < 0) { k = (int)combos.size(); combos.push_back(c); }
+        combo_of_row[row] = k;
+    }
+    const int K = ((int)combos.size() + 3) / 4 * 4;
+    if (K > 36) return nullptr;
+
+    std::string init;
+    for (int row = 0; row < R; ++row) { init += std::to_string(combo_of_row[row]); if (row + 1 < R) init += ","; }
+    const std::string dR = "-DPC_R=" + std::to_string(R), dK = "-DPC_K=" + std::to_string(K),
+                      dC = "-DPC_COMBO_INIT=" + init;
+    const char *opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", dR.c_str(), dK.c_str(), dC.c_str()};
+    hiprtcProgram prog = nullptr;
+    if (r.CreateProgram(&prog, kSpecSource, "pc_spec_score.hip", 0, nullptr, nullptr) != 0) return nullptr;
+    const hiprtcResult rc = r.CompileProgram(prog, 6, opts);
+    if (rc != 0) {
+        size_t n = 0;
+        r.GetProgramLogSize(prog, &n);
+        std::string log(n + 1, '\0');
+        if (n) r.GetProgramLog(prog, &log[0]);
+        fprintf(stderr, "porechop_amd: hiprtc compile failed (%d), using the generic kernels\n%s\n", rc, log.c_str());
+        r.DestroyProgram(&prog);
+        return nullptr;
+    }
+    size_t csz = 0;
+    r.GetCodeSize(prog, &csz);
+    std::vector<char> code(csz);
+    r.GetCode(prog, code.data());
+    r.DestroyProgram(&prog);
+
+    Spec *sp = new Spec();
+    sp->R = R; sp->K = K; sp->m_lo = m_lo; sp->m_hi = m_hi;
+    hipModule_t mod = nullptr;
+    hipFunction_t fn = nullptr;
+    if (hipModuleLoadData(&mod, code.data()) != hipSuccess || hipModuleGetFunction(&fn, mod, "pc_spec_score") != hipSuccess) {
+        fprintf(stderr, "porechop_amd: loading the specialised kernel failed, using the generic kernels\n");
+        delete sp;
+        return nullptr;
+    }
+    sp->module = mod; sp->function = fn;
+    // S table: [256 read bytes][K letter pairs] of packed (sub_lo - open) | (sub_hi - open) << 16
+    std::vector<uint32_t> tab((size_t)256 * K, 0);
+    auto term = [&](int letter, int code) -> int {
+        const int sub = letter == 5 ? 0 : (letter == code ? match : mismatch);
+        return sub - gap_open;
+    };
+    for (int b = 0; b < 256; ++b) {
+        const int code = dna5((unsigned char)b);
+        for (size_t k = 0; k < combos.size(); ++k) {
+            const int l = term(combos[k] / 6, code), h = term(combos[k] % 6, code);
+            tab[(size_t)b * K + k] = ((uint32_t)l & 0xFFFFu) | ((uint32_t)h << 16);
+        }
+    }
+    void *d = nullptr;
+    if (hipMalloc(&d, tab.size() * 4) != hipSuccess ||
+        hipMemcpy(d, tab.data(), tab.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
+        delete sp;
+        return nullptr;
+    }
+    sp->d_table = d;
+    g_cache[key] = sp;
+    return sp;
+}
+
+int launch(const Spec *sp, const SpecArgs &a, int grid, void *stream)
+{
+    SpecArgs args = a;
+    args.s_table = (const uint32_t *)sp->d_table;
+    args.m_lo = sp->m_lo; args.m_hi = sp->m_hi;
+    void *params[] = {&args};
+    const hipError_t e = hipModuleLaunchKernel((hipFunction_t)sp->function, (unsigned)grid, 1, 1, 64, 1, 1, 0,
+                                               (hipStream_t)stream, params, nullptr);
+    return e == hipSuccess ? 0 : -2;
+}
+
+}  // namespace pcj

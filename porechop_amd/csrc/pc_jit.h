@@ -1,0 +1,35 @@
+// pc_jit.h -- run-time specialised score-only scan kernels (see pc_jit_source.h / pc_jit.cpp).
+#pragma once
+#include <stdint.h>
+
+#include <string>
+
+#include "pc_kernels.h"
+
+namespace pcj {
+
+struct Spec {
+    int R = 0, K = 0, m_lo = 0, m_hi = 0;
+    void *module = nullptr, *function = nullptr;
+    void *d_table = nullptr;     // device [256][K] substitution-term table
+};
+
+// must match `struct SpecArgs` inside the JIT source
+struct SpecArgs {
+    const uint8_t *arena; const int64_t *win_off; const int32_t *win_len;
+    const pck::Tile *tiles; int32_t ntiles;
+    int32_t *out;
+    void *fin_scratch;
+    const uint32_t *s_table;
+    int32_t m_lo, m_hi, gap_open, gap_extend;
+    int32_t chunks, chunk_len, span;
+    uint32_t *err;
+};
+
+bool disabled();
+// nullptr when specialisation is unavailable for this pair (caller uses the generic kernels)
+Spec *get(int device, const std::string &ad_lo, const std::string &ad_hi, int match, int mismatch, int gap_open,
+          int gap_extend);
+int launch(const Spec *sp, const SpecArgs &a, int grid, void *stream);
+
+}  // namespace pcj

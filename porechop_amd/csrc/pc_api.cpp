@@ -440,9 +440,17 @@ int pc_scan_device(pc_ctx *c, const void *d_arena, const int64_t *d_win_off, con
                     while (e < g.tile_count && c->tiles[g.tile_begin + e].adapter_lo == t0.adapter_lo &&
                            c->tiles[g.tile_begin + e].adapter_hi == t0.adapter_hi)
                         ++e;
-                    pcj::Spec *sp = g.rows ? pcj::get(c->device, c->adapters[t0.adapter_lo], c->adapters[t0.adapter_hi],
-                                                      c->match, c->mismatch, c->gap_open, c->gap_extend)
-                                           : nullptr;
+                    // a hiprtc compile costs ~1 s and buys ~25 % of the scan: only for launches
+                    // big enough to pay for it (PC_JIT_MIN_CELLS overrides the 1e11-cell default)
+                    double est_cells = 0;
+                    for (size_t k = i; k < e; ++k)
+                        est_cells += (double)(c->tiles[g.tile_begin + k].count_lo + c->tiles[g.tile_begin + k].count_hi);
+                    est_cells *= (double)max_len * (double)std::max(1, g.rows);
+                    static const double min_cells = [] { const char *v = getenv("PC_JIT_MIN_CELLS"); return v ? atof(v) : 1e11; }();
+                    pcj::Spec *sp = (g.rows && est_cells >= min_cells)
+                                        ? pcj::get(c->device, c->adapters[t0.adapter_lo], c->adapters[t0.adapter_hi],
+                                                   c->match, c->mismatch, c->gap_open, c->gap_extend)
+                                        : nullptr;
                     const int sub_grid = (int)std::min<size_t>((size_t)grid, (e - i) * (size_t)chunks);
                     if (sp) {
                         pcj::SpecArgs sa;

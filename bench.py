@@ -179,13 +179,23 @@ def main():
             achieved = alg_bytes / per_launch_s / 1e9
             mean_m = float(np.mean([len(a[1]) for a in pl.middle_adapter_list(matching)]))
             cells = pairs_per_launch * mean_trim_len * mean_m
-            roof = {"bound": "hbm", "kernel": "scan_kernel<R,*,score-only> (whole-read pass 1)",
+            # VALU ceiling measured with tools/ubench_valu.hip: one wave64 packed-int16 op per ~4.3 cycles
+            # per SIMD = 39.3 T lane-ops/s; the specialised score kernel spends 8 ops per 2 cells
+            # (generic: 11), so its ceiling is 39.3e12 * 2 / 8 cell updates per second.
+            jit = os.environ.get("PC_DISABLE_JIT", "0") in ("", "0")
+            ops_per_pair = 8 if jit else 11
+            valu_peak_gcups = 39.3e12 * 2 / ops_per_pair / 1e9
+            roof = {"bound": "hbm",
+                    "kernel": ("pc_spec_score (run-time specialised score-only whole-read scan)" if jit
+                               else "scan_kernel<R,PAD,false> (generic score-only whole-read scan)"),
                     "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                     "traffic": None, "launches": int(launches), "avg_launch_ms": per_launch_s * 1e3,
                     "algorithmic_bytes_per_launch": alg_bytes,
                     "gcups": cells / per_launch_s / 1e9,
-                    "valu_note": "integer max-plus DP: 11 v_pk_*_i16 ops per 2 cells; VALU-bound by "
-                                 "construction (>=50 cells per algorithmic byte), see DESIGN.md"}
+                    "valu": {"achieved_gcups": cells / per_launch_s / 1e9, "peak_gcups": valu_peak_gcups,
+                             "frac": cells / per_launch_s / 1e9 / valu_peak_gcups, "ops_per_2_cells": ops_per_pair},
+                    "note": "integer max-plus DP, >= 50 cells per algorithmic byte: VALU-bound by construction; "
+                            "launch average includes the small mask-and-realign launches (DESIGN.md section 4)"}
         kern_ms = {k: v[0] / args.steps for k, v in timing.items()}
         out = {
             "metric": "reads/sec (and read-bp/sec) end+middle adapter scan, 8 kb reads",

@@ -86,7 +86,7 @@ Spec *get(int device, const std::string &ad_lo, const std::string &ad_hi, int ma
     if (disabled()) return nullptr;
     const int m_lo = (int)ad_lo.size(), m_hi = (int)ad_hi.size();
     const int R = m_lo > m_hi ? m_lo : m_hi;
-    if (R < 2 || R > 48) return nullptr;    // register budget of the specialised kernel
+    if (R < 2 || R > 36) return nullptr;    // register budget of the specialised kernel (2 waves per SIMD)
     char keybuf[64];
     snprintf(keybuf, sizeof keybuf, "|%d|%d,%d,%d,%d", device, match, mismatch, gap_open, gap_extend);
     const std::string key = ad_lo + "|" + ad_hi + keybuf;

@@ -96,36 +96,31 @@ extern "C" __global__ __launch_bounds__(64) void pc_spec_score(SpecArgs a)
 #pragma unroll
         for (int s = 32; s >= 1; s >>= 1) { const int o = __shfl_xor(nmax, s); nmax = o > nmax ? o : nmax; }
 
-        u32 cur_lo = 0, cur_hi = 0;
-        for (int j = 1; j <= nmax; ++j) {
-            if (((j - 1) & 3) == 0) {
-                const int kl = (j - 1 < n_lo) ? j - 1 : (n_lo > 0 ? ((n_lo - 1) & ~3) : 0);
-                cur_lo = *(const u32_unaligned *)(w_lo + kl);
-                if (!one_stream) {
-                    const int kh = (j - 1 < n_hi) ? j - 1 : (n_hi > 0 ? ((n_hi - 1) & ~3) : 0);
-                    cur_hi = *(const u32_unaligned *)(w_hi + kh);
+        // Read bytes are fetched a dword (4 columns) at a time, one dword ahead; the substitution
+        // terms S[] of column j+1 are fetched from the LDS table while column j computes (two
+        // register sets, the column loop statically unrolled by 4), so neither the global load nor
+        // the LDS read latency sits on the column's critical path.
+        auto load_dw = [&](const unsigned char *w, int n, int col) -> u32 {   // dword holding 0-based columns col..col+3
+            const int k = (col < n) ? col : (n > 0 ? ((n - 1) & ~3) : 0);      // finished streams re-read their last dword
+            return *(const u32_unaligned *)(w + k);
+        };
+        auto fetch_S = [&](u32 (&S)[K], u32 bl, u32 bh) {
+            const uint4 *row = s_tab + bl * (K / 4);
+#pragma clang loop unroll(full)
+            for (int q = 0; q < K / 4; ++q) { const uint4 v = row[q]; S[4*q] = v.x; S[4*q+1] = v.y; S[4*q+2] = v.z; S[4*q+3] = v.w; }
+            if (!one_stream) {
+                const uint4 *rowh = s_tab + bh * (K / 4);
+#pragma clang loop unroll(full)
+                for (int q = 0; q < K / 4; ++q) {
+                    const uint4 v = rowh[q];
+                    S[4*q]   = (S[4*q]   & 0xFFFFu) | (v.x & 0xFFFF0000u);
+                    S[4*q+1] = (S[4*q+1] & 0xFFFFu) | (v.y & 0xFFFF0000u);
+                    S[4*q+2] = (S[4*q+2] & 0xFFFFu) | (v.z & 0xFFFF0000u);
+                    S[4*q+3] = (S[4*q+3] & 0xFFFFu) | (v.w & 0xFFFF0000u);
                 }
             }
-            // substitution terms of this column for every letter pair of the adapter pair
-            u32 S[K];
-            {
-                const uint4 *row = s_tab + (cur_lo & 0xFF) * (K / 4);
-#pragma clang loop unroll(full)
-                for (int q = 0; q < K / 4; ++q) { const uint4 v = row[q]; S[4*q] = v.x; S[4*q+1] = v.y; S[4*q+2] = v.z; S[4*q+3] = v.w; }
-                if (!one_stream) {
-                    const uint4 *rowh = s_tab + (cur_hi & 0xFF) * (K / 4);
-#pragma clang loop unroll(full)
-                    for (int q = 0; q < K / 4; ++q) {
-                        const uint4 v = rowh[q];
-                        S[4*q]   = (S[4*q]   & 0xFFFFu) | (v.x & 0xFFFF0000u);
-                        S[4*q+1] = (S[4*q+1] & 0xFFFFu) | (v.y & 0xFFFF0000u);
-                        S[4*q+2] = (S[4*q+2] & 0xFFFFu) | (v.z & 0xFFFF0000u);
-                        S[4*q+3] = (S[4*q+3] & 0xFFFFu) | (v.w & 0xFFFF0000u);
-                    }
-                    cur_hi >>= 8;
-                }
-                cur_lo >>= 8;
-            }
+        };
+        auto column = [&](const int j, const u32 (&S)[K]) {
             const bool fin_lo = (j == n_lo) && tail_lo, fin_hi = (j == n_hi) && tail_hi;
             const bool any_fin = __any(fin_lo || fin_hi);
             if (any_fin && (fin_lo || fin_hi)) {
@@ -240,6 +235,23 @@ extern "C" __global__ __launch_bounds__(64) void pc_spec_score(SpecArgs a)
                 if (tr_lo && cl > bs_lo) { bs_lo = cl; bi_lo = a.m_lo; bj_lo = j; }
                 if (tr_hi && ch > bs_hi) { bs_hi = ch; bi_hi = a.m_hi; bj_hi = j; }
             }
+        };
+        u32 cur_lo = load_dw(w_lo, n_lo, 0), cur_hi = one_stream ? 0u : load_dw(w_hi, n_hi, 0);
+        u32 nxt_lo = load_dw(w_lo, n_lo, 4), nxt_hi = one_stream ? 0u : load_dw(w_hi, n_hi, 4);
+        u32 SA[K], SB[K];
+        fetch_S(SA, cur_lo & 0xFF, cur_hi & 0xFF);
+        for (int j0 = 1; j0 <= nmax; j0 += 4) {
+            fetch_S(SB, (cur_lo >> 8) & 0xFF, (cur_hi >> 8) & 0xFF);
+            column(j0, SA);
+            fetch_S(SA, (cur_lo >> 16) & 0xFF, (cur_hi >> 16) & 0xFF);
+            column(j0 + 1, SB);
+            fetch_S(SB, cur_lo >> 24, cur_hi >> 24);
+            column(j0 + 2, SA);
+            fetch_S(SA, nxt_lo & 0xFF, nxt_hi & 0xFF);
+            column(j0 + 3, SB);
+            cur_lo = nxt_lo; cur_hi = nxt_hi;
+            nxt_lo = load_dw(w_lo, n_lo, j0 + 7);
+            if (!one_stream) nxt_hi = load_dw(w_hi, n_hi, j0 + 7);
         }
         if (have_lo) { int4 o = {bs_lo, bi_lo, bj_lo + c0_lo, 0}; *(int4 *)(a.out + (p_lo * nchunks + chunk) * 4) = o; }
         if (have_hi) { int4 o = {bs_hi, bi_hi, bj_hi + c0_hi, 0}; *(int4 *)(a.out + (p_hi * nchunks + chunk) * 4) = o; }

@@ -15,11 +15,11 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $W/trace -o trace -- $CM
 find $W/trace -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats.csv \;
 # per-dispatch durations of our kernels only (start/end timestamps -> ns)
 KT=$(find $W/trace -name "*kernel_trace.csv" | head -1)
-if [ -n "$KT" ]; then head -1 $KT > $OUT/kernel_trace_scan.csv; grep -E "scan_kernel|plan_kernel" $KT >> $OUT/kernel_trace_scan.csv; fi
+if [ -n "$KT" ]; then head -1 $KT > $OUT/kernel_trace_scan.csv; grep -E "scan_kernel|plan_kernel|pc_spec" $KT >> $OUT/kernel_trace_scan.csv; fi
 for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $C --output-format csv -d $W/$C -o pmc -- $CMD > $OUT/bench_$C.log 2>&1
   CC=$(find $W/$C -name "*counter_collection.csv" | head -1)
-  if [ -n "$CC" ]; then head -1 $CC > $OUT/pmc_$C.csv; grep -E "scan_kernel|plan_kernel" $CC >> $OUT/pmc_$C.csv; fi
+  if [ -n "$CC" ]; then head -1 $CC > $OUT/pmc_$C.csv; grep -E "scan_kernel|plan_kernel|pc_spec" $CC >> $OUT/pmc_$C.csv; fi
 done
 for f in $OUT/bench_*.log; do tail -1 $f > $f.json; grep -v "^W2\|^I2\|^E2" $f | tail -5 > $f.tail; rm $f; done
 ls -la $OUT; du -sh $OUT

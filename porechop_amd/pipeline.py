@@ -170,14 +170,15 @@ class Pipeline:
             if s.end is not None:
                 jobs.append((self.seq_index[s.end[1]], eo, el)); where.append((si, 1))
         outs = self._scan_jobs(reads.arena, jobs, MODE_TRACE, self.p.end_size)
-        for (si, side), rec in zip(where, outs):
-            full, _ = _identities(rec)
-            full = torch.where(rec[:, 0] == -1, torch.zeros_like(full), full)
-            v = full.max()
-            if side == 0:
-                best_start[si] = torch.maximum(best_start[si], v)
-            else:
-                best_end[si] = torch.maximum(best_end[si], v)
+        # one vectorised reduction for all jobs (they all cover the same n check reads)
+        rec = torch.stack(outs)                                     # [J, n, 8]
+        m = rec[:, :, 5].to(torch.float64)
+        full = torch.round(100.0 * m / rec[:, :, 7].to(torch.float64) * 1e6) / 1e6
+        full = torch.where(rec[:, :, 0] == -1, torch.zeros_like(full), full).amax(dim=1)   # [J]
+        si = torch.tensor([w[0] for w in where], device=self.device)
+        side = torch.tensor([w[1] for w in where], device=self.device)
+        best_start.scatter_reduce_(0, si[side == 0], full[side == 0], reduce="amax")
+        best_end.scatter_reduce_(0, si[side == 1], full[side == 1], reduce="amax")
         self.stats["pairs_end"] += sum(int(j[1].shape[0]) for j in jobs)
         return best_start, best_end
 

@@ -125,7 +125,7 @@ extern "C" __global__ __launch_bounds__(64) void pc_spec_score(SpecArgs a)
             const bool any_fin = __any(fin_lo || fin_hi);
             if (any_fin && (fin_lo || fin_hi)) {
 #pragma clang loop unroll(full)
-                for (int r = 0; r < R; ++r) fin[r * 64 + lane] = make_uint2(T[r], U[r]);
+                for (int r = 0; r < R; ++r) fin[lane * R + r] = make_uint2(T[r], U[r]);
             }
             // ---- the column: 8 packed ops per row, hand-scheduled.  gfx950 needs a wait state
             // between dependent packed ops; each asm block issues row r's vertical chain
@@ -215,7 +215,7 @@ extern "C" __global__ __launch_bounds__(64) void pc_spec_score(SpecArgs a)
                 const int bh = one_stream ? bl : ((j - 1 < n_hi && n_hi > 0) ? w_hi[j - 1] : 0);
 #pragma unroll 1
                 for (int r = 0; r < R; ++r) {
-                    const uint2 old = (fin_lo || fin_hi) ? fin[r * 64 + lane] : make_uint2(0u, 0u);
+                    const uint2 old = (fin_lo || fin_hi) ? fin[lane * R + r] : make_uint2(0u, 0u);
                     const u32 s = (srow[bl * K + COMBO[r]] & 0xFFFFu) | (srow[bh * K + COMBO[r]] & 0xFFFF0000u);
                     const u32 d = pk_add(diag, s);
                     const u32 Hs = pk_max(pk_add(old.y, E2), old.x);

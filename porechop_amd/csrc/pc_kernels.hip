@@ -184,7 +184,8 @@ __global__ __launch_bounds__(64) void scan_kernel(ScanArgs a)
     extern __shared__ __attribute__((aligned(16))) uint2 dyn_lds[];   // GEN: consts + column state
     uint2 *lds_const = GEN ? dyn_lds : lds_const_s;
     uint2 *lds_col = dyn_lds + a.gen_max_rows;                        // GEN only: the DP column [row][lane]
-    // previous column kept for the (rare) last-column scan of the register variants: global scratch
+    // previous column kept for the (rare) last-column scan of the register variants: global scratch,
+    // [lane][row] so that the few lanes that finish at a given column write contiguous bytes
     uint2 *fin = GEN ? nullptr : (uint2 *)a.fin_scratch + (int64_t)blockIdx.x * RS * 64;
 
     const int lane = threadIdx.x;
@@ -383,7 +384,7 @@ __global__ __launch_bounds__(64) void scan_kernel(ScanArgs a)
                     // some pair reaches its last column: keep the previous column for the scan below
                     if (fin_lo || fin_hi) {
 #pragma clang loop unroll(full)
-                        for (int r = 0; r < R; ++r) fin[r * 64 + lane] = make_uint2(T[r], U[r]);
+                        for (int r = 0; r < R; ++r) fin[lane * RS + r] = make_uint2(T[r], U[r]);
                     }
                 }
                 u32 trw[(RS + 3) / 4];
@@ -399,7 +400,7 @@ __global__ __launch_bounds__(64) void scan_kernel(ScanArgs a)
                     u32 dq = k.A2, Tup = k.O2, Vprev = k.NEG2;
 #pragma unroll 1
                     for (int r = 0; r < R; ++r) {
-                        const uint2 old = (fin_lo || fin_hi) ? fin[r * 64 + lane] : make_uint2(0u, 0u);
+                        const uint2 old = (fin_lo || fin_hi) ? fin[lane * RS + r] : make_uint2(0u, 0u);
                         const uint2 c = lds_const[r];
                         const u32 z = pk_minu(pk_sub(h2, c.x), c.y);
                         const u32 d = pk_sub(dq, z);

@@ -118,11 +118,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # one process per GPU over RCCL (backend "nccl" IS RCCL on ROCm).  PC_DIST_BACKEND=gloo with more
+    # ranks than GPUs is only for functional checks of the N>1 path on a single-GPU box.
+    backend = os.environ.get("PC_DIST_BACKEND", "nccl")
+    dev_index = local_rank % max(1, torch.cuda.device_count())
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
 
     from porechop_amd.pipeline import Pipeline, ScanParams
     from porechop_amd.synth import make_reads
@@ -212,7 +219,7 @@ def main():
                        "kernel_ms_per_step": kern_ms},
             "roofline": roof,
         }
-        if args.cpu_seconds > 0 and world >= 1:
+        if args.cpu_seconds > 0 and world == 1:
             try:
                 out["cpu_baseline"] = cpu_baseline(reads, pl, matching, args.cpu_seconds, host_cores())
                 out["config"]["speedup_vs_cpu_baseline"] = reads_per_s / out["cpu_baseline"]["value"]

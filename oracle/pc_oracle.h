@@ -14,8 +14,8 @@ typedef struct {
     int failed; /* 1 => reference prints read_start == -1 (empty input) */
 } pc_oracle_result;
 
-/* returns 0 on success, -1 on allocation failure, -2 for gap_open == gap_extend (linear-gap
-   recurrence of the reference is not restated) */
+/* returns 0 on success, -1 on allocation failure.  gap_open == gap_extend follows the reference's
+   linear-gap (NeedlemanWunsch) dispatch. */
 int pc_oracle_align_raw(const char *read, int n, const char *adapter, int m,
                         int match, int mismatch, int gap_open, int gap_extend,
                         pc_oracle_result *res);

@@ -392,7 +392,10 @@ int pc_scan_device(pc_ctx *c, const void *d_arena, const int64_t *d_win_off, con
         a.ad_len = c->d_ad_len.as<int32_t>();
         a.tiles = c->d_tiles.as<pck::Tile>() + g.tile_begin;
         a.ntiles = (int32_t)g.tile_count;
-        a.match = c->match; a.mismatch = c->mismatch; a.gap_open = c->gap_open; a.gap_extend = c->gap_extend;
+        const bool linear = pcb::is_linear(c->gap_open, c->gap_extend);
+        a.match = c->match; a.mismatch = c->mismatch; a.gap_open = c->gap_open;
+        a.gap_extend = linear ? pcb::kLinearExtend : c->gap_extend;
+        a.init_extend = c->gap_extend; a.linear = linear ? 1 : 0;
         a.err = c->d_err.as<uint32_t>();
         a.slab = c->d_slab.as<uint32_t>();
         a.gen_max_rows = g.gen_max_rows;
@@ -447,7 +450,7 @@ int pc_scan_device(pc_ctx *c, const void *d_arena, const int64_t *d_win_off, con
                         est_cells += (double)(c->tiles[g.tile_begin + k].count_lo + c->tiles[g.tile_begin + k].count_hi);
                     est_cells *= (double)max_len * (double)std::max(1, g.rows);
                     static const double min_cells = [] { const char *v = getenv("PC_JIT_MIN_CELLS"); return v ? atof(v) : 1e11; }();
-                    pcj::Spec *sp = (g.rows && est_cells >= min_cells)
+                    pcj::Spec *sp = (g.rows && est_cells >= min_cells && !linear)
                                         ? pcj::get(c->device, c->adapters[t0.adapter_lo], c->adapters[t0.adapter_hi],
                                                    c->match, c->mismatch, c->gap_open, c->gap_extend)
                                         : nullptr;

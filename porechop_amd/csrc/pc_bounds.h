@@ -22,10 +22,9 @@
 //
 //  * trace bits of column k depend on columns k-1 and k, so  window = W + SPAN + 1.
 //
-// Preconditions (checked, not assumed): match > 0, match > mismatch, open < 0, ext < 0,
-// open != ext (the reference dispatches open == ext to a different, linear-gap recurrence,
-// seqan/align/global_alignment_unbanded.h:217-220), and every DP value must fit the packed
-// int16 lanes the kernels compute in.
+// Preconditions (checked, not assumed): match > 0, match > mismatch, open < 0, ext < 0, and every
+// DP value must fit the packed int16 lanes the kernels compute in.  open == ext is the
+// reference's linear-gap dispatch (seqan/align/global_alignment_unbanded.h:217-220), see below.
 #pragma once
 #include <stdint.h>
 
@@ -40,15 +39,25 @@ struct Bounds {
     int window;   // W + SPAN + 1
 };
 
+// gap_open == gap_extend selects the reference's LINEAR-gap recurrence (one matrix; ties prefer
+// diagonal, then vertical; no _correctTraceValue).  It is the affine recurrence with extension
+// made impossible: with H_ext = V_ext = "-infinity" every gap cell is an "open" from M, the
+// M-origin decisions (d >= max(H,V); V >= H) are exactly the linear ones, and the traceback takes
+// one gap cell per step.  The kernels therefore run the same code with kLinearExtend.
+constexpr int kLinearExtend = -12000;
+
+inline bool is_linear(int gap_open, int gap_extend) { return gap_open == gap_extend; }
+
 inline bool scores_supported(int match, int mismatch, int gap_open, int gap_extend, int max_m)
 {
     if (!(match > 0 && match > mismatch && gap_open < 0 && gap_extend < 0)) return false;
-    if (gap_open == gap_extend) return false;
     const long D = (long)match - mismatch;
     if (6 * D > 16000) return false;                         // spaced base codes 0..5*D in u16
-    if ((long)match * max_m > 8000) return false;            // upper range of M
-    if (2L * -gap_open + (long)max_m * -gap_extend > 8000) return false;   // lower range of M,H,V
-    if (-mismatch > 8000 || -gap_open > 8000 || -gap_extend > 8000) return false;
+    // linear mode adds -12000 to live values once per cell: keep them within +-4000
+    const long lim = is_linear(gap_open, gap_extend) ? 4000 : 8000;
+    if ((long)match * max_m > lim) return false;             // upper range of M
+    if (2L * -gap_open + (long)max_m * -gap_extend > lim) return false;   // lower range of M,H,V
+    if (-mismatch > lim || -gap_open > lim || -gap_extend > lim) return false;
     return true;
 }
 

@@ -36,7 +36,9 @@ struct ScanArgs {
     uint32_t *slab;              // trace scratch: [grid][slab_cols][NW][64] dwords
     int64_t slab_stride;         // dwords per block
     int32_t slab_cols;
-    int32_t match, mismatch, gap_open, gap_extend;
+    int32_t match, mismatch, gap_open, gap_extend;   // gap_extend = pcb::kLinearExtend in linear mode
+    int32_t init_extend;         // the scheme's real gap_extend (interior-window start state)
+    int32_t linear;              // gap_open == gap_extend: no _correctTraceValue at the end cell
     uint32_t *err;               // err[0] += 1 on any internal inconsistency (reported loudly by the host)
     uint32_t one2, two2, sixteen2;   // packed constants kept opaque to the compiler (set by the launcher)
     int32_t gen_max_rows;            // generic (LDS-state) variant: largest tile.rows in the launch

@@ -284,8 +284,8 @@ __global__ __launch_bounds__(64) void scan_kernel(ScanArgs a)
         // M = open + (i-1)*ext for adapter row i>=1, i.e. T = M + open.
         u32 T[RS], U[RS];
         auto init_T = [&](int r) -> u32 {
-            const int vl = (c0_lo > 0 && r >= pad_lo) ? 2 * a.gap_open + (r - pad_lo) * a.gap_extend : a.gap_open;
-            const int vh = (c0_hi > 0 && r >= pad_hi) ? 2 * a.gap_open + (r - pad_hi) * a.gap_extend : a.gap_open;
+            const int vl = (c0_lo > 0 && r >= pad_lo) ? 2 * a.gap_open + (r - pad_lo) * a.init_extend : a.gap_open;
+            const int vh = (c0_hi > 0 && r >= pad_hi) ? 2 * a.gap_open + (r - pad_hi) * a.init_extend : a.gap_open;
             return ((u32)vl & 0xFFFFu) | ((u32)vh << 16);
         };
         if constexpr (GEN) {
@@ -453,7 +453,7 @@ __global__ __launch_bounds__(64) void scan_kernel(ScanArgs a)
                     return dna5_code(w[col - 1]) == (int)codes[row - 1];
                 };
                 int tie_fix = 0;
-                if (b.J > 0 && b.I > 0) {
+                if (b.J > 0 && b.I > 0 && !a.linear) {
                     const int nb = nibf(b.J, b.I);
                     if ((nb & pcw::NIB_NOTDIAG) || b.tie) tie_fix = (nb & pcw::NIB_FROMH) ? 2 : 1;
                 }

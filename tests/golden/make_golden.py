@@ -39,7 +39,7 @@ REPO = os.path.dirname(os.path.dirname(HERE))
 REFERENCE = "/root/reference"
 sys.path.insert(0, REPO)
 
-from tests.pairgen import SCHEMES, case_stream  # noqa: E402
+from tests.pairgen import LINEAR_SCHEMES, SCHEMES, case_stream  # noqa: E402
 
 
 def stage_reference(tmp):
@@ -158,17 +158,18 @@ def synthetic(ref_so):
     lib.adapterAlignment.restype = ctypes.c_void_p
     lib.freeCString.argtypes = [ctypes.c_void_p]
     sets = []
-    for seed, count in [(101, 6000), (102, 6000)]:
+    for seed, count, schemes, tag in [(101, 6000, SCHEMES, "affine"), (102, 6000, SCHEMES, "affine"),
+                                      (103, 4000, LINEAR_SCHEMES, "linear")]:
         rng = random.Random(seed * 7 + 1)
         h = hashlib.sha1()
         outs = []
         for rd, ad in case_stream(seed, count):
-            sc = rng.choice(SCHEMES)
+            sc = rng.choice(schemes)
             h.update(("%s|%s|%r\n" % (rd, ad, sc)).encode())
             p = lib.adapterAlignment(rd.encode(), ad.encode(), *sc)
             outs.append(ctypes.cast(p, ctypes.c_char_p).value.decode())
             lib.freeCString(p)
-        sets.append({"seed": seed, "count": count, "scheme_seed": seed * 7 + 1,
+        sets.append({"seed": seed, "count": count, "scheme_seed": seed * 7 + 1, "schemes": tag,
                      "inputs_sha1": h.hexdigest(), "results": outs})
     return sets
 

@@ -5,7 +5,7 @@ import json
 import os
 import random
 
-from tests.pairgen import SCHEMES, case_stream
+from tests.pairgen import LINEAR_SCHEMES, SCHEMES, case_stream
 
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
@@ -29,9 +29,10 @@ def load_synthetic():
     out = []
     for s in d["sets"]:
         rng = random.Random(s["scheme_seed"])
+        schemes = LINEAR_SCHEMES if s.get("schemes") == "linear" else SCHEMES
         h = hashlib.sha1()
         for (rd, ad), res in zip(case_stream(s["seed"], s["count"]), s["results"]):
-            sc = rng.choice(SCHEMES)
+            sc = rng.choice(schemes)
             h.update(("%s|%s|%r\n" % (rd, ad, sc)).encode())
             out.append((rd, ad, sc, res))
         assert h.hexdigest() == s["inputs_sha1"], "tests/pairgen.py drifted from the goldens"

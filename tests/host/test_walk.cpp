@@ -37,12 +37,15 @@ static void run_dp(const std::string &rd, const std::string &ad, int c0, int w, 
 {
     const int m = (int)ad.size();
     const int NEG = -(1 << 28);
+    const bool linear = (o == e);
+    const int e_real = e;
+    if (linear) e = -(1 << 20);      // the kernels' way of running the linear recurrence (pc_bounds.h)
     dp.n = w; dp.m = m;
     dp.nib.assign((size_t)(w + 1) * (m + 1), 0);
     dp.tie.assign((size_t)(w + 1) * (m + 1), 0);
     std::vector<int> M(m + 1), H(m + 1, NEG), V(m + 1, NEG);
     for (int i = 0; i <= m; ++i) M[i] = 0;
-    if (c0 > 0) for (int i = 1; i <= m; ++i) { M[i] = o + (i - 1) * e; V[i] = M[i]; }
+    if (c0 > 0) for (int i = 1; i <= m; ++i) { M[i] = o + (i - 1) * e_real; V[i] = M[i]; }
     dp.bestM = 0; dp.bestI = m; dp.bestJ = 0;
     for (int j = 1; j <= w; ++j) {
         int diag = M[0], upM = 0, upV = NEG;
@@ -67,8 +70,9 @@ static void run_dp(const std::string &rd, const std::string &ad, int c0, int w, 
     dp.Mlast_col = M;
 }
 
+static bool g_linear = false;
 static int tie_fix_of(const Dp &dp, int I, int J) {
-    if (I <= 0 || J <= 0) return 0;
+    if (I <= 0 || J <= 0 || g_linear) return 0;
     const int nb = dp.nib[(size_t)J * (dp.m + 1) + I];
     const int tie = dp.tie[(size_t)J * (dp.m + 1) + I];
     if ((nb & pcw::NIB_NOTDIAG) || tie) return (nb & pcw::NIB_FROMH) ? 2 : 1;
@@ -78,6 +82,7 @@ static int tie_fix_of(const Dp &dp, int I, int J) {
 static bool check(const std::string &rd, const std::string &ad, int a, int b, int o, int e, long &nwin)
 {
     const int n = (int)rd.size(), m = (int)ad.size();
+    g_linear = (o == e);
     pc_oracle_result R;
     if (pc_oracle_align_raw(rd.c_str(), n, ad.c_str(), m, a, b, o, e, &R) != 0) return true;
     Dp dp;
@@ -128,11 +133,12 @@ int main(int argc, char **argv)
 {
     const long cases = argc > 1 ? atol(argv[1]) : 20000;
     std::mt19937 rng(12345);
-    const int schemes[][4] = {{3, -6, -5, -2}, {1, -1, -3, -1}, {5, -4, -10, -1}, {2, -3, -5, -2}, {3, -6, -2, -5}, {1, -5, -1, -3}};
+    const int schemes[][4] = {{3, -6, -5, -2}, {1, -1, -3, -1}, {5, -4, -10, -1}, {2, -3, -5, -2}, {3, -6, -2, -5}, {1, -5, -1, -3},
+                              {3, -6, -5, -5}, {2, -3, -4, -4}, {1, -1, -1, -1}};
     const char *alpha[] = {"ACGT", "ACGT", "ACGTN", "AC", "ACGT-"};
     long bad = 0, nwin = 0;
     for (long it = 0; it < cases; ++it) {
-        const int *sc = schemes[rng() % 6];
+        const int *sc = schemes[rng() % 9];
         const int nl[] = {1, 2, 5, 20, 50, 150, 150, 151, 300, 700, 1500};
         const int ml[] = {1, 3, 8, 22, 24, 28, 28, 33, 50, 63, 111};
         int n = nl[rng() % 11], m = ml[rng() % 11];

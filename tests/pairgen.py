@@ -17,6 +17,14 @@ SCHEMES = [
     (1, -5, -1, -3),
 ]
 
+# gap_open == gap_extend: the reference switches to its linear-gap recurrence
+LINEAR_SCHEMES = [
+    (3, -6, -5, -5),
+    (2, -3, -4, -4),
+    (1, -1, -1, -1),
+    (5, -4, -2, -2),
+]
+
 # lengths only; sequences themselves are random (the real panel is exercised by the goldens)
 ADAPTER_LENS = [1, 3, 8, 22, 24, 24, 28, 28, 32, 33, 40, 50, 63, 64, 65, 68, 102, 111]
 READ_LENS = [1, 2, 5, 20, 50, 149, 150, 150, 150, 151, 300]

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 from tests.golden_io import comparable, load_synthetic
-from tests.pairgen import SCHEMES, random_case
+from tests.pairgen import LINEAR_SCHEMES, SCHEMES, random_case
 
 pytestmark = pytest.mark.gpu
 
@@ -140,13 +140,28 @@ def test_ragged_and_unaligned_windows(pa, oracle):
         assert pa.format_result(r) == oracle.adapter_alignment(arena[o:o + n], ads[i]), (o, n, ads[i])
 
 
+def test_linear_gap_schemes_vs_oracle(pa, oracle):
+    """gap_open == gap_extend: the reference's linear-gap dispatch (global_alignment_unbanded.h:217-220),
+    end windows and whole reads (two-pass)."""
+    rng = random.Random(606)
+    for sc in LINEAR_SCHEMES:
+        cases = [random_case(rng) for _ in range(3000)]
+        cases += [random_case(rng, n=rng.choice([900, 4000]), m=rng.choice([22, 28, 33])) for _ in range(40)]
+        got = run_batch(pa, cases, sc)
+        bad = [(rd, ad, g) for (rd, ad), g in zip(cases, got)
+               if comparable(g) != comparable(oracle.adapter_alignment(rd, ad, sc))]
+        assert not bad, (sc, len(bad), bad[:3])
+
+
 def test_unsupported_scores_fail_loudly(pa):
-    with pytest.raises(RuntimeError):
-        pa.Aligner(["ACGT"], scores=(3, -6, -5, -5))      # linear gaps: different reference recurrence
     with pytest.raises(RuntimeError):
         pa.Aligner(["ACGT"], scores=(3, -6, 5, -2))       # positive gap score
     with pytest.raises(RuntimeError):
-        pa.adapter_alignment("ACGT", "ACGT", [3, -6, -5, -5])
+        pa.Aligner(["ACGT"], scores=(3, 4, -5, -2))       # match <= mismatch
+    with pytest.raises(RuntimeError):
+        pa.Aligner(["ACGT" * 8], scores=(3000, -6, -5, -2))   # overflows the int16 lanes
+    with pytest.raises(RuntimeError):
+        pa.adapter_alignment("ACGT", "ACGT", [3, -6, 5, -2])
 
 
 def test_specialised_kernel_matches_generic(pa, oracle):

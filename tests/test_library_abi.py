@@ -43,7 +43,7 @@ def test_dropin_twin_exists_and_exports_reference_symbols():
 def test_score_scheme_gate():
     lib = porechop_amd.load_library()
     assert lib.pc_scores_supported(3, -6, -5, -2, 111) == 1      # Porechop default
-    assert lib.pc_scores_supported(3, -6, -5, -5, 28) == 0       # linear gaps: other recurrence
+    assert lib.pc_scores_supported(3, -6, -5, -5, 28) == 1       # linear gaps: the reference's NW dispatch
     assert lib.pc_scores_supported(3, -6, 5, -2, 28) == 0        # non-negative gap score
     assert lib.pc_scores_supported(3, 3, -5, -2, 28) == 0        # match <= mismatch
     assert lib.pc_scores_supported(300, -6, -5, -2, 111) == 0    # would overflow int16 lanes

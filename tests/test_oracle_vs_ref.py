@@ -6,7 +6,7 @@ import random
 import pytest
 
 from oracle.oracle import Reference
-from tests.pairgen import SCHEMES, random_case
+from tests.pairgen import LINEAR_SCHEMES, SCHEMES, random_case
 
 pytestmark = pytest.mark.skipif(not Reference.available(), reason="no compiled reference here")
 
@@ -16,7 +16,7 @@ def test_oracle_equals_live_reference(oracle):
     rng = random.Random(20260925)
     bad = []
     for _ in range(15000):
-        sc = rng.choice(SCHEMES)
+        sc = rng.choice(SCHEMES + LINEAR_SCHEMES)
         rd, ad = random_case(rng)
         a, b = oracle.adapter_alignment(rd, ad, sc), ref.adapter_alignment(rd, ad, sc)
         if a != b:

@@ -71,8 +71,9 @@ const char *pc_version(void);
 const char *pc_strerror(int code);
 
 /* 1 if (match, mismatch, gap_open, gap_extend) is handled exactly by the GPU path for adapters
- * up to max_adapter_len bases; 0 otherwise (gap_open == gap_extend, non-negative gap scores,
- * match <= mismatch, or magnitudes that overflow the int16 lanes). */
+ * up to max_adapter_len bases; 0 otherwise (non-negative gap scores, match <= mismatch, or
+ * magnitudes that overflow the int16 lanes).  gap_open == gap_extend is supported: it selects the
+ * reference's linear-gap recurrence (seqan/align/global_alignment_unbanded.h:217-220). */
 int pc_scores_supported(int match, int mismatch, int gap_open, int gap_extend, int max_adapter_len);
 
 /* device < 0: current device.  The context owns its stream-ordered scratch buffers. */

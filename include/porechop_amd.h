@@ -133,6 +133,28 @@ void pc_memo_clear(void);
 /* hits, misses (single-pair launches), entries */
 void pc_memo_stats(int64_t *hits, int64_t *misses, int64_t *entries);
 
+/* ------------------------------------------------------------------------------------------
+ * Part 3 -- host ingest (the row after the hot path): FASTA / FASTQ, plain or
+ * gzip, parsed as porechop/misc.py:60-168 does and normalised as NanoporeRead.__init__
+ * (porechop/nanopore_read.py:23-35: upper-case; U->T when U's outnumber T's; qualities padded with
+ * '+'), but into ONE packed arena + offset/length tables -- the inputs of the batch API above --
+ * instead of per-read Python tuples.  Host code only.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct pc_readset pc_readset;
+/* Always sets *out (so pc_readset_error can be read); free it with pc_readset_free. */
+int pc_readset_load(const char *path, pc_readset **out);
+void pc_readset_free(pc_readset *rs);
+const char *pc_readset_error(const pc_readset *rs);
+int64_t pc_readset_count(const pc_readset *rs);
+int pc_readset_is_fastq(const pc_readset *rs);
+/* reads back to back, 1 byte per base, followed by 64 bytes of 'N' padding; *bytes includes it */
+const char *pc_readset_arena(const pc_readset *rs, int64_t *bytes);
+const int64_t *pc_readset_offsets(const pc_readset *rs);
+const int32_t *pc_readset_lengths(const pc_readset *rs);
+const char *pc_readset_name(const pc_readset *rs, int64_t i);     /* full header, no leading marker */
+const char *pc_readset_quals(const pc_readset *rs, int64_t i);    /* FASTQ only */
+int pc_readset_is_rna(const pc_readset *rs, int64_t i);
+
 #ifdef __cplusplus
 }
 #endif

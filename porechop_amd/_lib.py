@@ -15,6 +15,9 @@ EXPORTS = [
     "pc_version", "pc_strerror", "pc_scores_supported", "pc_create", "pc_destroy",
     "pc_set_scores", "pc_set_adapters", "pc_align_batch_host", "pc_scan_device", "pc_sync",
     "pc_format_result", "pc_prefetch", "pc_memo_clear", "pc_memo_stats", "pc_set_timing", "pc_get_timing",
+    "pc_readset_load", "pc_readset_free", "pc_readset_error", "pc_readset_count", "pc_readset_is_fastq",
+    "pc_readset_arena", "pc_readset_offsets", "pc_readset_lengths", "pc_readset_name", "pc_readset_quals",
+    "pc_readset_is_rna",
 ]
 
 
@@ -76,6 +79,28 @@ def load_library():
     L.pc_format_result.restype = c_int
     L.pc_prefetch.argtypes = [c_vp, c_i64, c_vp, c_vp, ctypes.POINTER(c_cp), c_vp, c_i64, c_int, c_int, c_int, c_int]
     L.pc_prefetch.restype = c_int
+    L.pc_readset_load.argtypes = [c_cp, ctypes.POINTER(c_vp)]
+    L.pc_readset_load.restype = c_int
+    L.pc_readset_free.argtypes = [c_vp]
+    L.pc_readset_free.restype = None
+    L.pc_readset_error.argtypes = [c_vp]
+    L.pc_readset_error.restype = c_cp
+    L.pc_readset_count.argtypes = [c_vp]
+    L.pc_readset_count.restype = c_i64
+    L.pc_readset_is_fastq.argtypes = [c_vp]
+    L.pc_readset_is_fastq.restype = c_int
+    L.pc_readset_arena.argtypes = [c_vp, ctypes.POINTER(c_i64)]
+    L.pc_readset_arena.restype = c_vp
+    L.pc_readset_offsets.argtypes = [c_vp]
+    L.pc_readset_offsets.restype = c_vp
+    L.pc_readset_lengths.argtypes = [c_vp]
+    L.pc_readset_lengths.restype = c_vp
+    L.pc_readset_name.argtypes = [c_vp, c_i64]
+    L.pc_readset_name.restype = c_cp
+    L.pc_readset_quals.argtypes = [c_vp, c_i64]
+    L.pc_readset_quals.restype = c_cp
+    L.pc_readset_is_rna.argtypes = [c_vp, c_i64]
+    L.pc_readset_is_rna.restype = c_int
     L.pc_memo_clear.argtypes = []
     L.pc_memo_clear.restype = None
     L.pc_memo_stats.argtypes = [ctypes.POINTER(c_i64)] * 3

@@ -91,28 +91,36 @@ struct Lines {
     }
 };
 
-void add_read(pc_readset *rs, const char *name_b, const char *name_e, const std::string &seq, const char *q_b, const char *q_e)
+struct UpperTable {
+    unsigned char t[256];
+    UpperTable() { for (int i = 0; i < 256; ++i) t[i] = (unsigned char)((i >= 'a' && i <= 'z') ? i - 32 : i); }
+};
+const UpperTable kUpper;
+
+void add_read(pc_readset *rs, const char *name_b, const char *name_e, const char *seq_b, const char *seq_e,
+              const char *q_b, const char *q_e)
 {
     // NanoporeRead.__init__: upper(); if count('U') > count('T'): U -> T
+    const size_t n = (size_t)(seq_e - seq_b);
     const size_t o = rs->arena.size();
-    rs->arena.resize(o + seq.size());
-    char *dst = rs->arena.data() + o;
+    rs->arena.resize(o + n);
+    unsigned char *dst = (unsigned char *)rs->arena.data() + o;
     size_t nu = 0, nt = 0;
-    for (size_t i = 0; i < seq.size(); ++i) {
-        const char c = (char)toupper((unsigned char)seq[i]);
+    for (size_t i = 0; i < n; ++i) {
+        const unsigned char c = kUpper.t[(unsigned char)seq_b[i]];
         dst[i] = c;
         nu += (c == 'U'); nt += (c == 'T');
     }
     const bool rna = nu > nt;
-    if (rna) for (size_t i = 0; i < seq.size(); ++i) if (dst[i] == 'U') dst[i] = 'T';
+    if (rna) for (size_t i = 0; i < n; ++i) if (dst[i] == 'U') dst[i] = 'T';
     rs->off.push_back((int64_t)o);
-    rs->len.push_back((int32_t)seq.size());
+    rs->len.push_back((int32_t)n);
     rs->rna.push_back(rna ? 1 : 0);
     rs->names.emplace_back(name_b, name_e);
     if (rs->fastq) {
-        std::string q(q_b, q_e);
-        if (q.size() < seq.size()) q.append(seq.size() - q.size(), '+');
-        rs->quals.push_back(std::move(q));
+        rs->quals.emplace_back(q_b, q_e);
+        std::string &q = rs->quals.back();
+        if (q.size() < n) q.append(n - q.size(), '+');
     }
 }
 
@@ -130,6 +138,7 @@ int pc_readset_load(const char *path, pc_readset **out)
     const char first = data.empty() ? '\0' : data[0];
     if (first != '>' && first != '@') { rs->error = "File is neither FASTA or FASTQ"; return PC_ERR_BAD_ARG; }
     rs->fastq = (first == '@');
+    rs->arena.reserve(data.size() / (rs->fastq ? 2 : 1) + 128);
     Lines ln{data.data(), data.data() + data.size()};
     const char *b, *e;
     if (rs->fastq) {
@@ -142,7 +151,7 @@ int pc_readset_load(const char *path, pc_readset **out)
                 return PC_ERR_BAD_ARG;
             }
             strip(sb, se); strip(qb, qe);
-            add_read(rs, nb, e, std::string(sb, se), qb, qe);
+            add_read(rs, nb, e, sb, se, qb, qe);
         }
     } else {
         std::string name, seq;
@@ -151,7 +160,7 @@ int pc_readset_load(const char *path, pc_readset **out)
             strip(b, e);
             if (b == e) continue;
             if (*b == '>') {
-                if (have && !name.empty()) add_read(rs, name.data(), name.data() + name.size(), seq, nullptr, nullptr);
+                if (have && !name.empty()) add_read(rs, name.data(), name.data() + name.size(), seq.data(), seq.data() + seq.size(), nullptr, nullptr);
                 seq.clear();
                 name.assign(b + 1, e);
                 have = true;
@@ -159,7 +168,7 @@ int pc_readset_load(const char *path, pc_readset **out)
                 seq.append(b, e);
             }
         }
-        if (have && !name.empty()) add_read(rs, name.data(), name.data() + name.size(), seq, nullptr, nullptr);
+        if (have && !name.empty()) add_read(rs, name.data(), name.data() + name.size(), seq.data(), seq.data() + seq.size(), nullptr, nullptr);
     }
     rs->arena.insert(rs->arena.end(), 64, 'N');           // the kernels fetch a dword at a time
     return PC_OK;

@@ -14,13 +14,12 @@ def shard_bounds(n_items, world, rank):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def check_read_share(check_reads, world, rank):
+def check_read_share(check_reads, world, rank, n_total):
     """Porechop checks the FIRST `check_reads` reads of the input (porechop.py:224-273).  With the
-    input sharded contiguously, rank r holds global reads [lo_r, hi_r); its share of the check set is
-    the overlap with [0, check_reads).  Returns how many of the rank's leading reads to check."""
-    def share(n_local_lo, n_local_hi):
-        return max(0, min(n_local_hi, check_reads) - n_local_lo)
-    return share
+    input sharded contiguously (shard_bounds), rank r holds global reads [lo, hi): its share of the
+    check set is the overlap with [0, check_reads).  Returns how many of its leading reads to check."""
+    lo, hi = shard_bounds(n_total, world, rank)
+    return max(0, min(hi, check_reads) - lo)
 
 
 def reduce_presence(best_start, best_end, group=None):

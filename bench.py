@@ -203,6 +203,23 @@ def main():
                              "frac": cells / per_launch_s / 1e9 / valu_peak_gcups, "ops_per_2_cells": ops_per_pair},
                     "note": "integer max-plus DP, >= 50 cells per algorithmic byte: VALU-bound by construction; "
                             "launch average includes the small mask-and-realign launches (DESIGN.md section 4)"}
+            # HBM-side traffic of that kernel comes from the separately collected rocprofv3 --pmc passes
+            # of this same command (tools/profile_round.sh -> profiles/<round>_summary.json): FETCH_SIZE +
+            # WRITE_SIZE of one launch, KB as reported.  (The guide's x2 correction is for wide 16-B/lane
+            # streams; here lanes gather 4 B each and the kernel provably consumes 7.95 GB per launch
+            # against a reported FETCH_SIZE of 6.4 GB, so no doubling is applied.)
+            try:
+                import glob
+                summ = sorted(glob.glob(os.path.join(REPO, "profiles", "*_summary.json")))
+                if summ:
+                    with open(summ[-1]) as f:
+                        sj = json.load(f)
+                    kk = sj["kernels"].get("pc_spec_score" if jit else "")
+                    if kk and sj.get("reads_per_gpu") == args.reads and world == 1:
+                        roof["traffic"] = (kk["FETCH_SIZE_KB_largest_launch"] + kk["WRITE_SIZE_KB_largest_launch"]) * 1024.0
+                        roof["traffic_source"] = os.path.relpath(summ[-1], REPO) + " (largest launch; FETCH_SIZE + WRITE_SIZE)"
+            except Exception:
+                pass
         kern_ms = {k: v[0] / args.steps for k, v in timing.items()}
         out = {
             "metric": "reads/sec (and read-bp/sec) end+middle adapter scan, 8 kb reads",

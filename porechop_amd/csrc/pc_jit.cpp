@@ -69,6 +69,18 @@ int dna5(unsigned char c)
     }
 }
 
+// IEEE half bit pattern of a small integer (|v| <= 2048 is exact)
+uint32_t half_bits(int v)
+{
+    if (v == 0) return 0;
+    const uint32_t sign = v < 0 ? 0x8000u : 0u;
+    uint32_t a = (uint32_t)(v < 0 ? -v : v);
+    int e = 0;
+    while ((a >> (e + 1)) != 0) ++e;                 // floor(log2(a)), <= 11
+    const uint32_t mant = e <= 10 ? ((a << (10 - e)) & 0x3FFu) : ((a >> (e - 10)) & 0x3FFu);
+    return sign | ((uint32_t)(e + 15) << 10) | mant;
+}
+
 std::mutex g_mu;
 std::map<std::string, Spec *> g_cache;   // key -> spec (null = failed, do not retry)
 
@@ -87,8 +99,13 @@ Spec *get(int device, const std::string &ad_lo, const std::string &ad_hi, int ma
     const int m_lo = (int)ad_lo.size(), m_hi = (int)ad_hi.size();
     const int R = m_lo > m_hi ? m_lo : m_hi;
     if (R < 2 || R > 36) return nullptr;    // register budget of the specialised kernel (2 waves per SIMD)
+    // packed-fp16 variant (7 ops per cell pair, v_pk_maximum3_f16) when every DP value is an integer
+    // fp16 holds exactly; otherwise the packed-int16 variant (8 ops).  PC_JIT_INT16=1 forces the latter.
+    const char *force_int = getenv("PC_JIT_INT16");
+    const bool f16 = !(force_int && *force_int && *force_int != '0') && (long)match * R <= 1000 &&
+                     2L * -gap_open + (long)R * -gap_extend <= 1000 && -mismatch <= 1000;
     char keybuf[64];
-    snprintf(keybuf, sizeof keybuf, "|%d|%d,%d,%d,%d", device, match, mismatch, gap_open, gap_extend);
+    snprintf(keybuf, sizeof keybuf, "|%d|%d,%d,%d,%d|%d", device, match, mismatch, gap_open, gap_extend, f16 ? 1 : 0);
     const std::string key = ad_lo + "|" + ad_hi + keybuf;
     std::lock_guard<std::mutex> lk(g_mu);
     auto it = g_cache.find(key);
@@ -119,11 +136,11 @@ Spec *get(int device, const std::string &ad_lo, const std::string &ad_hi, int ma
     std::string init;
     for (int row = 0; row < R; ++row) { init += std::to_string(combo_of_row[row]); if (row + 1 < R) init += ","; }
     const std::string dR = "-DPC_R=" + std::to_string(R), dK = "-DPC_K=" + std::to_string(K),
-                      dC = "-DPC_COMBO_INIT=" + init;
-    const char *opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", dR.c_str(), dK.c_str(), dC.c_str()};
+                      dC = "-DPC_COMBO_INIT=" + init, dF = std::string("-DPC_F16=") + (f16 ? "1" : "0");
+    const char *opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", dR.c_str(), dK.c_str(), dC.c_str(), dF.c_str()};
     hiprtcProgram prog = nullptr;
     if (r.CreateProgram(&prog, kSpecSource, "pc_spec_score.hip", 0, nullptr, nullptr) != 0) return nullptr;
-    const hiprtcResult rc = r.CompileProgram(prog, 6, opts);
+    const hiprtcResult rc = r.CompileProgram(prog, 7, opts);
     if (rc != 0) {
         size_t n = 0;
         r.GetProgramLogSize(prog, &n);
@@ -140,7 +157,7 @@ Spec *get(int device, const std::string &ad_lo, const std::string &ad_hi, int ma
     r.DestroyProgram(&prog);
 
     Spec *sp = new Spec();
-    sp->R = R; sp->K = K; sp->m_lo = m_lo; sp->m_hi = m_hi;
+    sp->R = R; sp->K = K; sp->m_lo = m_lo; sp->m_hi = m_hi; sp->f16 = f16;
     hipModule_t mod = nullptr;
     hipFunction_t fn = nullptr;
     if (hipModuleLoadData(&mod, code.data()) != hipSuccess || hipModuleGetFunction(&fn, mod, "pc_spec_score") != hipSuccess) {
@@ -159,7 +176,8 @@ Spec *get(int device, const std::string &ad_lo, const std::string &ad_hi, int ma
         const int code = dna5((unsigned char)b);
         for (size_t k = 0; k < combos.size(); ++k) {
             const int l = term(combos[k] / 6, code), h = term(combos[k] % 6, code);
-            tab[(size_t)b * K + k] = ((uint32_t)l & 0xFFFFu) | ((uint32_t)h << 16);
+            tab[(size_t)b * K + k] = f16 ? (half_bits(l) | (half_bits(h) << 16))
+                                         : (((uint32_t)l & 0xFFFFu) | ((uint32_t)h << 16));
         }
     }
     void *d = nullptr;

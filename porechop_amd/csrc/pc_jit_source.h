@@ -20,6 +20,22 @@ namespace pcj {
 static const char *kSpecSource = R"PCJIT(
 typedef unsigned int u32;
 typedef long long i64;
+#if PC_F16
+// Packed FP16 variant: every DP value is a small integer (|v| <= 1002 by the host-side gate), which
+// fp16 represents and adds exactly, and gfx950 has a 3-input packed max (v_pk_maximum3_f16) where
+// the integer ISA only has 2-input ones: 7 instead of 8 packed ops per cell pair.
+typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ h16x2 SV(u32 x) { return __builtin_bit_cast(h16x2, x); }
+__device__ __forceinline__ u32 WV(h16x2 x) { return __builtin_bit_cast(u32, x); }
+__device__ __forceinline__ u32 pk_add(u32 a, u32 b) { return WV(SV(a) + SV(b)); }
+__device__ __forceinline__ u32 pk_max(u32 a, u32 b) { return WV(__builtin_elementwise_max(SV(a), SV(b))); }
+__device__ __forceinline__ u32 pack2(int v) { const h16x2 h = {(_Float16)v, (_Float16)v}; return WV(h); }
+__device__ __forceinline__ int lo16(u32 x) { return (int)(float)SV(x).x; }
+__device__ __forceinline__ int hi16(u32 x) { return (int)(float)SV(x).y; }
+#define PC_NEG (-1000)
+#define PC_ADD "v_pk_add_f16"
+#define PC_MAX "v_pk_max_f16"
+#else
 typedef short s16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ s16x2 SV(u32 x) { return __builtin_bit_cast(s16x2, x); }
 __device__ __forceinline__ u32 WV(s16x2 x) { return __builtin_bit_cast(u32, x); }
@@ -28,6 +44,10 @@ __device__ __forceinline__ u32 pk_max(u32 a, u32 b) { return WV(__builtin_elemen
 __device__ __forceinline__ u32 pack2(int v) { return ((u32)v & 0xFFFFu) | ((u32)v << 16); }
 __device__ __forceinline__ int lo16(u32 x) { return (int)(short)(x & 0xFFFFu); }
 __device__ __forceinline__ int hi16(u32 x) { return (int)(short)(x >> 16); }
+#define PC_NEG (-16384)
+#define PC_ADD "v_pk_add_u16"
+#define PC_MAX "v_pk_max_i16"
+#endif
 
 struct Tile { i64 win_lo, win_hi, out_lo, out_hi; int count_lo, count_hi, adapter_lo, adapter_hi, rows, pad_; };
 struct SpecArgs {
@@ -52,7 +72,7 @@ extern "C" __global__ __launch_bounds__(64) void pc_spec_score(SpecArgs a)
     const int lane = threadIdx.x;
     for (int i = lane; i < 256 * K / 4; i += 64) s_tab[i] = ((const uint4 *)a.s_table)[i];
     __syncthreads();
-    const u32 E2 = pack2(a.gap_extend), O2 = pack2(a.gap_open), NEG2 = pack2(-16384);
+    const u32 E2 = pack2(a.gap_extend), O2 = pack2(a.gap_open), NEG2 = pack2(PC_NEG);
     const int pad_lo = R - a.m_lo, pad_hi = R - a.m_hi;
     uint2 *fin = a.fin_scratch + (i64)blockIdx.x * R * 64;
     const int nchunks = a.chunks > 1 ? a.chunks : 1;
@@ -87,11 +107,11 @@ extern "C" __global__ __launch_bounds__(64) void pc_spec_score(SpecArgs a)
         for (int r = 0; r < R; ++r) {
             const int vl = (c0_lo > 0 && r >= pad_lo) ? 2 * a.gap_open + (r - pad_lo) * a.gap_extend : a.gap_open;
             const int vh = (c0_hi > 0 && r >= pad_hi) ? 2 * a.gap_open + (r - pad_hi) * a.gap_extend : a.gap_open;
-            T[r] = ((u32)vl & 0xFFFFu) | ((u32)vh << 16);
+            T[r] = (pack2(vl) & 0xFFFFu) | (pack2(vh) & 0xFFFF0000u);
             U[r] = NEG2;
         }
         int bs_lo = 0, bi_lo = a.m_lo, bj_lo = 0, bs_hi = 0, bi_hi = a.m_hi, bj_hi = 0;
-        if (chunk > 0) { bs_lo = -32768; bj_lo = -1; bs_hi = -32768; bj_hi = -1; }
+        if (chunk > 0) { bs_lo = -32768; bj_lo = -1; bs_hi = -32768; bj_hi = -1; }   // (m,0) belongs to chunk 0
         int nmax = n_lo > n_hi ? n_lo : n_hi;
 #pragma unroll
         for (int s = 32; s >= 1; s >>= 1) { const int o = __shfl_xor(nmax, s); nmax = o > nmax ? o : nmax; }
@@ -134,47 +154,80 @@ extern "C" __global__ __launch_bounds__(64) void pc_spec_score(SpecArgs a)
             // across consecutive blocks -- and hipcc has nothing to pad.
             {
                 constexpr int KP = 2;
-                u32 dh[R];
+                u32 dh[R];     // int16: max(d, H) of the rows in flight;  fp16: d of the rows in flight
                 // H of the new column is written straight into U[q] (its old value is dead once
                 // Hx is formed), T' straight into T[r] (last read two blocks earlier): no copies
                 auto ind_only = [&](int q, u32 diag) {
                     u32 dq, hx;
-                    asm volatile("v_pk_add_u16 %[hx], %[uq], %[e2]\n\t"
-                                 "v_pk_add_u16 %[dq], %[diag], %[s]\n\t"
-                                 "v_pk_max_i16 %[uq], %[hx], %[tq]\n\t"
+#if PC_F16
+                    asm volatile(PC_ADD " %[hx], %[uq], %[e2]\n\t"
+                                 PC_ADD " %[dq], %[diag], %[s]\n\t"
+                                 PC_MAX " %[uq], %[hx], %[tq]"
+                                 : [hx] "=&v"(hx), [dq] "=&v"(dh[q]), [uq] "+v"(U[q])
+                                 : [e2] "s"(E2), [diag] "v"(diag), [s] "v"(S[COMBO[q]]), [tq] "v"(T[q]));
+                    (void)dq;
+#else
+                    asm volatile(PC_ADD " %[hx], %[uq], %[e2]\n\t"
+                                 PC_ADD " %[dq], %[diag], %[s]\n\t"
+                                 PC_MAX " %[uq], %[hx], %[tq]\n\t"
                                  "s_nop 0\n\t"
-                                 "v_pk_max_i16 %[dhq], %[dq], %[uq]"
+                                 PC_MAX " %[dhq], %[dq], %[uq]"
                                  : [hx] "=&v"(hx), [dq] "=&v"(dq), [uq] "+v"(U[q]), [dhq] "=&v"(dh[q])
                                  : [e2] "s"(E2), [diag] "v"(diag), [s] "v"(S[COMBO[q]]), [tq] "v"(T[q]));
+#endif
                 };
 #pragma clang loop unroll(full)
                 for (int q = 0; q < KP && q < R; ++q) ind_only(q, q == 0 ? O2 : T[q - 1]);
                 u32 Tup = O2, Vprev = NEG2;
                 // two rows per asm statement (hipcc pads a wait state between dependent asm
                 // statements it cannot see into, so fewer, larger statements)
-#define PC_ROW_FULL(VP, TU, DIAG, SS, UQ, TQ, DHR, TN, DHQ, VS)                      \
-    "v_pk_add_u16 %[vx], " VP ", %[e2]\n\t"                                           \
-    "v_pk_add_u16 %[dq], " DIAG ", " SS "\n\t"                                        \
-    "v_pk_max_i16 " VS ", %[vx], " TU "\n\t"                                          \
-    "v_pk_add_u16 %[hx], " UQ ", %[e2]\n\t"                                           \
-    "v_pk_max_i16 %[mn], " DHR ", " VS "\n\t"                                         \
-    "v_pk_max_i16 " UQ ", %[hx], " TQ "\n\t"                                          \
-    "v_pk_add_u16 " TN ", %[mn], %[o2]\n\t"                                           \
-    "v_pk_max_i16 " DHQ ", %[dq], " UQ "\n\t"
+#if PC_F16
+                // 7 ops: Vx, Hx', Vs, d', M = max3(d, H, Vs), H', T'   (primed = row r+2)
+#define PC_ROW_FULL(VP, TU, DIAG, SS, UQ, TQ, DHR, UR, TN, DHQ, VS)                  \
+    PC_ADD " %[vx], " VP ", %[e2]\n\t"                                                \
+    PC_ADD " %[hx], " UQ ", %[e2]\n\t"                                                \
+    PC_MAX " " VS ", %[vx], " TU "\n\t"                                               \
+    PC_ADD " " DHQ ", " DIAG ", " SS "\n\t"                                           \
+    "v_pk_maximum3_f16 %[mn], " DHR ", " UR ", " VS "\n\t"                            \
+    PC_MAX " " UQ ", %[hx], " TQ "\n\t"                                               \
+    PC_ADD " " TN ", %[mn], %[o2]\n\t"
+#define PC_ROW_TAIL                                                                    \
+    PC_ADD " %[vx], %[vprev], %[e2]\n\t" "s_nop 0\n\t"                                 \
+    PC_MAX " %[vs0], %[vx], %[tup]\n\t" "s_nop 0\n\t"                                  \
+    "v_pk_maximum3_f16 %[mn], %[dhr0], %[ur0], %[vs0]\n\t" "s_nop 0\n\t"               \
+    PC_ADD " %[tn0], %[mn], %[o2]"
+#else
+                // 8 ops: Vx, d', Vs, Hx', M = max(max(d,H), Vs), H', T', max(d',H')
+#define PC_ROW_FULL(VP, TU, DIAG, SS, UQ, TQ, DHR, UR, TN, DHQ, VS)                  \
+    PC_ADD " %[vx], " VP ", %[e2]\n\t"                                                \
+    PC_ADD " %[dq], " DIAG ", " SS "\n\t"                                             \
+    PC_MAX " " VS ", %[vx], " TU "\n\t"                                               \
+    PC_ADD " %[hx], " UQ ", %[e2]\n\t"                                                \
+    PC_MAX " %[mn], " DHR ", " VS "\n\t"                                              \
+    PC_MAX " " UQ ", %[hx], " TQ "\n\t"                                               \
+    PC_ADD " " TN ", %[mn], %[o2]\n\t"                                                \
+    PC_MAX " " DHQ ", %[dq], " UQ "\n\t"
+#define PC_ROW_TAIL                                                                    \
+    PC_ADD " %[vx], %[vprev], %[e2]\n\t" "s_nop 0\n\t"                                 \
+    PC_MAX " %[vs0], %[vx], %[tup]\n\t" "s_nop 0\n\t"                                  \
+    PC_MAX " %[mn], %[dhr0], %[vs0]\n\t" "s_nop 0\n\t"                                 \
+    PC_ADD " %[tn0], %[mn], %[o2]"
+#endif
 #pragma clang loop unroll(full)
                 for (int r = 0; r < R; r += 2) {
                     u32 vx, mn, dq, hx, vs0, vs1;
+                    (void)dq;
                     if (r + 1 + KP < R) {
                         const int q = r + KP;
                         asm volatile(
-                            PC_ROW_FULL("%[vprev]", "%[tup]", "%[d0]", "%[s0]", "%[u0]", "%[t0]", "%[dhr0]", "%[tn0]", "%[dhq0]", "%[vs0]")
-                            PC_ROW_FULL("%[vs0]", "%[tn0]", "%[t0]", "%[s1]", "%[u1]", "%[t1]", "%[dhr1]", "%[tn1]", "%[dhq1]", "%[vs1]")
+                            PC_ROW_FULL("%[vprev]", "%[tup]", "%[d0]", "%[s0]", "%[u0]", "%[t0]", "%[dhr0]", "%[ur0]", "%[tn0]", "%[dhq0]", "%[vs0]")
+                            PC_ROW_FULL("%[vs0]", "%[tn0]", "%[t0]", "%[s1]", "%[u1]", "%[t1]", "%[dhr1]", "%[ur1]", "%[tn1]", "%[dhq1]", "%[vs1]")
                             : [vx] "=&v"(vx), [dq] "=&v"(dq), [hx] "=&v"(hx), [mn] "=&v"(mn), [vs0] "=&v"(vs0), [vs1] "=&v"(vs1),
                               [u0] "+v"(U[q]), [u1] "+v"(U[q + 1]), [tn0] "=&v"(T[r]), [tn1] "=&v"(T[r + 1]),
                               [dhq0] "=&v"(dh[q]), [dhq1] "=&v"(dh[q + 1])
                             : [vprev] "v"(Vprev), [tup] "v"(Tup), [e2] "s"(E2), [o2] "s"(O2), [d0] "v"(T[q - 1]),
                               [t0] "v"(T[q]), [t1] "v"(T[q + 1]), [s0] "v"(S[COMBO[q]]), [s1] "v"(S[COMBO[q + 1]]),
-                              [dhr0] "v"(dh[r]), [dhr1] "v"(dh[r + 1]));
+                              [dhr0] "v"(dh[r]), [dhr1] "v"(dh[r + 1]), [ur0] "v"(U[r]), [ur1] "v"(U[r + 1]));
                         Tup = T[r + 1]; Vprev = vs1;
                     } else {
                         // tail rows (and an odd last row): one row at a time
@@ -183,27 +236,23 @@ extern "C" __global__ __launch_bounds__(64) void pc_spec_score(SpecArgs a)
                             if (rr + KP < R) {
                                 const int q = rr + KP;
                                 asm volatile(
-                                    PC_ROW_FULL("%[vprev]", "%[tup]", "%[d0]", "%[s0]", "%[u0]", "%[t0]", "%[dhr0]", "%[tn0]", "%[dhq0]", "%[vs0]")
+                                    PC_ROW_FULL("%[vprev]", "%[tup]", "%[d0]", "%[s0]", "%[u0]", "%[t0]", "%[dhr0]", "%[ur0]", "%[tn0]", "%[dhq0]", "%[vs0]")
                                     : [vx] "=&v"(vx), [dq] "=&v"(dq), [hx] "=&v"(hx), [mn] "=&v"(mn), [vs0] "=&v"(vs0),
                                       [u0] "+v"(U[q]), [tn0] "=&v"(T[rr]), [dhq0] "=&v"(dh[q])
                                     : [vprev] "v"(Vprev), [tup] "v"(Tup), [e2] "s"(E2), [o2] "s"(O2), [d0] "v"(T[q - 1]),
-                                      [t0] "v"(T[q]), [s0] "v"(S[COMBO[q]]), [dhr0] "v"(dh[rr]));
+                                      [t0] "v"(T[q]), [s0] "v"(S[COMBO[q]]), [dhr0] "v"(dh[rr]), [ur0] "v"(U[rr]));
                             } else {
-                                asm volatile("v_pk_add_u16 %[vx], %[vprev], %[e2]\n\t"
-                                             "s_nop 0\n\t"
-                                             "v_pk_max_i16 %[vs0], %[vx], %[tup]\n\t"
-                                             "s_nop 0\n\t"
-                                             "v_pk_max_i16 %[mn], %[dhr0], %[vs0]\n\t"
-                                             "s_nop 0\n\t"
-                                             "v_pk_add_u16 %[tn0], %[mn], %[o2]"
+                                asm volatile(PC_ROW_TAIL
                                              : [vx] "=&v"(vx), [vs0] "=&v"(vs0), [mn] "=&v"(mn), [tn0] "=&v"(T[rr])
-                                             : [vprev] "v"(Vprev), [e2] "s"(E2), [tup] "v"(Tup), [dhr0] "v"(dh[rr]), [o2] "s"(O2));
+                                             : [vprev] "v"(Vprev), [e2] "s"(E2), [tup] "v"(Tup), [dhr0] "v"(dh[rr]),
+                                               [ur0] "v"(U[rr]), [o2] "s"(O2));
                             }
                             Tup = T[rr]; Vprev = vs0;
                         }
                     }
                 }
 #undef PC_ROW_FULL
+#undef PC_ROW_TAIL
             }
             if (any_fin) {
                 // last column of a pair: rolled re-run from the saved previous column, tracked

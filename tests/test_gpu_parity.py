@@ -202,8 +202,9 @@ for (a, b) in [(0, 1), (2, 3), (1, -1)]:
             assert porechop_amd.format_result(rec[n + i]) == o.adapter_alignment(r, ads[b]), (b, i)
 print("SPEC_OK")
 '''
-    env = dict(os.environ, PC_JIT_MIN_CELLS="1")
-    res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600,
-                         cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    assert "SPEC_OK" in res.stdout, res.stdout[-2000:] + res.stderr[-3000:]
-    assert "hiprtc" not in res.stderr, res.stderr[-2000:]
+    for int16 in ("0", "1"):      # packed-fp16 (7 ops, v_pk_maximum3_f16) and packed-int16 (8 ops) variants
+        env = dict(os.environ, PC_JIT_MIN_CELLS="1", PC_JIT_INT16=int16)
+        res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600,
+                             cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        assert "SPEC_OK" in res.stdout, res.stdout[-2000:] + res.stderr[-3000:]
+        assert "hiprtc" not in res.stderr, res.stderr[-2000:]

@@ -24,6 +24,9 @@ __global__ __launch_bounds__(256) void k(unsigned *out, int iters, unsigned s0, 
                 if (KIND == 7) asm volatile("v_pk_max_i16 %0, %0, %0" : "+v"(a[0]));   // fully dependent chain
                 if (KIND == 8) asm volatile("v_max3_i32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(a[(i + 1) & 7]), "v"(a[(i + 2) & 7]));
                 if (KIND == 9) asm volatile("v_pk_fma_f16 %0, %0, %1, %2" : "+v"(a[i]) : "v"(a[(i + 1) & 7]), "v"(a[(i + 2) & 7]));
+                if (KIND == 10) asm volatile("v_pk_maximum3_f16 %0, %0, %1, %2" : "+v"(a[i]) : "v"(a[(i + 1) & 7]), "v"(a[(i + 2) & 7]));
+                if (KIND == 11) asm volatile("v_pk_add_f16 %0, %0, %1" : "+v"(a[i]) : "s"(s0));
+                if (KIND == 12) asm volatile("v_pk_max_f16 %0, %0, %1" : "+v"(a[i]) : "v"(a[(i + 1) & 7]));
             }
         }
     }
@@ -61,6 +64,9 @@ int main()
         run<5>("v_max_i32 (v,v)", w);
         run<8>("v_max3_i32", w);
         run<9>("v_pk_fma_f16", w);
+        run<10>("v_pk_maximum3_f16", w);
+        run<11>("v_pk_add_f16 (v,s)", w);
+        run<12>("v_pk_max_f16 (v,v)", w);
         run<7>("v_pk_max_i16 dependent chain", w);
     }
     return 0;

@@ -400,6 +400,8 @@ int pc_scan_device(pc_ctx *c, const void *d_arena, const int64_t *d_win_off, con
         a.slab = c->d_slab.as<uint32_t>();
         a.gen_max_rows = g.gen_max_rows;
         a.fin_scratch = c->d_fin.as<uint32_t>();
+        a.ad_span = c->d_ad_span.as<int32_t>();
+        a.ad_window = c->d_ad_window.as<int32_t>();
         a.win_by_out = 0;
         size_t stride;
         if (!g.two_pass) {

@@ -45,6 +45,7 @@ struct ScanArgs {
     uint32_t *fin_scratch;           // [grid][rows*64*2] dwords: previous column kept for the last-column scan
     int32_t chunks, chunk_len;       // score-only pass: column chunks per tile (1 = whole window) and their length
     const int32_t *ad_span;          // [nadapters] warm-up columns (SPAN) for chunked passes
+    const int32_t *ad_window;        // [nadapters] W + SPAN + 1 (pass-2 windows; W = window - SPAN - 1)
 };
 
 // pass-2 planner: from the score-only pass's (score, I, J) build the bounded windows

@@ -320,6 +320,21 @@ __global__ __launch_bounds__(64) void scan_kernel(ScanArgs a)
             }
         };
 
+        // Forced-end windows (pass 2 of a whole-read scan) only need trace for the last W+2 columns:
+        // the traced path cannot reach further left (pc_bounds.h), the columns before it are only
+        // the SPAN warm-up that makes the values exact.  Those run the score-only column.
+        int notrace_upto = 0;
+        if (TRACE && a.force_row && a.ad_window) {
+            const int w_lo = a.ad_window[tile.adapter_lo] - a.ad_span[tile.adapter_lo] - 1;
+            const int w_hi = a.ad_window[tile.adapter_hi] - a.ad_span[tile.adapter_hi] - 1;
+            int t0 = 1 << 30;
+            if (have_lo) t0 = n_lo - w_lo - 2;
+            if (have_hi && n_hi - w_hi - 2 < t0) t0 = n_hi - w_hi - 2;
+#pragma unroll
+            for (int s = 32; s >= 1; s >>= 1) { const int o = __shfl_xor(t0, s); t0 = o < t0 ? o : t0; }
+            notrace_upto = t0 > 0 ? t0 : 0;
+        }
+
         u32 cur_lo = 0, cur_hi = 0;
         for (int j = 1; j <= nmax; ++j) {
             if (((j - 1) & 3) == 0) {
@@ -363,7 +378,7 @@ __global__ __launch_bounds__(64) void scan_kernel(ScanArgs a)
                     const u32 Mn = pk_max(d, g);
                     const u32 Tn = pk_add(Mn, k.O2);
                     const u32 t01 = pk_minu(d ^ g, k.ONE2);
-                    if constexpr (TRACE) {
+                    if (TRACE && j > notrace_upto) {
                         const u32 b0 = pk_minu(pk_sub(Hs, Hx), k.ONE2);
                         const u32 b1 = pk_minu(pk_sub(Vs, Vx), k.ONE2);
                         const u32 b2 = pk_minu(pk_sub(g, Vs), k.ONE2);
@@ -388,12 +403,16 @@ __global__ __launch_bounds__(64) void scan_kernel(ScanArgs a)
                     }
                 }
                 u32 trw[(RS + 3) / 4];
-                column_step<RS, PAD, TRACE>(T, U, h2, cs, cv, lds_const, k, trw, tie01);
-                Tlast = T[RS - 1];
-                if constexpr (TRACE) {
+                if (TRACE && j <= notrace_upto) {
+                    column_step<RS, PAD, false>(T, U, h2, cs, cv, lds_const, k, trw, tie01);
+                } else {
+                    column_step<RS, PAD, TRACE>(T, U, h2, cs, cv, lds_const, k, trw, tie01);
+                    if constexpr (TRACE) {
 #pragma unroll
-                    for (int w = 0; w < (RS + 3) / 4; ++w) trace_dst[w * 64] = trw[w];
+                        for (int w = 0; w < (RS + 3) / 4; ++w) trace_dst[w * 64] = trw[w];
+                    }
                 }
+                Tlast = T[RS - 1];
                 if (any_fin) {
                     // Rare, so it is a rolled re-run of the column from the saved state (same
                     // packed arithmetic) that also yields the d == max(H,V) flag of every row.
@@ -441,7 +460,9 @@ __global__ __launch_bounds__(64) void scan_kernel(ScanArgs a)
                 const uint8_t *w = hf ? w_hi : w_lo;
                 const u32 *codes = hf ? codes_hi : codes_lo;
                 const int nt = a.n_total ? a.n_total[p] : (hf ? n_hi : n_lo);
+                bool left_trace = false;
                 auto nibf = [&](int col, int row) -> int {
+                    if (col <= notrace_upto) { left_trace = true; return 0; }   // never expected (bound)
                     const int r = pad + row - 1;
                     const int wq = r >> 2;
                     const int rows_in_group = (rows - 4 * wq) < 4 ? (rows - 4 * wq) : 4;
@@ -460,6 +481,7 @@ __global__ __launch_bounds__(64) void scan_kernel(ScanArgs a)
                 pcw::Digest dg;
                 int err = pcw::walk(nibf, eqf, b.I, b.J, m, c0, nt, b.score, tie_fix, dg);
                 if (a.force_score && a.force_score[p] != b.score) err = 1;
+                if (left_trace) err = 1;
                 if (err) atomicAdd(a.err, 1u);
                 int4 o0 = {dg.read_start, dg.read_end, dg.adapter_start, dg.adapter_end};
                 int4 o1 = {dg.score, dg.matches, dg.aligned_len, dg.full_len};

@@ -2,7 +2,8 @@
 //
 // hiprtc is loaded with dlopen (no link-time dependency); if it is missing, or a compile fails,
 // pcj::get() returns null and the caller keeps using the ahead-of-time generic kernels -- still
-// the GPU, only 11 instead of 8 packed ops per cell pair.  PC_DISABLE_JIT=1 forces that path.
+// the GPU, only 11 instead of 5 (fp16) / 6 (int16) packed ops per cell pair.  PC_DISABLE_JIT=1
+// forces that path.
 #include "pc_jit.h"
 
 #include <dlfcn.h>
@@ -11,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <map>
 #include <mutex>
 #include <string>
@@ -98,12 +100,35 @@ Spec *get(int device, const std::string &ad_lo, const std::string &ad_hi, int ma
     if (disabled()) return nullptr;
     const int m_lo = (int)ad_lo.size(), m_hi = (int)ad_hi.size();
     const int R = m_lo > m_hi ? m_lo : m_hi;
-    if (R < 2 || R > 36) return nullptr;    // register budget of the specialised kernel (2 waves per SIMD)
-    // packed-fp16 variant (7 ops per cell pair, v_pk_maximum3_f16) when every DP value is an integer
-    // fp16 holds exactly; otherwise the packed-int16 variant (8 ops).  PC_JIT_INT16=1 forces the latter.
+    static const bool verbose = [] { const char *v = getenv("PC_JIT_VERBOSE"); return v && *v && *v != '0'; }();
+    if (R < 2 || R > 36) {                  // register budget of the specialised kernel (2 waves per SIMD)
+        if (verbose) fprintf(stderr, "porechop_amd: no specialised kernel for %d rows\n", R);
+        return nullptr;
+    }
+    // Drifting coordinates (pc_jit_source.h): a value X of row rho, jj columns after the last
+    // renormalisation, is held as X + (rho + jj [+1]) * eps - C.  True values lie in
+    // [low, high]; C puts `low` at -lim and the renormalisation period KREN keeps the top below
+    // +lim, lim = what the lane type holds exactly (fp16: integers up to 2048).  Packed-fp16
+    // variant (5 ops per cell pair, v_pk_maximum3_f16) when that leaves a useful period, otherwise
+    // packed-int16 (6 ops).  PC_JIT_INT16=1 forces the latter.
+    const int eps = -gap_extend;
+    const long low = std::min<long>({2L * gap_open + (long)(R - 1) * gap_extend,
+                                     (long)gap_open + (long)(R - 1) * gap_extend + mismatch, (long)gap_open});
+    const long high = (long)match * R;
+    auto period = [&](long lim) -> long {
+        const long k = (2 * lim - (high - low) - (long)(R + 6) * eps) / eps;
+        return k < 0 ? 0 : std::min<long>(k / 4 * 4, 1L << 20);
+    };
     const char *force_int = getenv("PC_JIT_INT16");
-    const bool f16 = !(force_int && *force_int && *force_int != '0') && (long)match * R <= 1000 &&
-                     2L * -gap_open + (long)R * -gap_extend <= 1000 && -mismatch <= 1000;
+    const bool f16 = !(force_int && *force_int && *force_int != '0') && period(2040) >= 64 &&
+                     high + (long)R * eps <= 2040 && -mismatch <= 1000 && -gap_open <= 1000;
+    const long lim = f16 ? 2040 : 32000;
+    const long kren = period(lim);
+    if (kren < 64) {
+        if (verbose) fprintf(stderr, "porechop_amd: no specialised kernel: scores too large for drifting coordinates\n");
+        return nullptr;
+    }
+    const long cen = low + lim;
     char keybuf[64];
     snprintf(keybuf, sizeof keybuf, "|%d|%d,%d,%d,%d|%d", device, match, mismatch, gap_open, gap_extend, f16 ? 1 : 0);
     const std::string key = ad_lo + "|" + ad_hi + keybuf;
@@ -136,11 +161,14 @@ Spec *get(int device, const std::string &ad_lo, const std::string &ad_hi, int ma
     std::string init;
     for (int row = 0; row < R; ++row) { init += std::to_string(combo_of_row[row]); if (row + 1 < R) init += ","; }
     const std::string dR = "-DPC_R=" + std::to_string(R), dK = "-DPC_K=" + std::to_string(K),
-                      dC = "-DPC_COMBO_INIT=" + init, dF = std::string("-DPC_F16=") + (f16 ? "1" : "0");
-    const char *opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", dR.c_str(), dK.c_str(), dC.c_str(), dF.c_str()};
+                      dC = "-DPC_COMBO_INIT=" + init, dF = std::string("-DPC_F16=") + (f16 ? "1" : "0"),
+                      dE = "-DPC_EPS=" + std::to_string(eps), dO = "-DPC_OE=(" + std::to_string(gap_open + eps) + ")",
+                      dN = "-DPC_CEN=(" + std::to_string(cen) + ")", dP = "-DPC_KREN=" + std::to_string(kren);
+    const char *opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", dR.c_str(), dK.c_str(), dC.c_str(), dF.c_str(),
+                          dE.c_str(), dO.c_str(), dN.c_str(), dP.c_str()};
     hiprtcProgram prog = nullptr;
     if (r.CreateProgram(&prog, kSpecSource, "pc_spec_score.hip", 0, nullptr, nullptr) != 0) return nullptr;
-    const hiprtcResult rc = r.CompileProgram(prog, 7, opts);
+    const hiprtcResult rc = r.CompileProgram(prog, 11, opts);
     if (rc != 0) {
         size_t n = 0;
         r.GetProgramLogSize(prog, &n);
@@ -166,11 +194,11 @@ Spec *get(int device, const std::string &ad_lo, const std::string &ad_hi, int ma
         return nullptr;
     }
     sp->module = mod; sp->function = fn;
-    // S table: [256 read bytes][K letter pairs] of packed (sub_lo - open) | (sub_hi - open) << 16
+    // S table: [256 read bytes][K letter pairs] of packed (sub_lo - open + eps) | (sub_hi - open + eps) << 16
     std::vector<uint32_t> tab((size_t)256 * K, 0);
     auto term = [&](int letter, int code) -> int {
         const int sub = letter == 5 ? 0 : (letter == code ? match : mismatch);
-        return sub - gap_open;
+        return sub - gap_open + eps;
     };
     for (int b = 0; b < 256; ++b) {
         const int code = dna5((unsigned char)b);
@@ -187,6 +215,7 @@ Spec *get(int device, const std::string &ad_lo, const std::string &ad_hi, int ma
         return nullptr;
     }
     sp->d_table = d;
+    if (verbose) fprintf(stderr, "porechop_amd: specialised kernel R=%d K=%d f16=%d kren=%ld\n", R, K, f16 ? 1 : 0, kren);
     g_cache[key] = sp;
     return sp;
 }

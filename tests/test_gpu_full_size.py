@@ -107,3 +107,42 @@ def test_config2_end_trim_only_100k(oracle):
     for r in rng.sample(range(100_000), 64):
         assert (stl[r], etl[r]) == ref_pipeline.phase_b(oracle.adapter_alignment, host_seq(reads, r), pl.sets, matching, p), r
     pl.close()
+
+
+def test_specialised_score_pass_equals_generic_unchunked():
+    """160 k x 8 kb reads (enough tiles that the score pass is NOT column-chunked) scanned against an
+    adapter pair, once with the run-time specialised kernel (drifting coordinates, renormalised
+    every ~1900 / ~200 columns) and once with the generic ahead-of-time kernel (PC_DISABLE_JIT=1):
+    every output record must be bit-identical.  Two schemes; each variant in a fresh process."""
+    import hashlib
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import hashlib, sys
+sys.path.insert(0, ".")
+import torch
+import porechop_amd
+from porechop_amd.synth import make_reads
+ads = ["AATGTACTTCGTTCAGTTACGTATTGCT", "GCAATACGTAACTGAACGAAGT"]
+reads = make_reads(160_000, 8000, seed=11, start_frac=0.3, end_frac=0.3, chimera_frac=0.05)
+n = 160_000
+for scores in [(3, -6, -5, -2), (20, -30, -25, -12)]:
+    al = porechop_amd.Aligner(ads, scores=scores)
+    out = torch.zeros((2 * n, 8), dtype=torch.int32, device="cuda")
+    al.scan_device(reads.arena, reads.off, reads.length, [0], [0, n], 8000, out, porechop_amd.MODE_TWO_PASS, job_adapter_b=[1])
+    al.sync()
+    print("DIGEST", scores, hashlib.sha1(out.cpu().numpy().tobytes()).hexdigest(), int((out[:, 4] > 40).sum()))
+'''
+    outs = []
+    for env_extra in ({"PC_JIT_MIN_CELLS": "1", "PC_JIT_VERBOSE": "1"}, {"PC_DISABLE_JIT": "1"}):
+        res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900,
+                             env=dict(os.environ, **env_extra),
+                             cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        lines = [l for l in res.stdout.splitlines() if l.startswith("DIGEST")]
+        assert len(lines) == 2, res.stdout[-2000:] + res.stderr[-3000:]
+        if "PC_JIT_VERBOSE" in env_extra:
+            assert res.stderr.count("specialised kernel R=28") == 2, res.stderr[-2000:]
+        outs.append(lines)
+    assert outs[0] == outs[1]
+    assert int(outs[0][0].split()[-1]) > 1000        # the planted adapters were found

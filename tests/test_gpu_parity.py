@@ -167,8 +167,11 @@ def test_unsupported_scores_fail_loudly(pa):
 def test_specialised_kernel_matches_generic(pa, oracle):
     """The run-time specialised (hiprtc) score pass, forced on for a small job through
     PC_JIT_MIN_CELLS in a fresh process, against the oracle: dual-adapter one-stream tiles, padding
-    rows in the shorter half, chunked windows, odd row counts."""
+    rows in the shorter half, chunked windows, odd row counts; ragged tiles (per-stream masks) and
+    equal-length tiles (block-resolved maxima); a scheme whose drifting coordinates are
+    renormalised every ~200 columns, and one with gap_extend more negative than gap_open."""
     import os
+    import re
     import subprocess
     import sys
     code = r'''
@@ -181,30 +184,37 @@ from tests.pairgen import random_case
 rng = random.Random(77)
 o = Oracle()
 ads = ["AATGTACTTCGTTCAGTTACGTATTGCT", "GCAATACGTAACTGAACGAAGT", "CTTCGTTCAGTTACGTATTGCTGGCGTCTGCTT", "ACGTNACGTTAGC"]
-reads = [random_case(rng, n=rng.choice([900, 2500, 6000]), m=28)[0] for _ in range(150)]
-for i in range(0, 150, 3):                      # implant copies of each adapter
-    a = ads[(i // 3) % 4]; p = rng.randint(0, len(reads[i]) - 60)
-    reads[i] = reads[i][:p] + a + reads[i][p + len(a):]
-al = porechop_amd.Aligner(ads)
-arena = torch.from_numpy(np.frombuffer(("".join(reads)).encode() + b"N" * 64, dtype=np.uint8).copy()).cuda()
-lens = np.array([len(r) for r in reads], dtype=np.int32)
-offs = np.concatenate([[0], np.cumsum(lens[:-1].astype(np.int64))]).astype(np.int64)
-woff, wlen = torch.from_numpy(offs).cuda(), torch.from_numpy(lens).cuda()
-n = len(reads)
-for (a, b) in [(0, 1), (2, 3), (1, -1)]:
-    out = torch.zeros((n * (2 if b >= 0 else 1), 8), dtype=torch.int32, device="cuda")
-    al.scan_device(arena, woff, wlen, [a], [0, n], int(lens.max()), out, porechop_amd.MODE_TWO_PASS, job_adapter_b=[b])
-    al.sync()
-    rec = out.cpu().numpy()
-    for i, r in enumerate(reads):
-        assert porechop_amd.format_result(rec[i]) == o.adapter_alignment(r, ads[a]), (a, i)
-        if b >= 0:
-            assert porechop_amd.format_result(rec[n + i]) == o.adapter_alignment(r, ads[b]), (b, i)
+for scores, lengths in [((3, -6, -5, -2), [900, 2500, 6000]), ((3, -6, -5, -2), [5003]),
+                        ((20, -30, -25, -12), [3000]), ((3, -6, -2, -5), [1800, 1801]), ((20, -30, -25, -12), [700, 2100])]:
+    reads = [random_case(rng, n=rng.choice(lengths), m=28)[0] for _ in range(150)]
+    for i in range(0, 150, 3):                      # implant copies of each adapter
+        a = ads[(i // 3) % 4]; p = rng.randint(0, len(reads[i]) - 60)
+        reads[i] = reads[i][:p] + a + reads[i][p + len(a):]
+    al = porechop_amd.Aligner(ads, scores=scores)
+    arena = torch.from_numpy(np.frombuffer(("".join(reads)).encode() + b"N" * 64, dtype=np.uint8).copy()).cuda()
+    lens = np.array([len(r) for r in reads], dtype=np.int32)
+    offs = np.concatenate([[0], np.cumsum(lens[:-1].astype(np.int64))]).astype(np.int64)
+    woff, wlen = torch.from_numpy(offs).cuda(), torch.from_numpy(lens).cuda()
+    n = len(reads)
+    for (a, b) in [(0, 1), (2, 3), (1, -1)]:
+        out = torch.zeros((n * (2 if b >= 0 else 1), 8), dtype=torch.int32, device="cuda")
+        al.scan_device(arena, woff, wlen, [a], [0, n], int(lens.max()), out, porechop_amd.MODE_TWO_PASS, job_adapter_b=[b])
+        al.sync()
+        rec = out.cpu().numpy()
+        for i, r in enumerate(reads):
+            assert porechop_amd.format_result(rec[i]) == o.adapter_alignment(r, ads[a], scores), (scores, a, i)
+            if b >= 0:
+                assert porechop_amd.format_result(rec[n + i]) == o.adapter_alignment(r, ads[b], scores), (scores, b, i)
 print("SPEC_OK")
 '''
-    for int16 in ("0", "1"):      # packed-fp16 (7 ops, v_pk_maximum3_f16) and packed-int16 (8 ops) variants
-        env = dict(os.environ, PC_JIT_MIN_CELLS="1", PC_JIT_INT16=int16)
-        res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600,
+    for int16 in ("0", "1"):      # packed-fp16 (5 ops, v_pk_maximum3_f16) and packed-int16 (6 ops) variants
+        env = dict(os.environ, PC_JIT_MIN_CELLS="1", PC_JIT_INT16=int16, PC_JIT_VERBOSE="1")
+        res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=900,
                              cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
         assert "SPEC_OK" in res.stdout, res.stdout[-2000:] + res.stderr[-3000:]
-        assert "hiprtc" not in res.stderr, res.stderr[-2000:]
+        assert "hiprtc" not in res.stderr and "no specialised kernel" not in res.stderr, res.stderr[-2000:]
+        built = re.findall(r"specialised kernel R=(\d+) K=\d+ f16=(\d) kren=(\d+)", res.stderr)
+        assert len(built) == 9, res.stderr[-2000:]                   # 3 adapter pairs x 3 schemes
+        assert all(f == ("0" if int16 == "1" else "1") for _, f, _ in built)
+        if int16 == "0":
+            assert min(int(k) for _, _, k in built) < 300            # the renormalisation path ran

@@ -233,7 +233,19 @@ int build_tiles(pc_ctx *c, const int32_t *job_adapter, const int32_t *job_adapte
     return PC_OK;
 }
 
-constexpr int kMaxChunks = 16;
+constexpr int kMaxChunks = 64;
+
+// Column chunks of the score pass.  With enough tiles to fill the chip: 1 (no warm-up overhead).
+// Under-filled (small batches, mask-and-realign rounds): the launch's duration is the serial column
+// loop of one wave, so cut the windows into as many chunks as there are idle wave slots, down to
+// chunks about as long as their SPAN warm-up (exact, see pc_bounds.h).
+int chunks_for(int64_t tile_count, int capacity, int max_len, int max_window)
+{
+    if (tile_count <= 0 || tile_count * 2 > capacity) return 1;
+    int chunks = (int)std::min<int64_t>(kMaxChunks, capacity / tile_count);
+    const int min_len = std::max(128, max_window / 2);
+    return std::max(1, std::min(chunks, max_len / min_len));
+}
 
 struct ScopedTimer {
     pc_ctx *c; hipStream_t s; bool on; pc_ctx::Timed t;
@@ -366,19 +378,22 @@ int pc_scan_device(pc_ctx *c, const void *d_arena, const int64_t *d_win_off, con
     // scratch sizing over all groups
     size_t slab_bytes = 0, fin_bytes = 0;
     bool any_two = false;
+    int max_chunks = 1;
     for (const Group &g : c->groups) {
         size_t stride;
         const int cols = g.two_pass ? g.max_window + 1 : max_len;
         const int grid = grid_for(c, g, g.tile_count, cols, &stride);
         slab_bytes = std::max(slab_bytes, (size_t)grid * stride * 4);
-        const int grid1 = grid_for(c, g, g.tile_count * (size_t)kMaxChunks, 1, nullptr);   // chunked score pass
+        const int chunks = g.two_pass ? chunks_for((int64_t)g.tile_count, grid_for(c, g, (size_t)1 << 30, 1, nullptr), max_len, g.max_window) : 1;
+        max_chunks = std::max(max_chunks, chunks);
+        const int grid1 = grid_for(c, g, g.tile_count * (size_t)chunks, 1, nullptr);   // chunked score pass
         fin_bytes = std::max(fin_bytes, (size_t)std::max(grid, grid1) * std::max(1, g.rows) * 64 * 8);
         any_two |= g.two_pass;
     }
     if ((rc = c->d_slab.ensure(slab_bytes + 256)) || (rc = c->d_fin.ensure(fin_bytes + 256))) return rc;
     if (any_two) {
         const size_t n = (size_t)npairs;
-        if ((rc = c->d_k1.ensure(n * 16 * kMaxChunks)) || (rc = c->d_woff2.ensure(n * 8)) || (rc = c->d_wlen2.ensure(n * 4)) ||
+        if ((rc = c->d_k1.ensure(n * 16 * (size_t)max_chunks)) || (rc = c->d_woff2.ensure(n * 8)) || (rc = c->d_wlen2.ensure(n * 4)) ||
             (rc = c->d_col0.ensure(n * 4)) || (rc = c->d_ntot.ensure(n * 4)) || (rc = c->d_frow.ensure(n * 4)) ||
             (rc = c->d_fscore.ensure(n * 4)))
             return rc;
@@ -421,15 +436,8 @@ int pc_scan_device(pc_ctx *c, const void *d_arena, const int64_t *d_win_off, con
             a.win_off = d_win_off; a.win_len = d_win_len;
             a.out = c->d_k1.as<int32_t>();
             a.slab = nullptr; a.slab_cols = 0; a.slab_stride = 0;
-            // too few tiles to fill the chip (small batches, mask-and-realign rounds): cut the
-            // windows into column chunks, each warmed up by SPAN columns (exact, see pc_bounds.h)
             const int capacity = grid_for(c, g, (size_t)1 << 30, 1, nullptr);
-            int chunks = 1;
-            if ((int64_t)g.tile_count * 2 <= capacity) {
-                chunks = (int)std::min<int64_t>(kMaxChunks, capacity / (int64_t)g.tile_count);
-                const int min_len = 4 * g.max_window;          // keep the warm-up overhead under ~15 %
-                chunks = std::max(1, std::min(chunks, max_len / std::max(1, min_len)));
-            }
+            const int chunks = chunks_for((int64_t)g.tile_count, capacity, max_len, g.max_window);
             a.chunks = chunks;
             a.chunk_len = (max_len + chunks - 1) / chunks;
             a.ad_span = c->d_ad_span.as<int32_t>();
@@ -445,16 +453,17 @@ int pc_scan_device(pc_ctx *c, const void *d_arena, const int64_t *d_win_off, con
                     while (e < g.tile_count && c->tiles[g.tile_begin + e].adapter_lo == t0.adapter_lo &&
                            c->tiles[g.tile_begin + e].adapter_hi == t0.adapter_hi)
                         ++e;
-                    // a hiprtc compile costs ~1 s and buys ~25 % of the scan: only for launches
-                    // big enough to pay for it (PC_JIT_MIN_CELLS overrides the 1e11-cell default)
+                    // a hiprtc compile costs ~1 s and halves the scan: only launches big enough to
+                    // pay for it compile (PC_JIT_MIN_CELLS overrides the 1e11-cell default); smaller
+                    // ones (mask-and-realign rounds) reuse a kernel that is already there
                     double est_cells = 0;
                     for (size_t k = i; k < e; ++k)
                         est_cells += (double)(c->tiles[g.tile_begin + k].count_lo + c->tiles[g.tile_begin + k].count_hi);
                     est_cells *= (double)max_len * (double)std::max(1, g.rows);
                     static const double min_cells = [] { const char *v = getenv("PC_JIT_MIN_CELLS"); return v ? atof(v) : 1e11; }();
-                    pcj::Spec *sp = (g.rows && est_cells >= min_cells && !linear)
+                    pcj::Spec *sp = (g.rows && !linear)
                                         ? pcj::get(c->device, c->adapters[t0.adapter_lo], c->adapters[t0.adapter_hi],
-                                                   c->match, c->mismatch, c->gap_open, c->gap_extend)
+                                                   c->match, c->mismatch, c->gap_open, c->gap_extend, est_cells >= min_cells)
                                         : nullptr;
                     const int sub_grid = (int)std::min<size_t>((size_t)grid, (e - i) * (size_t)chunks);
                     if (sp) {

@@ -95,7 +95,7 @@ bool disabled()
 }
 
 Spec *get(int device, const std::string &ad_lo, const std::string &ad_hi, int match, int mismatch, int gap_open,
-          int gap_extend)
+          int gap_extend, bool compile)
 {
     if (disabled()) return nullptr;
     const int m_lo = (int)ad_lo.size(), m_hi = (int)ad_hi.size();
@@ -135,6 +135,7 @@ Spec *get(int device, const std::string &ad_lo, const std::string &ad_hi, int ma
     std::lock_guard<std::mutex> lk(g_mu);
     auto it = g_cache.find(key);
     if (it != g_cache.end()) return it->second;
+    if (!compile) return nullptr;
     g_cache[key] = nullptr;
     Rtc &r = rtc();
     if (!r.ok) {

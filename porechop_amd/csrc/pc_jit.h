@@ -28,9 +28,10 @@ struct SpecArgs {
 };
 
 bool disabled();
-// nullptr when specialisation is unavailable for this pair (caller uses the generic kernels)
+// nullptr when specialisation is unavailable for this pair (caller uses the generic kernels).
+// compile = false only looks up kernels that an earlier, larger launch already paid for.
 Spec *get(int device, const std::string &ad_lo, const std::string &ad_hi, int match, int mismatch, int gap_open,
-          int gap_extend);
+          int gap_extend, bool compile);
 int launch(const Spec *sp, const SpecArgs &a, int grid, void *stream);
 
 }  // namespace pcj

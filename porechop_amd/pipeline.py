@@ -240,8 +240,12 @@ class Pipeline:
 
         Round 0 aligns every adapter against every (unmasked) trimmed read in one go.  That is
         exact for a read up to and including its first hit; only reads with a hit ("dirty", ~1 %)
-        get a private masked copy and continue one alignment per round until they run out of
-        adapters -- same sequence of alignments as the reference's nested loops."""
+        get a private masked copy and continue.  Every later round does the same thing for the
+        dirty reads still active: ALL adapters against the current masked state, results consumed
+        in the reference's order (from the adapter that just hit, which the reference re-aligns)
+        up to and including the next hit.  The alignments consumed are exactly the ones the
+        reference's nested loops perform, on the same masked sequences; the ones after a hit are
+        speculative and discarded.  Rounds = hits of the most-hit read + 1, not alignments."""
         p = self.p
         dev = self.device
         ads = self.middle_adapter_list(matching)
@@ -269,74 +273,70 @@ class Pipeline:
         max_len = int(llen.max().item())
         aidx = [self.seq_index[a[1]] for a in ads]
 
+        def identity_of(rec):
+            full, _ = _identities(rec)
+            return torch.where(rec[..., 0] == -1, torch.zeros_like(full), full)
+
         # ---- round 0: all adapters x all reads, unmasked -------------------------------------
         outs = self._scan_jobs(reads.arena, [(ai, loff, llen) for ai in aidx], MODE_TWO_PASS, max_len)
-        n_align = A * int(live.numel())
-        self.stats["pairs_middle"] += n_align
-        fulls = []
-        for rec in outs:
-            full, _ = _identities(rec)
-            fulls.append(torch.where(rec[:, 0] == -1, torch.zeros_like(full), full))
-        fulls = torch.stack(fulls)                                   # [A, L]
-        hit0 = fulls >= p.middle_threshold
-        any_hit = hit0.any(dim=0)
-        first = torch.where(any_hit, hit0.to(torch.int32).argmax(dim=0), torch.full_like(any_hit, A, dtype=torch.int64))
-        d_sel = torch.nonzero(any_hit).flatten()                     # dirty reads (indices into live)
-        H_read, H_ad, H_s, H_e, H_id = [], [], [], [], []
+        fulls = torch.stack([identity_of(rec) for rec in outs])      # [A, L]
+        hit0 = (fulls >= p.middle_threshold) & torch.stack([rec[:, 0] != -1 for rec in outs])
+        d_sel = torch.nonzero(hit0.any(dim=0)).flatten()             # dirty reads (indices into live)
+        Dn = int(d_sel.numel())
+        n_align = A * int(live.numel())                              # alignments the reference performs
+        n_spec = 0                                                   # speculative ones, discarded
         rounds = 0
-        if d_sel.numel() > 0:
-            Dn = int(d_sel.numel())
-            cur = first[d_sel].clone()                               # adapter each dirty read is at
-            recs0 = torch.stack(outs)                                # [A, L, 8]
-            rec = recs0[cur, d_sel]                                  # the first hit of each
+        H_read, H_ad, H_s, H_e, H_id = [], [], [], [], []
+        if Dn > 0:
+            rec_all = torch.stack(outs)[:, d_sel]                    # [A, Dn, 8] for the current masked state
+            full_all = fulls[:, d_sel]
             # private, maskable copies of the dirty reads: [Dn, stride]
             dlen = llen[d_sel]
-            stride = (int(dlen.max().item()) + 8 + 15) // 16 * 16
+            dmax = int(dlen.max().item())
+            stride = (dmax + 8 + 15) // 16 * 16
             col = torch.arange(stride, device=dev, dtype=torch.int64)
             src = loff[d_sel][:, None] + torch.clamp(col[None, :], max=(dlen.to(torch.int64) - 1)[:, None])
             dirty = reads.arena[src]
             dirty[col[None, :] >= dlen[:, None]] = ord("N")
             d_off = torch.arange(Dn, device=dev, dtype=torch.int64) * stride
-            active = torch.ones(Dn, dtype=torch.bool, device=dev)
-            full_d = fulls[cur, d_sel]
+            arow = torch.arange(A, device=dev)[:, None]
+            cur = torch.zeros(Dn, dtype=torch.int64, device=dev)     # adapter each dirty read is at
+            act = torch.arange(Dn, device=dev)
+            n_align -= A * Dn                                        # re-counted below as consumed
+            scheduled = A * Dn
             while True:
-                # consume the alignment just made for every active dirty read
-                ishit = active & (full_d >= p.middle_threshold) & (rec[:, 0] != -1)
-                hsel = torch.nonzero(ishit).flatten()
-                if hsel.numel() > 0:
-                    rs = rec[hsel, 0]
-                    re = rec[hsel, 1] + 1
-                    H_read.append(live[d_sel[hsel]]); H_ad.append(cur[hsel].to(torch.int32))
-                    H_s.append(rs); H_e.append(re); H_id.append(full_d[hsel])
-                    m = (col[None, :] >= rs[:, None]) & (col[None, :] < re[:, None])
-                    rows = dirty[hsel]
-                    rows[m] = ord("-")                               # masked_seq[rs:re] = '-' * (re - rs)
-                    dirty[hsel] = rows
-                cur = torch.where(active & ~ishit, cur + 1, cur)     # no hit: next adapter
-                active = active & (cur < A)
-                act = torch.nonzero(active).flatten()
-                if act.numel() == 0:
+                # consume, per active read: adapters cur.. in order, up to and including the first hit
+                c = cur[act]
+                hm = (full_all[:, act] >= p.middle_threshold) & (rec_all[:, act, 0] != -1) & (arow >= c[None, :])
+                anyh = hm.any(dim=0)
+                a_hit = hm.to(torch.int32).argmax(dim=0)
+                used = torch.where(anyh, a_hit - c + 1, A - c)
+                n_used = int(used.sum().item())
+                n_align += n_used
+                n_spec += scheduled - n_used
+                hsel = act[anyh]
+                if hsel.numel() == 0:
                     break
+                ah = a_hit[anyh]
+                r = rec_all[ah, hsel]
+                rs, re = r[:, 0], r[:, 1] + 1
+                H_read.append(live[d_sel[hsel]]); H_ad.append(ah.to(torch.int32))
+                H_s.append(rs); H_e.append(re); H_id.append(full_all[ah, hsel])
+                rows = dirty[hsel]
+                rows[(col[None, :] >= rs[:, None]) & (col[None, :] < re[:, None])] = ord("-")   # masked_seq[rs:re] = '-' * n
+                dirty[hsel] = rows
+                cur[hsel] = ah                                       # the reference re-aligns the adapter that hit
+                act = hsel
                 rounds += 1
-                # one alignment per active dirty read, grouped by the adapter it is at
-                cur_h = cur[act].cpu().numpy()
-                order = np.argsort(cur_h, kind="stable")
-                act_sorted = act[torch.from_numpy(order).to(dev)]
-                cur_sorted = cur_h[order]
-                jobs = []
-                for a in np.unique(cur_sorted):
-                    sel = act_sorted[torch.from_numpy(np.nonzero(cur_sorted == a)[0]).to(dev)]
-                    jobs.append((aidx[int(a)], d_off[sel], dlen[sel], sel))
-                outs_r = self._scan_jobs(dirty.view(-1), [(j[0], j[1], j[2]) for j in jobs], MODE_TWO_PASS,
-                                         int(dlen.max().item()))
-                n_align += int(act.numel())
-                self.stats["pairs_middle"] += int(act.numel())
-                rec = rec.clone()
-                full_d = full_d.clone()
-                for j, o in zip(jobs, outs_r):
-                    f, _ = _identities(o)
-                    rec[j[3]] = o
-                    full_d[j[3]] = torch.where(o[:, 0] == -1, torch.zeros_like(f), f)
+                a0 = int(ah.min().item())
+                o_act, l_act = d_off[act], dlen[act]
+                outs_r = self._scan_jobs(dirty.view(-1), [(aidx[a], o_act, l_act) for a in range(a0, A)], MODE_TWO_PASS, dmax)
+                scheduled = (A - a0) * int(act.numel())
+                for a, o in zip(range(a0, A), outs_r):
+                    rec_all[a, act] = o
+                    full_all[a, act] = identity_of(o)
+        self.stats["pairs_middle"] += n_align
+        self.stats["pairs_middle_speculative"] = self.stats.get("pairs_middle_speculative", 0) + n_spec
         if not H_read:
             empty.rounds, empty.alignments = rounds, n_align
             return empty

@@ -74,11 +74,20 @@ def test_phases_match_sequential_reference_logic(oracle):
                                hits.end.cpu().tolist(), hits.identity.cpu().tolist()):
         got.setdefault(r, []).append((a, s, e, round(idn, 6)))
     n_hits = 0
+    calls = [0]
+
+    def counting(*a):
+        calls[0] += 1
+        return oracle.adapter_alignment(*a)
+
     for r, seq in enumerate(norm):
-        want = ref_pipeline.phase_c(oracle.adapter_alignment, seq, st[r], et[r], pl.middle_adapters, p)
+        want = ref_pipeline.phase_c(counting if ref_pipeline.trimmed(seq, st[r], et[r]) else oracle.adapter_alignment,
+                                    seq, st[r], et[r], pl.middle_adapters, p)
         want = [(a, s, e, round(f, 6)) for a, s, e, f in want]
         # the reference visits adapters in order and hits of one adapter in discovery order
         assert got.get(r, []) == want, (r, got.get(r), want)
         n_hits += len(want)
     assert n_hits >= 10 and hits.rounds >= 2
+    # the alignments consumed are exactly the reference's sequence of calls (the rest were speculative)
+    assert hits.alignments == calls[0]
     pl.close()

@@ -175,7 +175,11 @@ def main():
         # algorithmic bytes: per read |H| input bytes ONCE for all A middle
         # adapters + 28 B of result per (read, adapter); a launch scanning one of A adapters is
         # credited 1/A of the read bytes.  cells = sum |H| x |V|.
-        ms, launches, pairs = timing["score"]
+        # Dominant kernel = the run-time specialised scan (timing kind 'score_spec'); the generic
+        # ahead-of-time one ('score') only if specialisation is off.  One timed region per launch,
+        # so avg_launch_ms is directly rocprofv3's AverageNs for that kernel name.
+        jit = timing["score_spec"][1] > 0
+        ms, launches, pairs = timing["score_spec"] if jit else timing["score"]
         A = max(1, len(pl.middle_adapter_list(matching)))
         mean_trim_len = float((reads.length.to(torch.float64) - st.to(torch.float64) - et.to(torch.float64)).mean().item())
         roof = None
@@ -186,11 +190,11 @@ def main():
             achieved = alg_bytes / per_launch_s / 1e9
             mean_m = float(np.mean([len(a[1]) for a in pl.middle_adapter_list(matching)]))
             cells = pairs_per_launch * mean_trim_len * mean_m
-            # VALU ceiling measured with tools/ubench_valu.hip: one wave64 packed-int16 op per ~4.3 cycles
-            # per SIMD = 39.3 T lane-ops/s; the specialised score kernel spends 8 ops per 2 cells
-            # (generic: 11), so its ceiling is 39.3e12 * 2 / 8 cell updates per second.
-            jit = os.environ.get("PC_DISABLE_JIT", "0") in ("", "0")
-            ops_per_pair = 8 if jit else 11
+            # VALU ceiling measured with tools/ubench_valu.hip: one wave64 packed 16-bit op per ~4.3 cycles
+            # per SIMD = 39.3 T lane-ops/s; the specialised score kernel spends 5 packed-fp16 ops per 2
+            # cells (6 in its int16 variant; generic kernel: 11), so its ceiling is 39.3e12 * 2 / 5
+            # cell updates per second.
+            ops_per_pair = (6 if os.environ.get("PC_JIT_INT16", "0") not in ("", "0") else 5) if jit else 11
             valu_peak_gcups = 39.3e12 * 2 / ops_per_pair / 1e9
             roof = {"bound": "hbm",
                     "kernel": ("pc_spec_score (run-time specialised score-only whole-read scan)" if jit
@@ -202,7 +206,8 @@ def main():
                     "valu": {"achieved_gcups": cells / per_launch_s / 1e9, "peak_gcups": valu_peak_gcups,
                              "frac": cells / per_launch_s / 1e9 / valu_peak_gcups, "ops_per_2_cells": ops_per_pair},
                     "note": "integer max-plus DP, >= 50 cells per algorithmic byte: VALU-bound by construction; "
-                            "launch average includes the small mask-and-realign launches (DESIGN.md section 4)"}
+                            "the launch average includes the small mask-and-realign launches of the same kernel "
+                            "(DESIGN.md section 4)"}
             # HBM-side traffic of that kernel comes from the separately collected rocprofv3 --pmc passes
             # of this same command (tools/profile_round.sh -> profiles/<round>_summary.json): FETCH_SIZE +
             # WRITE_SIZE of one launch, KB as reported.  (The guide's x2 correction is for wide 16-B/lane
@@ -216,8 +221,8 @@ def main():
                         sj = json.load(f)
                     kk = sj["kernels"].get("pc_spec_score" if jit else "")
                     if kk and sj.get("reads_per_gpu") == args.reads and world == 1:
-                        roof["traffic"] = (kk["FETCH_SIZE_KB_largest_launch"] + kk["WRITE_SIZE_KB_largest_launch"]) * 1024.0
-                        roof["traffic_source"] = os.path.relpath(summ[-1], REPO) + " (largest launch; FETCH_SIZE + WRITE_SIZE)"
+                        roof["traffic"] = (kk["FETCH_SIZE_KB_mean_launch"] + kk["WRITE_SIZE_KB_mean_launch"]) * 1024.0
+                        roof["traffic_source"] = os.path.relpath(summ[-1], REPO) + " (mean over this kernel's launches; FETCH_SIZE + WRITE_SIZE)"
             except Exception:
                 pass
         kern_ms = {k: v[0] / args.steps for k, v in timing.items()}
@@ -225,7 +230,7 @@ def main():
             "metric": "reads/sec (and read-bp/sec) end+middle adapter scan, 8 kb reads",
             "value": reads_per_s, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "int16", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f16-held integers (score scan) / i16 (traced scan), exact", "data": "synthetic",
             "read_bp_per_s": reads_per_s * args.read_len,
             "config": {"workload": "BASELINE configs[3]: %d synthetic %d-bp reads per GPU, %.0f%% chimeras, "
                                    "phases A (119-set panel, %d check reads) + B + C (middle scan on)"

@@ -121,14 +121,15 @@ class Aligner:
         check(self.lib.pc_set_timing(self._ctx, 1 if enabled else 0), "pc_set_timing")
 
     def get_timing(self, stream=None):
-        """-> dict kind -> (ms, launches, pairs) for kinds 'score', 'plan', 'trace' since the last call."""
+        """-> dict kind -> (ms, launches, pairs) since the last call, for the kinds 'score' (generic
+        score-only scan), 'plan', 'trace' and 'score_spec' (run-time specialised score-only scan)."""
         import torch
         s = stream if stream is not None else torch.cuda.current_stream().cuda_stream
-        ms = (ctypes.c_double * 3)()
-        ln = (ctypes.c_int64 * 3)()
-        pr = (ctypes.c_int64 * 3)()
+        ms = (ctypes.c_double * 4)()
+        ln = (ctypes.c_int64 * 4)()
+        pr = (ctypes.c_int64 * 4)()
         check(self.lib.pc_get_timing(self._ctx, ctypes.c_void_p(s), ms, ln, pr), "pc_get_timing")
-        return {k: (ms[i], ln[i], pr[i]) for i, k in enumerate(("score", "plan", "trace"))}
+        return {k: (ms[i], ln[i], pr[i]) for i, k in enumerate(("score", "plan", "trace", "score_spec"))}
 
     def sync(self, stream=None):
         import torch

@@ -445,7 +445,6 @@ int pc_scan_device(pc_ctx *c, const void *d_arena, const int64_t *d_win_off, con
             {
                 // tiles of one job (= one adapter pair) are contiguous: a run-time specialised
                 // kernel per pair when hiprtc can provide one, the generic kernel otherwise
-                ScopedTimer tm(c, stream, 0, np);
                 size_t i = 0;
                 while (i < g.tile_count) {
                     const pck::Tile &t0 = c->tiles[g.tile_begin + i];
@@ -466,6 +465,9 @@ int pc_scan_device(pc_ctx *c, const void *d_arena, const int64_t *d_win_off, con
                                                    c->match, c->mismatch, c->gap_open, c->gap_extend, est_cells >= min_cells)
                                         : nullptr;
                     const int sub_grid = (int)std::min<size_t>((size_t)grid, (e - i) * (size_t)chunks);
+                    int64_t sub_pairs = 0;
+                    for (size_t k = i; k < e; ++k) sub_pairs += c->tiles[g.tile_begin + k].count_lo + c->tiles[g.tile_begin + k].count_hi;
+                    ScopedTimer tm(c, stream, sp ? 3 : 0, sub_pairs);     // one timed region per kernel launch
                     if (sp) {
                         pcj::SpecArgs sa;
                         memset(&sa, 0, sizeof(sa));

@@ -174,8 +174,12 @@ __device__ __forceinline__ void column_step(u32 (&T)[R], u32 (&U)[R], u32 h2,
 //         LDS ([row][lane], conflict-free), rows = tile.rows at run time, rolled row loop.
 // One wavefront per block; blocks stride over tiles.
 // ---------------------------------------------------------------------------------------------
+template <bool B> struct BoolTag { static constexpr bool value = B; };
+
+// Register budget: 3 resident waves per SIMD (<= 168 VGPRs) wherever the row count allows it --
+// the traced variants of 33..34 rows land a few registers above that without the hint.
 template <int R, bool PAD, bool TRACE>
-__global__ __launch_bounds__(64) void scan_kernel(ScanArgs a)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((R > 0 && R <= 34) ? 3 : 1))) void scan_kernel(ScanArgs a)
 {
     constexpr bool GEN = (R == 0);
     constexpr int RS = GEN ? 1 : R;          // static array extent
@@ -332,11 +336,13 @@ __global__ __launch_bounds__(64) void scan_kernel(ScanArgs a)
             if (have_hi && n_hi - w_hi - 2 < t0) t0 = n_hi - w_hi - 2;
 #pragma unroll
             for (int s = 32; s >= 1; s >>= 1) { const int o = __shfl_xor(t0, s); t0 = o < t0 ? o : t0; }
-            notrace_upto = t0 > 0 ? t0 : 0;
+            notrace_upto = __builtin_amdgcn_readfirstlane(t0 > 0 ? t0 : 0);   // wave-uniform: a scalar branch below
         }
 
         u32 cur_lo = 0, cur_hi = 0;
-        for (int j = 1; j <= nmax; ++j) {
+        // one column; TR = trace bits are formed and stored (always false in score-only kernels)
+        auto column = [&](const int j, auto trace_tag) {
+            constexpr bool TR = decltype(trace_tag)::value;
             if (((j - 1) & 3) == 0) {
                 // next 4 bases of each stream; finished streams re-read their last dword
                 const int kl = (j - 1 < n_lo) ? j - 1 : (n_lo > 0 ? ((n_lo - 1) & ~3) : 0);
@@ -359,7 +365,7 @@ __global__ __launch_bounds__(64) void scan_kernel(ScanArgs a)
             u32 tie01 = 0, Tlast = 0;
             const bool fin_lo = (j == n_lo) && tail_lo, fin_hi = (j == n_hi) && tail_hi;
             const bool any_fin = __any(fin_lo || fin_hi);
-            u32 *trace_dst = TRACE ? slab + ((int64_t)(j - 1) * NW) * 64 + lane : nullptr;
+            u32 *trace_dst = TR ? slab + ((int64_t)(j - 1) * NW) * 64 + lane : nullptr;
 
             if constexpr (GEN) {
                 // ---- rolled column over the LDS-resident state --------------------------
@@ -378,7 +384,7 @@ __global__ __launch_bounds__(64) void scan_kernel(ScanArgs a)
                     const u32 Mn = pk_max(d, g);
                     const u32 Tn = pk_add(Mn, k.O2);
                     const u32 t01 = pk_minu(d ^ g, k.ONE2);
-                    if (TRACE && j > notrace_upto) {
+                    if constexpr (TR) {
                         const u32 b0 = pk_minu(pk_sub(Hs, Hx), k.ONE2);
                         const u32 b1 = pk_minu(pk_sub(Vs, Vx), k.ONE2);
                         const u32 b2 = pk_minu(pk_sub(g, Vs), k.ONE2);
@@ -403,14 +409,10 @@ __global__ __launch_bounds__(64) void scan_kernel(ScanArgs a)
                     }
                 }
                 u32 trw[(RS + 3) / 4];
-                if (TRACE && j <= notrace_upto) {
-                    column_step<RS, PAD, false>(T, U, h2, cs, cv, lds_const, k, trw, tie01);
-                } else {
-                    column_step<RS, PAD, TRACE>(T, U, h2, cs, cv, lds_const, k, trw, tie01);
-                    if constexpr (TRACE) {
+                column_step<RS, PAD, TR>(T, U, h2, cs, cv, lds_const, k, trw, tie01);
+                if constexpr (TR) {
 #pragma unroll
-                        for (int w = 0; w < (RS + 3) / 4; ++w) trace_dst[w * 64] = trw[w];
-                    }
+                    for (int w = 0; w < (RS + 3) / 4; ++w) trace_dst[w * 64] = trw[w];
                 }
                 Tlast = T[RS - 1];
                 if (any_fin) {
@@ -441,7 +443,13 @@ __global__ __launch_bounds__(64) void scan_kernel(ScanArgs a)
                 if (tr_lo && fr_lo < 0 && cl > b_lo.score) { b_lo.score = cl; b_lo.I = m_lo; b_lo.J = j; b_lo.tie = !(tie01 & 0xFFFFu); }
                 if (tr_hi && fr_hi < 0 && ch > b_hi.score) { b_hi.score = ch; b_hi.I = m_hi; b_hi.J = j; b_hi.tie = !(tie01 >> 16); }
             }
+        };
+        // two loops rather than a branch per column: each gets its own register allocation
+        int j = 1;
+        if constexpr (TRACE) {
+            for (; j <= notrace_upto; ++j) column(j, BoolTag<false>{});
         }
+        for (; j <= nmax; ++j) column(j, BoolTag<TRACE>{});
 
         // ---- results -----------------------------------------------------------------
         if constexpr (!TRACE) {

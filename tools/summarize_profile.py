@@ -27,6 +27,8 @@ for counter in ("FETCH_SIZE", "WRITE_SIZE"):
     for k, v in agg.items():
         if k in out["kernels"]:
             out["kernels"][k][counter + "_KB_largest_launch"] = max(v)
+            out["kernels"][k][counter + "_KB_mean_launch"] = sum(v) / len(v)
+            out["kernels"][k][counter + "_launches"] = len(v)
 for f in ("kernel_stats.csv", "kernel_trace_scan.csv", "pmc_FETCH_SIZE.csv", "pmc_WRITE_SIZE.csv"):
     shutil.copy(os.path.join(src, f), os.path.join("profiles", "%s_%s" % (rnd, f)))
 with open(os.path.join("profiles", rnd + "_summary.json"), "w") as f:

@@ -101,7 +101,7 @@ Spec *get(int device, const std::string &ad_lo, const std::string &ad_hi, int ma
     const int m_lo = (int)ad_lo.size(), m_hi = (int)ad_hi.size();
     const int R = m_lo > m_hi ? m_lo : m_hi;
     static const bool verbose = [] { const char *v = getenv("PC_JIT_VERBOSE"); return v && *v && *v != '0'; }();
-    if (R < 2 || R > 36) {                  // register budget of the specialised kernel (2 waves per SIMD)
+    if (R < 2 || R > 40) {                  // register budget of the specialised kernel (2 waves per SIMD)
         if (verbose) fprintf(stderr, "porechop_amd: no specialised kernel for %d rows\n", R);
         return nullptr;
     }
@@ -157,7 +157,10 @@ Spec *get(int device, const std::string &ad_lo, const std::string &ad_hi, int ma
         combo_of_row[row] = k;
     }
     const int K = ((int)combos.size() + 3) / 4 * 4;
-    if (K > 36) return nullptr;
+    if (2 * R + 2 * K > 120) {               // T, U and two sets of substitution terms must stay in registers
+        if (verbose) fprintf(stderr, "porechop_amd: no specialised kernel for %d rows x %d letter pairs\n", R, K);
+        return nullptr;
+    }
 
     std::string init;
     for (int row = 0; row < R; ++row) { init += std::to_string(combo_of_row[row]); if (row + 1 < R) init += ","; }

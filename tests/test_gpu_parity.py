@@ -183,12 +183,13 @@ from oracle.oracle import Oracle
 from tests.pairgen import random_case
 rng = random.Random(77)
 o = Oracle()
-ads = ["AATGTACTTCGTTCAGTTACGTATTGCT", "GCAATACGTAACTGAACGAAGT", "CTTCGTTCAGTTACGTATTGCTGGCGTCTGCTT", "ACGTNACGTTAGC"]
+ads = ["AATGTACTTCGTTCAGTTACGTATTGCT", "GCAATACGTAACTGAACGAAGT", "CTTCGTTCAGTTACGTATTGCTGGCGTCTGCTT", "ACGTNACGTTAGC",
+       "GGTTGTTTCTGTTGGTGCTGATATTGCTGGCGTCTGCTT", "AAGCAGACGCCAGCAATATCAGCACCAACAGAAACAAC"]
 for scores, lengths in [((3, -6, -5, -2), [900, 2500, 6000]), ((3, -6, -5, -2), [5003]),
                         ((20, -30, -25, -12), [3000]), ((3, -6, -2, -5), [1800, 1801]), ((20, -30, -25, -12), [700, 2100])]:
     reads = [random_case(rng, n=rng.choice(lengths), m=28)[0] for _ in range(150)]
     for i in range(0, 150, 3):                      # implant copies of each adapter
-        a = ads[(i // 3) % 4]; p = rng.randint(0, len(reads[i]) - 60)
+        a = ads[(i // 3) % 6]; p = rng.randint(0, len(reads[i]) - 60)
         reads[i] = reads[i][:p] + a + reads[i][p + len(a):]
     al = porechop_amd.Aligner(ads, scores=scores)
     arena = torch.from_numpy(np.frombuffer(("".join(reads)).encode() + b"N" * 64, dtype=np.uint8).copy()).cuda()
@@ -196,7 +197,7 @@ for scores, lengths in [((3, -6, -5, -2), [900, 2500, 6000]), ((3, -6, -5, -2), 
     offs = np.concatenate([[0], np.cumsum(lens[:-1].astype(np.int64))]).astype(np.int64)
     woff, wlen = torch.from_numpy(offs).cuda(), torch.from_numpy(lens).cuda()
     n = len(reads)
-    for (a, b) in [(0, 1), (2, 3), (1, -1)]:
+    for (a, b) in [(0, 1), (2, 3), (1, -1), (4, 5)]:
         out = torch.zeros((n * (2 if b >= 0 else 1), 8), dtype=torch.int32, device="cuda")
         al.scan_device(arena, woff, wlen, [a], [0, n], int(lens.max()), out, porechop_amd.MODE_TWO_PASS, job_adapter_b=[b])
         al.sync()
@@ -214,7 +215,7 @@ print("SPEC_OK")
         assert "SPEC_OK" in res.stdout, res.stdout[-2000:] + res.stderr[-3000:]
         assert "hiprtc" not in res.stderr and "no specialised kernel" not in res.stderr, res.stderr[-2000:]
         built = re.findall(r"specialised kernel R=(\d+) K=\d+ f16=(\d) kren=(\d+)", res.stderr)
-        assert len(built) == 9, res.stderr[-2000:]                   # 3 adapter pairs x 3 schemes
+        assert len(built) == 12, res.stderr[-2000:]                  # 4 adapter pairs (22..39 rows) x 3 schemes
         assert all(f == ("0" if int16 == "1" else "1") for _, f, _ in built)
         if int16 == "0":
             assert min(int(k) for _, _, k in built) < 300            # the renormalisation path ran

@@ -155,6 +155,25 @@ const int32_t *pc_readset_lengths(const pc_readset *rs);
 const char *pc_readset_name(const pc_readset *rs, int64_t i);     /* full header, no leading marker */
 const char *pc_readset_quals(const pc_readset *rs, int64_t i);    /* FASTQ only */
 int pc_readset_is_rna(const pc_readset *rs, int64_t i);
+/* Several FASTQ (or several FASTA) files into ONE read set, in the order given -- the Albacore
+ * directory input of porechop/porechop.py:232-259; pc_readset_file_index()[i] = which path read i
+ * came from. */
+int pc_readset_load_many(const char *const *paths, int npaths, pc_readset **out);
+const int32_t *pc_readset_file_index(const pc_readset *rs);
+
+/* Output writer: the byte-level half of nanopore_read.py:97-147 (get_fasta /
+ * get_fastq) and porechop.py:607-734 (output_reads).  The caller has decided which pieces of which
+ * reads go where; piece k is bases [piece_start[k], piece_start[k] + piece_len[k]) of read
+ * piece_read[k] (coordinates in the whole read), written to file_paths[piece_file[k]] in the
+ * order given.  piece_number[k] > 0 appends "_<number>" to the read name the way
+ * add_number_to_read_name does (nanopore_read.py:494-498); piece_number may be NULL.  FASTQ:
+ * "@name\nseq\n+\nquals\n" (reads that came from FASTA get '+' qualities, as NanoporeRead pads
+ * them); FASTA: ">name\n" + sequence wrapped at 70.  RNA reads are written with U for T.  A path
+ * of "-" is stdout.  Files are created when their first piece arrives (a bin that receives
+ * nothing leaves no file, like the reference). */
+int pc_readset_write(const pc_readset *rs, int64_t npieces, const int64_t *piece_read, const int32_t *piece_start,
+                     const int32_t *piece_len, const int32_t *piece_number, const int32_t *piece_file, int nfiles,
+                     const char *const *file_paths, int fastq, int64_t *bytes_written);
 
 #ifdef __cplusplus
 }

@@ -17,7 +17,7 @@ EXPORTS = [
     "pc_format_result", "pc_prefetch", "pc_memo_clear", "pc_memo_stats", "pc_set_timing", "pc_get_timing",
     "pc_readset_load", "pc_readset_free", "pc_readset_error", "pc_readset_count", "pc_readset_is_fastq",
     "pc_readset_arena", "pc_readset_offsets", "pc_readset_lengths", "pc_readset_name", "pc_readset_quals",
-    "pc_readset_is_rna",
+    "pc_readset_is_rna", "pc_readset_load_many", "pc_readset_file_index", "pc_readset_write",
 ]
 
 
@@ -101,6 +101,13 @@ def load_library():
     L.pc_readset_quals.restype = c_cp
     L.pc_readset_is_rna.argtypes = [c_vp, c_i64]
     L.pc_readset_is_rna.restype = c_int
+    L.pc_readset_load_many.argtypes = [ctypes.POINTER(c_cp), c_int, ctypes.POINTER(c_vp)]
+    L.pc_readset_load_many.restype = c_int
+    L.pc_readset_file_index.argtypes = [c_vp]
+    L.pc_readset_file_index.restype = c_vp
+    L.pc_readset_write.argtypes = [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, ctypes.POINTER(c_cp), c_int,
+                                   ctypes.POINTER(c_i64)]
+    L.pc_readset_write.restype = c_int
     L.pc_memo_clear.argtypes = []
     L.pc_memo_clear.restype = None
     L.pc_memo_stats.argtypes = [ctypes.POINTER(c_i64)] * 3

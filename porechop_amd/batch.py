@@ -51,6 +51,10 @@ class Aligner:
         check(self.lib.pc_create(ctypes.byref(self._ctx), device), "pc_create")
         self.scores = tuple(int(s) for s in scores)
         check(self.lib.pc_set_scores(self._ctx, *self.scores), "pc_set_scores")
+        self.set_adapters(adapters)
+
+    def set_adapters(self, adapters):
+        """Replace the adapter table (indices used by later calls refer to the new list)."""
         self.adapters = [a if isinstance(a, bytes) else a.encode() for a in adapters]
         arr = (ctypes.c_char_p * max(1, len(self.adapters)))(*self.adapters)
         check(self.lib.pc_set_adapters(self._ctx, arr, len(self.adapters)), "pc_set_adapters")

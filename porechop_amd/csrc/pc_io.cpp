@@ -1,5 +1,6 @@
 // pc_io.cpp -- host ingest of FASTA/FASTQ(.gz) into the packed read arena the scan kernels consume
-// (the row after the hot path).  Pure host code, no GPU involved.
+// (the row after the hot path) and the output writer (8f-3).  Pure host
+// code, no GPU involved.
 //
 // Mirrors what the reference does between the file and the first alignment:
 //   porechop/misc.py:60-81    get_compression_type  (gzip by magic bytes; bz2/zip refused)
@@ -11,6 +12,11 @@
 // but produces one contiguous arena (1 byte per base, reads back to back, 64 bytes of 'N' padding
 // at the end) plus offset/length tables -- exactly the inputs of pc_align_batch_host /
 // pc_scan_device -- instead of millions of Python tuples.
+//
+// The writer (pc_readset_write) is the byte-level half of porechop/nanopore_read.py:97-147
+// (get_fasta / get_fastq) and porechop/porechop.py:607-734 (output_reads): the caller decides WHICH
+// pieces of which reads go to which file (trim amounts, split points, barcode bins -- integer
+// arrays), this code formats them straight from the arena.
 #include <zlib.h>
 
 #include <cctype>
@@ -30,6 +36,7 @@ struct pc_readset {
     std::vector<uint8_t> rna;
     std::vector<std::string> names;      // full header without the leading marker
     std::vector<std::string> quals;      // FASTQ only (padded with '+' to the sequence length)
+    std::vector<int32_t> file_index;     // which input file a read came from (pc_readset_load_many)
     std::string error;
 };
 
@@ -128,17 +135,18 @@ void add_read(pc_readset *rs, const char *name_b, const char *name_e, const char
 
 extern "C" {
 
-int pc_readset_load(const char *path, pc_readset **out)
+// parse one file into rs (reads appended); rs->fastq is set by the first file
+static int load_into(pc_readset *rs, const char *path, int32_t file_index, bool first)
 {
-    if (!path || !out) return PC_ERR_BAD_ARG;
-    pc_readset *rs = new pc_readset();
-    *out = rs;
     std::vector<char> data;
     if (!slurp(path, data, rs->error)) return PC_ERR_BAD_ARG;
-    const char first = data.empty() ? '\0' : data[0];
-    if (first != '>' && first != '@') { rs->error = "File is neither FASTA or FASTQ"; return PC_ERR_BAD_ARG; }
-    rs->fastq = (first == '@');
-    rs->arena.reserve(data.size() / (rs->fastq ? 2 : 1) + 128);
+    const char first_char = data.empty() ? '\0' : data[0];
+    if (first_char != '>' && first_char != '@') { rs->error = "File is neither FASTA or FASTQ"; return PC_ERR_BAD_ARG; }
+    const bool fastq = (first_char == '@');
+    if (first) rs->fastq = fastq;
+    else if (fastq != rs->fastq) { rs->error = std::string(path) + " is not of the same type as the files before it"; return PC_ERR_BAD_ARG; }
+    rs->arena.reserve(rs->arena.size() + data.size() / (rs->fastq ? 2 : 1) + 128);
+    const size_t before = rs->off.size();
     Lines ln{data.data(), data.data() + data.size()};
     const char *b, *e;
     if (rs->fastq) {
@@ -170,8 +178,28 @@ int pc_readset_load(const char *path, pc_readset **out)
         }
         if (have && !name.empty()) add_read(rs, name.data(), name.data() + name.size(), seq.data(), seq.data() + seq.size(), nullptr, nullptr);
     }
+    rs->file_index.resize(rs->off.size(), file_index);
+    (void)before;
+    return PC_OK;
+}
+
+int pc_readset_load_many(const char *const *paths, int npaths, pc_readset **out)
+{
+    if (!paths || npaths < 1 || !out) return PC_ERR_BAD_ARG;
+    pc_readset *rs = new pc_readset();
+    *out = rs;
+    for (int i = 0; i < npaths; ++i) {
+        const int rc = load_into(rs, paths[i], i, i == 0);
+        if (rc) return rc;
+    }
     rs->arena.insert(rs->arena.end(), 64, 'N');           // the kernels fetch a dword at a time
     return PC_OK;
+}
+
+int pc_readset_load(const char *path, pc_readset **out)
+{
+    if (!path || !out) return PC_ERR_BAD_ARG;
+    return pc_readset_load_many(&path, 1, out);
 }
 
 void pc_readset_free(pc_readset *rs) { delete rs; }
@@ -197,6 +225,84 @@ const char *pc_readset_quals(const pc_readset *rs, int64_t i)
 int pc_readset_is_rna(const pc_readset *rs, int64_t i)
 {
     return (rs && i >= 0 && i < (int64_t)rs->rna.size()) ? rs->rna[(size_t)i] : 0;
+}
+const int32_t *pc_readset_file_index(const pc_readset *rs) { return rs ? rs->file_index.data() : nullptr; }
+
+int pc_readset_write(const pc_readset *rs, int64_t npieces, const int64_t *piece_read, const int32_t *piece_start,
+                     const int32_t *piece_len, const int32_t *piece_number, const int32_t *piece_file, int nfiles,
+                     const char *const *file_paths, int fastq, int64_t *bytes_written)
+{
+    if (!rs || npieces < 0 || nfiles < 0 || (npieces > 0 && (!piece_read || !piece_start || !piece_len || !piece_file || !file_paths)))
+        return PC_ERR_BAD_ARG;
+    std::vector<FILE *> files((size_t)nfiles, nullptr);
+    std::vector<std::vector<char>> bufs((size_t)nfiles);
+    int64_t total = 0;
+    int rc = PC_OK;
+    auto flush = [&](int f) {
+        std::vector<char> &b = bufs[(size_t)f];
+        if (b.empty()) return;
+        if (fwrite(b.data(), 1, b.size(), files[(size_t)f]) != b.size()) rc = PC_ERR_BAD_ARG;
+        total += (int64_t)b.size();
+        b.clear();
+    };
+    const int64_t nreads = (int64_t)rs->off.size();
+    for (int64_t k = 0; k < npieces && rc == PC_OK; ++k) {
+        const int64_t r = piece_read[k];
+        const int f = piece_file[k];
+        if (r < 0 || r >= nreads || f < 0 || f >= nfiles) { rc = PC_ERR_BAD_ARG; break; }
+        const int64_t n = rs->len[(size_t)r];
+        const int64_t st = piece_start[k], ln = piece_len[k];
+        if (st < 0 || ln < 0 || st + ln > n) { rc = PC_ERR_BAD_ARG; break; }
+        if (!files[(size_t)f]) {                                   // opened on first use, like the reference's bins
+            const char *path = file_paths[f];
+            files[(size_t)f] = (path[0] == '-' && path[1] == '\0') ? stdout : fopen(path, "wb");
+            if (!files[(size_t)f]) { rc = PC_ERR_BAD_ARG; break; }
+            bufs[(size_t)f].reserve(1 << 22);
+        }
+        std::vector<char> &b = bufs[(size_t)f];
+        // header: add_number_to_read_name (nanopore_read.py:494-498): "_<k>" before the first space, or at the end
+        b.push_back(fastq ? '@' : '>');
+        const std::string &name = rs->names[(size_t)r];
+        const int number = piece_number ? piece_number[k] : 0;
+        if (number > 0) {
+            char tag[24];
+            const int tl = snprintf(tag, sizeof tag, "_%d", number);
+            const size_t sp = name.find(' ');
+            if (sp == std::string::npos) { b.insert(b.end(), name.begin(), name.end()); b.insert(b.end(), tag, tag + tl); }
+            else { b.insert(b.end(), name.begin(), name.begin() + (long)sp); b.insert(b.end(), tag, tag + tl); b.insert(b.end(), name.begin() + (long)sp, name.end()); }
+        } else {
+            b.insert(b.end(), name.begin(), name.end());
+        }
+        b.push_back('\n');
+        const char *seq = rs->arena.data() + rs->off[(size_t)r] + st;
+        const bool rna = rs->rna[(size_t)r] != 0;
+        const size_t seq_at = b.size();
+        if (fastq) {
+            b.insert(b.end(), seq, seq + ln);
+            b.push_back('\n'); b.push_back('+'); b.push_back('\n');
+            if (rs->fastq) { const std::string &q = rs->quals[(size_t)r]; b.insert(b.end(), q.begin() + st, q.begin() + st + ln); }
+            else b.insert(b.end(), (size_t)ln, '+');             // FASTA input: NanoporeRead pads the empty qualities with '+'
+            b.push_back('\n');
+            if (rna) for (size_t i = seq_at; i < seq_at + (size_t)ln; ++i) if (b[i] == 'T') b[i] = 'U';
+        } else {
+            // add_line_breaks_to_sequence(seq, 70): every line, the last included, ends in '\n'
+            if (ln == 0) b.push_back('\n');
+            for (int64_t pos = 0; pos < ln; pos += 70) {
+                const int64_t w = ln - pos < 70 ? ln - pos : 70;
+                b.insert(b.end(), seq + pos, seq + pos + w);
+                b.push_back('\n');
+            }
+            if (rna) for (size_t i = seq_at; i < b.size(); ++i) if (b[i] == 'T') b[i] = 'U';
+        }
+        if (b.size() >= ((size_t)1 << 22)) flush(f);
+    }
+    for (int f = 0; f < nfiles; ++f) {
+        if (!files[(size_t)f]) continue;
+        if (rc == PC_OK) flush(f);
+        if (files[(size_t)f] == stdout) fflush(stdout); else if (fclose(files[(size_t)f]) != 0) rc = PC_ERR_BAD_ARG;
+    }
+    if (bytes_written) *bytes_written = total;
+    return rc;
 }
 
 }  // extern "C"

@@ -1,5 +1,6 @@
-"""Host ingest: FASTA/FASTQ(.gz) -> packed arena + offset/length tables (the C side is
-porechop_amd/csrc/pc_io.cpp; semantics of porechop/misc.py:60-168 + nanopore_read.py:23-35)."""
+"""Host ingest: FASTA/FASTQ(.gz) -> packed arena + offset/length tables, and the output writer
+(the C side is porechop_amd/csrc/pc_io.cpp; semantics of porechop/misc.py:60-168,
+nanopore_read.py:23-35 and, for writing, nanopore_read.py:97-147 + porechop.py:607-734)."""
 import ctypes
 
 import numpy as np
@@ -8,12 +9,16 @@ from ._lib import load_library
 
 
 class ReadSet:
-    """Reads of one file, normalised like NanoporeRead.__init__, as numpy views over one arena."""
+    """Reads of one file -- or of several files, in order (Albacore directory input) -- normalised
+    like NanoporeRead.__init__, as numpy views over one arena."""
 
     def __init__(self, path):
         self.lib = load_library()
         self._h = ctypes.c_void_p()
-        rc = self.lib.pc_readset_load(str(path).encode(), ctypes.byref(self._h))
+        paths = [path] if isinstance(path, (str, bytes)) or hasattr(path, "__fspath__") else list(path)
+        self.paths = [str(p) for p in paths]
+        arr = (ctypes.c_char_p * len(self.paths))(*[p.encode() for p in self.paths])
+        rc = self.lib.pc_readset_load_many(arr, len(self.paths), ctypes.byref(self._h))
         if rc != 0:
             msg = self.lib.pc_readset_error(self._h).decode() if self._h else "load failed"
             self.close()
@@ -29,9 +34,12 @@ class ReadSet:
                 ctypes.cast(self.lib.pc_readset_offsets(self._h), ctypes.POINTER(ctypes.c_int64)), shape=(n,))
             self.lengths = np.ctypeslib.as_array(
                 ctypes.cast(self.lib.pc_readset_lengths(self._h), ctypes.POINTER(ctypes.c_int32)), shape=(n,))
+            self.file_index = np.ctypeslib.as_array(
+                ctypes.cast(self.lib.pc_readset_file_index(self._h), ctypes.POINTER(ctypes.c_int32)), shape=(n,))
         else:
             self.offsets = np.zeros(0, dtype=np.int64)
             self.lengths = np.zeros(0, dtype=np.int32)
+            self.file_index = np.zeros(0, dtype=np.int32)
 
     def name(self, i):
         return self.lib.pc_readset_name(self._h, i).decode()
@@ -54,6 +62,23 @@ class ReadSet:
         dev = torch.device(device)
         return DeviceReads(torch.from_numpy(self.arena.copy()).to(dev), torch.from_numpy(self.offsets.copy()).to(dev),
                            torch.from_numpy(self.lengths.copy()).to(dev))
+
+    def write(self, piece_read, piece_start, piece_len, piece_number, piece_file, file_paths, fastq):
+        """Write pieces of reads (see pc_readset_write in include/porechop_amd.h) -> bytes written."""
+        pr = np.ascontiguousarray(piece_read, dtype=np.int64)
+        ps = np.ascontiguousarray(piece_start, dtype=np.int32)
+        pl = np.ascontiguousarray(piece_len, dtype=np.int32)
+        pn = np.ascontiguousarray(piece_number, dtype=np.int32)
+        pf = np.ascontiguousarray(piece_file, dtype=np.int32)
+        assert pr.shape == ps.shape == pl.shape == pn.shape == pf.shape
+        paths = (ctypes.c_char_p * max(1, len(file_paths)))(*[str(p).encode() for p in file_paths])
+        written = ctypes.c_int64()
+        rc = self.lib.pc_readset_write(self._h, pr.shape[0], pr.ctypes.data, ps.ctypes.data, pl.ctypes.data,
+                                       pn.ctypes.data, pf.ctypes.data, len(file_paths), paths, 1 if fastq else 0,
+                                       ctypes.byref(written))
+        if rc != 0:
+            raise OSError("Error: could not write the output reads")
+        return written.value
 
     def close(self):
         if getattr(self, "_h", None):

@@ -1,0 +1,126 @@
+"""The adapter panel and the set-level rules that depend only on names and sequences.
+
+The 119 sets (names + sequences) are data recorded from porechop/adapters.py:78-463 by
+tests/golden/make_golden.py into porechop_amd/panel.json.  The rules mirrored here:
+
+  adapters.py:29-52    best_start_or_end_score, is_barcode, barcode_direction, get_barcode_name
+  adapters.py:466-499  the three "full sequence" barcode adapters (flanking sequences are ONT's)
+  porechop.py:374-390  fix_up_1d2_sets
+  porechop.py:330-371  choose_barcoding_kit
+  porechop.py:410-436  add_full_barcode_adapter_sets
+"""
+import json
+import os
+from typing import List, Optional
+
+from .pipeline import AdapterSet
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def load_panel() -> List[AdapterSet]:
+    with open(os.path.join(_HERE, "panel.json")) as f:
+        raw = json.load(f)
+    return [AdapterSet(a["name"], tuple(a["start"]) if a["start"] else None, tuple(a["end"]) if a["end"] else None)
+            for a in raw]
+
+
+def is_barcode(s: AdapterSet) -> bool:
+    return s.name.startswith("Barcode ")
+
+
+def barcode_direction(s: AdapterSet) -> str:
+    # decided on the START sequence's name alone (adapters.py:35-39)
+    return "reverse" if "_rev" in s.start[0] else "forward"
+
+
+def barcode_name(s: AdapterSet) -> str:
+    """Shortest of the set name and its sequence names (first wins ties), spaces -> '_'."""
+    names = [s.name]
+    if s.start is not None:
+        names.append(s.start[0])
+    if s.end is not None:
+        names.append(s.end[0])
+    return min(names, key=len).replace(" ", "_")       # min() keeps the first of equal lengths, like sorted()[0]
+
+
+def _barcode_set(panel: List[AdapterSet], number: int, direction: str) -> AdapterSet:
+    want = "Barcode %d (%s)" % (number, direction)
+    return next(s for s in panel if s.name == want)
+
+
+def full_native_barcode(panel, number) -> AdapterSet:
+    b = _barcode_set(panel, number, "reverse")
+    return AdapterSet("Native barcoding %d (full sequence)" % number,
+                      ("NB%02d_start" % number, "AATGTACTTCGTTCAGTTACGTATTGCTAAGGTTAA" + b.start[1] + "CAGCACCT"),
+                      ("NB%02d_end" % number, "AGGTGCTG" + b.end[1] + "TTAACCTTAGCAATACGTAACTGAACGAAGT"))
+
+
+_RAPID_TAIL = "GTTTTCGCATTTATCGTGAAACGCTTTCGCGTTTTTCGTGCGCCGCTTCA"
+
+
+def full_rapid_barcode_old(panel, number) -> AdapterSet:      # SQK-RBK001
+    b = _barcode_set(panel, number, "forward")
+    return AdapterSet("Rapid barcoding %d (full sequence, old)" % number,
+                      ("RB%02d_full" % number, "AATGTACTTCGTTCAGTTACG" + "TATTGCT" + b.start[1] + _RAPID_TAIL), None)
+
+
+def full_rapid_barcode_new(panel, number) -> AdapterSet:      # SQK-RBK004
+    b = _barcode_set(panel, number, "forward")
+    return AdapterSet("Rapid barcoding %d (full sequence, new)" % number,
+                      ("RB%02d_full" % number, "AATGTACTTCGTTCAGTTACG" + "GCTTGGGTGTTTAACC" + b.start[1] + _RAPID_TAIL), None)
+
+
+def fix_up_1d2(matching: List[AdapterSet], score) -> List[AdapterSet]:
+    """Drop 'SQK-MAP006 Short' when both 1D^2 parts score at least as well (score: set -> best
+    start-or-end identity)."""
+    by_name = {s.name: s for s in matching}
+    if all(n in by_name for n in ("1D^2 part 1", "1D^2 part 2", "SQK-MAP006 Short")):
+        sqk = score(by_name["SQK-MAP006 Short"])
+        if score(by_name["1D^2 part 1"]) >= sqk and score(by_name["1D^2 part 2"]) >= sqk:
+            return [s for s in matching if s.name != "SQK-MAP006 Short"]
+    return matching
+
+
+class NoBarcodes(Exception):
+    pass
+
+
+def choose_barcoding_kit(matching: List[AdapterSet], best_start, best_end) -> str:
+    """'forward' or 'reverse' from the matching barcode sets' best scores (best_start/best_end:
+    set -> identity).  Raises NoBarcodes with the reference's message when undecidable."""
+    f_or = r_or = f_and = r_and = 0.0
+    for s in matching:
+        low = s.name.lower()
+        if "barcode" not in low:
+            continue
+        bs, be = best_start(s), best_end(s)
+        if "(forward)" in low:
+            f_or += max(bs, be); f_and += bs; f_and += be
+        elif "(reverse)" in low:
+            r_or += max(bs, be); r_and += bs; r_and += be
+    if f_or == 0 and r_or == 0:
+        raise NoBarcodes("Error: no barcodes were found, so Porechop cannot perform barcode demultiplexing")
+    if f_or > r_or:
+        return "forward"
+    if r_or > f_or:
+        return "reverse"
+    if f_and > r_and:
+        return "forward"
+    if r_and > f_and:
+        return "reverse"
+    raise NoBarcodes("Error: Porechop could not determine barcode orientation")
+
+
+def add_full_barcode_sets(panel: List[AdapterSet], matching: List[AdapterSet]) -> List[AdapterSet]:
+    names = {s.name for s in matching}          # membership is tested against the list as it was on entry
+    out = list(matching)
+    for i in range(1, 97):
+        if "SQK-NSK007" in names and "Barcode %d (reverse)" % i in names:
+            out.append(full_native_barcode(panel, i))
+        if "Rapid" in names and "Barcode %d (forward)" % i in names:
+            if "RBK004_upstream" in names:
+                out.append(full_rapid_barcode_new(panel, i))
+            elif "SQK-NSK007" in names:
+                out.append(full_rapid_barcode_old(panel, i))
+    return out

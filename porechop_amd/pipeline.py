@@ -82,23 +82,56 @@ def _identities(rec):
     return full, partial
 
 
+def trimmed_interval(length, start_trim, end_trim):
+    """[s, e) of seq[start_trim : len(seq) - end_trim] with Python's slice semantics, the whole read
+    when both trims are 0 (nanopore_read.py:56-62): a start beyond the end clamps, a negative end
+    index counts from the end.  Tensors in, int64 tensors out (e < s means empty)."""
+    ln = length.to(torch.int64)
+    s_pos = torch.clamp(start_trim.to(torch.int64), max=ln)
+    e_pos = ln - end_trim.to(torch.int64)
+    e_pos = torch.where(e_pos < 0, torch.clamp(ln + e_pos, min=0), e_pos)
+    untouched = (start_trim == 0) & (end_trim == 0)
+    s_pos = torch.where(untouched, torch.zeros_like(s_pos), s_pos)
+    e_pos = torch.where(untouched, ln, e_pos)
+    return s_pos, e_pos
+
+
 class Pipeline:
-    def __init__(self, sets: List[AdapterSet], params: ScanParams = None, device=None):
-        self.sets = list(sets)
+    def __init__(self, sets: List[AdapterSet], params: ScanParams = None, device=None, aligner=None):
+        """aligner: an object with the Aligner interface.  The default -- and the only product
+        path -- is the GPU library; tests inject an oracle-backed stand-in to check the host logic
+        on machines without a GPU."""
+        self.sets = []
         self.p = params or ScanParams()
-        self.device = torch.device(device if device is not None else "cuda")
-        # one adapter table for everything (deduplicated sequences)
         self.seq_index = {}
-        seqs = []
-        for s in self.sets:
+        self.seqs = []
+        self._register(sets)
+        if aligner is None:
+            self.device = torch.device(device if device is not None else "cuda")
+            dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+            self.aligner = Aligner(self.seqs, self.p.scores, device=dev_index)
+        else:
+            self.device = torch.device(device if device is not None else "cpu")
+            self.aligner = aligner
+            self.aligner.set_adapters(self.seqs)
+        self.stats = {"pairs_end": 0, "pairs_middle": 0, "cells_end": 0, "cells_middle": 0}
+
+    def _register(self, sets):
+        # one adapter table for everything (deduplicated sequences)
+        for s in sets:
+            self.sets.append(s)
             for side in (s.start, s.end):
                 if side is not None and side[1] not in self.seq_index:
-                    self.seq_index[side[1]] = len(seqs)
-                    seqs.append(side[1])
-        self.seqs = seqs
-        dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
-        self.aligner = Aligner(seqs, self.p.scores, device=dev_index)
-        self.stats = {"pairs_end": 0, "pairs_middle": 0, "cells_end": 0, "cells_middle": 0}
+                    self.seq_index[side[1]] = len(self.seqs)
+                    self.seqs.append(side[1])
+
+    def add_sets(self, sets: List[AdapterSet]) -> List[int]:
+        """Append adapter sets found necessary after phase A (porechop.py:410-436: the full barcode
+        adapters) -> their indices in self.sets."""
+        first = len(self.sets)
+        self._register(sets)
+        self.aligner.set_adapters(self.seqs)
+        return list(range(first, len(self.sets)))
 
     # ------------------------------------------------------------------------------------------
     def _end_windows(self, reads: DeviceReads, idx: Optional[torch.Tensor], side: str):
@@ -189,8 +222,10 @@ class Pipeline:
                 if "(full sequence)" not in s.name and best[i] >= self.p.adapter_threshold]
 
     # ------------------------------------------------------------------------------------------
-    def phase_b(self, reads: DeviceReads, matching: List[int]):
-        """-> (start_trim[R], end_trim[R]) int32: nanopore_read.py:166-208 for every read."""
+    def phase_b(self, reads: DeviceReads, matching: List[int], full_for=()):
+        """-> (start_trim[R], end_trim[R]) int32: nanopore_read.py:166-208 for every read.
+        full_for: set indices whose full-adapter identities are wanted too (barcode calling,
+        nanopore_read.py:185-187,206-208) -> third result {(set, side): float64[R]}, side 0 = start."""
         R = reads.n
         p = self.p
         start_trim = torch.zeros(R, dtype=torch.int32, device=self.device)
@@ -201,15 +236,18 @@ class Pipeline:
         for si in matching:
             s = self.sets[si]
             if s.start is not None:
-                jobs.append((self.seq_index[s.start[1]], so, sl)); where.append(0)
+                jobs.append((self.seq_index[s.start[1]], so, sl)); where.append((0, si))
             if s.end is not None:
-                jobs.append((self.seq_index[s.end[1]], eo, el)); where.append(1)
+                jobs.append((self.seq_index[s.end[1]], eo, el)); where.append((1, si))
+        fulls = {}
         if not jobs:
-            return start_trim, end_trim
+            return (start_trim, end_trim, fulls) if full_for else (start_trim, end_trim)
         outs = self._scan_jobs(reads.arena, jobs, MODE_TRACE, p.end_size)
-        for side, rec in zip(where, outs):
-            _, partial = _identities(rec)
+        for (side, si), rec in zip(where, outs):
+            full, partial = _identities(rec)
             ok = rec[:, 0] != -1
+            if si in full_for:
+                fulls[(si, side)] = torch.where(ok, full, torch.zeros_like(full))
             rs = rec[:, 0]
             re = rec[:, 1] + 1
             if side == 0:
@@ -219,7 +257,7 @@ class Pipeline:
                 cond = ok & (partial > p.end_threshold) & (rs != 0) & ((re - rs) >= p.min_trim_size)
                 end_trim = torch.where(cond, torch.maximum(end_trim, (p.end_size - rs) + p.extra_end_trim), end_trim)
         self.stats["pairs_end"] += sum(int(j[1].shape[0]) for j in jobs)
-        return start_trim, end_trim
+        return (start_trim, end_trim, fulls) if full_for else (start_trim, end_trim)
 
     # ------------------------------------------------------------------------------------------
     def middle_adapter_list(self, matching: List[int]):
@@ -257,13 +295,7 @@ class Pipeline:
         if A == 0 or R == 0:
             return empty
         # masked_seq = seq[start_trim : len - end_trim] with Python slice semantics (nanopore_read.py:56-62)
-        ln = reads.length.to(torch.int64)
-        s_pos = torch.clamp(start_trim.to(torch.int64), max=ln)
-        e_pos = ln - end_trim.to(torch.int64)
-        e_pos = torch.where(e_pos < 0, torch.clamp(ln + e_pos, min=0), e_pos)
-        untouched = (start_trim == 0) & (end_trim == 0)
-        s_pos = torch.where(untouched, torch.zeros_like(s_pos), s_pos)
-        e_pos = torch.where(untouched, ln, e_pos)
+        s_pos, e_pos = trimmed_interval(reads.length, start_trim, end_trim)
         tlen = torch.clamp(e_pos - s_pos, min=0).to(torch.int32)
         toff = reads.off + s_pos
         live = torch.nonzero(tlen > 0).flatten()

@@ -1,0 +1,397 @@
+"""End to end: reads in -> adapters found, ends trimmed, barcodes called, chimeras split -> reads out.
+
+This is the batch form of everything porechop/porechop.py:33-79 (main) does around the hot path --
+SURVEY.md section 8f rows 2 (per-read orchestration) and 3 (output) -- written against arrays
+instead of per-read Python objects:
+
+  loading            porechop.py:216-268   (file, or Albacore directory with per-file check reads
+                                            and barcode calls read off the path)  -> io.ReadSet (C++)
+  phase A + rules    porechop.py:286-327, 374-390, 330-371, 410-436              -> Pipeline.phase_a, panel.py
+  phase B            porechop.py:438-514 + nanopore_read.py:166-208              -> Pipeline.phase_b
+  barcode calls      nanopore_read.py:399-473 (determine_barcode)                -> call_barcodes (tensor ops)
+  phase C            porechop.py:533-595 + nanopore_read.py:210-243              -> Pipeline.phase_c
+  pieces to write    nanopore_read.py:56-147 (trim slices, split parts, naming)  -> plan_output (numpy)
+  writing            porechop.py:607-734                                         -> ReadSet.write (C++)
+
+The alignments come from the GPU library only (Pipeline's default aligner); output files are
+byte-identical to the reference's (tests/test_runner_*.py).  Progress tables and coloured
+per-read dumps (verbosity >= 1 in the reference) are not reproduced: run() returns the numbers.
+"""
+import gzip
+import os
+import re
+import shutil
+import tempfile
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import panel as panel_rules
+from .io import ReadSet
+from .pipeline import AdapterSet, DeviceReads, Pipeline, ScanParams, trimmed_interval
+
+
+@dataclass
+class Options:
+    """Defaults of porechop/porechop.py:85-185 (get_arguments)."""
+    format: str = "auto"                      # auto | fasta | fastq | fasta.gz | fastq.gz
+    barcode_threshold: float = 75.0
+    barcode_diff: float = 5.0
+    require_two_barcodes: bool = False
+    untrimmed: bool = False
+    discard_unassigned: bool = False
+    adapter_threshold: float = 90.0
+    check_reads: int = 10000
+    scoring_scheme: Tuple[int, int, int, int] = (3, -6, -5, -2)
+    end_size: int = 150
+    min_trim_size: int = 4
+    extra_end_trim: int = 2
+    end_threshold: float = 75.0
+    no_split: bool = False
+    discard_middle: bool = False
+    middle_threshold: float = 90.0
+    extra_middle_trim_good_side: int = 10
+    extra_middle_trim_bad_side: int = 100
+    min_split_read_size: int = 1000
+
+
+@dataclass
+class RunResult:
+    n_reads: int = 0
+    read_type: str = "FASTQ"
+    matching_sets: List[str] = field(default_factory=list)       # after the 1D^2 fix-up and the full barcode sets
+    barcode_orientation: Optional[str] = None
+    start_trim: Optional[np.ndarray] = None                      # int32 [R]
+    end_trim: Optional[np.ndarray] = None
+    barcode_calls: Optional[List[str]] = None                    # per read, when binning
+    middle_hit_reads: int = 0
+    files: Dict[str, Tuple[int, int]] = field(default_factory=dict)   # path -> (records written, bases)
+    out_format: str = "fastq"
+
+
+class UsageError(ValueError):
+    """What the reference reports with sys.exit('Error: ...')."""
+
+
+def _albacore_barcode(path):
+    # porechop.py:271-278
+    if "/unclassified/" in path:
+        return "none"
+    m = re.findall(r"/barcode(\d\d)/", path)
+    if m:
+        return "BC" + m[-1]
+    return None
+
+
+def _load(input_path, check_read_count):
+    """-> (ReadSet, check-read indices, per-read Albacore call or None)."""
+    if os.path.isfile(input_path):
+        rs = ReadSet(input_path)
+        return rs, np.arange(min(rs.count, max(0, check_read_count)), dtype=np.int64), None
+    if os.path.isdir(input_path):
+        fastqs = sorted(os.path.join(d, f) for d, _, fs in os.walk(input_path) for f in fs
+                        if f.lower().endswith(".fastq") or f.lower().endswith(".fastq.gz"))
+        if not fastqs:
+            raise UsageError("Error: could not find fastq files in " + input_path)
+        rs = ReadSet(fastqs)
+        if not rs.is_fastq:
+            raise UsageError("Error: " + fastqs[0] + " is not FASTQ")
+        per_file = int(round(check_read_count / len(fastqs)))
+        fi = rs.file_index
+        first_of_file = np.searchsorted(fi, np.arange(len(fastqs)), side="left")
+        rank_in_file = np.arange(rs.count, dtype=np.int64) - first_of_file[fi]
+        check = np.nonzero(rank_in_file < per_file)[0].astype(np.int64)
+        calls = [_albacore_barcode(p) for p in fastqs]
+        return rs, check, [calls[i] for i in fi]
+    raise UsageError("Error: could not find " + input_path)
+
+
+def call_barcodes(names: List[str], start_scores: torch.Tensor, end_scores: torch.Tensor, opts: Options) -> np.ndarray:
+    """nanopore_read.py:399-466 for every read at once.
+
+    names[k] is barcode k's bin name; start_scores / end_scores are float64 [R, K]: the full-adapter
+    identity of barcode k's start / end sequence (the reference's two dicts, in insertion order).
+    -> int64 [R] index into names, or -1 for 'none'.
+
+    Ties are resolved as Python's stable sorted(..., reverse=True) resolves them there: among equal
+    scores the entry inserted first wins, start entries before end entries."""
+    R, K = start_scores.shape
+    dev = start_scores.device
+    none = torch.full((R,), -1, dtype=torch.int64, device=dev)
+    if K == 0:
+        return none.cpu().numpy()       # best = ('none', 0.0): the call is 'none' whatever the thresholds
+
+    def best_two(x):
+        order = torch.sort(x, dim=1, descending=True, stable=True)
+        second = order.values[:, 1] if x.shape[1] >= 2 else torch.zeros(R, dtype=x.dtype, device=dev)
+        return order.indices[:, 0], order.values[:, 0], second
+
+    if opts.require_two_barcodes:
+        si, sv, s2 = best_two(start_scores)
+        ei, ev, e2 = best_two(end_scores)
+        ok = (sv >= opts.barcode_threshold) & (ev >= opts.barcode_threshold) & \
+             (sv >= s2 + opts.barcode_diff) & (ev >= e2 + opts.barcode_diff)
+        # start_end_match compares NAMES
+        name_id = {}
+        ids = torch.tensor([name_id.setdefault(n, len(name_id)) for n in names], device=dev)
+        ok &= ids[si] == ids[ei]
+        call = torch.where(ok, si, none)
+    else:
+        both = torch.cat([start_scores, end_scores], dim=1)            # start entries first
+        bi, bv, _ = best_two(both)
+        bk = bi % K
+        # second best = best score among the OTHER names (each name keeps its best of start/end)
+        name_id = {}
+        ids = torch.tensor([name_id.setdefault(n, len(name_id)) for n in names], device=dev)
+        per_name = torch.maximum(start_scores, end_scores)
+        other = per_name.masked_fill(ids[None, :] == ids[bk][:, None], -1.0)
+        second = torch.clamp(other.max(dim=1).values, min=0.0)
+        ok = (bv >= opts.barcode_threshold) & (bv >= second + opts.barcode_diff)
+        call = torch.where(ok, bk, none)
+    return call.cpu().numpy()
+
+
+def _split_parts(tlen, intervals, min_size):
+    """get_split_read_parts (nanopore_read.py:76-95): positions of the trimmed read not covered by
+    any [trim_start, trim_end) -> maximal runs -> those of at least min_size bases."""
+    cover = np.zeros(tlen + 1, dtype=np.int32)
+    for a, b in intervals:
+        a, b = max(a, 0), min(b, tlen)
+        if b > a:
+            cover[a] += 1
+            cover[b] -= 1
+    keep = np.cumsum(cover[:tlen]) == 0
+    edges = np.diff(np.concatenate([[0], keep.astype(np.int8), [0]]))
+    starts, ends = np.nonzero(edges == 1)[0], np.nonzero(edges == -1)[0]
+    return [(int(s), int(e - s)) for s, e in zip(starts, ends) if e - s >= min_size]
+
+
+def _resolve_format(opts: Options, output, barcode_dir, read_type, input_path):
+    # porechop.py:627-655
+    fmt = opts.format
+    if fmt == "auto":
+        if output is None:
+            fmt = read_type.lower()
+            if barcode_dir is not None and input_path.lower().endswith(".gz"):
+                fmt += ".gz"
+        elif ".fasta.gz" in output.lower():
+            fmt = "fasta.gz"
+        elif ".fastq.gz" in output.lower():
+            fmt = "fastq.gz"
+        elif ".fasta" in output.lower():
+            fmt = "fasta"
+        elif ".fastq" in output.lower():
+            fmt = "fastq"
+        else:
+            fmt = read_type.lower()
+    gz = fmt.endswith(".gz") and (barcode_dir is not None or output is not None)
+    if gz:
+        fmt = fmt[:-3]
+    # (to stdout a '.gz' format is left as it is and, not being 'fasta', prints FASTQ -- as there)
+    return fmt, gz
+
+
+def _gzip_file(src, dst):
+    with open(src, "rb") as fi, gzip.open(dst, "wb") as fo:
+        shutil.copyfileobj(fi, fo, 1 << 22)
+    os.remove(src)
+
+
+def run(input_path, output=None, barcode_dir=None, options: Options = None, device=None, aligner=None,
+        adapter_panel: List[AdapterSet] = None) -> RunResult:
+    """Porechop's main() on arrays.  output=None and barcode_dir=None writes to stdout.
+    `aligner` is for tests only (see Pipeline)."""
+    opts = options or Options()
+    if len(tuple(opts.scoring_scheme)) != 4:
+        raise UsageError("Error: incorrectly formatted scoring scheme")
+    if barcode_dir is not None and output is not None:
+        raise UsageError("Error: only one of the following options may be used: --output, --barcode_dir")
+    if opts.untrimmed and barcode_dir is None:
+        raise UsageError("Error: --untrimmed can only be used with --barcode_dir")
+    discard_middle = opts.discard_middle or barcode_dir is not None          # porechop.py:203-204
+    input_path = str(input_path)
+
+    rs, check_idx, albacore = _load(input_path, opts.check_reads)
+    res = RunResult(n_reads=rs.count, read_type="FASTQ" if rs.is_fastq else "FASTA")
+    R = rs.count
+
+    panel = list(adapter_panel) if adapter_panel is not None else panel_rules.load_panel()
+    params = ScanParams(end_size=opts.end_size, min_trim_size=opts.min_trim_size, extra_end_trim=opts.extra_end_trim,
+                        end_threshold=opts.end_threshold, middle_threshold=opts.middle_threshold,
+                        adapter_threshold=opts.adapter_threshold, check_reads=opts.check_reads,
+                        scores=tuple(int(x) for x in opts.scoring_scheme))
+    pl = Pipeline(panel, params, device=device, aligner=aligner)
+    dev = pl.device
+    try:
+        reads = DeviceReads(torch.from_numpy(rs.arena).to(dev), torch.from_numpy(rs.offsets).to(dev),
+                            torch.from_numpy(rs.lengths).to(dev)) if R else None
+
+        # ---- phase A and the set-level rules ---------------------------------------------
+        if R and check_idx.size:
+            bs, be = pl.phase_a(reads, torch.from_numpy(check_idx).to(dev))
+            bs, be = bs.cpu().numpy(), be.cpu().numpy()
+        else:
+            bs = be = np.zeros(len(panel))
+        index_of = {id(s): i for i, s in enumerate(pl.sets)}
+        score = lambda s: max(bs[index_of[id(s)]], be[index_of[id(s)]])
+        matching = [s for s in panel if "(full sequence)" not in s.name and score(s) >= opts.adapter_threshold]
+        matching = panel_rules.fix_up_1d2(matching, score)
+        orientation = None
+        if barcode_dir is not None:
+            try:
+                orientation = panel_rules.choose_barcoding_kit(matching, lambda s: bs[index_of[id(s)]],
+                                                               lambda s: be[index_of[id(s)]])
+            except panel_rules.NoBarcodes as e:
+                raise UsageError(str(e))
+        with_full = panel_rules.add_full_barcode_sets(panel, matching)
+        pl.add_sets(with_full[len(matching):])
+        index_of = {id(s): i for i, s in enumerate(pl.sets)}
+        matching = with_full
+        match_idx = [index_of[id(s)] for s in matching]
+        res.matching_sets = [s.name for s in matching]
+        res.barcode_orientation = orientation
+
+        start_trim = torch.zeros(R, dtype=torch.int32, device=dev)
+        end_trim = torch.zeros(R, dtype=torch.int32, device=dev)
+        calls = None
+        hits = None
+        if matching and R:
+            # ---- phase B (+ barcode calls) ------------------------------------------------
+            check_barcodes = barcode_dir is not None
+            bc_sets = [i for i in match_idx if check_barcodes and panel_rules.is_barcode(pl.sets[i])
+                       and panel_rules.barcode_direction(pl.sets[i]) == orientation]
+            out_b = pl.phase_b(reads, match_idx, full_for=set(bc_sets))
+            start_trim, end_trim = out_b[0], out_b[1]
+            if check_barcodes:
+                fulls = out_b[2] if bc_sets else {}
+                # the reference's two dicts are keyed by bin name: a later set with the same name
+                # overwrites the value but keeps the first insertion's position
+                names, col = [], {}
+                for i in bc_sets:
+                    n = panel_rules.barcode_name(pl.sets[i])
+                    if n not in col:
+                        col[n] = len(names)
+                        names.append(n)
+                zeros = torch.zeros(R, dtype=torch.float64, device=dev)
+                s_cols, e_cols = [zeros] * len(names), [zeros] * len(names)
+                for i in bc_sets:
+                    k = col[panel_rules.barcode_name(pl.sets[i])]
+                    if (i, 0) in fulls:
+                        s_cols[k] = fulls[(i, 0)]
+                    if (i, 1) in fulls:
+                        e_cols[k] = fulls[(i, 1)]
+                S = torch.stack(s_cols, dim=1) if names else torch.zeros((R, 0), dtype=torch.float64, device=dev)
+                E = torch.stack(e_cols, dim=1) if names else torch.zeros((R, 0), dtype=torch.float64, device=dev)
+                ci = call_barcodes(names, S, E, opts)
+                calls = [names[k] if k >= 0 else "none" for k in ci]
+            # ---- phase C -------------------------------------------------------------------
+            if not opts.no_split:
+                hits = pl.phase_c(reads, start_trim, end_trim, match_idx)
+        elif barcode_dir is not None:
+            calls = ["none"] * R
+        if calls is not None and albacore is not None:             # nanopore_read.py:468-473
+            calls = [c if (a is None or a == c) else "none" for c, a in zip(calls, albacore)]
+        if hasattr(pl.aligner, "sync"):
+            pl.aligner.sync()
+
+        st = start_trim.cpu().numpy()
+        et = end_trim.cpu().numpy()
+        res.start_trim, res.end_trim, res.barcode_calls = st, et, calls
+
+        # ---- which pieces of which reads -------------------------------------------------
+        s_pos, e_pos = trimmed_interval(torch.from_numpy(rs.lengths.copy()), torch.from_numpy(st), torch.from_numpy(et))
+        s_pos, e_pos = s_pos.numpy(), e_pos.numpy()
+        tlen = np.maximum(e_pos - s_pos, 0)
+        split_of = {}
+        if hits is not None and hits.read.numel():
+            start_names = {s.start[0] for s in matching if s.start is not None}
+            end_names = {s.end[0] for s in matching if s.end is not None}
+            good, bad = opts.extra_middle_trim_good_side, opts.extra_middle_trim_bad_side
+            ad_names = [a[0] for a in pl.middle_adapters]
+            lo = np.array([bad if n in start_names else good for n in ad_names], dtype=np.int64)
+            hi = np.array([bad if n in end_names else good for n in ad_names], dtype=np.int64)
+            h_read = hits.read.cpu().numpy()
+            h_ad = hits.adapter.cpu().numpy()
+            h_s = hits.start.cpu().numpy().astype(np.int64)
+            h_e = hits.end.cpu().numpy().astype(np.int64)
+            for r, a, s, e in zip(h_read, h_ad, h_s, h_e):
+                split_of.setdefault(int(r), []).append((int(s - lo[a]), int(e + hi[a])))
+        res.middle_hit_reads = len(split_of)
+
+        fmt, gz = _resolve_format(opts, output, barcode_dir, res.read_type, input_path)
+        res.out_format = fmt
+        whole = opts.untrimmed
+        p_start = np.where(whole, 0, s_pos).astype(np.int64)
+        p_len = np.where(whole, rs.lengths, tlen).astype(np.int64)
+        emit = p_len > 0                                            # "Don't return empty sequences"
+        if split_of:
+            emit[np.fromiter(split_of.keys(), dtype=np.int64)] = False
+        if barcode_dir is not None and opts.discard_unassigned:
+            emit &= np.array([c != "none" for c in calls], dtype=bool)
+        # reads with middle hits: dropped when discarding, otherwise split and numbered
+        extra = []                                                  # (read, start, len, number)
+        if split_of and not discard_middle:
+            for r, ivs in split_of.items():
+                if barcode_dir is not None and opts.discard_unassigned and calls[r] == "none":
+                    continue
+                for k, (ps, pn) in enumerate(_split_parts(int(tlen[r]), ivs, opts.min_split_read_size)):
+                    extra.append((r, int(s_pos[r]) + ps, pn, k + 1))
+        base_reads = np.nonzero(emit)[0].astype(np.int64)
+        if extra:
+            ex = np.array(extra, dtype=np.int64)
+            pr = np.concatenate([base_reads, ex[:, 0]])
+            ps_ = np.concatenate([p_start[base_reads], ex[:, 1]])
+            pn_ = np.concatenate([p_len[base_reads], ex[:, 2]])
+            num = np.concatenate([np.zeros(base_reads.size, dtype=np.int64), ex[:, 3]])
+            order = np.lexsort((num, pr))                           # read order, pieces of a read in order
+            pr, ps_, pn_, num = pr[order], ps_[order], pn_[order], num[order]
+        else:
+            pr, ps_, pn_, num = base_reads, p_start[base_reads], p_len[base_reads], np.zeros(base_reads.size, dtype=np.int64)
+
+        # ---- write -------------------------------------------------------------------------
+        fastq = fmt != "fasta"                                      # porechop.py:667,711,727
+        if barcode_dir is not None:
+            os.makedirs(barcode_dir, exist_ok=True)
+            all_bins = sorted(set(calls))
+            lookup = {b: k for k, b in enumerate(all_bins)}
+            bin_of_read = np.fromiter((lookup[c] for c in calls), dtype=np.int32, count=len(calls))
+            used = np.unique(bin_of_read[pr]) if pr.size else np.zeros(0, dtype=np.int32)
+            bins = [all_bins[k] for k in used]
+            remap = np.full(len(all_bins), -1, dtype=np.int32)
+            remap[used] = np.arange(used.size, dtype=np.int32)
+            pf = remap[bin_of_read[pr]] if pr.size else np.zeros(0, dtype=np.int32)
+            paths = [os.path.join(barcode_dir, b + "." + fmt) for b in bins]
+            rs.write(pr, ps_, pn_, num, pf, paths, fastq)
+            for k, (b, path) in enumerate(zip(bins, paths)):
+                sel = pf == k
+                # the reference counts reads (not pieces) and their end-trimmed (or whole) lengths
+                rr = np.unique(pr[sel])
+                res.files[path + (".gz" if gz else "")] = (int(rr.size), int((rs.lengths[rr] if whole else tlen[rr]).sum()))
+                if gz:
+                    if os.path.isfile(path + ".gz"):
+                        os.remove(path + ".gz")
+                    _gzip_file(path, path + ".gz")
+        elif output is None:
+            rs.write(pr, ps_, pn_, num, np.zeros(pr.size, dtype=np.int32), ["-"], fastq)
+        else:
+            if gz:
+                tmp = tempfile.NamedTemporaryFile(prefix="porechop_amd_", suffix="." + fmt, delete=False,
+                                                  dir=os.path.dirname(os.path.abspath(output)))
+                tmp.close()
+                target = tmp.name
+            else:
+                target = output
+            if pr.size == 0:
+                open(target, "wb").close()                          # the reference always creates the file
+            else:
+                rs.write(pr, ps_, pn_, num, np.zeros(pr.size, dtype=np.int32), [target], fastq)
+            if gz:
+                _gzip_file(target, output)
+            res.files[output] = (int(np.unique(pr).size), int(pn_.sum()))
+        return res
+    finally:
+        if aligner is None:
+            pl.close()
+        rs.close()

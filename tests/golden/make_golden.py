@@ -151,6 +151,47 @@ def record_reference_runs(refdir, tmp):
     return strings, calls, runs, panel
 
 
+def runner_goldens(refdir, tmp):
+    """Whole-run goldens on the seeded synthetic inputs of tests/readgen.py: the unchanged reference
+    CLI's output files (md5 of their content) for every case in readgen.RUNNER_CASES."""
+    from tests import readgen
+    import porechop.porechop as pp
+    import porechop.adapters as adapters_mod
+    out = {}
+    built = {}
+    cwd = os.getcwd()
+    for name, dataset, mode, extra in readgen.RUNNER_CASES:
+        if dataset not in built:
+            built[dataset] = readgen.build_dataset(dataset, os.path.join(tmp, "datasets"))
+        inp = built[dataset]
+        for a in adapters_mod.ADAPTERS:
+            a.best_start_score, a.best_end_score = 0.0, 0.0
+        work = os.path.join(tmp, "run_" + name)
+        os.makedirs(work)
+        if mode == "b":
+            target = os.path.join(work, "bins")
+            argv = ["porechop", "-i", inp, "-b", target, "-v", "0", "--threads", "1"] + extra
+        else:
+            target = os.path.join(work, mode[2:])
+            argv = ["porechop", "-i", inp, "-o", target, "-v", "0", "--threads", "1"] + extra
+        sys.argv = argv
+        os.chdir(work)                       # the reference writes a TEMP_<pid> file into the cwd for .gz outputs
+        buf = io.StringIO()
+        try:
+            with redirect_stdout(buf), redirect_stderr(buf):
+                pp.main()
+            outputs = readgen.output_md5s(target)
+            error = None
+        except SystemExit as e:
+            outputs, error = {}, str(e)
+        finally:
+            os.chdir(cwd)
+        out[name] = {"dataset": dataset, "mode": mode, "argv": extra, "input_sha1": readgen.dataset_sha1(inp),
+                     "outputs": outputs, "exit": error}
+        print("  case %-28s files=%d %s" % (name, len(outputs), error or ""))
+    return out
+
+
 def synthetic(ref_so):
     import ctypes
     lib = ctypes.CDLL(ref_so)
@@ -185,9 +226,15 @@ def main():
                 "n_strings": len(strings), "n_calls": len(calls)}
         with gzip.open(os.path.join(HERE, "ref_calls.json.gz"), "wt", compresslevel=9) as f:
             json.dump({"meta": meta, "runs": runs, "strings": strings, "calls": calls}, f)
-        with open(os.path.join(HERE, "panel.json"), "w") as f:
-            json.dump(panel, f, indent=0)
+        # the adapter panel (names + sequences: data, not code) -- once for the tests, once as the
+        # package's own table (porechop_amd/panel.py)
+        for dst in (os.path.join(HERE, "panel.json"), os.path.join(REPO, "porechop_amd", "panel.json")):
+            with open(dst, "w") as f:
+                json.dump(panel, f, indent=0)
         print("unique calls: %d, unique strings: %d" % (len(calls), len(strings)))
+        print("whole-run goldens on synthetic inputs ...")
+        with open(os.path.join(HERE, "runner_goldens.json"), "w") as f:
+            json.dump({"meta": meta, "cases": runner_goldens(refdir, tmp)}, f, indent=1, sort_keys=True)
         print("synthetic cases ...")
         sets = synthetic(os.path.join(REPO, "oracle", "_ref", "cpp_functions.so"))
         with gzip.open(os.path.join(HERE, "ref_synthetic.json.gz"), "wt", compresslevel=9) as f:

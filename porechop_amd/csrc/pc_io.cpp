@@ -19,30 +19,86 @@
 // arrays), this code formats them straight from the arena.
 #include <zlib.h>
 
+#include <fcntl.h>
+#include <sched.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
 #include <cctype>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/porechop_amd.h"
 
+// Growable byte buffer WITHOUT value-initialisation: the big arenas are sized once and filled by
+// several threads; std::vector::resize would first zero gigabytes on one core.
+struct RawBuf {
+    char *p = nullptr;
+    size_t n = 0, cap = 0;
+    RawBuf() = default;
+    RawBuf(const RawBuf &) = delete;
+    RawBuf &operator=(const RawBuf &) = delete;
+    ~RawBuf() { free(p); }
+    char *data() { return p; }
+    const char *data() const { return p; }
+    size_t size() const { return n; }
+    void reserve(size_t c)
+    {
+        if (c <= cap) return;
+        size_t nc = cap ? cap : 4096;
+        while (nc < c) nc += nc / 2 + 4096;
+        char *q = (char *)realloc(p, nc);
+        if (!q) abort();
+        p = q; cap = nc;
+    }
+    void resize(size_t c) { reserve(c); n = c; }                       // new bytes are NOT initialised
+    void append(const char *b, const char *e) { const size_t k = (size_t)(e - b); reserve(n + k); if (k) memcpy(p + n, b, k); n += k; }
+    void fill(size_t k, char c) { reserve(n + k); memset(p + n, c, k); n += k; }
+    void push_back(char c) { reserve(n + 1); p[n++] = c; }
+    char &operator[](size_t i) { return p[i]; }
+};
+
 struct pc_readset {
     bool fastq = false;
-    std::vector<char> arena;
+    RawBuf arena;
     std::vector<int64_t> off;
     std::vector<int32_t> len;
     std::vector<uint8_t> rna;
-    std::vector<std::string> names;      // full header without the leading marker
-    std::vector<std::string> quals;      // FASTQ only (padded with '+' to the sequence length)
+    // NUL-terminated strings back to back: read i's name at name_arena[name_off[i]], its qualities
+    // (FASTQ only, padded with '+' to the sequence length) at qual_arena[qual_off[i]]
+    RawBuf name_arena, qual_arena;
+    std::vector<int64_t> name_off, qual_off;
+    const char *name_of(size_t i) const { return name_arena.data() + name_off[i]; }
+    size_t name_len(size_t i) const { return strlen(name_of(i)); }
+    const char *qual_of(size_t i) const { return qual_arena.data() + qual_off[i]; }
     std::vector<int32_t> file_index;     // which input file a read came from (pc_readset_load_many)
     std::string error;
 };
 
 namespace {
 
-bool slurp(const char *path, std::vector<char> &data, std::string &err)
+// The bytes of a file: plain files are mapped (no copy), gzip files are inflated into memory.
+struct FileData {
+    const char *p = nullptr;
+    size_t n = 0;
+    void *map = nullptr;
+    size_t map_len = 0;
+    std::vector<char> owned;
+    FileData() = default;
+    FileData(const FileData &) = delete;
+    ~FileData() { if (map) munmap(map, map_len); }
+    const char *data() const { return p; }
+    size_t size() const { return n; }
+    bool empty() const { return n == 0; }
+};
+
+bool slurp(const char *path, FileData &data, std::string &err)
 {
     FILE *f = fopen(path, "rb");
     if (!f) { err = std::string("could not find ") + path; return false; }
@@ -62,18 +118,34 @@ bool slurp(const char *path, std::vector<char> &data, std::string &err)
             const int n = gzread(g, buf.data(), (unsigned)buf.size());
             if (n < 0) { err = "gzip stream error"; gzclose(g); return false; }
             if (n == 0) break;
-            data.insert(data.end(), buf.begin(), buf.begin() + n);
+            data.owned.insert(data.owned.end(), buf.begin(), buf.begin() + n);
         }
         gzclose(g);
+        data.p = data.owned.data(); data.n = data.owned.size();
     } else {
-        f = fopen(path, "rb");
-        if (!f) { err = std::string("could not open ") + path; return false; }
-        fseek(f, 0, SEEK_END);
-        const long sz = ftell(f);
-        fseek(f, 0, SEEK_SET);
-        data.resize(sz > 0 ? (size_t)sz : 0);
-        if (sz > 0 && fread(data.data(), 1, (size_t)sz, f) != (size_t)sz) { err = "short read"; fclose(f); return false; }
-        fclose(f);
+        const int fd = open(path, O_RDONLY);
+        if (fd < 0) { err = std::string("could not open ") + path; return false; }
+        struct stat st;
+        if (fstat(fd, &st) != 0) { err = std::string("could not open ") + path; close(fd); return false; }
+        if (st.st_size > 0) {
+            void *m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+            if (m == MAP_FAILED) {                               // e.g. a pipe: read it
+                data.owned.resize((size_t)st.st_size);
+                size_t have = 0;
+                while (have < data.owned.size()) {
+                    const ssize_t k = read(fd, data.owned.data() + have, data.owned.size() - have);
+                    if (k <= 0) break;
+                    have += (size_t)k;
+                }
+                data.owned.resize(have);
+                data.p = data.owned.data(); data.n = have;
+            } else {
+                madvise(m, (size_t)st.st_size, MADV_WILLNEED);
+                data.map = m; data.map_len = (size_t)st.st_size;
+                data.p = (const char *)m; data.n = (size_t)st.st_size;
+            }
+        }
+        close(fd);
     }
     return true;
 }
@@ -123,12 +195,137 @@ void add_read(pc_readset *rs, const char *name_b, const char *name_e, const char
     rs->off.push_back((int64_t)o);
     rs->len.push_back((int32_t)n);
     rs->rna.push_back(rna ? 1 : 0);
-    rs->names.emplace_back(name_b, name_e);
+    rs->name_off.push_back((int64_t)rs->name_arena.size());
+    rs->name_arena.append(name_b, name_e);
+    rs->name_arena.push_back('\0');
     if (rs->fastq) {
-        rs->quals.emplace_back(q_b, q_e);
-        std::string &q = rs->quals.back();
-        if (q.size() < n) q.append(n - q.size(), '+');
+        rs->qual_off.push_back((int64_t)rs->qual_arena.size());
+        rs->qual_arena.append(q_b, q_e);
+        const size_t ql = (size_t)(q_e - q_b);
+        if (ql < n) rs->qual_arena.fill(n - ql, '+');
+        rs->qual_arena.push_back('\0');
     }
+}
+
+int usable_threads()
+{
+    cpu_set_t set;
+    int n = 0;
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) n = CPU_COUNT(&set);
+    if (n <= 0) n = (int)std::thread::hardware_concurrency();
+    if (const char *e = getenv("PC_IO_THREADS")) { const int v = atoi(e); if (v > 0) n = v; }
+    return std::max(1, std::min(n, 64));
+}
+
+// ---- parallel FASTQ parse ---------------------------------------------------------------------
+// The reference's loader takes FASTQ strictly as 4 stripped lines per record (misc.py:151-168).
+// A record start is therefore a line beginning with '@' whose next-but-one line begins with '+':
+// a quality line may begin with '@', but then the line two below it is a sequence line, never '+'.
+// The file is cut at such boundaries into one span per thread; pass 1 sizes every span, a prefix
+// sum places it, pass 2 writes reads straight into their final position.  Anything irregular
+// (missing lines, blank lines, a header that is not '@') is left to the serial parser, which
+// reproduces the reference's behaviour and error messages for those cases.
+struct Span { const char *b, *e; size_t reads = 0, seq = 0, name = 0, qual = 0; bool ok = true; };
+
+inline const char *line_end(const char *p, const char *end) { const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p)); return nl ? nl : end; }
+inline const char *next_line(const char *p, const char *end) { const char *nl = line_end(p, end); return nl < end ? nl + 1 : end; }
+
+const char *find_record_start(const char *p, const char *begin, const char *end)
+{
+    if (p <= begin) return begin;
+    p = next_line(p - 1, end);                                   // first line start at or after p
+    for (int tries = 0; tries < 8 && p < end; ++tries) {
+        const char *l2 = next_line(next_line(p, end), end);
+        if (*p == '@' && l2 < end && *l2 == '+') return p;
+        p = next_line(p, end);
+    }
+    return nullptr;                                               // not a regular 4-line FASTQ around here
+}
+
+template <class Fn> bool for_each_record(const Span &sp, Fn fn)
+{
+    const char *p = sp.b;
+    while (p < sp.e) {
+        const char *b0 = p, *e0 = line_end(p, sp.e);
+        if (e0 >= sp.e) return false;                             // a record needs four lines
+        const char *b1 = e0 + 1, *e1 = line_end(b1, sp.e);
+        if (e1 >= sp.e) return false;
+        const char *b2 = e1 + 1, *e2 = line_end(b2, sp.e);
+        if (e2 >= sp.e) return false;
+        const char *b3 = e2 + 1, *e3 = line_end(b3, sp.e);
+        if (b3 >= sp.e) return false;
+        const char *nb = b0, *ne = e0;
+        strip(nb, ne);
+        if (nb == ne || *nb != '@' || *b2 != '+') return false;
+        ++nb;
+        if (nb == ne) return false;                               // empty name: the reference fails on it
+        const char *sb = b1, *se = e1, *qb = b3, *qe = e3;
+        strip(sb, se); strip(qb, qe);
+        fn(nb, ne, sb, se, qb, qe);
+        p = e3 < sp.e ? e3 + 1 : sp.e;
+    }
+    return true;
+}
+
+bool parse_fastq_parallel(pc_readset *rs, const FileData &data, int nthreads)
+{
+    const char *begin = data.data(), *end = begin + data.size();
+    std::vector<Span> spans;
+    const char *prev = begin;
+    for (int t = 1; t <= nthreads; ++t) {
+        const char *cut = t == nthreads ? end : find_record_start(begin + data.size() / (size_t)nthreads * (size_t)t, begin, end);
+        if (!cut) return false;
+        if (cut > prev) { Span sp; sp.b = prev; sp.e = cut; spans.push_back(sp); prev = cut; }
+    }
+    auto run = [&](auto fn) {
+        std::vector<std::thread> th;
+        for (size_t k = 1; k < spans.size(); ++k) th.emplace_back(fn, k);
+        fn((size_t)0);
+        for (auto &x : th) x.join();
+    };
+    run([&](size_t k) {
+        Span &sp = spans[k];
+        sp.ok = for_each_record(sp, [&](const char *nb, const char *ne, const char *sb, const char *se, const char *qb, const char *qe) {
+            const size_t n = (size_t)(se - sb), q = (size_t)(qe - qb);
+            ++sp.reads; sp.seq += n; sp.name += (size_t)(ne - nb) + 1; sp.qual += std::max(n, q) + 1;
+        });
+    });
+    for (const Span &sp : spans) if (!sp.ok) return false;
+    // placement
+    const size_t r0 = rs->off.size(), s0 = rs->arena.size(), n0 = rs->name_arena.size(), q0 = rs->qual_arena.size();
+    std::vector<size_t> rb(spans.size() + 1, r0), sb_(spans.size() + 1, s0), nb_(spans.size() + 1, n0), qb_(spans.size() + 1, q0);
+    for (size_t k = 0; k < spans.size(); ++k) {
+        rb[k + 1] = rb[k] + spans[k].reads; sb_[k + 1] = sb_[k] + spans[k].seq;
+        nb_[k + 1] = nb_[k] + spans[k].name; qb_[k + 1] = qb_[k] + spans[k].qual;
+    }
+    rs->off.resize(rb.back()); rs->len.resize(rb.back()); rs->rna.resize(rb.back());
+    rs->name_off.resize(rb.back()); rs->qual_off.resize(rb.back());
+    rs->arena.resize(sb_.back()); rs->name_arena.resize(nb_.back()); rs->qual_arena.resize(qb_.back());
+    run([&](size_t k) {
+        size_t r = rb[k], so = sb_[k], no = nb_[k], qo = qb_[k];
+        for_each_record(spans[k], [&](const char *nb, const char *ne, const char *sb, const char *se, const char *qb, const char *qe) {
+            const size_t n = (size_t)(se - sb), q = (size_t)(qe - qb);
+            unsigned char *dst = (unsigned char *)rs->arena.data() + so;
+            size_t nu = 0, nt = 0;
+            for (size_t i = 0; i < n; ++i) {
+                const unsigned char c = kUpper.t[(unsigned char)sb[i]];
+                dst[i] = c;
+                nu += (c == 'U'); nt += (c == 'T');
+            }
+            const bool rna = nu > nt;
+            if (rna) for (size_t i = 0; i < n; ++i) if (dst[i] == 'U') dst[i] = 'T';
+            rs->off[r] = (int64_t)so; rs->len[r] = (int32_t)n; rs->rna[r] = rna ? 1 : 0;
+            rs->name_off[r] = (int64_t)no;
+            memcpy(rs->name_arena.data() + no, nb, (size_t)(ne - nb));
+            rs->name_arena[no + (size_t)(ne - nb)] = '\0';
+            rs->qual_off[r] = (int64_t)qo;
+            memcpy(rs->qual_arena.data() + qo, qb, q);
+            if (q < n) memset(rs->qual_arena.data() + qo + q, '+', n - q);
+            rs->qual_arena[qo + std::max(n, q)] = '\0';
+            ++r; so += n; no += (size_t)(ne - nb) + 1; qo += std::max(n, q) + 1;
+        });
+    });
+    return true;
 }
 
 }  // namespace
@@ -138,9 +335,9 @@ extern "C" {
 // parse one file into rs (reads appended); rs->fastq is set by the first file
 static int load_into(pc_readset *rs, const char *path, int32_t file_index, bool first)
 {
-    std::vector<char> data;
+    FileData data;
     if (!slurp(path, data, rs->error)) return PC_ERR_BAD_ARG;
-    const char first_char = data.empty() ? '\0' : data[0];
+    const char first_char = data.empty() ? '\0' : data.data()[0];
     if (first_char != '>' && first_char != '@') { rs->error = "File is neither FASTA or FASTQ"; return PC_ERR_BAD_ARG; }
     const bool fastq = (first_char == '@');
     if (first) rs->fastq = fastq;
@@ -149,7 +346,10 @@ static int load_into(pc_readset *rs, const char *path, int32_t file_index, bool 
     const size_t before = rs->off.size();
     Lines ln{data.data(), data.data() + data.size()};
     const char *b, *e;
-    if (rs->fastq) {
+    static const bool serial_only = [] { const char *e = getenv("PC_IO_SERIAL"); return e && *e && *e != '0'; }();
+    if (rs->fastq && !serial_only && data.size() >= ((size_t)1 << 20) && parse_fastq_parallel(rs, data, usable_threads())) {
+        // regular 4-line FASTQ, parsed in parallel
+    } else if (rs->fastq) {
         while (ln.next(b, e)) {
             strip(b, e);
             const char *nb = b < e ? b + 1 : b;           // line.strip()[1:]
@@ -192,7 +392,7 @@ int pc_readset_load_many(const char *const *paths, int npaths, pc_readset **out)
         const int rc = load_into(rs, paths[i], i, i == 0);
         if (rc) return rc;
     }
-    rs->arena.insert(rs->arena.end(), 64, 'N');           // the kernels fetch a dword at a time
+    rs->arena.fill(64, 'N');                              // the kernels fetch a dword at a time
     return PC_OK;
 }
 
@@ -216,11 +416,11 @@ const int64_t *pc_readset_offsets(const pc_readset *rs) { return rs ? rs->off.da
 const int32_t *pc_readset_lengths(const pc_readset *rs) { return rs ? rs->len.data() : nullptr; }
 const char *pc_readset_name(const pc_readset *rs, int64_t i)
 {
-    return (rs && i >= 0 && i < (int64_t)rs->names.size()) ? rs->names[(size_t)i].c_str() : nullptr;
+    return (rs && i >= 0 && i < (int64_t)rs->name_off.size()) ? rs->name_of((size_t)i) : nullptr;
 }
 const char *pc_readset_quals(const pc_readset *rs, int64_t i)
 {
-    return (rs && rs->fastq && i >= 0 && i < (int64_t)rs->quals.size()) ? rs->quals[(size_t)i].c_str() : nullptr;
+    return (rs && rs->fastq && i >= 0 && i < (int64_t)rs->qual_off.size()) ? rs->qual_of((size_t)i) : nullptr;
 }
 int pc_readset_is_rna(const pc_readset *rs, int64_t i)
 {
@@ -234,72 +434,126 @@ int pc_readset_write(const pc_readset *rs, int64_t npieces, const int64_t *piece
 {
     if (!rs || npieces < 0 || nfiles < 0 || (npieces > 0 && (!piece_read || !piece_start || !piece_len || !piece_file || !file_paths)))
         return PC_ERR_BAD_ARG;
-    std::vector<FILE *> files((size_t)nfiles, nullptr);
-    std::vector<std::vector<char>> bufs((size_t)nfiles);
-    int64_t total = 0;
-    int rc = PC_OK;
-    auto flush = [&](int f) {
-        std::vector<char> &b = bufs[(size_t)f];
-        if (b.empty()) return;
-        if (fwrite(b.data(), 1, b.size(), files[(size_t)f]) != b.size()) rc = PC_ERR_BAD_ARG;
-        total += (int64_t)b.size();
-        b.clear();
-    };
     const int64_t nreads = (int64_t)rs->off.size();
-    for (int64_t k = 0; k < npieces && rc == PC_OK; ++k) {
+    for (int64_t k = 0; k < npieces; ++k) {
         const int64_t r = piece_read[k];
-        const int f = piece_file[k];
-        if (r < 0 || r >= nreads || f < 0 || f >= nfiles) { rc = PC_ERR_BAD_ARG; break; }
-        const int64_t n = rs->len[(size_t)r];
-        const int64_t st = piece_start[k], ln = piece_len[k];
-        if (st < 0 || ln < 0 || st + ln > n) { rc = PC_ERR_BAD_ARG; break; }
-        if (!files[(size_t)f]) {                                   // opened on first use, like the reference's bins
-            const char *path = file_paths[f];
-            files[(size_t)f] = (path[0] == '-' && path[1] == '\0') ? stdout : fopen(path, "wb");
-            if (!files[(size_t)f]) { rc = PC_ERR_BAD_ARG; break; }
-            bufs[(size_t)f].reserve(1 << 22);
-        }
-        std::vector<char> &b = bufs[(size_t)f];
-        // header: add_number_to_read_name (nanopore_read.py:494-498): "_<k>" before the first space, or at the end
-        b.push_back(fastq ? '@' : '>');
-        const std::string &name = rs->names[(size_t)r];
+        if (r < 0 || r >= nreads || piece_file[k] < 0 || piece_file[k] >= nfiles) return PC_ERR_BAD_ARG;
+        if (piece_start[k] < 0 || piece_len[k] < 0 || (int64_t)piece_start[k] + piece_len[k] > rs->len[(size_t)r]) return PC_ERR_BAD_ARG;
+    }
+    // header: add_number_to_read_name (nanopore_read.py:494-498): "_<k>" before the first space, or at the end
+    auto tag_of = [&](int64_t k, char *tag) -> int {
         const int number = piece_number ? piece_number[k] : 0;
-        if (number > 0) {
-            char tag[24];
-            const int tl = snprintf(tag, sizeof tag, "_%d", number);
-            const size_t sp = name.find(' ');
-            if (sp == std::string::npos) { b.insert(b.end(), name.begin(), name.end()); b.insert(b.end(), tag, tag + tl); }
-            else { b.insert(b.end(), name.begin(), name.begin() + (long)sp); b.insert(b.end(), tag, tag + tl); b.insert(b.end(), name.begin() + (long)sp, name.end()); }
-        } else {
-            b.insert(b.end(), name.begin(), name.end());
-        }
-        b.push_back('\n');
-        const char *seq = rs->arena.data() + rs->off[(size_t)r] + st;
-        const bool rna = rs->rna[(size_t)r] != 0;
-        const size_t seq_at = b.size();
+        return number > 0 ? snprintf(tag, 24, "_%d", number) : 0;
+    };
+    auto size_of = [&](int64_t k) -> size_t {
+        char tag[24];
+        const size_t ln = (size_t)piece_len[k];
+        const size_t head = 1 + rs->name_len((size_t)piece_read[k]) + (size_t)tag_of(k, tag) + 1;
+        if (fastq) return head + ln + 3 + ln + 1;
+        return head + (ln == 0 ? 1 : ln + (ln + 69) / 70);
+    };
+    auto format = [&](int64_t k, char *o) -> char * {
+        const size_t r = (size_t)piece_read[k];
+        const size_t st = (size_t)piece_start[k], ln = (size_t)piece_len[k];
+        char tag[24];
+        const int tl = tag_of(k, tag);
+        const char *name = rs->name_of(r);
+        const size_t name_n = strlen(name);
+        *o++ = fastq ? '@' : '>';
+        const char *sp = tl ? (const char *)memchr(name, ' ', name_n) : nullptr;
+        if (tl && sp) { memcpy(o, name, (size_t)(sp - name)); o += sp - name; memcpy(o, tag, (size_t)tl); o += tl; memcpy(o, sp, name_n - (size_t)(sp - name)); o += name_n - (size_t)(sp - name); }
+        else { memcpy(o, name, name_n); o += name_n; if (tl) { memcpy(o, tag, (size_t)tl); o += tl; } }
+        *o++ = '\n';
+        const char *seq = rs->arena.data() + rs->off[r] + st;
+        const bool rna = rs->rna[r] != 0;
+        char *seq_at = o;
         if (fastq) {
-            b.insert(b.end(), seq, seq + ln);
-            b.push_back('\n'); b.push_back('+'); b.push_back('\n');
-            if (rs->fastq) { const std::string &q = rs->quals[(size_t)r]; b.insert(b.end(), q.begin() + st, q.begin() + st + ln); }
-            else b.insert(b.end(), (size_t)ln, '+');             // FASTA input: NanoporeRead pads the empty qualities with '+'
-            b.push_back('\n');
-            if (rna) for (size_t i = seq_at; i < seq_at + (size_t)ln; ++i) if (b[i] == 'T') b[i] = 'U';
+            memcpy(o, seq, ln); o += ln;
+            *o++ = '\n'; *o++ = '+'; *o++ = '\n';
+            if (rs->fastq) memcpy(o, rs->qual_of(r) + st, ln);
+            else memset(o, '+', ln);                              // FASTA input: NanoporeRead pads the empty qualities with '+'
+            o += ln;
+            *o++ = '\n';
+            if (rna) for (char *c = seq_at; c < seq_at + ln; ++c) if (*c == 'T') *c = 'U';
         } else {
             // add_line_breaks_to_sequence(seq, 70): every line, the last included, ends in '\n'
-            if (ln == 0) b.push_back('\n');
-            for (int64_t pos = 0; pos < ln; pos += 70) {
-                const int64_t w = ln - pos < 70 ? ln - pos : 70;
-                b.insert(b.end(), seq + pos, seq + pos + w);
-                b.push_back('\n');
+            if (ln == 0) *o++ = '\n';
+            for (size_t pos = 0; pos < ln; pos += 70) {
+                const size_t w = ln - pos < 70 ? ln - pos : 70;
+                memcpy(o, seq + pos, w); o += w;
+                *o++ = '\n';
             }
-            if (rna) for (size_t i = seq_at; i < b.size(); ++i) if (b[i] == 'T') b[i] = 'U';
+            if (rna) for (char *c = seq_at; c < o; ++c) if (*c == 'T') *c = 'U';
         }
-        if (b.size() >= ((size_t)1 << 22)) flush(f);
-    }
-    for (int f = 0; f < nfiles; ++f) {
-        if (!files[(size_t)f]) continue;
-        if (rc == PC_OK) flush(f);
-        if (files[(size_t)f] == stdout) fflush(stdout); else if (fclose(files[(size_t)f]) != 0) rc = PC_ERR_BAD_ARG;
+        return o;
+    };
+
+    int64_t total = 0;
+    int rc = PC_OK;
+    std::vector<std::vector<int64_t>> of_file((size_t)nfiles);
+    for (int64_t k = 0; k < npieces; ++k) of_file[(size_t)piece_file[k]].push_back(k);
+    const int nthreads = usable_threads();
+    for (int f = 0; f < nfiles && rc == PC_OK; ++f) {
+        const std::vector<int64_t> &idx = of_file[(size_t)f];
+        if (idx.empty()) continue;                                 // a bin that receives nothing leaves no file
+        const char *path = file_paths[f];
+        const bool to_stdout = path[0] == '-' && path[1] == '\0';
+        // where every piece lands
+        std::vector<size_t> at(idx.size() + 1, 0);
+        for (size_t i = 0; i < idx.size(); ++i) at[i + 1] = at[i] + size_of(idx[i]);
+        const size_t bytes = at.back();
+        if (to_stdout) {
+            std::vector<char> buf;
+            for (size_t i = 0; i < idx.size() && rc == PC_OK; ) {
+                size_t j = i;
+                while (j < idx.size() && at[j + 1] - at[i] <= ((size_t)1 << 24)) ++j;
+                if (j == i) j = i + 1;
+                buf.resize(at[j] - at[i]);
+                char *o = buf.data();
+                for (size_t q = i; q < j; ++q) o = format(idx[q], o);
+                if (fwrite(buf.data(), 1, buf.size(), stdout) != buf.size()) rc = PC_ERR_BAD_ARG;
+                i = j;
+            }
+            fflush(stdout);
+        } else {
+            const int fd = open(path, O_WRONLY | O_CREAT | O_TRUNC, 0666);
+            if (fd < 0) { rc = PC_ERR_BAD_ARG; break; }
+            // spans of pieces with about equal bytes, formatted by one thread each and written in place
+            const int T = (int)std::max<size_t>(1, std::min<size_t>((size_t)nthreads, bytes / ((size_t)1 << 22) + 1));
+            std::vector<size_t> cut((size_t)T + 1, idx.size());
+            cut[0] = 0;
+            for (int t = 1; t < T; ++t)
+                cut[(size_t)t] = (size_t)(std::lower_bound(at.begin(), at.end(), bytes / (size_t)T * (size_t)t) - at.begin());
+            std::vector<int> ok((size_t)T, 1);
+            auto work = [&](int t) {
+                std::vector<char> buf;
+                size_t i = cut[(size_t)t];
+                const size_t stop = std::max(cut[(size_t)t], cut[(size_t)t + 1]);
+                while (i < stop) {
+                    size_t j = i;
+                    while (j < stop && at[j + 1] - at[i] <= ((size_t)1 << 23)) ++j;
+                    if (j == i) j = i + 1;
+                    buf.resize(at[j] - at[i]);
+                    char *o = buf.data();
+                    for (size_t q = i; q < j; ++q) o = format(idx[q], o);
+                    if ((size_t)(o - buf.data()) != buf.size()) { ok[(size_t)t] = 0; return; }
+                    size_t done = 0;
+                    while (done < buf.size()) {
+                        const ssize_t w = pwrite(fd, buf.data() + done, buf.size() - done, (off_t)(at[i] + done));
+                        if (w <= 0) { ok[(size_t)t] = 0; return; }
+                        done += (size_t)w;
+                    }
+                    i = j;
+                }
+            };
+            std::vector<std::thread> th;
+            for (int t = 1; t < T; ++t) th.emplace_back(work, t);
+            work(0);
+            for (auto &x : th) x.join();
+            for (int t = 0; t < T; ++t) if (!ok[(size_t)t]) rc = PC_ERR_BAD_ARG;
+            if (close(fd) != 0) rc = PC_ERR_BAD_ARG;
+        }
+        total += (int64_t)bytes;
     }
     if (bytes_written) *bytes_written = total;
     return rc;

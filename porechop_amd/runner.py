@@ -22,6 +22,7 @@ import os
 import re
 import shutil
 import tempfile
+import time
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Tuple
 
@@ -69,6 +70,7 @@ class RunResult:
     middle_hit_reads: int = 0
     files: Dict[str, Tuple[int, int]] = field(default_factory=dict)   # path -> (records written, bases)
     out_format: str = "fastq"
+    seconds: Dict[str, float] = field(default_factory=dict)      # wall-clock per stage
 
 
 class UsageError(ValueError):
@@ -213,9 +215,19 @@ def run(input_path, output=None, barcode_dir=None, options: Options = None, devi
     discard_middle = opts.discard_middle or barcode_dir is not None          # porechop.py:203-204
     input_path = str(input_path)
 
+    t_last = [time.perf_counter()]
+
+    def lap(stage, sync=False):
+        if sync and aligner is None and torch.cuda.is_available():
+            torch.cuda.synchronize()
+        now = time.perf_counter()
+        res.seconds[stage] = res.seconds.get(stage, 0.0) + now - t_last[0]
+        t_last[0] = now
+
     rs, check_idx, albacore = _load(input_path, opts.check_reads)
     res = RunResult(n_reads=rs.count, read_type="FASTQ" if rs.is_fastq else "FASTA")
     R = rs.count
+    lap("load")
 
     panel = list(adapter_panel) if adapter_panel is not None else panel_rules.load_panel()
     params = ScanParams(end_size=opts.end_size, min_trim_size=opts.min_trim_size, extra_end_trim=opts.extra_end_trim,
@@ -227,6 +239,7 @@ def run(input_path, output=None, barcode_dir=None, options: Options = None, devi
     try:
         reads = DeviceReads(torch.from_numpy(rs.arena).to(dev), torch.from_numpy(rs.offsets).to(dev),
                             torch.from_numpy(rs.lengths).to(dev)) if R else None
+        lap("upload", sync=True)
 
         # ---- phase A and the set-level rules ---------------------------------------------
         if R and check_idx.size:
@@ -252,6 +265,7 @@ def run(input_path, output=None, barcode_dir=None, options: Options = None, devi
         match_idx = [index_of[id(s)] for s in matching]
         res.matching_sets = [s.name for s in matching]
         res.barcode_orientation = orientation
+        lap("phase_a", sync=True)
 
         start_trim = torch.zeros(R, dtype=torch.int32, device=dev)
         end_trim = torch.zeros(R, dtype=torch.int32, device=dev)
@@ -286,9 +300,11 @@ def run(input_path, output=None, barcode_dir=None, options: Options = None, devi
                 E = torch.stack(e_cols, dim=1) if names else torch.zeros((R, 0), dtype=torch.float64, device=dev)
                 ci = call_barcodes(names, S, E, opts)
                 calls = [names[k] if k >= 0 else "none" for k in ci]
+            lap("phase_b", sync=True)
             # ---- phase C -------------------------------------------------------------------
             if not opts.no_split:
                 hits = pl.phase_c(reads, start_trim, end_trim, match_idx)
+                lap("phase_c", sync=True)
         elif barcode_dir is not None:
             calls = ["none"] * R
         if calls is not None and albacore is not None:             # nanopore_read.py:468-473
@@ -350,6 +366,7 @@ def run(input_path, output=None, barcode_dir=None, options: Options = None, devi
         else:
             pr, ps_, pn_, num = base_reads, p_start[base_reads], p_len[base_reads], np.zeros(base_reads.size, dtype=np.int64)
 
+        lap("plan_output")
         # ---- write -------------------------------------------------------------------------
         fastq = fmt != "fasta"                                      # porechop.py:667,711,727
         if barcode_dir is not None:
@@ -390,6 +407,7 @@ def run(input_path, output=None, barcode_dir=None, options: Options = None, devi
             if gz:
                 _gzip_file(target, output)
             res.files[output] = (int(np.unique(pr).size), int(pn_.sum()))
+        lap("write")
         return res
     finally:
         if aligner is None:

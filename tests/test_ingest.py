@@ -141,3 +141,82 @@ def test_against_reference_loaders_on_its_fixtures():
                 q += "+" * (len(seq) - len(q))
             want.append((name, s, q, rna))
         check(path, want, kind == "FASTQ")
+
+
+def test_parallel_fastq_parse_equals_the_semantics(tmp_path):
+    """Files above 1 MB are parsed by several threads cut at record boundaries (a quality line may
+    start with '@'); the result must be what the reference's line-by-line loader yields.  Also
+    CRLF line ends and a file that is NOT regular 4-line FASTQ (falls back to the serial parser
+    and its error)."""
+    rng = random.Random(8)
+    recs = []
+    for i in range(1500):
+        n = rng.choice([1, 40, 700, 5000])
+        seq = "".join(rng.choice("ACGTacgtNU") for _ in range(n))
+        q = "".join(rng.choice("@+5!~I") for _ in range(n if rng.random() < 0.9 else max(0, n - 3)))
+        recs.append("@r%d desc %d\n%s\n+%s\n%s\n" % (i, i, seq, "" if i % 3 else "r%d" % i, q))
+    for name, text in (("big.fastq", "".join(recs)), ("crlf.fastq", "".join(recs).replace("\n", "\r\n"))):
+        path = tmp_path / name
+        with open(path, "w", newline="") as f:
+            f.write(text)
+        assert os.path.getsize(path) > (1 << 20)
+        want, is_fastq = python_semantics(str(path))
+        for threads in ("1", "3", "16"):
+            os.environ["PC_IO_THREADS"] = threads
+            check(str(path), want, True)
+    os.environ.pop("PC_IO_THREADS", None)
+    bad = tmp_path / "bad.fastq"
+    with open(bad, "w") as f:
+        f.write("".join(recs) + "@dangling\nACGT\n")
+    with pytest.raises(ValueError, match="could not be parsed"):
+        ReadSet(str(bad))
+
+
+def test_writer_large_outputs(tmp_path):
+    """pc_readset_write formats big files with several threads writing in place: FASTQ and FASTA,
+    numbered pieces, RNA, FASTA-sourced '+' qualities -- against plain Python formatting."""
+    import numpy as np
+    rng = random.Random(9)
+    recs = []
+    for i in range(3000):
+        n = rng.choice([30, 800, 5000])
+        alpha = "ACGU" if i % 11 == 0 else "ACGT"
+        recs.append(("w%d%s" % (i, " extra words" if i % 2 else ""), "".join(rng.choice(alpha) for _ in range(n)),
+                     "".join(rng.choice("!5I~") for _ in range(n))))
+    fq = tmp_path / "w.fastq"
+    with open(fq, "w") as f:
+        f.write("".join("@%s\n%s\n+\n%s\n" % r for r in recs))
+    fa = tmp_path / "w.fasta"
+    with open(fa, "w") as f:
+        f.write("".join(">%s\n%s\n" % (r[0], r[1]) for r in recs))
+
+    def numbered(name, k):
+        if k == 0:
+            return name
+        return name + "_%d" % k if " " not in name else name.replace(" ", "_%d " % k, 1)
+
+    for src, from_fastq in ((fq, True), (fa, False)):
+        rs = ReadSet(str(src))
+        n = rs.count
+        pr = np.repeat(np.arange(n), 2)
+        st = np.tile(np.array([0, 7]), n).astype(np.int64)
+        ln = np.maximum(np.repeat(rs.lengths, 2) - st - np.tile(np.array([0, 3]), n), 0)
+        num = np.tile(np.array([0, 2]), n)
+        for fastq in (True, False):
+            out = tmp_path / ("o_%d_%d" % (from_fastq, fastq))
+            for threads in ("1", "5"):
+                os.environ["PC_IO_THREADS"] = threads
+                rs.write(pr, st, ln, num, np.zeros(2 * n), [str(out)], fastq)
+                want = []
+                for k in range(2 * n):
+                    name, seq, q = recs[pr[k]]
+                    s = seq[st[k]:st[k] + ln[k]]           # RNA reads are stored with T and written back with U
+                    qq = (q if from_fastq else "+" * len(seq))[st[k]:st[k] + ln[k]]
+                    if fastq:
+                        want.append("@%s\n%s\n+\n%s\n" % (numbered(name, num[k]), s, qq))
+                    else:
+                        body = "".join(s[p:p + 70] + "\n" for p in range(0, len(s), 70)) or "\n"
+                        want.append(">%s\n%s" % (numbered(name, num[k]), body))
+                assert open(out).read() == "".join(want), (from_fastq, fastq, threads)
+        rs.close()
+    os.environ.pop("PC_IO_THREADS", None)

@@ -151,6 +151,29 @@ def build_dataset(name, root):
     if name == "nothing":
         rng = random.Random(41)
         return put("nothing.fastq", fastq_text([("plain%d" % i, _body(rng, 700), "5" * 700) for i in range(12)]))
+    if name == "edge":
+        # boundary shapes: empty / 1-base / exactly end_size reads, adapter-only reads, reads that trim to
+        # nothing, names with tabs and repeated spaces, short qualities, a read that is all N, CRLF-free
+        rng = random.Random(61)
+        panel = _panel()
+        bc = panel["Barcode 5 (reverse)"]
+        start = "AATGTACTTCGTTCAGTTACGTATTGCTAAGGTTAA" + bc["start"][1] + "CAGCACCT"
+        end = "AGGTGCTG" + bc["end"][1] + "TTAACCTTAGCAATACGTAACTGAACGAAGT"
+        rr = [("empty", "", ""), ("one", "A", "I"), ("two words\ttab  double", start + end, "5" * len(start + end)),
+              ("only_start", start, "5" * len(start)), ("only_end", end, "5" * len(end)),
+              ("exact150", start + _body(rng, 150 - len(start)), "5" * 150),
+              ("exact151 x", start + _body(rng, 151 - len(start)), "5" * 151),
+              ("alln", "N" * 400, "5" * 400), ("dashes", start + "-" * 30 + _body(rng, 300) + end, "5" * (330 + len(start + end))),
+              ("shortq", start + _body(rng, 500) + end, "5" * 100)]
+        for i in range(40):
+            body = _body(rng, rng.choice([10, 60, 149, 150, 151, 299, 300, 301, 1000, 2300]))
+            s5 = mutate(rng, start, 0.05) if rng.random() < 0.8 else ""
+            e5 = mutate(rng, end, 0.05) if rng.random() < 0.8 else ""
+            seq = s5 + body + e5
+            if i % 9 == 0 and len(body) >= 1000:
+                seq = s5 + body[:500] + end + start + body[500:] + e5          # junction close to both ends
+            rr.append(("e%02d" % i, seq, _quals(rng, len(seq))))
+        return put("edge.fastq", fastq_text(rr))
     if name == "albacore":
         # workspace/pass/barcodeXX/*.fastq + unclassified, as Albacore lays them out
         reads = native_reads(51, 150, barcodes=(1, 2, 3))
@@ -219,6 +242,19 @@ RUNNER_CASES = [
     ("ligation_default", "ligation", "o:out.fastq", []),
     ("ligation_mid80", "ligation", "o:out.fastq", ["--middle_threshold", "80"]),
     ("nothing_found", "nothing", "o:out.fastq", []),
+    ("native_gap_scheme", "native", "o:out.fastq", ["--scoring_scheme", "3,-6,-2,-5"]),
+    ("native_loose", "native", "b", ["--barcode_threshold", "0", "--barcode_diff", "0", "--end_threshold", "50",
+                                     "--middle_threshold", "70", "--adapter_threshold", "60"]),
+    ("native_tight", "native", "o:out.fastq", ["--end_threshold", "100", "--middle_threshold", "100", "--min_trim_size", "0",
+                                               "--extra_end_trim", "0", "--min_split_read_size", "1"]),
+    ("native_end20", "native", "o:out.fastq", ["--end_size", "20"]),
+    ("native_check0", "native", "o:out.fastq", ["--check_reads", "0"]),
+    ("edge_default", "edge", "o:out.fastq", []),
+    ("edge_fasta", "edge", "o:out.fasta", []),
+    ("edge_bins", "edge", "b", []),
+    ("edge_bins_two_untrimmed", "edge", "b", ["--require_two_barcodes", "--untrimmed"]),
+    ("edge_small_split", "edge", "o:out.fastq", ["--min_split_read_size", "0", "--extra_middle_trim_good_side", "0",
+                                                 "--extra_middle_trim_bad_side", "0"]),
     ("albacore_bins", "albacore", "b", []),
     ("albacore_bins_check30", "albacore", "b", ["--check_reads", "30"]),
     ("albacore_file_out", "albacore", "o:out.fastq", []),

@@ -19,6 +19,10 @@ _VALUES = {"--format": ("format", str), "--min_split_read_size": ("min_split_rea
            "--scoring_scheme": ("scoring_scheme", lambda v: tuple(int(x) for x in v.split(",")))}
 
 
+# too much alignment work for the CPU stand-in (hundreds of adapters x many mask rounds): GPU test only
+GPU_ONLY = {"native_loose"}
+
+
 def load_cases():
     with open(GOLDENS) as f:
         return json.load(f)["cases"]
@@ -52,10 +56,15 @@ def run_case(name, case, workdir, datasets, make_aligner=None, device=None):
     kw = {"options": opts, "device": device}
     if make_aligner is not None:
         kw["aligner"] = make_aligner(opts.scoring_scheme)
-    if case["mode"] == "b":
-        target = os.path.join(work, "bins")
-        runner.run(inp, barcode_dir=target, **kw)
-    else:
-        target = os.path.join(work, case["mode"][2:])
-        runner.run(inp, output=target, **kw)
+    target = os.path.join(work, "bins" if case["mode"] == "b" else case["mode"][2:])
+    try:
+        if case["mode"] == "b":
+            runner.run(inp, barcode_dir=target, **kw)
+        else:
+            runner.run(inp, output=target, **kw)
+    except runner.UsageError as e:
+        # the reference ends such runs with sys.exit(message): same message, no output
+        assert case["exit"] == str(e), (name, case["exit"], str(e))
+        return {}
+    assert case["exit"] is None, (name, "the reference exits with: " + str(case["exit"]))
     return readgen.output_md5s(target)

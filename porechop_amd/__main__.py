@@ -44,12 +44,31 @@ def main(argv=None):
     if a.threads < 1:
         sys.exit("Error: at least one thread required")
     opts = Options(**{k: getattr(a, k) for k in Options.__dataclass_fields__ if k != "scoring_scheme"}, scoring_scheme=scheme)
+    # launched by `python -m torch.distributed.run --nproc-per-node N -m porechop_amd ...`: one process per GPU,
+    # reads sharded over the ranks (runner.run), RCCL for the one small reduction
+    import os
+    device = None
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(local)
+        device = "cuda:%d" % local
+        dist.init_process_group(os.environ.get("PC_DIST_BACKEND", "nccl"))
     try:
-        res = run(a.input, output=a.output, barcode_dir=a.barcode_dir, options=opts)
+        res = run(a.input, output=a.output, barcode_dir=a.barcode_dir, options=opts, device=device)
     except (UsageError, ValueError) as e:
         sys.exit(str(e))
     except RuntimeError as e:                 # no GPU / no HIP library: there is no CPU path to fall back to
         sys.exit("Error: " + str(e))
+    if world > 1:
+        import torch.distributed as dist
+        rank = dist.get_rank()
+        dist.barrier()
+        dist.destroy_process_group()
+        if rank != 0:
+            return
     if a.verbosity > 0:
         dest = sys.stderr if (a.output is None and a.barcode_dir is None) else sys.stdout
         print("%d reads; adapter sets: %s" % (res.n_reads, ", ".join(res.matching_sets) or "none"), file=dest)

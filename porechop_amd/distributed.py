@@ -14,6 +14,23 @@ def shard_bounds(n_items, world, rank):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def shard_by_bases(lengths, world, rank):
+    """Contiguous, order-preserving shard [lo, hi) of rank `rank` with about 1/world of the BASES
+    (the middle scan's work is proportional to read length)."""
+    import numpy as np
+    n = int(len(lengths))
+    if world <= 1 or n == 0:
+        return 0, n
+    ends = np.cumsum(np.asarray(lengths, dtype=np.int64))
+    total = int(ends[-1])
+    cuts = [0]
+    for r in range(1, world):
+        cuts.append(int(np.searchsorted(ends, total * r / world, side="left")))
+    cuts.append(n)
+    cuts = np.maximum.accumulate(np.array(cuts))
+    return int(cuts[rank]), int(cuts[rank + 1])
+
+
 def check_read_share(check_reads, world, rank, n_total):
     """Porechop checks the FIRST `check_reads` reads of the input (porechop.py:224-273).  With the
     input sharded contiguously (shard_bounds), rank r holds global reads [lo, hi): its share of the

@@ -30,6 +30,7 @@ import numpy as np
 import torch
 
 from . import panel as panel_rules
+from .distributed import gather_in_order, reduce_presence, shard_by_bases
 from .io import ReadSet
 from .pipeline import AdapterSet, DeviceReads, Pipeline, ScanParams, trimmed_interval
 
@@ -155,6 +156,20 @@ def call_barcodes(names: List[str], start_scores: torch.Tensor, end_scores: torc
     return call.cpu().numpy()
 
 
+def _bin_names(pl, bc_sets):
+    names = []
+    for i in bc_sets:
+        n = panel_rules.barcode_name(pl.sets[i])
+        if n not in names:
+            names.append(n)
+    return names
+
+
+def _barcode_bin_names(pl, match_idx, orientation):
+    return _bin_names(pl, [i for i in match_idx if panel_rules.is_barcode(pl.sets[i])
+                           and panel_rules.barcode_direction(pl.sets[i]) == orientation])
+
+
 def _split_parts(tlen, intervals, min_size):
     """get_split_read_parts (nanopore_read.py:76-95): positions of the trimmed read not covered by
     any [trim_start, trim_end) -> maximal runs -> those of at least min_size bases."""
@@ -204,7 +219,13 @@ def _gzip_file(src, dst):
 def run(input_path, output=None, barcode_dir=None, options: Options = None, device=None, aligner=None,
         adapter_panel: List[AdapterSet] = None) -> RunResult:
     """Porechop's main() on arrays.  output=None and barcode_dir=None writes to stdout.
-    `aligner` is for tests only (see Pipeline)."""
+    `aligner` is for tests only (see Pipeline).
+
+    Under torch.distributed (one process per GPU) the reads are sharded over the ranks in
+    contiguous blocks of about equal bases: every rank scans its block, the adapter-set presence
+    table of phase A is MAX-all-reduced (the only cross-read quantity in Porechop), the per-read
+    results are gathered in rank order, and rank 0 alone plans and writes the output -- the files
+    are the single-process ones."""
     opts = options or Options()
     if len(tuple(opts.scoring_scheme)) != 4:
         raise UsageError("Error: incorrectly formatted scoring scheme")
@@ -226,7 +247,13 @@ def run(input_path, output=None, barcode_dir=None, options: Options = None, devi
 
     rs, check_idx, albacore = _load(input_path, opts.check_reads)
     res = RunResult(n_reads=rs.count, read_type="FASTQ" if rs.is_fastq else "FASTA")
-    R = rs.count
+    R_all = rs.count
+    import torch.distributed as dist
+    sharded = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    rank, world = (dist.get_rank(), dist.get_world_size()) if sharded else (0, 1)
+    lo_r, hi_r = shard_by_bases(rs.lengths, world, rank)
+    R = hi_r - lo_r                                             # reads this rank scans
+    check_idx = check_idx[(check_idx >= lo_r) & (check_idx < hi_r)] - lo_r
     lap("load")
 
     panel = list(adapter_panel) if adapter_panel is not None else panel_rules.load_panel()
@@ -237,16 +264,23 @@ def run(input_path, output=None, barcode_dir=None, options: Options = None, devi
     pl = Pipeline(panel, params, device=device, aligner=aligner)
     dev = pl.device
     try:
-        reads = DeviceReads(torch.from_numpy(rs.arena).to(dev), torch.from_numpy(rs.offsets).to(dev),
-                            torch.from_numpy(rs.lengths).to(dev)) if R else None
+        reads = None
+        if R:
+            a0 = int(rs.offsets[lo_r])
+            a1 = min(int(rs.offsets[hi_r - 1]) + int(rs.lengths[hi_r - 1]) + 64, rs.arena.size)   # >= 8 readable bytes past the end
+            reads = DeviceReads(torch.from_numpy(rs.arena[a0:a1]).to(dev), torch.from_numpy(rs.offsets[lo_r:hi_r] - a0).to(dev),
+                                torch.from_numpy(rs.lengths[lo_r:hi_r].copy()).to(dev))
         lap("upload", sync=True)
 
         # ---- phase A and the set-level rules ---------------------------------------------
         if R and check_idx.size:
             bs, be = pl.phase_a(reads, torch.from_numpy(check_idx).to(dev))
-            bs, be = bs.cpu().numpy(), be.cpu().numpy()
         else:
-            bs = be = np.zeros(len(panel))
+            bs = torch.zeros(len(panel), dtype=torch.float64, device=dev)
+            be = torch.zeros(len(panel), dtype=torch.float64, device=dev)
+        if sharded:
+            bs, be = reduce_presence(bs, be)                    # nanopore_read.py:159,164 across all ranks' check reads
+        bs, be = bs.cpu().numpy(), be.cpu().numpy()
         index_of = {id(s): i for i, s in enumerate(pl.sets)}
         score = lambda s: max(bs[index_of[id(s)]], be[index_of[id(s)]])
         matching = [s for s in panel if "(full sequence)" not in s.name and score(s) >= opts.adapter_threshold]
@@ -271,6 +305,8 @@ def run(input_path, output=None, barcode_dir=None, options: Options = None, devi
         end_trim = torch.zeros(R, dtype=torch.int32, device=dev)
         calls = None
         hits = None
+        ci = np.full(R, -1, dtype=np.int64)
+        names = []
         if matching and R:
             # ---- phase B (+ barcode calls) ------------------------------------------------
             check_barcodes = barcode_dir is not None
@@ -282,12 +318,8 @@ def run(input_path, output=None, barcode_dir=None, options: Options = None, devi
                 fulls = out_b[2] if bc_sets else {}
                 # the reference's two dicts are keyed by bin name: a later set with the same name
                 # overwrites the value but keeps the first insertion's position
-                names, col = [], {}
-                for i in bc_sets:
-                    n = panel_rules.barcode_name(pl.sets[i])
-                    if n not in col:
-                        col[n] = len(names)
-                        names.append(n)
+                names = _bin_names(pl, bc_sets)
+                col = {n: k for k, n in enumerate(names)}
                 zeros = torch.zeros(R, dtype=torch.float64, device=dev)
                 s_cols, e_cols = [zeros] * len(names), [zeros] * len(names)
                 for i in bc_sets:
@@ -299,21 +331,36 @@ def run(input_path, output=None, barcode_dir=None, options: Options = None, devi
                 S = torch.stack(s_cols, dim=1) if names else torch.zeros((R, 0), dtype=torch.float64, device=dev)
                 E = torch.stack(e_cols, dim=1) if names else torch.zeros((R, 0), dtype=torch.float64, device=dev)
                 ci = call_barcodes(names, S, E, opts)
-                calls = [names[k] if k >= 0 else "none" for k in ci]
             lap("phase_b", sync=True)
             # ---- phase C -------------------------------------------------------------------
             if not opts.no_split:
                 hits = pl.phase_c(reads, start_trim, end_trim, match_idx)
                 lap("phase_c", sync=True)
-        elif barcode_dir is not None:
-            calls = ["none"] * R
-        if calls is not None and albacore is not None:             # nanopore_read.py:468-473
-            calls = [c if (a is None or a == c) else "none" for c, a in zip(calls, albacore)]
         if hasattr(pl.aligner, "sync"):
             pl.aligner.sync()
 
+        # ---- per-read results of all ranks, in read order --------------------------------
+        if hits is not None and hits.read.numel():
+            h = torch.stack([hits.read + lo_r, hits.adapter.to(torch.int64), hits.start.to(torch.int64),
+                             hits.end.to(torch.int64)], dim=1)
+        else:
+            h = torch.zeros((0, 4), dtype=torch.int64, device=dev)
+        ci_t = torch.from_numpy(ci).to(dev)
+        if sharded:
+            start_trim, end_trim, ci_t, h = (gather_in_order(x) for x in (start_trim, end_trim, ci_t, h))
+            lap("gather", sync=True)
+            if rank != 0:
+                res.start_trim, res.end_trim = start_trim.cpu().numpy(), end_trim.cpu().numpy()
+                return res                                       # rank 0 writes
+        R = R_all
         st = start_trim.cpu().numpy()
         et = end_trim.cpu().numpy()
+        h = h.cpu().numpy()
+        if barcode_dir is not None:
+            names_all = _barcode_bin_names(pl, match_idx, orientation)     # the same list on every rank
+            calls = [names_all[k] if k >= 0 else "none" for k in ci_t.cpu().numpy()]
+            if albacore is not None:                               # nanopore_read.py:468-473
+                calls = [c if (a is None or a == c) else "none" for c, a in zip(calls, albacore)]
         res.start_trim, res.end_trim, res.barcode_calls = st, et, calls
 
         # ---- which pieces of which reads -------------------------------------------------
@@ -321,18 +368,14 @@ def run(input_path, output=None, barcode_dir=None, options: Options = None, devi
         s_pos, e_pos = s_pos.numpy(), e_pos.numpy()
         tlen = np.maximum(e_pos - s_pos, 0)
         split_of = {}
-        if hits is not None and hits.read.numel():
+        if h.shape[0]:
             start_names = {s.start[0] for s in matching if s.start is not None}
             end_names = {s.end[0] for s in matching if s.end is not None}
             good, bad = opts.extra_middle_trim_good_side, opts.extra_middle_trim_bad_side
-            ad_names = [a[0] for a in pl.middle_adapters]
+            ad_names = [a[0] for a in pl.middle_adapter_list(match_idx)]
             lo = np.array([bad if n in start_names else good for n in ad_names], dtype=np.int64)
             hi = np.array([bad if n in end_names else good for n in ad_names], dtype=np.int64)
-            h_read = hits.read.cpu().numpy()
-            h_ad = hits.adapter.cpu().numpy()
-            h_s = hits.start.cpu().numpy().astype(np.int64)
-            h_e = hits.end.cpu().numpy().astype(np.int64)
-            for r, a, s, e in zip(h_read, h_ad, h_s, h_e):
+            for r, a, s, e in h:
                 split_of.setdefault(int(r), []).append((int(s - lo[a]), int(e + hi[a])))
         res.middle_hit_reads = len(split_of)
 

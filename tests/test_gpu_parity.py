@@ -219,3 +219,61 @@ print("SPEC_OK")
         assert all(f == ("0" if int16 == "1" else "1") for _, f, _ in built)
         if int16 == "0":
             assert min(int(k) for _, _, k in built) < 300            # the renormalisation path ran
+
+
+def test_specialised_kernel_random_schemes(pa, oracle):
+    """Drifting-coordinate constants (centre, renormalisation period, fp16 vs int16 choice) are
+    derived from the scoring scheme: random valid schemes, whole reads, specialised kernels forced
+    on, against the oracle."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import random, sys
+sys.path.insert(0, ".")
+import numpy as np, torch
+import porechop_amd
+from oracle.oracle import Oracle
+from tests.pairgen import random_case
+rng = random.Random(4242)
+o = Oracle()
+ads = ["AATGTACTTCGTTCAGTTACGTATTGCT", "GCAATACGTAACTGAACGAAGT", "CTTCGTTCAGTTACGTATTGCTGGCGTCTGCTT"]
+done = 0
+while done < 10:
+    match = rng.randint(1, 40); mismatch = -rng.randint(0, 60); go = -rng.randint(1, 60); ge = -rng.randint(1, 60)
+    if go == ge or match <= mismatch:
+        continue
+    scores = (match, mismatch, go, ge)
+    try:
+        al = porechop_amd.Aligner(ads, scores=scores)
+    except RuntimeError:
+        continue                                   # outside the exact path: refused loudly, fine
+    done += 1
+    reads = [random_case(rng, n=rng.choice([1500, 4000]), m=28)[0] for _ in range(96)]
+    for i in range(0, 96, 2):
+        a = ads[(i // 2) % 3]; p = rng.randint(0, len(reads[i]) - 60)
+        reads[i] = reads[i][:p] + a + reads[i][p + len(a):]
+    arena = torch.from_numpy(np.frombuffer(("".join(reads)).encode() + b"N" * 64, dtype=np.uint8).copy()).cuda()
+    lens = np.array([len(r) for r in reads], dtype=np.int32)
+    offs = np.concatenate([[0], np.cumsum(lens[:-1].astype(np.int64))]).astype(np.int64)
+    woff, wlen = torch.from_numpy(offs).cuda(), torch.from_numpy(lens).cuda()
+    n = len(reads)
+    for (a, b) in [(0, 1), (2, -1)]:
+        out = torch.zeros((n * (2 if b >= 0 else 1), 8), dtype=torch.int32, device="cuda")
+        al.scan_device(arena, woff, wlen, [a], [0, n], int(lens.max()), out, porechop_amd.MODE_TWO_PASS, job_adapter_b=[b])
+        al.sync()
+        rec = out.cpu().numpy()
+        for i, r in enumerate(reads):
+            assert porechop_amd.format_result(rec[i]) == o.adapter_alignment(r, ads[a], scores), (scores, a, i)
+            if b >= 0:
+                assert porechop_amd.format_result(rec[n + i]) == o.adapter_alignment(r, ads[b], scores), (scores, b, i)
+    al.close()
+    print("SCHEME", scores)
+print("SPEC_OK")
+'''
+    env = dict(os.environ, PC_JIT_MIN_CELLS="1", PC_JIT_VERBOSE="1")
+    res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=900,
+                         cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert "SPEC_OK" in res.stdout, res.stdout[-2000:] + res.stderr[-3000:]
+    assert "hiprtc" not in res.stderr, res.stderr[-2000:]
+    assert res.stderr.count("specialised kernel R=") >= 6, res.stderr[-2000:]      # most schemes do specialise

@@ -259,17 +259,30 @@ struct ScopedTimer {
     ~ScopedTimer() { if (on) { (void)hipEventRecord(t.e1, s); c->timed.push_back(t); } }
 };
 
+// Resident waves the chip holds for this group's kernels: by register footprint (2 packed VGPRs per
+// row + ~48) for the register variants, by LDS (8 B per row per lane) for the generic one.
+int resident_waves(const pc_ctx *c, const Group &g)
+{
+    const int rows = g.rows ? g.rows : g.gen_max_rows;
+    int per_simd = g.rows ? 512 / (2 * rows + 48) : (int)((160 * 1024) / ((size_t)rows * 520 + 1024)) / 4;
+    per_simd = std::max(1, std::min(8, per_simd));
+    return c->ncu * 4 * per_simd;
+}
+
+// Workgroups to launch for `ntiles` tiles.  Measured on MI355X (tools/time_score.py, time_trace.py):
+// handing the hardware dispatcher one tile per workgroup beats a persistent grid of exactly the
+// resident waves striding over the tiles -- 4-5 % on the uniform whole-read score pass, 13 % on the
+// traced end windows, whose tiles differ in cost (window lengths, traceback lengths).  The grid is
+// therefore the tile count, bounded only by the per-workgroup scratch (trace slab, last-column
+// save); above the bound the kernels stride.
+constexpr int64_t kMaxGrid = 32768;
 int grid_for(const pc_ctx *c, const Group &g, size_t ntiles, int slab_cols, size_t *slab_stride_dwords)
 {
     const int rows = g.rows ? g.rows : g.gen_max_rows;
-    // resident waves per SIMD: by register footprint (2 packed VGPRs per row + ~48) for the
-    // register variants, by LDS (8 B per row per lane) for the generic one
-    int per_simd = g.rows ? 512 / (2 * rows + 48) : (int)((160 * 1024) / ((size_t)rows * 520 + 1024)) / 4;
-    per_simd = std::max(1, std::min(8, per_simd));
-    int64_t grid = (int64_t)c->ncu * 4 * per_simd;
+    int64_t grid = std::max<int64_t>(kMaxGrid, resident_waves(c, g));
     const size_t stride = (size_t)std::max(1, slab_cols) * pck::trace_words_per_col(rows) * 64;
-    const size_t budget = (size_t)6 << 30;    // keep the trace scratch under 6 GiB
-    while (grid > 1 && (size_t)grid * stride * 4 > budget) grid /= 2;
+    const size_t budget = (size_t)8 << 30;    // keep the trace scratch under 8 GiB
+    while (grid > 1 && (size_t)grid * stride * 4 > budget) grid = grid * 3 / 4;
     grid = std::min<int64_t>(grid, (int64_t)ntiles);
     if (slab_stride_dwords) *slab_stride_dwords = stride;
     return (int)std::max<int64_t>(1, grid);
@@ -384,7 +397,7 @@ int pc_scan_device(pc_ctx *c, const void *d_arena, const int64_t *d_win_off, con
         const int cols = g.two_pass ? g.max_window + 1 : max_len;
         const int grid = grid_for(c, g, g.tile_count, cols, &stride);
         slab_bytes = std::max(slab_bytes, (size_t)grid * stride * 4);
-        const int chunks = g.two_pass ? chunks_for((int64_t)g.tile_count, grid_for(c, g, (size_t)1 << 30, 1, nullptr), max_len, g.max_window) : 1;
+        const int chunks = g.two_pass ? chunks_for((int64_t)g.tile_count, resident_waves(c, g), max_len, g.max_window) : 1;
         max_chunks = std::max(max_chunks, chunks);
         const int grid1 = grid_for(c, g, g.tile_count * (size_t)chunks, 1, nullptr);   // chunked score pass
         fin_bytes = std::max(fin_bytes, (size_t)std::max(grid, grid1) * std::max(1, g.rows) * 64 * 8);
@@ -436,7 +449,7 @@ int pc_scan_device(pc_ctx *c, const void *d_arena, const int64_t *d_win_off, con
             a.win_off = d_win_off; a.win_len = d_win_len;
             a.out = c->d_k1.as<int32_t>();
             a.slab = nullptr; a.slab_cols = 0; a.slab_stride = 0;
-            const int capacity = grid_for(c, g, (size_t)1 << 30, 1, nullptr);
+            const int capacity = resident_waves(c, g);
             const int chunks = chunks_for((int64_t)g.tile_count, capacity, max_len, g.max_window);
             a.chunks = chunks;
             a.chunk_len = (max_len + chunks - 1) / chunks;

@@ -167,12 +167,13 @@ Spec *get(int device, const std::string &ad_lo, const std::string &ad_hi, int ma
     const std::string dR = "-DPC_R=" + std::to_string(R), dK = "-DPC_K=" + std::to_string(K),
                       dC = "-DPC_COMBO_INIT=" + init, dF = std::string("-DPC_F16=") + (f16 ? "1" : "0"),
                       dE = "-DPC_EPS=" + std::to_string(eps), dO = "-DPC_OE=(" + std::to_string(gap_open + eps) + ")",
-                      dN = "-DPC_CEN=(" + std::to_string(cen) + ")", dP = "-DPC_KREN=" + std::to_string(kren);
+                      dN = "-DPC_CEN=(" + std::to_string(cen) + ")", dP = "-DPC_KREN=" + std::to_string(kren),
+                      dW = std::string("-DPC_WAVES=") + (getenv("PC_JIT_WAVES") ? getenv("PC_JIT_WAVES") : "2");
     const char *opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", dR.c_str(), dK.c_str(), dC.c_str(), dF.c_str(),
-                          dE.c_str(), dO.c_str(), dN.c_str(), dP.c_str()};
+                          dE.c_str(), dO.c_str(), dN.c_str(), dP.c_str(), dW.c_str()};
     hiprtcProgram prog = nullptr;
     if (r.CreateProgram(&prog, kSpecSource, "pc_spec_score.hip", 0, nullptr, nullptr) != 0) return nullptr;
-    const hiprtcResult rc = r.CompileProgram(prog, 11, opts);
+    const hiprtcResult rc = r.CompileProgram(prog, 12, opts);
     if (rc != 0) {
         size_t n = 0;
         r.GetProgramLogSize(prog, &n);

@@ -34,7 +34,8 @@
 namespace pcj {
 
 // defines prepended by pc_jit.cpp: PC_R, PC_K (multiple of 4), PC_COMBO_INIT (R comma-separated
-// ints), PC_F16, PC_EPS (= -gap_extend), PC_OE (= gap_open + PC_EPS), PC_CEN (C), PC_KREN
+// ints), PC_F16, PC_EPS (= -gap_extend), PC_OE (= gap_open + PC_EPS), PC_CEN (C), PC_KREN,
+// PC_WAVES (resident waves per SIMD the register allocation must allow)
 static const char *kSpecSource = R"PCJIT(
 typedef unsigned int u32;
 typedef long long i64;
@@ -90,7 +91,7 @@ __device__ static const unsigned char COMBO[PC_R] = { PC_COMBO_INIT };
 
 typedef u32 u32_unaligned __attribute__((aligned(1)));
 
-extern "C" __global__ __launch_bounds__(64) void pc_spec_score(SpecArgs a)
+extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PC_WAVES))) void pc_spec_score(SpecArgs a)
 {
     constexpr int R = PC_R, K = PC_K;
     __shared__ uint4 s_tab[256 * K / 4];

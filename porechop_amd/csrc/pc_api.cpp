@@ -465,17 +465,15 @@ int pc_scan_device(pc_ctx *c, const void *d_arena, const int64_t *d_win_off, con
                     while (e < g.tile_count && c->tiles[g.tile_begin + e].adapter_lo == t0.adapter_lo &&
                            c->tiles[g.tile_begin + e].adapter_hi == t0.adapter_hi)
                         ++e;
-                    // a hiprtc compile costs ~1 s and halves the scan: only launches big enough to
-                    // pay for it compile (PC_JIT_MIN_CELLS overrides the 1e11-cell default); smaller
-                    // ones (mask-and-realign rounds) reuse a kernel that is already there
+                    // the specialised kernel for this pair, once the work seen for the pair has
+                    // paid for its compile (pc_jit.cpp); until then the generic one
                     double est_cells = 0;
                     for (size_t k = i; k < e; ++k)
                         est_cells += (double)(c->tiles[g.tile_begin + k].count_lo + c->tiles[g.tile_begin + k].count_hi);
                     est_cells *= (double)max_len * (double)std::max(1, g.rows);
-                    static const double min_cells = [] { const char *v = getenv("PC_JIT_MIN_CELLS"); return v ? atof(v) : 1e11; }();
                     pcj::Spec *sp = (g.rows && !linear)
                                         ? pcj::get(c->device, c->adapters[t0.adapter_lo], c->adapters[t0.adapter_hi],
-                                                   c->match, c->mismatch, c->gap_open, c->gap_extend, est_cells >= min_cells)
+                                                   c->match, c->mismatch, c->gap_open, c->gap_extend, est_cells)
                                         : nullptr;
                     const int sub_grid = (int)std::min<size_t>((size_t)grid, (e - i) * (size_t)chunks);
                     int64_t sub_pairs = 0;

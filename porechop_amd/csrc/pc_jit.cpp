@@ -85,6 +85,7 @@ uint32_t half_bits(int v)
 
 std::mutex g_mu;
 std::map<std::string, Spec *> g_cache;   // key -> spec (null = failed, do not retry)
+std::map<std::string, double> g_seen;    // key -> cells scanned with the generic kernel so far
 
 }  // namespace
 
@@ -95,7 +96,7 @@ bool disabled()
 }
 
 Spec *get(int device, const std::string &ad_lo, const std::string &ad_hi, int match, int mismatch, int gap_open,
-          int gap_extend, bool compile)
+          int gap_extend, double cells)
 {
     if (disabled()) return nullptr;
     const int m_lo = (int)ad_lo.size(), m_hi = (int)ad_hi.size();
@@ -135,7 +136,13 @@ Spec *get(int device, const std::string &ad_lo, const std::string &ad_hi, int ma
     std::lock_guard<std::mutex> lk(g_mu);
     auto it = g_cache.find(key);
     if (it != g_cache.end()) return it->second;
-    if (!compile) return nullptr;
+    // a hiprtc compile costs 0.3-1 s and halves the scan: compile once the work seen for this
+    // adapter pair, over all launches so far, would have paid for it (PC_JIT_MIN_CELLS overrides
+    // the 1e11-cell default)
+    static const double min_cells = [] { const char *v = getenv("PC_JIT_MIN_CELLS"); return v ? atof(v) : 1e11; }();
+    double &seen = g_seen[key];
+    seen += cells;
+    if (seen < min_cells) return nullptr;
     g_cache[key] = nullptr;
     Rtc &r = rtc();
     if (!r.ok) {

@@ -28,10 +28,11 @@ struct SpecArgs {
 };
 
 bool disabled();
-// nullptr when specialisation is unavailable for this pair (caller uses the generic kernels).
-// compile = false only looks up kernels that an earlier, larger launch already paid for.
+// nullptr when specialisation is unavailable for this pair, or not yet worth its compile: `cells`
+// (the launch's work) is added to the pair's running total, and the kernel is compiled once that
+// total reaches PC_JIT_MIN_CELLS (caller uses the generic kernels until then).
 Spec *get(int device, const std::string &ad_lo, const std::string &ad_hi, int match, int mismatch, int gap_open,
-          int gap_extend, bool compile);
+          int gap_extend, double cells);
 int launch(const Spec *sp, const SpecArgs &a, int grid, void *stream);
 
 }  // namespace pcj

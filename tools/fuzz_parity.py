@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""Large randomised parity run (GPU box): the HIP library against the C oracle, bit for bit, on
+millions of end-window pairs and tens of thousands of whole reads, over random valid scoring
+schemes and adapters of 1..120 bases.  Prints one line per block and a final tally.
+    python tools/fuzz_parity.py [blocks] [seed]"""
+import random
+import sys
+import time
+
+sys.path.insert(0, ".")
+import numpy as np
+
+import porechop_amd
+from oracle.oracle import Oracle
+from tests.pairgen import mutate
+
+blocks = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+rng = random.Random(seed)
+nrng = np.random.default_rng(seed)
+o = Oracle()
+bad = total = 0
+t0 = time.time()
+for blk in range(blocks):
+    while True:
+        sc = (rng.randint(1, 30), -rng.randint(0, 40), -rng.randint(1, 40), -rng.randint(1, 40))
+        if sc[0] > sc[1]:
+            try:
+                ads = ["".join(rng.choice("ACGT") for _ in range(rng.choice([1, 5, 22, 24, 24, 28, 33, 38, 50, 64, 87, 120]))) for _ in range(6)]
+                al = porechop_amd.Aligner(ads, scores=sc)
+                break
+            except RuntimeError:
+                continue
+    whole = blk % 4 == 3
+    n = 2000 if whole else 100_000
+    lens = nrng.choice([3000, 8000], size=n) if whole else nrng.choice([1, 7, 60, 149, 150, 150, 150, 151], size=n)
+    lens = lens.astype(np.int32)
+    offs = np.concatenate([[0], np.cumsum(lens[:-1].astype(np.int64))]).astype(np.int64)
+    alphabet = np.frombuffer(rng.choice([b"ACGT", b"ACGT", b"ACGTN", b"AC", b"ACGT-", b"acgtACGTUu"]), dtype=np.uint8)
+    arena = alphabet[nrng.integers(0, len(alphabet), int(lens.sum()) + 64)]
+    aidx = nrng.integers(0, len(ads), n).astype(np.int32)
+    # implant mutated adapter copies in two thirds of the windows
+    for i in nrng.choice(n, size=2 * n // 3, replace=False):
+        m = mutate(rng, ads[aidx[i]], rng.choice([0.0, 0.05, 0.12, 0.25])).encode()
+        if not m or lens[i] < 8:
+            continue
+        p = rng.randint(0, int(lens[i]) - 1)
+        m = m[: int(lens[i]) - p]
+        arena[offs[i] + p: offs[i] + p + len(m)] = np.frombuffer(m, dtype=np.uint8)
+    got = al.align_host(arena, offs, lens, aidx, porechop_amd.MODE_TWO_PASS if whole else porechop_amd.MODE_AUTO)
+    ad_arena = np.frombuffer("".join(ads).encode(), dtype=np.uint8)
+    ad_len = np.array([len(a) for a in ads], dtype=np.int32)
+    ad_off = np.concatenate([[0], np.cumsum(ad_len[:-1].astype(np.int64))]).astype(np.int64)
+    want = o.align_many(arena, offs, lens, ad_arena, ad_off[aidx], ad_len[aidx], sc)
+    want8 = np.concatenate([want[:, :7], want[:, 8:9]], axis=1)
+    ok = (got == want8).all(axis=1) | ((want[:, 0] == -1) & (got[:, 0] == -1))
+    bad += int((~ok).sum())
+    total += n
+    print("block %2d scheme %-20s %s n=%6d mismatches=%d  (%.0f s)" % (blk, sc, "whole reads" if whole else "end windows", n, int((~ok).sum()), time.time() - t0), flush=True)
+    if (~ok).any():
+        i = int(np.nonzero(~ok)[0][0])
+        print("   first:", arena[offs[i]:offs[i] + lens[i]].tobytes()[:200], ads[aidx[i]], got[i], want8[i])
+    al.close()
+print("TOTAL pairs=%d mismatches=%d" % (total, bad))

@@ -457,37 +457,57 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((R > 0 && R 
             if (have_lo) { int4 o = {b_lo.score, b_lo.I, b_lo.J + c0_lo, 0}; *(int4 *)(a.out + (p_lo * nchunks + chunk) * SCORE_OUT_INTS) = o; }
             if (have_hi) { int4 o = {b_hi.score, b_hi.I, b_hi.J + c0_hi, 0}; *(int4 *)(a.out + (p_hi * nchunks + chunk) * SCORE_OUT_INTS) = o; }
         } else {
-#pragma unroll 1
+            // Traceback + digest of the lane's two pairs, SIDE BY SIDE: each walk is a chain of
+            // dependent loads (trace word -> next cell), so the two are advanced in one loop and
+            // their loads are in flight together (pc_walk.h: Walk::consume takes one cell's nibble).
+            auto fetch = [&](int hf, int pad, const uint8_t *w, const u32 *codes, int col, int row, int &nib, bool &eq) {
+                const int r = pad + row - 1;
+                const int wq = r >> 2;
+                const int rows_in_group = (rows - 4 * wq) < 4 ? (rows - 4 * wq) : 4;
+                const int pos = rows_in_group - 1 - (r & 3);
+                const u32 dw = slab[((int64_t)(col - 1) * NW + wq) * 64 + lane];
+                nib = (int)((dw >> (16 * hf + 4 * pos)) & 0xFu);
+                eq = dna5_code(w[col - 1]) == (int)codes[row - 1];
+            };
+            pcw::Walk wk_lo, wk_hi;
+            const int nt_lo = a.n_total ? (have_lo ? a.n_total[p_lo] : 0) : n_lo;
+            const int nt_hi = a.n_total ? (have_hi ? a.n_total[p_hi] : 0) : n_hi;
+            // _correctTraceValue needs the end cell's nibble before the walk starts
+            auto tie_fix_of = [&](int hf, bool have, const Best &b, int pad, const uint8_t *w, const u32 *codes) -> int {
+                if (!have || !(b.J > 0 && b.I > 0) || a.linear) return 0;
+                int nb; bool eq;
+                fetch(hf, pad, w, codes, b.J, b.I, nb, eq);
+                return ((nb & pcw::NIB_NOTDIAG) || b.tie) ? ((nb & pcw::NIB_FROMH) ? 2 : 1) : 0;
+            };
+            const int tiefix_lo = tie_fix_of(0, have_lo, b_lo, pad_lo, w_lo, codes_lo);
+            const int tiefix_hi = tie_fix_of(1, have_hi, b_hi, pad_hi, w_hi, codes_hi);
+            wk_lo.start(b_lo.I, b_lo.J, m_lo, c0_lo, nt_lo, b_lo.score, tiefix_lo);
+            wk_hi.start(b_hi.I, b_hi.J, m_hi, c0_hi, nt_hi, b_hi.score, tiefix_hi);
+            if (!have_lo) wk_lo.done = 1;
+            if (!have_hi) wk_hi.done = 1;
+            bool left_trace = false;
+            while (!wk_lo.done || !wk_hi.done) {
+                int nb_lo = 0, nb_hi = 0;
+                bool eq_lo = false, eq_hi = false;
+                const bool go_lo = !wk_lo.done, go_hi = !wk_hi.done;
+                // a walk that leaves the traced columns of a pass-2 window is stopped and flagged
+                // (never expected: the bound of pc_bounds.h)
+                if (go_lo && wk_lo.col <= notrace_upto) { left_trace = true; wk_lo.done = 1; }
+                else if (go_lo) fetch(0, pad_lo, w_lo, codes_lo, wk_lo.col, wk_lo.row, nb_lo, eq_lo);
+                if (go_hi && wk_hi.col <= notrace_upto) { left_trace = true; wk_hi.done = 1; }
+                else if (go_hi) fetch(1, pad_hi, w_hi, codes_hi, wk_hi.col, wk_hi.row, nb_hi, eq_hi);
+                if (go_lo && !wk_lo.done) wk_lo.consume(nb_lo, eq_lo);
+                if (go_hi && !wk_hi.done) wk_hi.consume(nb_hi, eq_hi);
+            }
+#pragma unroll
             for (int hf = 0; hf < 2; ++hf) {
                 const bool have = hf ? have_hi : have_lo;
                 if (!have) continue;
+                pcw::Walk &wk = hf ? wk_hi : wk_lo;
                 const Best b = hf ? b_hi : b_lo;
-                const int m = hf ? m_hi : m_lo, pad = hf ? pad_hi : pad_lo;
-                const int c0 = hf ? c0_hi : c0_lo;
                 const int64_t p = hf ? p_hi : p_lo;
-                const uint8_t *w = hf ? w_hi : w_lo;
-                const u32 *codes = hf ? codes_hi : codes_lo;
-                const int nt = a.n_total ? a.n_total[p] : (hf ? n_hi : n_lo);
-                bool left_trace = false;
-                auto nibf = [&](int col, int row) -> int {
-                    if (col <= notrace_upto) { left_trace = true; return 0; }   // never expected (bound)
-                    const int r = pad + row - 1;
-                    const int wq = r >> 2;
-                    const int rows_in_group = (rows - 4 * wq) < 4 ? (rows - 4 * wq) : 4;
-                    const int pos = rows_in_group - 1 - (r & 3);
-                    const u32 dw = slab[((int64_t)(col - 1) * NW + wq) * 64 + lane];
-                    return (int)((dw >> (16 * hf + 4 * pos)) & 0xFu);
-                };
-                auto eqf = [&](int col, int row) -> bool {
-                    return dna5_code(w[col - 1]) == (int)codes[row - 1];
-                };
-                int tie_fix = 0;
-                if (b.J > 0 && b.I > 0 && !a.linear) {
-                    const int nb = nibf(b.J, b.I);
-                    if ((nb & pcw::NIB_NOTDIAG) || b.tie) tie_fix = (nb & pcw::NIB_FROMH) ? 2 : 1;
-                }
                 pcw::Digest dg;
-                int err = pcw::walk(nibf, eqf, b.I, b.J, m, c0, nt, b.score, tie_fix, dg);
+                int err = wk.finish(dg);
                 if (a.force_score && a.force_score[p] != b.score) err = 1;
                 if (left_trace) err = 1;
                 if (err) atomicAdd(a.err, 1u);

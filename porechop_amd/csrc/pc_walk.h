@@ -85,62 +85,97 @@ struct Acc {
     }
 };
 
-// TraceFn:   int nib(int local_col, int adapter_row)  for local_col>=1, adapter_row>=1
-// MatchFn:   bool eq(int local_col, int adapter_row)  -> read base (col-1) == adapter base (row-1)
+// The traceback as a resumable state machine: every call of consume() takes the trace nibble of
+// ONE cell -- the cell (col,row) the state asked for -- and leaves in (col,row) the next cell it
+// needs, or done.  That is the reference's _doTraceback loop (dp_traceback_impl.h:376-450) cut at
+// its trace-matrix reads, so that a caller can fetch for several independent walks at once (the
+// kernels run a lane's two pairs side by side: two load chains in flight instead of one).
 //
 // (I,J) is the end cell in LOCAL columns (J in [0, ncols]); col0 is the global column of local 0;
 // n_total the whole read length; tie_fix: 0 none, 1 force "from V", 2 force "from H"
 // (the _correctTraceValue outcome, decided by the kernel from d==max(H,V) at the end cell).
-// Returns 0, or 1 if the walk ran into the left edge of a window that does not start at the
-// read's column 0 (impossible when the window obeys the bound in DESIGN.md; reported loudly).
+// err = 1 if the walk ran into the left edge of a window that does not start at the read's
+// column 0 (impossible when the window obeys the bound in pc_bounds.h; reported loudly).
+struct Walk {
+    enum : int { DISPATCH = 0, VRUN = 1, HRUN = 2 };
+    Acc acc;
+    int col, row, mode, first, tie_fix, done, err;
+    int m, col0, n_total, score;
+
+    PC_HD void start(int I, int J, int m_, int col0_, int n_total_, int score_, int tie_fix_) {
+        acc.init();
+        col = J; row = I; mode = DISPATCH; first = 1; tie_fix = tie_fix_; err = 0;
+        m = m_; col0 = col0_; n_total = n_total_; score = score_;
+        // tail segments: adapter bases hanging past the read end / read bases after the alignment
+        acc.run(T_V, m - row);
+        acc.run(T_H, n_total - (col0 + col));
+        done = !(col > 0 && row > 0);
+    }
+    PC_HD void next_cell() { mode = DISPATCH; done = !(col > 0 && row > 0); }
+    // nib: trace nibble of cell (col,row); eq: read base (col-1) == adapter base (row-1)
+    PC_HD void consume(int nib, bool eq) {
+        int tv = nib_to_byte(nib);
+        if (mode == DISPATCH) {
+            if (first) {
+                first = 0;
+                if (tie_fix == 1)      tv = (tv & ~T_DIAG) | T_MAXV;
+                else if (tie_fix == 2) tv = (tv & ~T_DIAG) | T_MAXH;
+                if (tv & T_MAXV)       tv &= (T_V | T_VOPEN | T_MAXV);
+                else if (tv & T_MAXH)  tv &= (T_H | T_HOPEN | T_MAXH);
+            }
+            if (tv & T_DIAG) {
+                acc.matches += eq ? 1 : 0;
+                acc.run(T_DIAG, 1);
+                col--; row--;
+                next_cell();
+            } else if ((tv & T_MAXV) && (tv & T_V)) {
+                // gap run: follow the extend bits of the cells being left, then the opening step
+                acc.run(T_V, 1); row--;
+                if (row >= 1) mode = VRUN;      // the run continues through cell (col,row): its bits decide
+                else next_cell();
+            } else if ((tv & T_MAXV) && (tv & T_VOPEN)) {
+                acc.run(T_V, 1); row--;
+                next_cell();
+            } else if ((tv & T_MAXH) && (tv & T_H)) {
+                acc.run(T_H, 1); col--;
+                if (col >= 1) mode = HRUN;
+                else next_cell();
+            } else if ((tv & T_MAXH) && (tv & T_HOPEN)) {
+                acc.run(T_H, 1); col--;
+                next_cell();
+            } else {
+                err = 1; done = 1;
+            }
+        } else if (mode == VRUN) {
+            // inside a vertical run: this cell's own extend/open bit says whether the run goes on
+            if ((!(tv & T_VOPEN) || (tv & T_V)) && row != 1) { acc.run(T_V, 1); row--; }
+            else { acc.run(T_V, 1); row--; next_cell(); }
+        } else {
+            if ((!(tv & T_HOPEN) || (tv & T_H)) && col != 1) { acc.run(T_H, 1); col--; }
+            else { acc.run(T_H, 1); col--; next_cell(); }
+        }
+    }
+    PC_HD int finish(Digest &out) {
+        if (row > 0 && col == 0 && col0 > 0) err = 1;   // left the window: bound violated
+        // head segments
+        acc.run(T_V, row);
+        acc.run(T_H, col0 + col);
+        acc.finish(n_total, m, score, out);
+        return err;
+    }
+};
+
+// TraceFn:   int nib(int local_col, int adapter_row)  for local_col>=1, adapter_row>=1
+// MatchFn:   bool eq(int local_col, int adapter_row)  -> read base (col-1) == adapter base (row-1)
+// One walk, start to finish (host tests; the kernels drive two Walk states themselves).
 template <typename TraceFn, typename MatchFn>
 PC_HD int walk(TraceFn nib, MatchFn eq, int I, int J, int m, int col0, int n_total, int score,
                int tie_fix, Digest &out)
 {
-    Acc acc; acc.init();
-    int col = J, row = I;
-    int tv = (col > 0 && row > 0) ? nib_to_byte(nib(col, row)) : T_NONE;
-    if (tie_fix == 1)      tv = (tv & ~T_DIAG) | T_MAXV;
-    else if (tie_fix == 2) tv = (tv & ~T_DIAG) | T_MAXH;
-    if (tv & T_MAXV)       tv &= (T_V | T_VOPEN | T_MAXV);
-    else if (tv & T_MAXH)  tv &= (T_H | T_HOPEN | T_MAXH);
-    // tail segments: adapter bases hanging past the read end / read bases after the alignment
-    acc.run(T_V, m - row);
-    acc.run(T_H, n_total - (col0 + col));
-    int err = 0;
-    while (col > 0 && row > 0 && tv != T_NONE) {
-        if (tv & T_DIAG) {
-            acc.matches += eq(col, row) ? 1 : 0;
-            acc.run(T_DIAG, 1);
-            col--; row--;
-        } else if ((tv & T_MAXV) && (tv & T_V)) {
-            // gap run: follow the extend bits of the cells being left, then the opening step
-            while (((!(tv & T_VOPEN)) || (tv & T_V)) && row != 1) {
-                acc.run(T_V, 1); row--;
-                tv = nib_to_byte(nib(col, row));
-            }
-            acc.run(T_V, 1); row--;
-        } else if ((tv & T_MAXV) && (tv & T_VOPEN)) {
-            acc.run(T_V, 1); row--;
-        } else if ((tv & T_MAXH) && (tv & T_H)) {
-            while (((!(tv & T_HOPEN)) || (tv & T_H)) && col != 1) {
-                acc.run(T_H, 1); col--;
-                tv = nib_to_byte(nib(col, row));
-            }
-            acc.run(T_H, 1); col--;
-        } else if ((tv & T_MAXH) && (tv & T_HOPEN)) {
-            acc.run(T_H, 1); col--;
-        } else {
-            err = 1; break;
-        }
-        tv = (col > 0 && row > 0) ? nib_to_byte(nib(col, row)) : T_NONE;
-    }
-    if (row > 0 && col == 0 && col0 > 0) err = 1;   // left the window: bound violated
-    // head segments
-    acc.run(T_V, row);
-    acc.run(T_H, col0 + col);
-    acc.finish(n_total, m, score, out);
-    return err;
+    Walk w;
+    w.start(I, J, m, col0, n_total, score, tie_fix);
+    while (!w.done) w.consume(nib(w.col, w.row), eq(w.col, w.row));
+    return w.finish(out);
 }
 
 }  // namespace pcw

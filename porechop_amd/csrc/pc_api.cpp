@@ -400,7 +400,7 @@ int pc_scan_device(pc_ctx *c, const void *d_arena, const int64_t *d_win_off, con
         const int chunks = g.two_pass ? chunks_for((int64_t)g.tile_count, resident_waves(c, g), max_len, g.max_window) : 1;
         max_chunks = std::max(max_chunks, chunks);
         const int grid1 = grid_for(c, g, g.tile_count * (size_t)chunks, 1, nullptr);   // chunked score pass
-        fin_bytes = std::max(fin_bytes, (size_t)std::max(grid, grid1) * std::max(1, g.rows) * 64 * 8);
+        fin_bytes = std::max(fin_bytes, (size_t)std::max(grid, grid1) * (size_t)std::max(1, g.rows ? g.rows : g.gen_max_rows) * 64 * 8);
         any_two |= g.two_pass;
     }
     if ((rc = c->d_slab.ensure(slab_bytes + 256)) || (rc = c->d_fin.ensure(fin_bytes + 256))) return rc;
@@ -470,8 +470,8 @@ int pc_scan_device(pc_ctx *c, const void *d_arena, const int64_t *d_win_off, con
                     double est_cells = 0;
                     for (size_t k = i; k < e; ++k)
                         est_cells += (double)(c->tiles[g.tile_begin + k].count_lo + c->tiles[g.tile_begin + k].count_hi);
-                    est_cells *= (double)max_len * (double)std::max(1, g.rows);
-                    pcj::Spec *sp = (g.rows && !linear)
+                    est_cells *= (double)max_len * (double)(g.rows ? g.rows : g.gen_max_rows);
+                    pcj::Spec *sp = !linear
                                         ? pcj::get(c->device, c->adapters[t0.adapter_lo], c->adapters[t0.adapter_hi],
                                                    c->match, c->mismatch, c->gap_open, c->gap_extend, est_cells)
                                         : nullptr;

@@ -18,6 +18,7 @@
 #include <string>
 #include <vector>
 
+#include "pc_bounds.h"
 #include "pc_jit_source.h"
 
 namespace pcj {
@@ -102,7 +103,7 @@ Spec *get(int device, const std::string &ad_lo, const std::string &ad_hi, int ma
     const int m_lo = (int)ad_lo.size(), m_hi = (int)ad_hi.size();
     const int R = m_lo > m_hi ? m_lo : m_hi;
     static const bool verbose = [] { const char *v = getenv("PC_JIT_VERBOSE"); return v && *v && *v != '0'; }();
-    if (R < 2 || R > 40) {                  // register budget of the specialised kernel (2 waves per SIMD)
+    if (R < 2 || R > pcb::MAX_ADAPTER) {
         if (verbose) fprintf(stderr, "porechop_amd: no specialised kernel for %d rows\n", R);
         return nullptr;
     }
@@ -164,10 +165,11 @@ Spec *get(int device, const std::string &ad_lo, const std::string &ad_hi, int ma
         combo_of_row[row] = k;
     }
     const int K = ((int)combos.size() + 3) / 4 * 4;
-    if (2 * R + 2 * K > 120) {               // T, U and two sets of substitution terms must stay in registers
-        if (verbose) fprintf(stderr, "porechop_amd: no specialised kernel for %d rows x %d letter pairs\n", R, K);
-        return nullptr;
-    }
+    // Register budget: T, U and two sets of substitution terms.  Up to 2R + 2K = 120 the kernel fits
+    // 256 VGPRs (two waves per SIMD); longer adapters (full barcode sequences, 63-111 bases) get the
+    // whole register file of a SIMD -- one wave, the rows beyond 256 VGPRs parked in AGPRs -- which
+    // is still several times faster than the generic kernel's column in LDS.
+    const int waves = (2 * R + 2 * K <= 120) ? 2 : 1;
 
     std::string init;
     for (int row = 0; row < R; ++row) { init += std::to_string(combo_of_row[row]); if (row + 1 < R) init += ","; }
@@ -175,7 +177,7 @@ Spec *get(int device, const std::string &ad_lo, const std::string &ad_hi, int ma
                       dC = "-DPC_COMBO_INIT=" + init, dF = std::string("-DPC_F16=") + (f16 ? "1" : "0"),
                       dE = "-DPC_EPS=" + std::to_string(eps), dO = "-DPC_OE=(" + std::to_string(gap_open + eps) + ")",
                       dN = "-DPC_CEN=(" + std::to_string(cen) + ")", dP = "-DPC_KREN=" + std::to_string(kren),
-                      dW = std::string("-DPC_WAVES=") + (getenv("PC_JIT_WAVES") ? getenv("PC_JIT_WAVES") : "2");
+                      dW = std::string("-DPC_WAVES=") + (getenv("PC_JIT_WAVES") ? getenv("PC_JIT_WAVES") : std::to_string(waves));
     const char *opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", dR.c_str(), dK.c_str(), dC.c_str(), dF.c_str(),
                           dE.c_str(), dO.c_str(), dN.c_str(), dP.c_str(), dW.c_str()};
     hiprtcProgram prog = nullptr;
@@ -197,7 +199,7 @@ Spec *get(int device, const std::string &ad_lo, const std::string &ad_hi, int ma
     r.DestroyProgram(&prog);
 
     Spec *sp = new Spec();
-    sp->R = R; sp->K = K; sp->m_lo = m_lo; sp->m_hi = m_hi; sp->f16 = f16;
+    sp->R = R; sp->K = K; sp->m_lo = m_lo; sp->m_hi = m_hi; sp->f16 = f16; sp->waves = waves;
     hipModule_t mod = nullptr;
     hipFunction_t fn = nullptr;
     if (hipModuleLoadData(&mod, code.data()) != hipSuccess || hipModuleGetFunction(&fn, mod, "pc_spec_score") != hipSuccess) {

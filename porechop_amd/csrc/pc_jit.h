@@ -10,6 +10,7 @@ namespace pcj {
 
 struct Spec {
     int R = 0, K = 0, m_lo = 0, m_hi = 0;
+    int waves = 2;               // resident waves per SIMD the register allocation allows
     bool f16 = false;            // packed-fp16 variant (5 ops per cell pair) vs packed-int16 (6)
     void *module = nullptr, *function = nullptr;
     void *d_table = nullptr;     // device [256][K] substitution-term table

@@ -184,12 +184,16 @@ from tests.pairgen import random_case
 rng = random.Random(77)
 o = Oracle()
 ads = ["AATGTACTTCGTTCAGTTACGTATTGCT", "GCAATACGTAACTGAACGAAGT", "CTTCGTTCAGTTACGTATTGCTGGCGTCTGCTT", "ACGTNACGTTAGC",
-       "GGTTGTTTCTGTTGGTGCTGATATTGCTGGCGTCTGCTT", "AAGCAGACGCCAGCAATATCAGCACCAACAGAAACAAC"]
+       "GGTTGTTTCTGTTGGTGCTGATATTGCTGGCGTCTGCTT", "AAGCAGACGCCAGCAATATCAGCACCAACAGAAACAAC",
+       # full native-barcode adapters (68 / 63 bases) and a 111-base one: one wave per SIMD, rows parked in AGPRs
+       "AATGTACTTCGTTCAGTTACGTATTGCTAAGGTTAACACAAAGACACCGACAACTTTCTTCAGCACCT",
+       "AGGTGCTGAAGAAAGTTGTCGGTGTCTTTGTGTTAACCTTAGCAATACGTAACTGAACGAAGT",
+       "AATGTACTTCGTTCAGTTACGGCTTGGGTGTTTAACCAAGAAAGTTGTCGGTGTCTTTGTGGTTTTCGCATTTATCGTGAAACGCTTTCGCGTTTTTCGTGCGCCGCTTCA"]
 for scores, lengths in [((3, -6, -5, -2), [900, 2500, 6000]), ((3, -6, -5, -2), [5003]),
                         ((20, -30, -25, -12), [3000]), ((3, -6, -2, -5), [1800, 1801]), ((20, -30, -25, -12), [700, 2100])]:
     reads = [random_case(rng, n=rng.choice(lengths), m=28)[0] for _ in range(150)]
     for i in range(0, 150, 3):                      # implant copies of each adapter
-        a = ads[(i // 3) % 6]; p = rng.randint(0, len(reads[i]) - 60)
+        a = ads[(i // 3) % 9]; p = rng.randint(0, len(reads[i]) - 120)
         reads[i] = reads[i][:p] + a + reads[i][p + len(a):]
     al = porechop_amd.Aligner(ads, scores=scores)
     arena = torch.from_numpy(np.frombuffer(("".join(reads)).encode() + b"N" * 64, dtype=np.uint8).copy()).cuda()
@@ -197,7 +201,7 @@ for scores, lengths in [((3, -6, -5, -2), [900, 2500, 6000]), ((3, -6, -5, -2), 
     offs = np.concatenate([[0], np.cumsum(lens[:-1].astype(np.int64))]).astype(np.int64)
     woff, wlen = torch.from_numpy(offs).cuda(), torch.from_numpy(lens).cuda()
     n = len(reads)
-    for (a, b) in [(0, 1), (2, 3), (1, -1), (4, 5)]:
+    for (a, b) in [(0, 1), (2, 3), (1, -1), (4, 5), (6, 7), (8, -1)]:
         out = torch.zeros((n * (2 if b >= 0 else 1), 8), dtype=torch.int32, device="cuda")
         al.scan_device(arena, woff, wlen, [a], [0, n], int(lens.max()), out, porechop_amd.MODE_TWO_PASS, job_adapter_b=[b])
         al.sync()
@@ -215,8 +219,13 @@ print("SPEC_OK")
         assert "SPEC_OK" in res.stdout, res.stdout[-2000:] + res.stderr[-3000:]
         assert "hiprtc" not in res.stderr and "no specialised kernel" not in res.stderr, res.stderr[-2000:]
         built = re.findall(r"specialised kernel R=(\d+) K=\d+ f16=(\d) kren=(\d+)", res.stderr)
-        assert len(built) == 12, res.stderr[-2000:]                  # 4 adapter pairs (22..39 rows) x 3 schemes
-        assert all(f == ("0" if int16 == "1" else "1") for _, f, _ in built)
+        assert len(built) == 18, res.stderr[-2000:]                  # 6 adapter pairs (22..111 rows) x 3 schemes
+        if int16 == "1":
+            assert all(f == "0" for _, f, _ in built)
+        else:
+            # fp16 wherever every value fits its exact-integer range (the long adapters under the
+            # 20/-30/-25/-12 scheme do not: they take the int16 variant)
+            assert all(f == "1" for r, f, _ in built if int(r) <= 40) and sum(f == "1" for _, f, _ in built) >= 16
         if int16 == "0":
             assert min(int(k) for _, _, k in built) < 300            # the renormalisation path ran
 

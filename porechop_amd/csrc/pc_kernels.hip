@@ -573,7 +573,8 @@ static int launch_scan(const ScanArgs &a0, int rows, bool pad, int grid, void *s
     } else {
         switch (rows) {
             PC_PADDED(16) PC_PADDED(20) PC_PADDED(24) PC_PADDED(26) PC_PADDED(28) PC_PADDED(30) PC_PADDED(32) PC_PADDED(34)
-            PC_PADDED(36) PC_PADDED(38) PC_PADDED(40) PC_PADDED(48) PC_PADDED(56)
+            PC_PADDED(36) PC_PADDED(38) PC_PADDED(40) PC_PADDED(48) PC_PADDED(56) PC_PADDED(64) PC_PADDED(72)
+            PC_PADDED(112) PC_PADDED(128)
             default: return -1;
         }
     }

@@ -121,6 +121,12 @@ int pc_sync(pc_ctx *ctx, void *stream);
 int pc_set_timing(pc_ctx *ctx, int enabled);
 int pc_get_timing(pc_ctx *ctx, void *stream, double *ms, int64_t *launches, int64_t *pairs);
 
+/* Run-time specialised score kernels are compiled (hiprtc) once an adapter pair's accumulated work
+ * pays for it.  By default the compile happens in place, inside the pc_scan_device call that
+ * crosses the threshold; with pc_jit_async(1) it runs on a worker thread and launches keep using
+ * the generic kernels until the kernel is ready -- no stall for one-shot runs.  Process-wide. */
+void pc_jit_async(int enabled);
+
 /* Format one result record exactly as the reference prints it; buf must hold >= 160 bytes. */
 int pc_format_result(const int32_t *rec, char *buf, size_t buflen);
 

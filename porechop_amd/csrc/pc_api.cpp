@@ -530,6 +530,8 @@ int pc_scan_device(pc_ctx *c, const void *d_arena, const int64_t *d_win_off, con
     return PC_OK;
 }
 
+void pc_jit_async(int enabled) { pcj::set_async(enabled); }
+
 int pc_set_timing(pc_ctx *c, int enabled)
 {
     if (!c) return PC_ERR_BAD_ARG;

@@ -13,8 +13,10 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <atomic>
 #include <map>
 #include <mutex>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -84,9 +86,153 @@ uint32_t half_bits(int v)
     return sign | ((uint32_t)(e + 15) << 10) | mant;
 }
 
-std::mutex g_mu;
-std::map<std::string, Spec *> g_cache;   // key -> spec (null = failed, do not retry)
-std::map<std::string, double> g_seen;    // key -> cells scanned with the generic kernel so far
+// One adapter pair + scheme: its specialised kernel goes through
+//   ABSENT (work seen so far below the threshold) -> COMPILING (hiprtc, possibly on a worker
+//   thread) -> READY (module loaded, table uploaded) | FAILED (never retried)
+struct Entry {
+    enum State { ABSENT, COMPILING, READY, FAILED } state = ABSENT;
+    double seen = 0;                 // cells scanned with the generic kernel so far
+    Spec *spec = nullptr;
+    // product of the compile step (no HIP calls in it: it may run on a worker thread)
+    std::vector<char> code;
+    std::vector<uint32_t> table;
+    std::string log;
+    bool compiled_ok = false;
+    std::atomic<bool> compile_done{false};
+    std::thread worker;
+    int R = 0, K = 0, m_lo = 0, m_hi = 0, waves = 2;
+    bool f16 = false;
+    long kren = 0;
+};
+
+std::mutex g_mu;                               // the cache
+std::mutex g_compile_mu;                       // one hiprtc compile at a time
+std::map<std::string, Entry *> g_cache;
+std::atomic<int> g_async{0};
+
+struct JoinAtExit {                            // worker threads must not outlive the process image
+    ~JoinAtExit() {
+        for (auto &kv : g_cache) if (kv.second->worker.joinable()) kv.second->worker.join();
+    }
+} g_join_at_exit;
+
+struct Recipe {                                // everything the compile step needs, by value
+    std::string ad_lo, ad_hi;
+    int match, mismatch, gap_open, gap_extend;
+    int R, m_lo, m_hi, eps, waves;
+    bool f16;
+    long kren, cen;
+};
+
+// hiprtc compile + substitution table.  No HIP runtime calls.
+void compile_entry(Entry *e, const Recipe rc)
+{
+    std::lock_guard<std::mutex> one(g_compile_mu);
+    Rtc &r = rtc();                      // first use loads libhiprtc (hundreds of ms): also off the caller's thread
+    if (!r.ok) {
+        e->log = "hiprtc not available";
+        e->compile_done.store(true, std::memory_order_release);
+        return;
+    }
+    const int R = rc.R;
+    // letters per register row of each half (bottom-aligned): 0..4 = Dna5 code, 5 = padding row
+    std::vector<int> lo(R, 5), hi(R, 5);
+    for (int i = 0; i < rc.m_lo; ++i) lo[R - rc.m_lo + i] = dna5((unsigned char)rc.ad_lo[i]);
+    for (int i = 0; i < rc.m_hi; ++i) hi[R - rc.m_hi + i] = dna5((unsigned char)rc.ad_hi[i]);
+    std::vector<int> combos;             // distinct lo*6+hi
+    std::vector<int> combo_of_row(R);
+    for (int row = 0; row < R; ++row) {
+        const int c = lo[row] * 6 + hi[row];
+        int k = -1;
+        for (size_t i = 0; i < combos.size(); ++i) if (combos[i] == c) k = (int)i;
+        if (k < 0) { k = (int)combos.size(); combos.push_back(c); }
+        combo_of_row[row] = k;
+    }
+    const int K = ((int)combos.size() + 3) / 4 * 4;
+    // Register budget: T, U and two sets of substitution terms.  Up to 2R + 2K = 120 the kernel fits
+    // 256 VGPRs (two waves per SIMD); longer adapters (full barcode sequences, 63-111 bases) get the
+    // whole register file of a SIMD -- one wave, the rows beyond 256 VGPRs parked in AGPRs -- which
+    // is still several times faster than the generic kernel's column in LDS.
+    const int waves = (2 * R + 2 * K <= 120) ? 2 : 1;
+    e->R = R; e->K = K; e->m_lo = rc.m_lo; e->m_hi = rc.m_hi; e->f16 = rc.f16; e->waves = waves; e->kren = rc.kren;
+
+    std::string init;
+    for (int row = 0; row < R; ++row) { init += std::to_string(combo_of_row[row]); if (row + 1 < R) init += ","; }
+    const std::string dR = "-DPC_R=" + std::to_string(R), dK = "-DPC_K=" + std::to_string(K),
+                      dC = "-DPC_COMBO_INIT=" + init, dF = std::string("-DPC_F16=") + (rc.f16 ? "1" : "0"),
+                      dE = "-DPC_EPS=" + std::to_string(rc.eps), dO = "-DPC_OE=(" + std::to_string(rc.gap_open + rc.eps) + ")",
+                      dN = "-DPC_CEN=(" + std::to_string(rc.cen) + ")", dP = "-DPC_KREN=" + std::to_string(rc.kren),
+                      dW = std::string("-DPC_WAVES=") + (getenv("PC_JIT_WAVES") ? getenv("PC_JIT_WAVES") : std::to_string(waves));
+    const char *opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", dR.c_str(), dK.c_str(), dC.c_str(), dF.c_str(),
+                          dE.c_str(), dO.c_str(), dN.c_str(), dP.c_str(), dW.c_str()};
+    hiprtcProgram prog = nullptr;
+    if (r.CreateProgram(&prog, kSpecSource, "pc_spec_score.hip", 0, nullptr, nullptr) == 0) {
+        const hiprtcResult rcode = r.CompileProgram(prog, 12, opts);
+        if (rcode != 0) {
+            size_t n = 0;
+            r.GetProgramLogSize(prog, &n);
+            e->log.assign(n + 1, '\0');
+            if (n) r.GetProgramLog(prog, &e->log[0]);
+        } else {
+            size_t csz = 0;
+            r.GetCodeSize(prog, &csz);
+            e->code.resize(csz);
+            r.GetCode(prog, e->code.data());
+            e->compiled_ok = csz > 0;
+        }
+        r.DestroyProgram(&prog);
+    }
+    // S table: [256 read bytes][K letter pairs] of packed (sub_lo - open + eps) | (sub_hi - open + eps) << 16
+    e->table.assign((size_t)256 * K, 0);
+    auto term = [&](int letter, int code) -> int {
+        const int sub = letter == 5 ? 0 : (letter == code ? rc.match : rc.mismatch);
+        return sub - rc.gap_open + rc.eps;
+    };
+    for (int b = 0; b < 256; ++b) {
+        const int code = dna5((unsigned char)b);
+        for (size_t k = 0; k < combos.size(); ++k) {
+            const int l = term(combos[k] / 6, code), h = term(combos[k] % 6, code);
+            e->table[(size_t)b * K + k] = rc.f16 ? (half_bits(l) | (half_bits(h) << 16))
+                                                 : (((uint32_t)l & 0xFFFFu) | ((uint32_t)h << 16));
+        }
+    }
+    e->compile_done.store(true, std::memory_order_release);
+}
+
+// Module load + table upload on the caller's thread (the one that owns the device context).
+void finalize_entry(Entry *e, bool verbose)
+{
+    if (e->worker.joinable()) e->worker.join();
+    e->state = Entry::FAILED;
+    if (!e->compiled_ok) {
+        static bool told = false;
+        if (!told || e->log != "hiprtc not available")
+            fprintf(stderr, "porechop_amd: no specialised kernel (%s), using the generic scan kernels\n", e->log.c_str());
+        told = true;
+        return;
+    }
+    Spec *sp = new Spec();
+    sp->R = e->R; sp->K = e->K; sp->m_lo = e->m_lo; sp->m_hi = e->m_hi; sp->f16 = e->f16; sp->waves = e->waves;
+    hipModule_t mod = nullptr;
+    hipFunction_t fn = nullptr;
+    if (hipModuleLoadData(&mod, e->code.data()) != hipSuccess || hipModuleGetFunction(&fn, mod, "pc_spec_score") != hipSuccess) {
+        fprintf(stderr, "porechop_amd: loading the specialised kernel failed, using the generic kernels\n");
+        delete sp;
+        return;
+    }
+    sp->module = mod; sp->function = fn;
+    void *d = nullptr;
+    if (hipMalloc(&d, e->table.size() * 4) != hipSuccess ||
+        hipMemcpy(d, e->table.data(), e->table.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
+        delete sp;
+        return;
+    }
+    sp->d_table = d;
+    if (verbose) fprintf(stderr, "porechop_amd: specialised kernel R=%d K=%d f16=%d kren=%ld\n", e->R, e->K, e->f16 ? 1 : 0, e->kren);
+    e->code.clear(); e->code.shrink_to_fit();
+    e->spec = sp;
+    e->state = Entry::READY;
+}
 
 }  // namespace
 
@@ -95,6 +241,8 @@ bool disabled()
     const char *e = getenv("PC_DISABLE_JIT");
     return e && *e && *e != '0';
 }
+
+void set_async(int on) { g_async.store(on ? 1 : 0); }
 
 Spec *get(int device, const std::string &ad_lo, const std::string &ad_hi, int match, int mismatch, int gap_open,
           int gap_extend, double cells)
@@ -135,103 +283,33 @@ Spec *get(int device, const std::string &ad_lo, const std::string &ad_hi, int ma
     snprintf(keybuf, sizeof keybuf, "|%d|%d,%d,%d,%d|%d", device, match, mismatch, gap_open, gap_extend, f16 ? 1 : 0);
     const std::string key = ad_lo + "|" + ad_hi + keybuf;
     std::lock_guard<std::mutex> lk(g_mu);
-    auto it = g_cache.find(key);
-    if (it != g_cache.end()) return it->second;
-    // a hiprtc compile costs 0.3-1 s and halves the scan: compile once the work seen for this
-    // adapter pair, over all launches so far, would have paid for it (PC_JIT_MIN_CELLS overrides
-    // the 1e11-cell default)
+    Entry *&slot = g_cache[key];
+    if (!slot) slot = new Entry();
+    Entry *e = slot;
+    if (e->state == Entry::READY) return e->spec;
+    if (e->state == Entry::FAILED) return nullptr;
+    if (e->state == Entry::COMPILING) {
+        // asynchronous mode: the generic kernel keeps running until the worker is done
+        if (!e->compile_done.load(std::memory_order_acquire)) return nullptr;
+        finalize_entry(e, verbose);
+        return e->spec;
+    }
+    // a hiprtc compile costs 0.3-2 s and halves the scan (x6-10 for long adapters): start it once
+    // the work seen for this adapter pair, over all launches so far, would have paid for it
+    // (PC_JIT_MIN_CELLS overrides the 1e11-cell default)
     static const double min_cells = [] { const char *v = getenv("PC_JIT_MIN_CELLS"); return v ? atof(v) : 1e11; }();
-    double &seen = g_seen[key];
-    seen += cells;
-    if (seen < min_cells) return nullptr;
-    g_cache[key] = nullptr;
-    Rtc &r = rtc();
-    if (!r.ok) {
-        static bool told = false;
-        if (!told) { fprintf(stderr, "porechop_amd: hiprtc not available, using the generic scan kernels\n"); told = true; }
+    e->seen += cells;
+    if (e->seen < min_cells) return nullptr;
+    const Recipe rc{ad_lo, ad_hi, match, mismatch, gap_open, gap_extend, R, m_lo, m_hi, eps, 2, f16, kren, cen};
+    e->state = Entry::COMPILING;
+    if (g_async.load()) {
+        // the caller does not wait: this launch and the next ones use the generic kernel
+        e->worker = std::thread(compile_entry, e, rc);
         return nullptr;
     }
-    // letters per register row of each half (bottom-aligned): 0..4 = Dna5 code, 5 = padding row
-    std::vector<int> lo(R, 5), hi(R, 5);
-    for (int i = 0; i < m_lo; ++i) lo[R - m_lo + i] = dna5((unsigned char)ad_lo[i]);
-    for (int i = 0; i < m_hi; ++i) hi[R - m_hi + i] = dna5((unsigned char)ad_hi[i]);
-    std::vector<int> combos;             // distinct lo*6+hi
-    std::vector<int> combo_of_row(R);
-    for (int row = 0; row < R; ++row) {
-        const int c = lo[row] * 6 + hi[row];
-        int k = -1;
-        for (size_t i = 0; i < combos.size(); ++i) if (combos[i] == c) k = (int)i;
-        if (k < 0) { k = (int)combos.size(); combos.push_back(c); }
-        combo_of_row[row] = k;
-    }
-    const int K = ((int)combos.size() + 3) / 4 * 4;
-    // Register budget: T, U and two sets of substitution terms.  Up to 2R + 2K = 120 the kernel fits
-    // 256 VGPRs (two waves per SIMD); longer adapters (full barcode sequences, 63-111 bases) get the
-    // whole register file of a SIMD -- one wave, the rows beyond 256 VGPRs parked in AGPRs -- which
-    // is still several times faster than the generic kernel's column in LDS.
-    const int waves = (2 * R + 2 * K <= 120) ? 2 : 1;
-
-    std::string init;
-    for (int row = 0; row < R; ++row) { init += std::to_string(combo_of_row[row]); if (row + 1 < R) init += ","; }
-    const std::string dR = "-DPC_R=" + std::to_string(R), dK = "-DPC_K=" + std::to_string(K),
-                      dC = "-DPC_COMBO_INIT=" + init, dF = std::string("-DPC_F16=") + (f16 ? "1" : "0"),
-                      dE = "-DPC_EPS=" + std::to_string(eps), dO = "-DPC_OE=(" + std::to_string(gap_open + eps) + ")",
-                      dN = "-DPC_CEN=(" + std::to_string(cen) + ")", dP = "-DPC_KREN=" + std::to_string(kren),
-                      dW = std::string("-DPC_WAVES=") + (getenv("PC_JIT_WAVES") ? getenv("PC_JIT_WAVES") : std::to_string(waves));
-    const char *opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", dR.c_str(), dK.c_str(), dC.c_str(), dF.c_str(),
-                          dE.c_str(), dO.c_str(), dN.c_str(), dP.c_str(), dW.c_str()};
-    hiprtcProgram prog = nullptr;
-    if (r.CreateProgram(&prog, kSpecSource, "pc_spec_score.hip", 0, nullptr, nullptr) != 0) return nullptr;
-    const hiprtcResult rc = r.CompileProgram(prog, 12, opts);
-    if (rc != 0) {
-        size_t n = 0;
-        r.GetProgramLogSize(prog, &n);
-        std::string log(n + 1, '\0');
-        if (n) r.GetProgramLog(prog, &log[0]);
-        fprintf(stderr, "porechop_amd: hiprtc compile failed (%d), using the generic kernels\n%s\n", rc, log.c_str());
-        r.DestroyProgram(&prog);
-        return nullptr;
-    }
-    size_t csz = 0;
-    r.GetCodeSize(prog, &csz);
-    std::vector<char> code(csz);
-    r.GetCode(prog, code.data());
-    r.DestroyProgram(&prog);
-
-    Spec *sp = new Spec();
-    sp->R = R; sp->K = K; sp->m_lo = m_lo; sp->m_hi = m_hi; sp->f16 = f16; sp->waves = waves;
-    hipModule_t mod = nullptr;
-    hipFunction_t fn = nullptr;
-    if (hipModuleLoadData(&mod, code.data()) != hipSuccess || hipModuleGetFunction(&fn, mod, "pc_spec_score") != hipSuccess) {
-        fprintf(stderr, "porechop_amd: loading the specialised kernel failed, using the generic kernels\n");
-        delete sp;
-        return nullptr;
-    }
-    sp->module = mod; sp->function = fn;
-    // S table: [256 read bytes][K letter pairs] of packed (sub_lo - open + eps) | (sub_hi - open + eps) << 16
-    std::vector<uint32_t> tab((size_t)256 * K, 0);
-    auto term = [&](int letter, int code) -> int {
-        const int sub = letter == 5 ? 0 : (letter == code ? match : mismatch);
-        return sub - gap_open + eps;
-    };
-    for (int b = 0; b < 256; ++b) {
-        const int code = dna5((unsigned char)b);
-        for (size_t k = 0; k < combos.size(); ++k) {
-            const int l = term(combos[k] / 6, code), h = term(combos[k] % 6, code);
-            tab[(size_t)b * K + k] = f16 ? (half_bits(l) | (half_bits(h) << 16))
-                                         : (((uint32_t)l & 0xFFFFu) | ((uint32_t)h << 16));
-        }
-    }
-    void *d = nullptr;
-    if (hipMalloc(&d, tab.size() * 4) != hipSuccess ||
-        hipMemcpy(d, tab.data(), tab.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
-        delete sp;
-        return nullptr;
-    }
-    sp->d_table = d;
-    if (verbose) fprintf(stderr, "porechop_amd: specialised kernel R=%d K=%d f16=%d kren=%ld\n", R, K, f16 ? 1 : 0, kren);
-    g_cache[key] = sp;
-    return sp;
+    compile_entry(e, rc);
+    finalize_entry(e, verbose);
+    return e->spec;
 }
 
 int launch(const Spec *sp, const SpecArgs &a, int grid, void *stream)

@@ -35,5 +35,8 @@ bool disabled();
 Spec *get(int device, const std::string &ad_lo, const std::string &ad_hi, int match, int mismatch, int gap_open,
           int gap_extend, double cells);
 int launch(const Spec *sp, const SpecArgs &a, int grid, void *stream);
+// Asynchronous specialisation: compiles run on a worker thread and launches keep using the generic
+// kernels until a kernel is ready (no stall for one-shot runs); default off (compile in place).
+void set_async(int on);
 
 }  // namespace pcj

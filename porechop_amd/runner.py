@@ -263,6 +263,10 @@ def run(input_path, output=None, barcode_dir=None, options: Options = None, devi
                         scores=tuple(int(x) for x in opts.scoring_scheme))
     pl = Pipeline(panel, params, device=device, aligner=aligner)
     dev = pl.device
+    if aligner is None:
+        # a one-shot run should not wait for hiprtc: specialised kernels are compiled on a worker
+        # thread and picked up by later launches (pc_jit_async, include/porechop_amd.h)
+        pl.aligner.lib.pc_jit_async(1)
     try:
         reads = None
         if R:

@@ -126,6 +126,10 @@ int pc_get_timing(pc_ctx *ctx, void *stream, double *ms, int64_t *launches, int6
  * crosses the threshold; with pc_jit_async(1) it runs on a worker thread and launches keep using
  * the generic kernels until the kernel is ready -- no stall for one-shot runs.  Process-wide. */
 void pc_jit_async(int enabled);
+/* With asynchronous specialisation on, call this before the process exits: it drops compiles that
+ * have not started and waits for the one in flight (a worker thread must not be inside hiprtc while
+ * the process image is torn down).  The Python binding registers it with atexit. */
+void pc_jit_shutdown(void);
 
 /* Format one result record exactly as the reference prints it; buf must hold >= 160 bytes. */
 int pc_format_result(const int32_t *rec, char *buf, size_t buflen);

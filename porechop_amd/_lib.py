@@ -14,7 +14,7 @@ EXPORTS = [
     "adapterAlignment", "freeCString",
     "pc_version", "pc_strerror", "pc_scores_supported", "pc_create", "pc_destroy",
     "pc_set_scores", "pc_set_adapters", "pc_align_batch_host", "pc_scan_device", "pc_sync",
-    "pc_format_result", "pc_jit_async", "pc_prefetch", "pc_memo_clear", "pc_memo_stats", "pc_set_timing", "pc_get_timing",
+    "pc_format_result", "pc_jit_async", "pc_jit_shutdown", "pc_prefetch", "pc_memo_clear", "pc_memo_stats", "pc_set_timing", "pc_get_timing",
     "pc_readset_load", "pc_readset_free", "pc_readset_error", "pc_readset_count", "pc_readset_is_fastq",
     "pc_readset_arena", "pc_readset_offsets", "pc_readset_lengths", "pc_readset_name", "pc_readset_quals",
     "pc_readset_is_rna", "pc_readset_load_many", "pc_readset_file_index", "pc_readset_write",
@@ -77,6 +77,10 @@ def load_library():
     L.pc_get_timing.restype = c_int
     L.pc_jit_async.argtypes = [c_int]
     L.pc_jit_async.restype = None
+    L.pc_jit_shutdown.argtypes = []
+    L.pc_jit_shutdown.restype = None
+    import atexit
+    atexit.register(L.pc_jit_shutdown)       # no worker thread inside hiprtc while the process is torn down
     L.pc_format_result.argtypes = [c_vp, c_cp, ctypes.c_size_t]
     L.pc_format_result.restype = c_int
     L.pc_prefetch.argtypes = [c_vp, c_i64, c_vp, c_vp, ctypes.POINTER(c_cp), c_vp, c_i64, c_int, c_int, c_int, c_int]

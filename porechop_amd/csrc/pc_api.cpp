@@ -531,6 +531,7 @@ int pc_scan_device(pc_ctx *c, const void *d_arena, const int64_t *d_win_off, con
 }
 
 void pc_jit_async(int enabled) { pcj::set_async(enabled); }
+void pc_jit_shutdown(void) { pcj::wait_idle(true); }
 
 int pc_set_timing(pc_ctx *c, int enabled)
 {

@@ -109,12 +109,7 @@ std::mutex g_mu;                               // the cache
 std::mutex g_compile_mu;                       // one hiprtc compile at a time
 std::map<std::string, Entry *> g_cache;
 std::atomic<int> g_async{0};
-
-struct JoinAtExit {                            // worker threads must not outlive the process image
-    ~JoinAtExit() {
-        for (auto &kv : g_cache) if (kv.second->worker.joinable()) kv.second->worker.join();
-    }
-} g_join_at_exit;
+std::atomic<bool> g_cancel{false};             // set at shutdown: queued compiles are dropped
 
 struct Recipe {                                // everything the compile step needs, by value
     std::string ad_lo, ad_hi;
@@ -128,6 +123,7 @@ struct Recipe {                                // everything the compile step ne
 void compile_entry(Entry *e, const Recipe rc)
 {
     std::lock_guard<std::mutex> one(g_compile_mu);
+    if (g_cancel.load()) { e->log = "cancelled"; e->compile_done.store(true, std::memory_order_release); return; }
     Rtc &r = rtc();                      // first use loads libhiprtc (hundreds of ms): also off the caller's thread
     if (!r.ok) {
         e->log = "hiprtc not available";
@@ -243,6 +239,20 @@ bool disabled()
 }
 
 void set_async(int on) { g_async.store(on ? 1 : 0); }
+
+void wait_idle(bool cancel_queued)
+{
+    // a worker must not be inside hiprtc when the process image is torn down: callers with
+    // asynchronous specialisation on call this before exiting (the Python binding registers it with
+    // atexit).  Compiles that have not started yet are dropped; the one in flight is waited for.
+    if (cancel_queued) g_cancel.store(true);
+    std::vector<Entry *> es;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        for (auto &kv : g_cache) es.push_back(kv.second);
+    }
+    for (Entry *e : es) if (e->worker.joinable()) e->worker.join();
+}
 
 Spec *get(int device, const std::string &ad_lo, const std::string &ad_hi, int match, int mismatch, int gap_open,
           int gap_extend, double cells)

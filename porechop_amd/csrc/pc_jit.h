@@ -38,5 +38,7 @@ int launch(const Spec *sp, const SpecArgs &a, int grid, void *stream);
 // Asynchronous specialisation: compiles run on a worker thread and launches keep using the generic
 // kernels until a kernel is ready (no stall for one-shot runs); default off (compile in place).
 void set_async(int on);
+// Join the worker threads (dropping compiles that have not started when cancel_queued).
+void wait_idle(bool cancel_queued);
 
 }  // namespace pcj

@@ -66,6 +66,9 @@ enum {
 #define PC_MODE_AUTO 0      /* by window length */
 #define PC_MODE_TRACE 1     /* one pass, full trace (end windows) */
 #define PC_MODE_TWO_PASS 2  /* score-only pass + bounded traced window (whole reads) */
+#define PC_MODE_SCORE 3     /* score-only pass alone: records are (-2, J, I, 0, score, 0, 0, 0) -- the
+                             * reference's end cell (row I of the adapter, window column J) and raw
+                             * score, no traceback (pc_scan_device only) */
 
 const char *pc_version(void);
 const char *pc_strerror(int code);

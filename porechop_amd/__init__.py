@@ -7,7 +7,7 @@ compute entry points without the built library, or calling them without a GPU, f
 """
 from ._lib import LIB_PATH, load_library, LibraryMissing  # noqa: F401
 from .cpp_function_wrappers import adapter_alignment  # noqa: F401
-from .batch import (Aligner, RESULT_INTS, MODE_AUTO, MODE_TRACE, MODE_TWO_PASS,  # noqa: F401
+from .batch import (Aligner, RESULT_INTS, MODE_AUTO, MODE_TRACE, MODE_TWO_PASS, MODE_SCORE,  # noqa: F401
                     format_result, records_to_fields)
 
 __all__ = ["adapter_alignment", "Aligner", "load_library", "LIB_PATH", "format_result"]

@@ -10,7 +10,7 @@ import numpy as np
 from ._lib import check, load_library
 
 RESULT_INTS = 8      # readStart, readEnd, adapterStart, adapterEnd, rawScore, matches, alignedLen, fullLen
-MODE_AUTO, MODE_TRACE, MODE_TWO_PASS = 0, 1, 2
+MODE_AUTO, MODE_TRACE, MODE_TWO_PASS, MODE_SCORE = 0, 1, 2, 3
 DEFAULT_SCORES = (3, -6, -5, -2)   # porechop/porechop.py:145
 INT_MIN = -2147483648
 

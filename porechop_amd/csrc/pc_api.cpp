@@ -178,7 +178,7 @@ int build_tiles(pc_ctx *c, const int32_t *job_adapter, const int32_t *job_adapte
         bool pad = false;
         const int rows = pck::pick_rows(m, mb, &pad);     // 0 => generic LDS-state kernel
         const int window = std::max(c->ad_window[ad], adb >= 0 ? c->ad_window[adb] : 0);
-        bool two = (mode == PC_MODE_TWO_PASS) || (mode == PC_MODE_AUTO && max_len > 2 * window + 64);
+        bool two = (mode == PC_MODE_TWO_PASS) || (mode == PC_MODE_SCORE) || (mode == PC_MODE_AUTO && max_len > 2 * window + 64);
         auto key = std::make_pair(rows * 2 + (pad ? 1 : 0), two ? 1 : 0);
         auto &v = by_group[key];
         group_window[key] = std::max(group_window[key], window);
@@ -457,8 +457,18 @@ int pc_scan_device(pc_ctx *c, const void *d_arena, const int64_t *d_win_off, con
             int grid = grid_for(c, g, g.tile_count * (size_t)chunks, 1, nullptr);
             {
                 // tiles of one job (= one adapter pair) are contiguous: a run-time specialised
-                // kernel per pair when hiprtc can provide one, the generic kernel otherwise
-                size_t i = 0;
+                // kernel per pair when hiprtc can provide one; runs of pairs without one share a
+                // launch of the generic kernel (which takes the adapter from each tile)
+                auto launch_generic = [&](size_t b0, size_t e0) -> int {
+                    if (e0 <= b0) return 0;
+                    int64_t sub_pairs = 0;
+                    for (size_t k = b0; k < e0; ++k) sub_pairs += c->tiles[g.tile_begin + k].count_lo + c->tiles[g.tile_begin + k].count_hi;
+                    ScopedTimer tm(c, stream, 0, sub_pairs);                // one timed region per kernel launch
+                    pck::ScanArgs b = a;
+                    b.tiles = a.tiles + b0; b.ntiles = (int32_t)(e0 - b0);
+                    return pck::launch_score(b, g.rows, g.pad, (int)std::min<size_t>((size_t)grid, (e0 - b0) * (size_t)chunks), stream);
+                };
+                size_t i = 0, run_begin = 0;
                 while (i < g.tile_count) {
                     const pck::Tile &t0 = c->tiles[g.tile_begin + i];
                     size_t e = i + 1;
@@ -475,11 +485,13 @@ int pc_scan_device(pc_ctx *c, const void *d_arena, const int64_t *d_win_off, con
                                         ? pcj::get(c->device, c->adapters[t0.adapter_lo], c->adapters[t0.adapter_hi],
                                                    c->match, c->mismatch, c->gap_open, c->gap_extend, est_cells)
                                         : nullptr;
-                    const int sub_grid = (int)std::min<size_t>((size_t)grid, (e - i) * (size_t)chunks);
-                    int64_t sub_pairs = 0;
-                    for (size_t k = i; k < e; ++k) sub_pairs += c->tiles[g.tile_begin + k].count_lo + c->tiles[g.tile_begin + k].count_hi;
-                    ScopedTimer tm(c, stream, sp ? 3 : 0, sub_pairs);     // one timed region per kernel launch
                     if (sp) {
+                        if ((rc = launch_generic(run_begin, i))) return PC_ERR_NO_DEVICE;
+                        run_begin = e;
+                        const int sub_grid = (int)std::min<size_t>((size_t)grid, (e - i) * (size_t)chunks);
+                        int64_t sub_pairs = 0;
+                        for (size_t k = i; k < e; ++k) sub_pairs += c->tiles[g.tile_begin + k].count_lo + c->tiles[g.tile_begin + k].count_hi;
+                        ScopedTimer tm(c, stream, 3, sub_pairs);
                         pcj::SpecArgs sa;
                         memset(&sa, 0, sizeof(sa));
                         sa.arena = a.arena; sa.win_off = a.win_off; sa.win_len = a.win_len;
@@ -490,13 +502,10 @@ int pc_scan_device(pc_ctx *c, const void *d_arena, const int64_t *d_win_off, con
                         sa.span = std::max(c->ad_span[t0.adapter_lo], c->ad_span[t0.adapter_hi]);
                         sa.err = a.err;
                         if (pcj::launch(sp, sa, sub_grid, stream)) return PC_ERR_NO_DEVICE;
-                    } else {
-                        pck::ScanArgs b = a;
-                        b.tiles = a.tiles + i; b.ntiles = (int32_t)(e - i);
-                        if ((rc = pck::launch_score(b, g.rows, g.pad, sub_grid, stream))) return PC_ERR_NO_DEVICE;
                     }
                     i = e;
                 }
+                if ((rc = launch_generic(run_begin, g.tile_count))) return PC_ERR_NO_DEVICE;
             }
             // plan the bounded windows
             pck::PlanArgs pl;
@@ -508,10 +517,12 @@ int pc_scan_device(pc_ctx *c, const void *d_arena, const int64_t *d_win_off, con
             pl.tiles = a.tiles; pl.ntiles = a.ntiles; pl.chunks = chunks;
             a.chunks = 1;
             pl.ad_window = c->d_ad_window.as<int32_t>();
+            pl.score_out = (mode == PC_MODE_SCORE) ? d_out : nullptr;
             {
                 ScopedTimer tm(c, stream, 1, np);
                 if ((rc = pck::launch_plan(pl, stream))) return PC_ERR_NO_DEVICE;
             }
+            if (mode == PC_MODE_SCORE) continue;      // no traceback asked for
             // pass 2: traced window ending at the max cell
             a.win_off = pl.win_off2; a.win_len = pl.win_len2; a.col0 = pl.col02; a.n_total = pl.ntot2;
             a.win_by_out = 1;

@@ -56,6 +56,7 @@ struct PlanArgs {
     const Tile *tiles; int32_t ntiles;                  // same tiles as the score pass
     int32_t chunks;                                     // chunk results per pair in k1 (>= 1)
     const int32_t *ad_window;                           // [nadapters] W+SPAN+1 for that adapter length
+    int32_t *score_out;                                 // PC_MODE_SCORE: [npairs][8] records (-2, J, I, 0, score, 0, 0, 0)
 };
 
 constexpr int TRACE_OUT_INTS = 8;

@@ -537,6 +537,12 @@ __global__ void plan_kernel(PlanArgs a)
         const int sc = a.k1[(p * nch + c) * 4 + 0];
         if (sc > score) { score = sc; I = a.k1[(p * nch + c) * 4 + 1]; J = a.k1[(p * nch + c) * 4 + 2]; }
     }
+    if (a.score_out) {       // score-only request: the end cell and its score are the whole answer
+        int4 *o = (int4 *)(a.score_out + p * TRACE_OUT_INTS);
+        o[0] = make_int4(-2, J, I, 0);
+        o[1] = make_int4(score, 0, 0, 0);
+        return;
+    }
     const int window = a.ad_window[hi ? tile.adapter_hi : tile.adapter_lo];
     int c0 = J - window;
     if (c0 < 0) c0 = 0;

@@ -18,7 +18,7 @@ from typing import List, Optional, Tuple
 import numpy as np
 import torch
 
-from .batch import MODE_TRACE, MODE_TWO_PASS, Aligner, RESULT_INTS
+from .batch import MODE_SCORE, MODE_TRACE, MODE_TWO_PASS, Aligner, RESULT_INTS
 
 
 @dataclass
@@ -182,10 +182,29 @@ class Pipeline:
         return res
 
     # ------------------------------------------------------------------------------------------
-    def phase_a(self, reads: DeviceReads, check_idx: Optional[torch.Tensor] = None):
+    def presence_score_bound(self, m: int) -> Optional[int]:
+        """Smallest raw score an alignment of an m-base adapter can have if its full-adapter identity
+        reaches --adapter_threshold (None when the scheme gives no bound).  With t = threshold/100:
+        identity >= t means matches M >= t * L_full >= t * m and non-match columns N <= M (1-t)/t;
+        every scored non-match column costs at most P = max(|mismatch|, |gap_open|, |gap_extend|) and
+        overhanging adapter bases cost nothing, so score >= match*M - P*N >= m * (t*match - P*(1-t))."""
+        match, mismatch, go, ge = self.p.scores
+        t = (self.p.adapter_threshold - 1e-6) / 100.0          # the identity is compared after %f rounding
+        per_base = t * match - max(-mismatch, -go, -ge) * (1.0 - t)
+        if per_base <= 0:
+            return None
+        return int(np.floor(m * per_base))
+
+    def phase_a(self, reads: DeviceReads, check_idx: Optional[torch.Tensor] = None, prune: bool = False):
         """-> (best_start[S], best_end[S]) float64 on device: the max full-adapter identity of every
         set's start / end sequence over the check reads.  This table is the only cross-read
-        reduction in Porechop (nanopore_read.py:159,164); a multi-GPU run all-reduces it (MAX)."""
+        reduction in Porechop (nanopore_read.py:159,164); a multi-GPU run all-reduces it (MAX).
+
+        prune=True: a score-only pass first, then traceback only for the pairs whose
+        score can still mean an identity >= --adapter_threshold (presence_score_bound).  Which sets
+        reach the threshold, and their best identities, are exactly the unpruned ones; the table
+        entries of sets that do NOT reach it become lower bounds (they only feed a display in the
+        reference), which is why this is an option and not the default."""
         S = len(self.sets)
         best_start = torch.zeros(S, dtype=torch.float64, device=self.device)
         best_end = torch.zeros(S, dtype=torch.float64, device=self.device)
@@ -202,6 +221,8 @@ class Pipeline:
                 jobs.append((self.seq_index[s.start[1]], so, sl)); where.append((si, 0))
             if s.end is not None:
                 jobs.append((self.seq_index[s.end[1]], eo, el)); where.append((si, 1))
+        if prune:
+            return self._phase_a_pruned(reads, jobs, where, best_start, best_end)
         outs = self._scan_jobs(reads.arena, jobs, MODE_TRACE, self.p.end_size)
         # one vectorised reduction for all jobs (they all cover the same n check reads)
         rec = torch.stack(outs)                                     # [J, n, 8]
@@ -213,6 +234,37 @@ class Pipeline:
         best_start.scatter_reduce_(0, si[side == 0], full[side == 0], reduce="amax")
         best_end.scatter_reduce_(0, si[side == 1], full[side == 1], reduce="amax")
         self.stats["pairs_end"] += sum(int(j[1].shape[0]) for j in jobs)
+        return best_start, best_end
+
+    def _phase_a_pruned(self, reads, jobs, where, best_start, best_end):
+        scores = torch.stack(self._scan_jobs(reads.arena, jobs, MODE_SCORE, self.p.end_size))[:, :, 4]   # [J, n]
+        bounds = [self.presence_score_bound(len(self.seqs[j[0]])) for j in jobs]
+        need = torch.tensor([b if b is not None else -(1 << 30) for b in bounds], device=self.device)
+        cand = scores >= need[:, None]
+        hit = torch.nonzero(cand)                              # [C, 2] (job, window), job-major: one sync
+        counts = torch.bincount(hit[:, 0], minlength=len(jobs)).cpu().numpy()
+        cjobs, cwhere = [], []
+        pos = 0
+        for k, (j, w) in enumerate(zip(jobs, where)):
+            if counts[k]:
+                sel = hit[pos:pos + int(counts[k]), 1]
+                pos += int(counts[k])
+                cjobs.append((j[0], j[1][sel], j[2][sel])); cwhere.append(w)
+        self.stats["pairs_end"] += sum(int(j[1].shape[0]) for j in jobs)
+        self.stats["pairs_end_traced_after_pruning"] = self.stats.get("pairs_end_traced_after_pruning", 0) + int(counts.sum())
+        if not cjobs:
+            return best_start, best_end
+        outs = self._scan_jobs(reads.arena, cjobs, MODE_TRACE, self.p.end_size)
+        rec = torch.cat(outs)                                   # one reduction for all candidate jobs
+        full, _ = _identities(rec)
+        full = torch.where(rec[:, 0] == -1, torch.zeros_like(full), full)
+        job_of = torch.repeat_interleave(torch.arange(len(cjobs), device=self.device),
+                                         torch.tensor([int(j[1].shape[0]) for j in cjobs], device=self.device))
+        top = torch.zeros(len(cjobs), dtype=torch.float64, device=self.device).scatter_reduce_(0, job_of, full, reduce="amax")
+        si = torch.tensor([w[0] for w in cwhere], device=self.device)
+        side = torch.tensor([w[1] for w in cwhere], device=self.device)
+        best_start.scatter_reduce_(0, si[side == 0], top[side == 0], reduce="amax")
+        best_end.scatter_reduce_(0, si[side == 1], top[side == 1], reduce="amax")
         return best_start, best_end
 
     def matching_sets(self, best_start, best_end):

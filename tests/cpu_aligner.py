@@ -46,6 +46,15 @@ class OracleAligner:
         out[:, 7] = r9[:, 8]
         return out
 
+    def _records(self, arena, woff, wlen, ad, mode):
+        rec = self._align(arena, woff, wlen, ad)
+        if mode == 3:                       # MODE_SCORE: only the raw score is defined here (end cell omitted)
+            out = np.zeros_like(rec)
+            out[:, 0] = -2
+            out[:, 4] = rec[:, 4]
+            return out
+        return rec
+
     def scan_device(self, arena, win_off, win_len, job_adapter, job_start, max_len, out, mode=0, stream=None, job_adapter_b=None):
         a = arena.cpu().numpy()
         wo, wl = win_off.cpu().numpy(), win_len.cpu().numpy()
@@ -53,10 +62,10 @@ class OracleAligner:
         for k, ad in enumerate(job_adapter):
             s, e = int(job_start[k]), int(job_start[k + 1])
             n = e - s
-            out[pos:pos + n] = torch.from_numpy(self._align(a, wo[s:e], wl[s:e], int(ad)))
+            out[pos:pos + n] = torch.from_numpy(self._records(a, wo[s:e], wl[s:e], int(ad), mode))
             pos += n
             if job_adapter_b is not None and int(job_adapter_b[k]) >= 0:
-                out[pos:pos + n] = torch.from_numpy(self._align(a, wo[s:e], wl[s:e], int(job_adapter_b[k])))
+                out[pos:pos + n] = torch.from_numpy(self._records(a, wo[s:e], wl[s:e], int(job_adapter_b[k]), mode))
                 pos += n
 
     def sync(self, stream=None):

@@ -91,3 +91,27 @@ def test_phases_match_sequential_reference_logic(oracle):
     # the alignments consumed are exactly the reference's sequence of calls (the rest were speculative)
     assert hits.alignments == calls[0]
     pl.close()
+
+
+def test_pruned_phase_a_on_gpu():
+    """SURVEY.md 8f-4 on the device: score-only pass (PC_MODE_SCORE) + traceback of the candidates
+    only; same matching sets and best identities as the full search, 10 000 check reads."""
+    import time
+    import torch
+    from porechop_amd.panel import load_panel
+    from porechop_amd.pipeline import Pipeline, ScanParams
+    from porechop_amd.synth import make_reads
+    from tests.test_phase_a_pruning import check_pruned_equals_full
+    pl = Pipeline(load_panel(), ScanParams())
+    reads = make_reads(20_000, 8000, seed=3, start_frac=0.9, end_frac=0.5, chimera_frac=0.01)
+    check = torch.arange(10_000, device="cuda")
+    names = [pl.sets[i].name for i in check_pruned_equals_full(pl, reads, check)]
+    assert "SQK-NSK007" in names
+    assert pl.stats["pairs_end_traced_after_pruning"] < 0.05 * pl.stats["pairs_end"]
+    for prune in (False, True):
+        torch.cuda.synchronize(); t = time.perf_counter()
+        for _ in range(3):
+            pl.phase_a(reads, check, prune=prune)
+        torch.cuda.synchronize()
+        print("phase A, prune=%s: %.2f ms" % (prune, (time.perf_counter() - t) / 3 * 1e3))
+    pl.close()

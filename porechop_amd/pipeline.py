@@ -183,13 +183,16 @@ class Pipeline:
 
     # ------------------------------------------------------------------------------------------
     def presence_score_bound(self, m: int) -> Optional[int]:
+        return self.identity_score_bound(m, self.p.adapter_threshold)
+
+    def identity_score_bound(self, m: int, threshold: float) -> Optional[int]:
         """Smallest raw score an alignment of an m-base adapter can have if its full-adapter identity
-        reaches --adapter_threshold (None when the scheme gives no bound).  With t = threshold/100:
+        reaches `threshold` percent (None when the scheme gives no bound).  With t = threshold/100:
         identity >= t means matches M >= t * L_full >= t * m and non-match columns N <= M (1-t)/t;
         every scored non-match column costs at most P = max(|mismatch|, |gap_open|, |gap_extend|) and
         overhanging adapter bases cost nothing, so score >= match*M - P*N >= m * (t*match - P*(1-t))."""
         match, mismatch, go, ge = self.p.scores
-        t = (self.p.adapter_threshold - 1e-6) / 100.0          # the identity is compared after %f rounding
+        t = (threshold - 1e-6) / 100.0                          # the identity is compared after %f rounding
         per_base = t * match - max(-mismatch, -go, -ge) * (1.0 - t)
         if per_base <= 0:
             return None
@@ -324,7 +327,7 @@ class Pipeline:
                 ads.append(s.end)
         return ads
 
-    def phase_c(self, reads: DeviceReads, start_trim, end_trim, matching: List[int]) -> MiddleHits:
+    def phase_c(self, reads: DeviceReads, start_trim, end_trim, matching: List[int], prove: bool = False) -> MiddleHits:
         """nanopore_read.py:210-243 for every read: adapters in order, and for each adapter keep
         re-aligning against the progressively masked read while the hit reaches --middle_threshold.
 
@@ -335,7 +338,13 @@ class Pipeline:
         in the reference's order (from the adapter that just hit, which the reference re-aligns)
         up to and including the next hit.  The alignments consumed are exactly the ones the
         reference's nested loops perform, on the same masked sequences; the ones after a hit are
-        speculative and discarded.  Rounds = hits of the most-hit read + 1, not alignments."""
+        speculative and discarded.  Rounds = hits of the most-hit read + 1, not alignments.
+
+        prove=True: round 0 runs the score-only pass for every (read, adapter) pair and the
+        traceback only for pairs whose score can still mean an identity >= --middle_threshold
+        (identity_score_bound) -- everything else is PROVEN not to be a hit, which is all the
+        reference does with those alignments.  Hits, masks and splits are identical; the records of
+        the proven non-hits are simply not produced (an option: the default computes them all)."""
         p = self.p
         dev = self.device
         ads = self.middle_adapter_list(matching)
@@ -362,8 +371,30 @@ class Pipeline:
             return torch.where(rec[..., 0] == -1, torch.zeros_like(full), full)
 
         # ---- round 0: all adapters x all reads, unmasked -------------------------------------
-        outs = self._scan_jobs(reads.arena, [(ai, loff, llen) for ai in aidx], MODE_TWO_PASS, max_len)
-        fulls = torch.stack([identity_of(rec) for rec in outs])      # [A, L]
+        jobs0 = [(ai, loff, llen) for ai in aidx]
+        bounds = [self.identity_score_bound(len(self.seqs[ai]), p.middle_threshold) for ai in aidx] if prove else None
+        if prove and all(b is not None for b in bounds):
+            score = torch.stack(self._scan_jobs(reads.arena, jobs0, MODE_SCORE, max_len))[:, :, 4]      # [A, L]
+            cand = torch.nonzero(score >= torch.tensor(bounds, device=dev)[:, None])                     # adapter-major
+            counts = torch.bincount(cand[:, 0], minlength=A).cpu().numpy()
+            L = int(live.numel())
+            recs = torch.zeros((A, L, RESULT_INTS), dtype=torch.int32, device=dev)
+            cjobs, csel, pos = [], [], 0
+            for a in range(A):
+                if counts[a]:
+                    sel = cand[pos:pos + int(counts[a]), 1]
+                    pos += int(counts[a])
+                    cjobs.append((aidx[a], loff[sel], llen[sel])); csel.append((a, sel))
+            if cjobs:
+                for (a, sel), o in zip(csel, self._scan_jobs(reads.arena, cjobs, MODE_TWO_PASS, max_len)):
+                    recs[a, sel] = o
+            outs = [recs[a] for a in range(A)]
+            # an all-zero record (rs = 0, lengths 0) is "not a hit" below: 0/0 identities are masked
+            fulls = torch.stack([torch.nan_to_num(identity_of(rec), nan=0.0) for rec in outs])
+            self.stats["pairs_middle_traced_after_proof"] = self.stats.get("pairs_middle_traced_after_proof", 0) + int(counts.sum())
+        else:
+            outs = self._scan_jobs(reads.arena, jobs0, MODE_TWO_PASS, max_len)
+            fulls = torch.stack([identity_of(rec) for rec in outs])  # [A, L]
         hit0 = (fulls >= p.middle_threshold) & torch.stack([rec[:, 0] != -1 for rec in outs])
         d_sel = torch.nonzero(hit0.any(dim=0)).flatten()             # dirty reads (indices into live)
         Dn = int(d_sel.numel())

@@ -115,3 +115,26 @@ def test_pruned_phase_a_on_gpu():
         torch.cuda.synchronize()
         print("phase A, prune=%s: %.2f ms" % (prune, (time.perf_counter() - t) / 3 * 1e3))
     pl.close()
+
+
+def test_proven_middle_scan_on_gpu():
+    """phase_c(prove=True) on the device, 200 k x 8 kb reads with 1 % chimeras: identical hits."""
+    import torch
+    from porechop_amd.panel import load_panel
+    from porechop_amd.pipeline import Pipeline, ScanParams
+    from porechop_amd.synth import make_reads
+    p = ScanParams()
+    pl = Pipeline(load_panel(), p)
+    reads = make_reads(200_000, 8000, seed=3, start_frac=0.9, end_frac=0.5, chimera_frac=0.01)
+    bs, be = pl.phase_a(reads, torch.arange(10_000, device="cuda"))
+    matching = pl.matching_sets(bs, be)
+    st, et = pl.phase_b(reads, matching)
+    h0 = pl.phase_c(reads, st, et, matching)
+    h1 = pl.phase_c(reads, st, et, matching, prove=True)
+    pl.aligner.sync()
+    assert h0.read.numel() > 1000
+    for f in ("read", "adapter", "start", "end", "identity"):
+        assert torch.equal(getattr(h0, f), getattr(h1, f)), f
+    assert (h0.rounds, h0.alignments) == (h1.rounds, h1.alignments)
+    assert pl.stats["pairs_middle_traced_after_proof"] < 0.05 * 200_000 * len(pl.middle_adapters)
+    pl.close()

@@ -278,7 +278,9 @@ def run(input_path, output=None, barcode_dir=None, options: Options = None, devi
 
         # ---- phase A and the set-level rules ---------------------------------------------
         if R and check_idx.size:
-            bs, be = pl.phase_a(reads, torch.from_numpy(check_idx).to(dev))
+            # the pruned search: same matching sets and best identities (the table entries of sets
+            # below the threshold are lower bounds, and this runner displays no table)
+            bs, be = pl.phase_a(reads, torch.from_numpy(check_idx).to(dev), prune=True)
         else:
             bs = torch.zeros(len(panel), dtype=torch.float64, device=dev)
             be = torch.zeros(len(panel), dtype=torch.float64, device=dev)
@@ -338,7 +340,7 @@ def run(input_path, output=None, barcode_dir=None, options: Options = None, devi
             lap("phase_b", sync=True)
             # ---- phase C -------------------------------------------------------------------
             if not opts.no_split:
-                hits = pl.phase_c(reads, start_trim, end_trim, match_idx)
+                hits = pl.phase_c(reads, start_trim, end_trim, match_idx, prove=True)   # identical hits, fewer tracebacks
                 lap("phase_c", sync=True)
         if hasattr(pl.aligner, "sync"):
             pl.aligner.sync()

@@ -189,7 +189,7 @@ def build_dataset(name, root):
 def _content(path):
     with open(path, "rb") as fh:
         data = fh.read()
-    return gzip.decompress(data) if path.endswith(".gz") else data     # hash what is IN a .gz, not its framing
+    return gzip.decompress(data) if data[:3] == b"\x1f\x8b\x08" else data   # hash what is IN a gzip file, not its framing
 
 
 def dataset_sha1(path):

@@ -1,0 +1,113 @@
+#!/usr/bin/env python3
+"""Differential fuzz of the end-to-end runner's HOST logic against the unchanged reference CLI
+(build container only: needs /root/reference and the compiled reference, oracle/_ref).  Random small
+inputs and random option combinations; the runner's alignments come from the oracle through the
+test stand-in (tests/cpu_aligner.py), so this exercises loading, set rules, trims, barcode calls,
+splits, naming and writing -- not the kernels.      python tools/diff_fuzz.py [cases] [seed]"""
+import io
+import os
+import random
+import shutil
+import sys
+import tempfile
+from contextlib import redirect_stderr, redirect_stdout
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+from tests import readgen  # noqa: E402
+from tests.cpu_aligner import OracleAligner  # noqa: E402
+from tests.golden.make_golden import stage_reference  # noqa: E402
+from tests.runner_cases import options_from_argv  # noqa: E402
+from oracle.oracle import Oracle  # noqa: E402
+from porechop_amd import runner  # noqa: E402
+
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+tmp = tempfile.mkdtemp(prefix="pc_fuzz_")
+refdir = stage_reference(tmp)
+sys.path.insert(0, refdir)
+import porechop.porechop as pp  # noqa: E402
+import porechop.adapters as adapters_mod  # noqa: E402
+oracle = Oracle()
+
+
+def random_options(barcodes):
+    o = []
+    def maybe(p, *args):
+        if rng.random() < p:
+            o.extend(args)
+    maybe(0.3, "--end_size", str(rng.choice([30, 80, 120, 150, 200])))
+    maybe(0.3, "--min_trim_size", str(rng.choice([0, 2, 4, 10])))
+    maybe(0.3, "--extra_end_trim", str(rng.choice([0, 1, 2, 7])))
+    maybe(0.3, "--end_threshold", str(rng.choice([60, 75, 90])))
+    maybe(0.3, "--middle_threshold", str(rng.choice([75, 85, 90, 97])))
+    maybe(0.2, "--adapter_threshold", str(rng.choice([80, 90, 97])))
+    maybe(0.2, "--check_reads", str(rng.choice([5, 40, 10000])))
+    maybe(0.2, "--min_split_read_size", str(rng.choice([1, 200, 1000, 3000])))
+    maybe(0.2, "--extra_middle_trim_good_side", str(rng.choice([0, 10, 50])))
+    maybe(0.2, "--extra_middle_trim_bad_side", str(rng.choice([0, 100, 300])))
+    maybe(0.15, "--scoring_scheme", rng.choice(["3,-6,-5,-2", "2,-3,-5,-2", "3,-6,-2,-5", "4,-5,-6,-6"]))
+    maybe(0.15, "--no_split")
+    maybe(0.15, "--discard_middle")
+    maybe(0.25, "--format", rng.choice(["fasta", "fastq", "fastq.gz", "auto"]))
+    if barcodes:
+        maybe(0.3, "--require_two_barcodes")
+        maybe(0.3, "--barcode_threshold", str(rng.choice([60, 75, 85])))
+        maybe(0.3, "--barcode_diff", str(rng.choice([0, 5, 15])))
+        maybe(0.2, "--untrimmed")
+        maybe(0.2, "--discard_unassigned")
+    return o
+
+
+bad = 0
+for k in range(cases):
+    kind = rng.choice(["native", "native", "rapid", "ligation", "edge"])
+    seed = rng.randint(1, 10 ** 6)
+    nreads = rng.choice([25, 60])
+    reads = {"native": lambda: readgen.native_reads(seed, nreads, barcodes=tuple(rng.sample(range(1, 13), 3))),
+             "rapid": lambda: readgen.rapid_reads(seed, nreads), "ligation": lambda: readgen.ligation_reads(seed, nreads),
+             "edge": lambda: None}[kind]()
+    work = os.path.join(tmp, "case%d" % k)
+    os.makedirs(work)
+    if reads is None:
+        inp = readgen.build_dataset("edge", work)
+    else:
+        as_fasta = rng.random() < 0.2
+        inp = os.path.join(work, "in.fasta" if as_fasta else "in.fastq")
+        with open(inp, "w") as f:
+            f.write(readgen.fasta_text(reads) if as_fasta else readgen.fastq_text(reads))
+    barcodes = kind in ("native", "rapid", "edge") and rng.random() < 0.5
+    extra = random_options(barcodes)
+    if not barcodes and "--untrimmed" in extra:
+        extra.remove("--untrimmed")
+    mode = "b" if barcodes else "o:" + rng.choice(["out.fastq", "out.fasta", "out.fastq.gz", "out.txt"])
+    # ---- reference
+    for a in adapters_mod.ADAPTERS:
+        a.best_start_score, a.best_end_score = 0.0, 0.0
+    rwork = os.path.join(work, "ref"); os.makedirs(rwork)
+    rtarget = os.path.join(rwork, "bins" if mode == "b" else mode[2:])
+    sys.argv = ["porechop", "-i", inp, "-v", "0", "--threads", "1"] + (["-b", rtarget] if mode == "b" else ["-o", rtarget]) + extra
+    cwd = os.getcwd(); os.chdir(rwork)
+    try:
+        with redirect_stdout(io.StringIO()), redirect_stderr(io.StringIO()):
+            pp.main()
+        want, wexit = readgen.output_md5s(rtarget) if os.path.exists(rtarget) else {}, None
+    except SystemExit as e:
+        want, wexit = {}, str(e)
+    finally:
+        os.chdir(cwd)
+    # ---- runner
+    opts = options_from_argv(extra)
+    gtarget = os.path.join(work, "got", "bins" if mode == "b" else mode[2:])
+    os.makedirs(os.path.dirname(gtarget))
+    try:
+        runner.run(inp, barcode_dir=gtarget if mode == "b" else None, output=None if mode == "b" else gtarget,
+                   options=opts, aligner=OracleAligner(oracle, opts.scoring_scheme))
+        got, gexit = readgen.output_md5s(gtarget) if os.path.exists(gtarget) else {}, None
+    except runner.UsageError as e:
+        got, gexit = {}, str(e)
+    ok = (got == want) and (gexit == wexit)
+    bad += not ok
+    print("%s case %2d %-8s %-14s %s%s" % ("ok " if ok else "BAD", k, kind, mode, " ".join(extra), "" if ok else "\n     want %r %r\n     got  %r %r" % (wexit, want, gexit, got)), flush=True)
+shutil.rmtree(tmp, ignore_errors=True)
+print("cases=%d mismatches=%d" % (cases, bad))

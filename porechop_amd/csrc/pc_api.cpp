@@ -85,6 +85,8 @@ struct pc_ctx {
 
 namespace {
 
+int drift_period(const pc_ctx *c);
+
 int dna5(unsigned char c)
 {
     switch (c) {
@@ -176,7 +178,11 @@ int build_tiles(pc_ctx *c, const int32_t *job_adapter, const int32_t *job_adapte
         if (m <= 0 || mb <= 0) return PC_ERR_BAD_ARG;
         if (m > pcb::MAX_ADAPTER || mb > pcb::MAX_ADAPTER) return PC_ERR_ADAPTER_TOO_LONG;
         bool pad = false;
-        const int rows = pck::pick_rows(m, mb, &pad);     // 0 => generic LDS-state kernel
+        int rows = pck::pick_rows(m, mb, &pad);           // 0 => generic LDS-state kernel
+        // the register variants run in drifting coordinates: linear-gap schemes (extension made
+        // impossible, pc_bounds.h) and schemes whose gap extension is too large to drift in int16 take
+        // the generic kernel
+        if (drift_period(c) < 64) { rows = 0; pad = true; }
         const int window = std::max(c->ad_window[ad], adb >= 0 ? c->ad_window[adb] : 0);
         bool two = (mode == PC_MODE_TWO_PASS) || (mode == PC_MODE_SCORE) || (mode == PC_MODE_AUTO && max_len > 2 * window + 64);
         auto key = std::make_pair(rows * 2 + (pad ? 1 : 0), two ? 1 : 0);
@@ -234,6 +240,18 @@ int build_tiles(pc_ctx *c, const int32_t *job_adapter, const int32_t *job_adapte
 }
 
 constexpr int kMaxChunks = 64;
+
+// Columns the register variants' drifting coordinates (pc_kernels.hip, column_step) can run before
+// int16 needs a renormalisation: values drift up by eps = -gap_extend per column on top of a true
+// range of at most +-8000 (pcb::scores_supported) and (rows + 2) * eps of row offsets.  0 = the
+// scheme cannot drift (linear-gap mode replaces gap_extend by a huge value).
+int drift_period(const pc_ctx *c)
+{
+    if (pcb::is_linear(c->gap_open, c->gap_extend)) return 0;
+    const long eps = -(long)c->gap_extend;
+    const long k = (24000 - (long)(pcb::MAX_ADAPTER + 2) * eps) / eps;
+    return (int)std::max<long>(0, std::min<long>(k, 1 << 20));
+}
 
 // Column chunks of the score pass.  With enough tiles to fill the chip: 1 (no warm-up overhead).
 // Under-filled (small batches, mask-and-realign rounds): the launch's duration is the serial column
@@ -424,6 +442,7 @@ int pc_scan_device(pc_ctx *c, const void *d_arena, const int64_t *d_win_off, con
         a.match = c->match; a.mismatch = c->mismatch; a.gap_open = c->gap_open;
         a.gap_extend = linear ? pcb::kLinearExtend : c->gap_extend;
         a.init_extend = c->gap_extend; a.linear = linear ? 1 : 0;
+        a.kren = std::max(1, drift_period(c));
         a.err = c->d_err.as<uint32_t>();
         a.slab = c->d_slab.as<uint32_t>();
         a.gen_max_rows = g.gen_max_rows;

@@ -39,6 +39,7 @@ struct ScanArgs {
     int32_t match, mismatch, gap_open, gap_extend;   // gap_extend = pcb::kLinearExtend in linear mode
     int32_t init_extend;         // the scheme's real gap_extend (interior-window start state)
     int32_t linear;              // gap_open == gap_extend: no _correctTraceValue at the end cell
+    int32_t kren;                // register variants: columns between renormalisations of the drifting coordinates
     uint32_t *err;               // err[0] += 1 on any internal inconsistency (reported loudly by the host)
     uint32_t one2, two2, sixteen2;   // packed constants kept opaque to the compiler (set by the launcher)
     int32_t gen_max_rows;            // generic (LDS-state) variant: largest tile.rows in the launch

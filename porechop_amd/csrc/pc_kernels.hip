@@ -73,19 +73,28 @@ __device__ __forceinline__ u32 load_u32_unaligned(const uint8_t *p) {
 struct Best { int score, I, J, tie; };
 
 // ---------------------------------------------------------------------------------------------
-// One DP column for both halves of every lane.
-//   T[r] = M[r][j-1] + open      U[r] = H[r][j-1]          (packed lo/hi int16)
+// One DP column for both halves of every lane, in DRIFTING COORDINATES: a value X of register row
+// rho = r+1, jj columns after the window start / the last renormalisation, is held as
+// X + (rho + jj) * eps with eps = -gap_extend (T one step ahead: + (rho + jj + 1) * eps).  A gap
+// extension moves one row or one column and costs -eps, so it needs no add:
+//   H' = max(H, T_left)      V' = max(V_up, T_up)      d = (T_diag + (match - open + eps)) - z
+//   M = max(d, H', V')       T' = M + (open + eps)
+// 9 packed ops per two cells instead of 11 (plus 12 for the trace bits, which are differences of
+// values in the same coordinates and so unchanged).  Row 0 (M = 0) becomes the per-column values
+// topT = T(0,j) and topD = T(0,j-1) + (match - open + eps), advanced by eps per column by the caller.
+//   T[r] = M[r][j-1] + open      U[r] = H[r][j-1]          (packed lo/hi int16, drifted)
 //   h2   = spaced Dna5 codes of the two reads' bases at this column
 //   per-row adapter constants: spaced code vc, and the min-constant dm (D=match-mismatch for a
 //   real adapter row, `match` for a padding row above the adapter: padding rows then
 //   reproduce row 0 exactly -- M stays 0, V re-opens -- see DESIGN.md "top padding")
 //   PAD=false: both adapters fill all R rows, dm is the uniform D and vc lives in SGPRs.
 //   PAD=true : (vc, dm) come from an LDS broadcast read per row.
-// The row loop is software-pipelined by hand: the 6 ops of row r+2 that do not depend on the
-// vertical chain are issued between the 5 chain ops of row r, so dependent v_pk ops are never
+// The row loop is software-pipelined by hand: the ops of row r+2 that do not depend on the
+// vertical chain are issued between the chain ops of row r, so dependent v_pk ops are never
 // adjacent (gfx950 needs a wait state between them) and one wave alone keeps the VALU busy.
 // ---------------------------------------------------------------------------------------------
-struct KConst { u32 A2, AO2, E2, O2, NEG2, D2, ONE2, TWO2, SIXTEEN2; };
+struct KConst { u32 A2, AO2, E2, O2, NEG2, D2, ONE2, TWO2, SIXTEEN2;
+                u32 AOE2, OE2, EPS2; };      // drifting coordinates: match-open+eps, open+eps, eps
 
 // where the per-row adapter constants live
 enum ConstMode { CONST_EXACT = 0,   // no padding rows: code in SGPRs, min-constant is the uniform D
@@ -100,13 +109,13 @@ template <int R, bool PAD> struct Cfg {
 template <int R, bool PAD, bool TRACE>
 __device__ __forceinline__ void column_step(u32 (&T)[R], u32 (&U)[R], u32 h2,
                                             const u32 (&cs)[Cfg<R, PAD>::kNS], const u32 (&cv)[Cfg<R, PAD>::kNV],
-                                            const uint2 *lds_const, const KConst &k,
+                                            const uint2 *lds_const, const KConst &k, const u32 topD, const u32 topT,
                                             u32 (&trw)[(R + 3) / 4], u32 &last_tie01)
 {
     constexpr int MODE = Cfg<R, PAD>::kMode;
     constexpr int K = 2;                    // pipeline depth (rows ahead)
     u32 dd[R], Hh[R], dh[R], b0s[TRACE ? R : 1];   // only a window of K+1 entries is ever live
-    u32 dq = k.A2;                          // M[-1][j-1] + match = match
+    u32 dq = topD;                          // row 0's diagonal term (M = 0 there)
     auto ind = [&](int r) {
         u32 vc, dm;
         if constexpr (MODE == CONST_LDS) {
@@ -115,18 +124,17 @@ __device__ __forceinline__ void column_step(u32 (&T)[R], u32 (&U)[R], u32 h2,
         } else if constexpr (MODE == CONST_REGS) { vc = cv[r]; dm = cs[r]; }
         else { vc = cs[r]; dm = k.D2; }
         const u32 y = pk_sub(h2, vc);
-        const u32 Hx = pk_add(U[r], k.E2);
         const u32 z = pk_minu(y, dm);
-        const u32 Hs = pk_max(Hx, T[r]);
+        const u32 Hs = pk_max(U[r], T[r]);
         const u32 d = pk_sub(dq, z);
-        dq = pk_add(T[r], k.AO2);           // diagonal term of row r+1, from the OLD T[r]
+        dq = pk_add(T[r], k.AOE2);          // diagonal term of row r+1, from the OLD T[r]
         dd[r] = d; Hh[r] = Hs;
         dh[r] = pk_max(d, Hs);              // off the vertical chain: M = max(max(d,H), V)
-        if constexpr (TRACE) b0s[r] = pk_minu(pk_sub(Hs, Hx), k.ONE2);   // HOPEN
+        if constexpr (TRACE) b0s[r] = pk_minu(pk_sub(Hs, U[r]), k.ONE2);   // HOPEN
     };
 #pragma clang loop unroll(full)
     for (int r = 0; r < K && r < R; ++r) ind(r);
-    u32 Tup = k.O2, Vprev = k.NEG2, acc = 0;
+    u32 Tup = topT, Vprev = k.NEG2, acc = 0;
 #pragma clang loop unroll(full)
     for (int r = 0; r < R; ++r) {
         if (r + K < R) {
@@ -137,13 +145,12 @@ __device__ __forceinline__ void column_step(u32 (&T)[R], u32 (&U)[R], u32 h2,
             ind(r + K);
         }
         // the vertical chain: 3 dependent ops per row (Vs, M, T')
-        const u32 Vx = pk_add(Vprev, k.E2);
-        const u32 Vs = pk_max(Vx, Tup);
+        const u32 Vs = pk_max(Vprev, Tup);
         const u32 Mn = pk_max(dh[r], Vs);
-        const u32 Tn = pk_add(Mn, k.O2);
+        const u32 Tn = pk_add(Mn, k.OE2);
         if constexpr (TRACE) {
             const u32 g = pk_max(Hh[r], Vs);
-            const u32 b1 = pk_minu(pk_sub(Vs, Vx), k.ONE2);      // VOPEN
+            const u32 b1 = pk_minu(pk_sub(Vs, Vprev), k.ONE2);   // VOPEN
             const u32 b2 = pk_minu(pk_sub(g, Vs), k.ONE2);       // FROMH
             const u32 b3 = pk_minu(pk_sub(Mn, dd[r]), k.ONE2);   // NOTDIAG
             u32 nib = pk_madu(b3, k.TWO2, b2);
@@ -199,6 +206,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((R > 0 && R 
     KConst k;
     k.A2 = pack2(a.match); k.AO2 = pack2(a.match - a.gap_open); k.E2 = pack2(a.gap_extend);
     k.O2 = pack2(a.gap_open); k.NEG2 = pack2(pcb::NEG16); k.D2 = pack2(D);
+    // register variants run in drifting coordinates (column_step); the LDS-state generic variant --
+    // linear-gap schemes, schemes whose gap extension is too large to drift -- does not
+    const int eps = GEN ? 0 : -a.gap_extend;
+    k.AOE2 = pack2(a.match - a.gap_open + eps); k.OE2 = pack2(a.gap_open + eps); k.EPS2 = pack2(eps);
     k.ONE2 = a.one2; k.TWO2 = a.two2; k.SIXTEEN2 = a.sixteen2;   // opaque on purpose
     const u32 NEG2 = k.NEG2;
     u32 *slab = TRACE ? a.slab + (int64_t)blockIdx.x * a.slab_stride : nullptr;
@@ -298,8 +309,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((R > 0 && R 
             T[0] = 0; U[0] = 0;
         } else {
 #pragma clang loop unroll(full)
-            for (int r = 0; r < R; ++r) { T[r] = init_T(r); U[r] = NEG2; }
+            for (int r = 0; r < R; ++r) { T[r] = pk_add(init_T(r), pack2((r + 2) * eps)); U[r] = NEG2; }
         }
+        // row 0 in drifting coordinates: T(0,j) = open + (jj+1)*eps; unshift = what to take off the
+        // bottom row's T to get the true M: open + (R + jj + 1)*eps, jj = columns since (re)start
+        u32 topT = pack2(a.gap_open + eps);            // T(0,0)
+        int jj = 0;
         Best b_lo = {0, m_lo, 0, 0}, b_hi = {0, m_hi, 0, 0};
         if (chunk > 0) { b_lo.score = -32768; b_lo.J = -1; b_hi.score = -32768; b_hi.J = -1; }   // (m,0) belongs to chunk 0
 
@@ -315,7 +330,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((R > 0 && R 
         // dp_scout.h:165-179; a forced end cell just records that row)
         auto scan_row = [&](int r, int j, u32 Tn, u32 t01, bool fin_lo, bool fin_hi) {
             const int il = r - pad_lo + 1, ih = r - pad_hi + 1;
-            const int cl = lo16(Tn) - a.gap_open, ch = hi16(Tn) - a.gap_open;
+            const int off = a.gap_open + (GEN ? 0 : (r + 1 + jj + 1) * eps);      // T -> true M of this row
+            const int cl = lo16(Tn) - off, ch = hi16(Tn) - off;
             if (fin_lo && il >= 1 && (fr_lo >= 0 ? (il == fr_lo) : (cl > b_lo.score))) {
                 b_lo.score = cl; b_lo.I = il; b_lo.J = j; b_lo.tie = !(t01 & 0xFFFFu);
             }
@@ -401,6 +417,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((R > 0 && R 
                     tie01 = t01; Tlast = Tn;
                 }
             } else {
+                if (jj >= a.kren) {
+                    // shift the state back down before int16 runs out (every value moves by the same amount)
+                    const u32 DK = pack2(jj * eps);
+#pragma clang loop unroll(full)
+                    for (int r = 0; r < R; ++r) { T[r] = pk_sub(T[r], DK); U[r] = pk_sub(U[r], DK); }
+                    topT = pk_sub(topT, DK);
+                    jj = 0;
+                }
                 if (any_fin) {
                     // some pair reaches its last column: keep the previous column for the scan below
                     if (fin_lo || fin_hi) {
@@ -409,7 +433,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((R > 0 && R 
                     }
                 }
                 u32 trw[(RS + 3) / 4];
-                column_step<RS, PAD, TR>(T, U, h2, cs, cv, lds_const, k, trw, tie01);
+                const u32 topD = pk_add(topT, k.AOE2);             // T(0,j-1) + (match - open + eps)
+                topT = pk_add(topT, k.EPS2);                        // T(0,j)
+                ++jj;
+                const u32 topT_col = topT;
+                column_step<RS, PAD, TR>(T, U, h2, cs, cv, lds_const, k, topD, topT_col, trw, tie01);
                 if constexpr (TR) {
 #pragma unroll
                     for (int w = 0; w < (RS + 3) / 4; ++w) trace_dst[w * 64] = trw[w];
@@ -418,26 +446,27 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((R > 0 && R 
                 if (any_fin) {
                     // Rare, so it is a rolled re-run of the column from the saved state (same
                     // packed arithmetic) that also yields the d == max(H,V) flag of every row.
-                    u32 dq = k.A2, Tup = k.O2, Vprev = k.NEG2;
+                    u32 dq = topD, Tup = topT_col, Vprev = k.NEG2;
 #pragma unroll 1
                     for (int r = 0; r < R; ++r) {
                         const uint2 old = (fin_lo || fin_hi) ? fin[lane * RS + r] : make_uint2(0u, 0u);
                         const uint2 c = lds_const[r];
                         const u32 z = pk_minu(pk_sub(h2, c.x), c.y);
                         const u32 d = pk_sub(dq, z);
-                        const u32 Hs = pk_max(pk_add(old.y, k.E2), old.x);
-                        const u32 Vs = pk_max(pk_add(Vprev, k.E2), Tup);
+                        const u32 Hs = pk_max(old.y, old.x);
+                        const u32 Vs = pk_max(Vprev, Tup);
                         const u32 g = pk_max(Hs, Vs);
-                        const u32 Tn = pk_add(pk_max(d, g), k.O2);
+                        const u32 Tn = pk_add(pk_max(d, g), k.OE2);
                         const u32 t01 = pk_minu(d ^ g, k.ONE2);
-                        dq = pk_add(old.x, k.AO2); Tup = Tn; Vprev = Vs;
+                        dq = pk_add(old.x, k.AOE2); Tup = Tn; Vprev = Vs;
                         scan_row(r, j, Tn, t01, fin_lo, fin_hi);
                     }
                 }
             }
             // last adapter row of columns 1..n-1 (bottom register row for both halves)
             {
-                const int cl = lo16(Tlast) - a.gap_open, ch = hi16(Tlast) - a.gap_open;
+                const int off = a.gap_open + (GEN ? 0 : (rows + jj + 1) * eps);
+                const int cl = lo16(Tlast) - off, ch = hi16(Tlast) - off;
                 const bool tr_lo = j > tf_lo && (tail_lo ? j < n_lo : j <= n_lo);
                 const bool tr_hi = j > tf_hi && (tail_hi ? j < n_hi : j <= n_hi);
                 if (tr_lo && fr_lo < 0 && cl > b_lo.score) { b_lo.score = cl; b_lo.I = m_lo; b_lo.J = j; b_lo.tie = !(tie01 & 0xFFFFu); }

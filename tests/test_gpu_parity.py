@@ -112,6 +112,12 @@ def test_whole_read_two_pass_vs_oracle(pa, oracle):
     got = run_batch(pa, cases, (3, -6, -5, -2))
     bad = [(len(rd), ad, g) for (rd, ad), g in zip(cases, got) if g != oracle.adapter_alignment(rd, ad)]
     assert not bad, (len(bad), bad[:3])
+    # large gap-extension penalties: the register kernels' drifting coordinates are renormalised every
+    # few hundred columns (eps = 40 -> every ~470), or cannot drift at all (eps = 140 -> LDS-state kernel)
+    for sc in ((5, -4, -10, -40), (4, -7, -10, -140)):
+        got = run_batch(pa, cases[:120], sc)
+        bad = [(len(rd), ad, g) for (rd, ad), g in zip(cases[:120], got) if g != oracle.adapter_alignment(rd, ad, sc)]
+        assert not bad, (sc, len(bad), bad[:3])
 
 
 def test_modes_agree(pa):

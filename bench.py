@@ -212,9 +212,9 @@ def main():
             cells = pairs_per_launch * mean_trim_len * mean_m
             # VALU ceiling measured with tools/ubench_valu.hip: one wave64 packed 16-bit op per ~4.3 cycles
             # per SIMD = 39.3 T lane-ops/s; the specialised score kernel spends 5 packed-fp16 ops per 2
-            # cells (6 in its int16 variant; generic kernel: 11), so its ceiling is 39.3e12 * 2 / 5
+            # cells (6 in its int16 variant; generic kernel: 9), so its ceiling is 39.3e12 * 2 / 5
             # cell updates per second.
-            ops_per_pair = (6 if os.environ.get("PC_JIT_INT16", "0") not in ("", "0") else 5) if jit else 11
+            ops_per_pair = (6 if os.environ.get("PC_JIT_INT16", "0") not in ("", "0") else 5) if jit else 9
             valu_peak_gcups = 39.3e12 * 2 / ops_per_pair / 1e9
             roof = {"bound": "hbm",
                     "kernel": ("pc_spec_score (run-time specialised score-only whole-read scan)" if jit

@@ -2,7 +2,7 @@
 //
 // hiprtc is loaded with dlopen (no link-time dependency); if it is missing, or a compile fails,
 // pcj::get() returns null and the caller keeps using the ahead-of-time generic kernels -- still
-// the GPU, only 11 instead of 5 (fp16) / 6 (int16) packed ops per cell pair.  PC_DISABLE_JIT=1
+// the GPU, only 9 instead of 5 (fp16) / 6 (int16) packed ops per cell pair.  PC_DISABLE_JIT=1
 // forces that path.
 #include "pc_jit.h"
 

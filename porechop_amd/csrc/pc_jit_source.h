@@ -1,7 +1,7 @@
 // pc_jit_source.h -- source of the adapter-SPECIALISED score-only scan kernel, compiled at run
 // time with hiprtc for one (adapter_lo, adapter_hi, scoring scheme) (pc_jit.cpp).
 //
-// Two things make it cheaper than the generic kernels' 11 packed ops per cell pair:
+// Two things make it cheaper than the generic kernels' 9 packed ops per cell pair:
 //
 //  1. Adapter known at compile time.  The per-column substitution terms of the (few) distinct
 //     letter pairs k that occur in the adapter pair are fetched once per column from an LDS table

@@ -21,6 +21,15 @@ from tests.runner_cases import options_from_argv  # noqa: E402
 from oracle.oracle import Oracle  # noqa: E402
 from porechop_amd import runner  # noqa: E402
 
+# --emit DIR: besides comparing, keep every case's input and the reference's output md5s under DIR
+# (cases.json), so that tools/replay_fuzz.py can run the same cases on a GPU box without the reference
+emit = None
+if "--emit" in sys.argv:
+    i = sys.argv.index("--emit")
+    emit = sys.argv[i + 1]
+    del sys.argv[i:i + 2]
+    os.makedirs(emit, exist_ok=True)
+emitted = []
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 tmp = tempfile.mkdtemp(prefix="pc_fuzz_")
@@ -106,8 +115,19 @@ for k in range(cases):
         got, gexit = readgen.output_md5s(gtarget) if os.path.exists(gtarget) else {}, None
     except runner.UsageError as e:
         got, gexit = {}, str(e)
+    if emit:
+        keep = os.path.join(emit, "case%d_%s" % (k, os.path.basename(inp)))
+        if os.path.isdir(inp):
+            shutil.copytree(inp, keep)
+        else:
+            shutil.copy(inp, keep)
+        emitted.append({"input": os.path.basename(keep), "mode": mode, "argv": extra, "outputs": want, "exit": wexit})
     ok = (got == want) and (gexit == wexit)
     bad += not ok
     print("%s case %2d %-8s %-14s %s%s" % ("ok " if ok else "BAD", k, kind, mode, " ".join(extra), "" if ok else "\n     want %r %r\n     got  %r %r" % (wexit, want, gexit, got)), flush=True)
 shutil.rmtree(tmp, ignore_errors=True)
+if emit:
+    import json
+    with open(os.path.join(emit, "cases.json"), "w") as f:
+        json.dump(emitted, f)
 print("cases=%d mismatches=%d" % (cases, bad))

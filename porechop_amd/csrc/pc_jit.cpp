@@ -145,11 +145,11 @@ void compile_entry(Entry *e, const Recipe rc)
         combo_of_row[row] = k;
     }
     const int K = ((int)combos.size() + 3) / 4 * 4;
-    // Register budget: T, U and two sets of substitution terms.  Up to 2R + 2K = 120 the kernel fits
-    // 256 VGPRs (two waves per SIMD); longer adapters (full barcode sequences, 63-111 bases) get the
+    // Register budget: T, U and four sets of substitution terms (two columns in flight, two being
+    // fetched).  Up to 2R + 4K = 140 the kernel fits 256 VGPRs (two waves per SIMD); longer adapters (full barcode sequences, 63-111 bases) get the
     // whole register file of a SIMD -- one wave, the rows beyond 256 VGPRs parked in AGPRs -- which
     // is still several times faster than the generic kernel's column in LDS.
-    const int waves = (2 * R + 2 * K <= 120) ? 2 : 1;
+    const int waves = (2 * R + 4 * K <= 140) ? 2 : 1;
     e->R = R; e->K = K; e->m_lo = rc.m_lo; e->m_hi = rc.m_hi; e->f16 = rc.f16; e->waves = waves; e->kren = rc.kren;
 
     std::string init;

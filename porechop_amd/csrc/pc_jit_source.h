@@ -25,6 +25,9 @@
 //     (2R+1 ops per PC_KREN columns).  PC_KREN and C are chosen by the host so that every value
 //     ever formed is an integer fp16 (|v| <= 2048) or int16 represents exactly (pc_jit.cpp).
 //
+//  3. Two columns per wave, skewed by three rows (column2 below): two independent dependency chains
+//     interleaved instruction by instruction instead of one chain padded with wait states.
+//
 // Padding rows (shorter adapter of a pair) use a letter whose substitution score is 0, which
 // keeps M = 0 like row 0.  The kernel is score-only (pass 1 of the whole-read scan) and
 // bit-identical in outputs to scan_kernel<R, *, false>; tests run both (PC_DISABLE_JIT=1 selects
@@ -312,9 +315,140 @@ extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P
             top = topn;
             return cand;
         };
+
+        // Two columns at once, SKEWED: chain A walks column j, chain B column j+1 three rows behind,
+        // on the same T/U registers (B reads what A has just produced and overwrites it in turn).
+        // Each asm statement carries one row of A and one row of B interleaved instruction by
+        // instruction, so every dependent pair of packed ops is separated by the other chain's op:
+        // no s_nop, and the two chains give the VALU independent work (profiles/r01_ubench_row.txt:
+        // 22.4 instead of 23.75 cycles per row at two waves per SIMD).  Only for blocks in which every
+        // stream of the tile tracks the columns and none ends (the caller's fast path).
+        auto column2 = [&](const u32 (&S1)[K], const u32 (&S2)[K], u32 &c1, u32 &c2) {
+            constexpr int L = 3, KP = 2;
+            const u32 topA = pk_add(top, EPS2), topB = pk_add(topA, EPS2);     // T~(0,j), T~(0,j+1)
+            u32 dhA[R], dhB[R];
+            auto ind = [&](u32 (&dh)[R], const u32 (&S)[K], int q, u32 diag) {
+                asm volatile(PC_MAX " %[uq], %[uq], %[tq]\n\t"
+                             PC_ADD " %[dq], %[diag], %[s]"
+                             : [dq] "=&v"(dh[q]), [uq] "+v"(U[q])
+                             : [diag] "v"(diag), [s] "v"(S[COMBO[q]]), [tq] "v"(T[q]));
+            };
+#if PC_F16
+#define PC_ONE_FULL                                                                    \
+    PC_MAX " %[uq], %[uq], %[tq]\n\t"                                                  \
+    PC_MAX " %[vs], %[vp], %[tu]\n\t"                                                  \
+    PC_ADD " %[dq], %[dg], %[s]\n\t"                                                   \
+    "v_pk_maximum3_f16 %[mn], %[dr], %[ur], %[vs]\n\t" "s_nop 0\n\t"                   \
+    PC_ADD " %[tn], %[mn], %[oe]"
+#define PC_ONE_TAIL                                                                    \
+    "s_nop 0\n\t"                                                                      \
+    PC_MAX " %[vs], %[vp], %[tu]\n\t" "s_nop 0\n\t"                                    \
+    "v_pk_maximum3_f16 %[mn], %[dr], %[ur], %[vs]\n\t" "s_nop 0\n\t"                   \
+    PC_ADD " %[tn], %[mn], %[oe]"
+#define PC_PAIR_FULL                                                                   \
+    PC_MAX " %[uqa], %[uqa], %[tqa]\n\t"  PC_MAX " %[uqb], %[uqb], %[tqb]\n\t"         \
+    PC_MAX " %[vsa], %[vpa], %[tua]\n\t"  PC_MAX " %[vsb], %[vpb], %[tub]\n\t"         \
+    PC_ADD " %[dqa], %[dga], %[sa]\n\t"   PC_ADD " %[dqb], %[dgb], %[sb]\n\t"          \
+    "v_pk_maximum3_f16 %[mna], %[dra], %[ura], %[vsa]\n\t"                             \
+    "v_pk_maximum3_f16 %[mnb], %[drb], %[urb], %[vsb]\n\t"                             \
+    PC_ADD " %[tna], %[mna], %[oe]\n\t"   PC_ADD " %[tnb], %[mnb], %[oe]"
+#define PC_PAIR_ATAIL                                                                  \
+    PC_MAX " %[uqb], %[uqb], %[tqb]\n\t"                                               \
+    PC_MAX " %[vsa], %[vpa], %[tua]\n\t"  PC_MAX " %[vsb], %[vpb], %[tub]\n\t"         \
+    PC_ADD " %[dqb], %[dgb], %[sb]\n\t"                                                \
+    "v_pk_maximum3_f16 %[mna], %[dra], %[ura], %[vsa]\n\t"                             \
+    "v_pk_maximum3_f16 %[mnb], %[drb], %[urb], %[vsb]\n\t"                             \
+    PC_ADD " %[tna], %[mna], %[oe]\n\t"   PC_ADD " %[tnb], %[mnb], %[oe]"
+#else
+#define PC_ONE_FULL                                                                    \
+    PC_MAX " %[mn], %[dr], %[ur]\n\t"                                                  \
+    PC_MAX " %[uq], %[uq], %[tq]\n\t"                                                  \
+    PC_MAX " %[vs], %[vp], %[tu]\n\t"                                                  \
+    PC_ADD " %[dq], %[dg], %[s]\n\t"                                                   \
+    PC_MAX " %[mn], %[mn], %[vs]\n\t" "s_nop 0\n\t"                                    \
+    PC_ADD " %[tn], %[mn], %[oe]"
+#define PC_ONE_TAIL                                                                    \
+    PC_MAX " %[mn], %[dr], %[ur]\n\t"                                                  \
+    PC_MAX " %[vs], %[vp], %[tu]\n\t" "s_nop 0\n\t"                                    \
+    PC_MAX " %[mn], %[mn], %[vs]\n\t" "s_nop 0\n\t"                                    \
+    PC_ADD " %[tn], %[mn], %[oe]"
+#define PC_PAIR_FULL                                                                   \
+    PC_MAX " %[mna], %[dra], %[ura]\n\t"  PC_MAX " %[mnb], %[drb], %[urb]\n\t"         \
+    PC_MAX " %[uqa], %[uqa], %[tqa]\n\t"  PC_MAX " %[uqb], %[uqb], %[tqb]\n\t"         \
+    PC_MAX " %[vsa], %[vpa], %[tua]\n\t"  PC_MAX " %[vsb], %[vpb], %[tub]\n\t"         \
+    PC_ADD " %[dqa], %[dga], %[sa]\n\t"   PC_ADD " %[dqb], %[dgb], %[sb]\n\t"          \
+    PC_MAX " %[mna], %[mna], %[vsa]\n\t"  PC_MAX " %[mnb], %[mnb], %[vsb]\n\t"         \
+    PC_ADD " %[tna], %[mna], %[oe]\n\t"   PC_ADD " %[tnb], %[mnb], %[oe]"
+#define PC_PAIR_ATAIL                                                                  \
+    PC_MAX " %[mna], %[dra], %[ura]\n\t"  PC_MAX " %[mnb], %[drb], %[urb]\n\t"         \
+    PC_MAX " %[uqb], %[uqb], %[tqb]\n\t"                                               \
+    PC_MAX " %[vsa], %[vpa], %[tua]\n\t"  PC_MAX " %[vsb], %[vpb], %[tub]\n\t"         \
+    PC_ADD " %[dqb], %[dgb], %[sb]\n\t"                                                \
+    PC_MAX " %[mna], %[mna], %[vsa]\n\t"  PC_MAX " %[mnb], %[mnb], %[vsb]\n\t"         \
+    PC_ADD " %[tna], %[mna], %[oe]\n\t"   PC_ADD " %[tnb], %[mnb], %[oe]"
+#endif
+            // one row of one chain on its own (prologue of A, epilogue of B)
+            auto row_alone = [&](u32 (&dh)[R], const u32 (&S)[K], int rr, u32 &Vprev, u32 &Tup) {
+                u32 mn, vs;
+                if (rr + KP < R) {
+                    const int q = rr + KP;
+                    asm volatile(PC_ONE_FULL
+                                 : [mn] "=&v"(mn), [vs] "=&v"(vs), [uq] "+v"(U[q]), [tn] "=&v"(T[rr]), [dq] "=&v"(dh[q])
+                                 : [vp] "v"(Vprev), [tu] "v"(Tup), [oe] "s"(OE2), [dg] "v"(T[q - 1]), [tq] "v"(T[q]),
+                                   [s] "v"(S[COMBO[q]]), [dr] "v"(dh[rr]), [ur] "v"(U[rr]));
+                } else {
+                    asm volatile(PC_ONE_TAIL
+                                 : [mn] "=&v"(mn), [vs] "=&v"(vs), [tn] "=&v"(T[rr])
+                                 : [vp] "v"(Vprev), [tu] "v"(Tup), [oe] "s"(OE2), [dr] "v"(dh[rr]), [ur] "v"(U[rr]));
+                }
+                Tup = T[rr]; Vprev = vs;
+            };
+            // chain A alone for its first L rows
+#pragma clang loop unroll(full)
+            for (int q = 0; q < KP && q < R; ++q) ind(dhA, S1, q, q == 0 ? top : T[q - 1]);
+            u32 TupA = topA, VpA = NEG2;
+#pragma clang loop unroll(full)
+            for (int r = 0; r < L && r < R; ++r) row_alone(dhA, S1, r, VpA, TupA);
+            // chain B starts: its rows 0 and 1 read column j's T(0), T(1), which A has produced
+#pragma clang loop unroll(full)
+            for (int q = 0; q < KP && q < R; ++q) ind(dhB, S2, q, q == 0 ? topA : T[q - 1]);
+            u32 TupB = topB, VpB = NEG2;
+#pragma clang loop unroll(full)
+            for (int r = L; r < R; ++r) {
+                const int pb = r - L, qb = pb + KP;
+                u32 mna, mnb, vsa, vsb;
+                if (r + KP < R) {
+                    const int qa = r + KP;
+                    asm volatile(PC_PAIR_FULL
+                                 : [mna] "=&v"(mna), [mnb] "=&v"(mnb), [vsa] "=&v"(vsa), [vsb] "=&v"(vsb),
+                                   [uqa] "+v"(U[qa]), [uqb] "+v"(U[qb]), [tna] "=&v"(T[r]), [tnb] "=&v"(T[pb]),
+                                   [dqa] "=&v"(dhA[qa]), [dqb] "=&v"(dhB[qb])
+                                 : [vpa] "v"(VpA), [tua] "v"(TupA), [vpb] "v"(VpB), [tub] "v"(TupB), [oe] "s"(OE2),
+                                   [dga] "v"(T[qa - 1]), [tqa] "v"(T[qa]), [sa] "v"(S1[COMBO[qa]]), [dra] "v"(dhA[r]), [ura] "v"(U[r]),
+                                   [dgb] "v"(T[qb - 1]), [tqb] "v"(T[qb]), [sb] "v"(S2[COMBO[qb]]), [drb] "v"(dhB[pb]), [urb] "v"(U[pb]));
+                } else {
+                    asm volatile(PC_PAIR_ATAIL
+                                 : [mna] "=&v"(mna), [mnb] "=&v"(mnb), [vsa] "=&v"(vsa), [vsb] "=&v"(vsb),
+                                   [uqb] "+v"(U[qb]), [tna] "=&v"(T[r]), [tnb] "=&v"(T[pb]), [dqb] "=&v"(dhB[qb])
+                                 : [vpa] "v"(VpA), [tua] "v"(TupA), [vpb] "v"(VpB), [tub] "v"(TupB), [oe] "s"(OE2),
+                                   [dra] "v"(dhA[r]), [ura] "v"(U[r]),
+                                   [dgb] "v"(T[qb - 1]), [tqb] "v"(T[qb]), [sb] "v"(S2[COMBO[qb]]), [drb] "v"(dhB[pb]), [urb] "v"(U[pb]));
+                }
+                TupA = T[r]; VpA = vsa; TupB = T[pb]; VpB = vsb;
+            }
+            c1 = pk_sub(T[R - 1], topA);               // column j's last row, before chain B overwrites it
+#pragma clang loop unroll(full)
+            for (int pb = (R > L ? R - L : 0); pb < R; ++pb) row_alone(dhB, S2, pb, VpB, TupB);
+            c2 = pk_sub(T[R - 1], topB);
+            top = topB;
+#undef PC_ONE_FULL
+#undef PC_ONE_TAIL
+#undef PC_PAIR_FULL
+#undef PC_PAIR_ATAIL
+        };
         u32 cur_lo = load_dw(w_lo, n_lo, 0), cur_hi = one_stream ? 0u : load_dw(w_hi, n_hi, 0);
         u32 nxt_lo = load_dw(w_lo, n_lo, 4), nxt_hi = one_stream ? 0u : load_dw(w_hi, n_hi, 4);
-        u32 SA[K], SB[K];
+        u32 SA[K], SB[K], SC[K], SD[K];
         fetch_S(SA, cur_lo & 0xFF, cur_hi & 0xFF);
         int jj = 0;                                           // columns since the last renormalisation
         for (int j0 = 1; j0 <= nmax; j0 += 4) {
@@ -326,14 +460,13 @@ extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P
                 jj = 0;
             }
             if (j0 > tfmax && j0 + 3 < nmin) {
+                u32 c0, c1, c2, c3;
                 fetch_S(SB, (cur_lo >> 8) & 0xFF, (cur_hi >> 8) & 0xFF);
-                const u32 c0 = column(FastT{}, j0, SA);
-                fetch_S(SA, (cur_lo >> 16) & 0xFF, (cur_hi >> 16) & 0xFF);
-                const u32 c1 = column(FastT{}, j0 + 1, SB);
-                fetch_S(SB, cur_lo >> 24, cur_hi >> 24);
-                const u32 c2 = column(FastT{}, j0 + 2, SA);
+                fetch_S(SC, (cur_lo >> 16) & 0xFF, (cur_hi >> 16) & 0xFF);
+                fetch_S(SD, cur_lo >> 24, cur_hi >> 24);
+                column2(SA, SB, c0, c1);
                 fetch_S(SA, nxt_lo & 0xFF, nxt_hi & 0xFF);
-                const u32 c3 = column(FastT{}, j0 + 3, SB);
+                column2(SC, SD, c2, c3);
                 const u32 nb = pk_max(pk_max(best2, pk_max(c0, c1)), pk_max(c2, c3));
                 if (__any(nb != best2)) {
                     // a new maximum somewhere in the block: resolve the column, in visiting order

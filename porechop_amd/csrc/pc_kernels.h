@@ -67,7 +67,7 @@ constexpr int SCORE_OUT_INTS = 4;
 //  exact : adapter fills all R rows (no padding rows, adapter codes in SGPRs) -- the fast path
 //  padded: any adapter length <= R (top padding rows; per-row constants via LDS broadcast)
 static const int kExactRows[] = {22, 24, 28, 32};
-static const int kPaddedRows[] = {16, 20, 24, 26, 28, 30, 32, 34, 36, 38, 40, 48, 56, 64, 72, 112, 128};
+static const int kPaddedRows[] = {16, 20, 24, 26, 28, 30, 32, 34, 36, 38, 40, 48, 56, 64, 68, 72, 112, 128};
 constexpr int kMaxRows = 128;
 
 // m_lo/m_hi: adapter lengths of the two halves.  -> rows, *pad; 0 = no register variant fits: use

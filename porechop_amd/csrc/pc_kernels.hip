@@ -183,10 +183,10 @@ __device__ __forceinline__ void column_step(u32 (&T)[R], u32 (&U)[R], u32 h2,
 // ---------------------------------------------------------------------------------------------
 template <bool B> struct BoolTag { static constexpr bool value = B; };
 
-// Register budget: 3 resident waves per SIMD (<= 168 VGPRs) wherever the row count allows it --
-// the traced variants of 33..34 rows land a few registers above that without the hint.
+// Register budget: 3 resident waves per SIMD (<= 168 VGPRs) up to 34 rows, 2 (<= 256) up to 72 --
+// the traced variants of 33..34 and 68..72 rows land a few registers above that without the hint.
 template <int R, bool PAD, bool TRACE>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((R > 0 && R <= 34) ? 3 : 1))) void scan_kernel(ScanArgs a)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((R > 0 && R <= 34) ? 3 : (R > 0 && R <= 72) ? 2 : 1))) void scan_kernel(ScanArgs a)
 {
     constexpr bool GEN = (R == 0);
     constexpr int RS = GEN ? 1 : R;          // static array extent
@@ -608,7 +608,7 @@ static int launch_scan(const ScanArgs &a0, int rows, bool pad, int grid, void *s
     } else {
         switch (rows) {
             PC_PADDED(16) PC_PADDED(20) PC_PADDED(24) PC_PADDED(26) PC_PADDED(28) PC_PADDED(30) PC_PADDED(32) PC_PADDED(34)
-            PC_PADDED(36) PC_PADDED(38) PC_PADDED(40) PC_PADDED(48) PC_PADDED(56) PC_PADDED(64) PC_PADDED(72)
+            PC_PADDED(36) PC_PADDED(38) PC_PADDED(40) PC_PADDED(48) PC_PADDED(56) PC_PADDED(64) PC_PADDED(68) PC_PADDED(72)
             PC_PADDED(112) PC_PADDED(128)
             default: return -1;
         }

@@ -306,6 +306,72 @@ int grid_for(const pc_ctx *c, const Group &g, size_t ntiles, int slab_cols, size
     return (int)std::max<int64_t>(1, grid);
 }
 
+// One launch of the score pass: a run of tiles, each cut into `chunks` column chunks, writing its
+// [pair][chunk] maxima at k1_ints of the pass-1 buffer; spec = the run-time specialised kernel of
+// the run's adapter pair, or null for the generic kernel (which takes the adapter from each tile).
+struct ScoreLaunch { size_t begin, count; int chunks; size_t k1_ints; pcj::Spec *spec; };
+
+// Launch plan of a two-pass group.  Tiles of one job (= one adapter pair) are contiguous.  A job
+// with a specialised kernel and more tiles than resident waves is launched as a balanced head (a
+// multiple of the resident waves, whole windows) plus a tail whose tiles are cut into column
+// chunks: the last, partly filled round of whole tiles would idle part of the chip for a whole tile
+// (measured 5 % at 7.6 tiles per wave, 11 % at 4.05), the chunked tail fills it.  Each chunked tail
+// gets its own region of the pass-1 buffer (its [pair][chunk] indexing differs from the head's).
+std::vector<ScoreLaunch> plan_score_launches(pc_ctx *c, const Group &g, int max_len, int64_t npairs, bool linear,
+                                             int group_chunks, size_t *k1_ints_needed)
+{
+    std::vector<ScoreLaunch> out;
+    size_t k1 = (size_t)npairs * 4 * (size_t)group_chunks;
+    size_t i = 0;
+    while (i < g.tile_count) {
+        const pck::Tile &t0 = c->tiles[g.tile_begin + i];
+        size_t e = i + 1;
+        while (e < g.tile_count && c->tiles[g.tile_begin + e].adapter_lo == t0.adapter_lo &&
+               c->tiles[g.tile_begin + e].adapter_hi == t0.adapter_hi)
+            ++e;
+        // the specialised kernel for this pair, once the work seen for the pair has paid for its
+        // compile (pc_jit.cpp); until then the generic one
+        double est_cells = 0;
+        for (size_t k = i; k < e; ++k)
+            est_cells += (double)(c->tiles[g.tile_begin + k].count_lo + c->tiles[g.tile_begin + k].count_hi);
+        est_cells *= (double)max_len * (double)(g.rows ? g.rows : g.gen_max_rows);
+        pcj::Spec *sp = !linear ? pcj::get(c->device, c->adapters[t0.adapter_lo], c->adapters[t0.adapter_hi], c->match,
+                                           c->mismatch, c->gap_open, c->gap_extend, est_cells)
+                                : nullptr;
+        const size_t n = e - i;
+        if (!sp) {
+            if (!out.empty() && !out.back().spec && out.back().begin + out.back().count == i && out.back().chunks == group_chunks)
+                out.back().count += n;                       // runs of pairs without a kernel share a launch
+            else
+                out.push_back({i, n, group_chunks, 0, nullptr});
+        } else {
+            size_t head = n;
+            int tail_chunks = 1;
+            const size_t slots = (size_t)c->ncu * 4 * (size_t)sp->waves;
+            if (group_chunks == 1 && n > slots && n % slots) {
+                const size_t tail = n % slots;
+                double best = 1.0;                           // in tile-times: one more round of whole tiles
+                const double span = 0.5 * g.max_window;
+                for (int cc = 2; cc <= 8; ++cc) {
+                    if (max_len / cc < std::max(128, g.max_window / 2)) break;
+                    const double rounds = (double)((tail * (size_t)cc + slots - 1) / slots);
+                    const double cost = rounds / cc * (1.0 + cc * span / std::max(1, max_len));
+                    if (cost < best - 0.05) { best = cost; tail_chunks = cc; }
+                }
+                if (tail_chunks > 1) head = n - tail;
+            }
+            out.push_back({i, head, group_chunks, 0, sp});
+            if (head < n) {
+                out.push_back({i + head, n - head, tail_chunks, k1, sp});
+                k1 += (size_t)npairs * 4 * (size_t)tail_chunks;
+            }
+        }
+        i = e;
+    }
+    if (k1_ints_needed) *k1_ints_needed = k1;
+    return out;
+}
+
 }  // namespace
 
 extern "C" {
@@ -417,14 +483,33 @@ int pc_scan_device(pc_ctx *c, const void *d_arena, const int64_t *d_win_off, con
         slab_bytes = std::max(slab_bytes, (size_t)grid * stride * 4);
         const int chunks = g.two_pass ? chunks_for((int64_t)g.tile_count, resident_waves(c, g), max_len, g.max_window) : 1;
         max_chunks = std::max(max_chunks, chunks);
-        const int grid1 = grid_for(c, g, g.tile_count * (size_t)chunks, 1, nullptr);   // chunked score pass
+        // score pass: chunked launches, and the chunked tails of big jobs (at most 8 chunks x resident waves)
+        const int grid1 = grid_for(c, g, std::max<size_t>(g.tile_count * (size_t)chunks, (size_t)c->ncu * 64), 1, nullptr);
         fin_bytes = std::max(fin_bytes, (size_t)std::max(grid, grid1) * (size_t)std::max(1, g.rows ? g.rows : g.gen_max_rows) * 64 * 8);
         any_two |= g.two_pass;
     }
     if ((rc = c->d_slab.ensure(slab_bytes + 256)) || (rc = c->d_fin.ensure(fin_bytes + 256))) return rc;
+    // launch plans of the score pass of every two-pass group, made BEFORE anything is enqueued: they
+    // decide how large the pass-1 buffer must be, and growing it later would pull it from under
+    // kernels already in flight
+    std::vector<std::vector<ScoreLaunch>> score_plan(c->groups.size());
+    std::vector<int> group_chunks(c->groups.size(), 1);
+    size_t k1_ints = 0;
+    {
+        const bool lin = pcb::is_linear(c->gap_open, c->gap_extend);
+        for (size_t gi = 0; gi < c->groups.size(); ++gi) {
+            const Group &g = c->groups[gi];
+            if (!g.two_pass) continue;
+            group_chunks[gi] = chunks_for((int64_t)g.tile_count, resident_waves(c, g), max_len, g.max_window);
+            size_t need = 0;
+            score_plan[gi] = plan_score_launches(c, g, max_len, npairs, lin, group_chunks[gi], &need);
+            k1_ints = std::max(k1_ints, need);
+        }
+    }
+    (void)max_chunks;
     if (any_two) {
         const size_t n = (size_t)npairs;
-        if ((rc = c->d_k1.ensure(n * 16 * (size_t)max_chunks)) || (rc = c->d_woff2.ensure(n * 8)) || (rc = c->d_wlen2.ensure(n * 4)) ||
+        if ((rc = c->d_k1.ensure(k1_ints * 4 + 256)) || (rc = c->d_woff2.ensure(n * 8)) || (rc = c->d_wlen2.ensure(n * 4)) ||
             (rc = c->d_col0.ensure(n * 4)) || (rc = c->d_ntot.ensure(n * 4)) || (rc = c->d_frow.ensure(n * 4)) ||
             (rc = c->d_fscore.ensure(n * 4)))
             return rc;
@@ -468,78 +553,52 @@ int pc_scan_device(pc_ctx *c, const void *d_arena, const int64_t *d_win_off, con
             a.win_off = d_win_off; a.win_len = d_win_len;
             a.out = c->d_k1.as<int32_t>();
             a.slab = nullptr; a.slab_cols = 0; a.slab_stride = 0;
-            const int capacity = resident_waves(c, g);
-            const int chunks = chunks_for((int64_t)g.tile_count, capacity, max_len, g.max_window);
-            a.chunks = chunks;
-            a.chunk_len = (max_len + chunks - 1) / chunks;
             a.ad_span = c->d_ad_span.as<int32_t>();
-            int grid = grid_for(c, g, g.tile_count * (size_t)chunks, 1, nullptr);
-            {
-                // tiles of one job (= one adapter pair) are contiguous: a run-time specialised
-                // kernel per pair when hiprtc can provide one; runs of pairs without one share a
-                // launch of the generic kernel (which takes the adapter from each tile)
-                auto launch_generic = [&](size_t b0, size_t e0) -> int {
-                    if (e0 <= b0) return 0;
-                    int64_t sub_pairs = 0;
-                    for (size_t k = b0; k < e0; ++k) sub_pairs += c->tiles[g.tile_begin + k].count_lo + c->tiles[g.tile_begin + k].count_hi;
-                    ScopedTimer tm(c, stream, 0, sub_pairs);                // one timed region per kernel launch
+            const size_t gi = (size_t)(&g - &c->groups[0]);
+            for (const ScoreLaunch &L : score_plan[gi]) {
+                const pck::Tile &t0 = c->tiles[g.tile_begin + L.begin];
+                const int chunk_len = (max_len + L.chunks - 1) / L.chunks;
+                const int grid = grid_for(c, g, L.count * (size_t)L.chunks, 1, nullptr);
+                int64_t sub_pairs = 0;
+                for (size_t k = 0; k < L.count; ++k)
+                    sub_pairs += c->tiles[g.tile_begin + L.begin + k].count_lo + c->tiles[g.tile_begin + L.begin + k].count_hi;
+                ScopedTimer tm(c, stream, L.spec ? 3 : 0, sub_pairs);       // one timed region per kernel launch
+                if (L.spec) {
+                    pcj::SpecArgs sa;
+                    memset(&sa, 0, sizeof(sa));
+                    sa.arena = a.arena; sa.win_off = a.win_off; sa.win_len = a.win_len;
+                    sa.tiles = a.tiles + L.begin; sa.ntiles = (int32_t)L.count;
+                    sa.out = c->d_k1.as<int32_t>() + L.k1_ints; sa.fin_scratch = c->d_fin.p;
+                    sa.gap_open = c->gap_open; sa.gap_extend = c->gap_extend;
+                    sa.chunks = L.chunks; sa.chunk_len = chunk_len;
+                    sa.span = std::max(c->ad_span[t0.adapter_lo], c->ad_span[t0.adapter_hi]);
+                    sa.err = a.err;
+                    if (pcj::launch(L.spec, sa, grid, stream)) return PC_ERR_NO_DEVICE;
+                } else {
                     pck::ScanArgs b = a;
-                    b.tiles = a.tiles + b0; b.ntiles = (int32_t)(e0 - b0);
-                    return pck::launch_score(b, g.rows, g.pad, (int)std::min<size_t>((size_t)grid, (e0 - b0) * (size_t)chunks), stream);
-                };
-                size_t i = 0, run_begin = 0;
-                while (i < g.tile_count) {
-                    const pck::Tile &t0 = c->tiles[g.tile_begin + i];
-                    size_t e = i + 1;
-                    while (e < g.tile_count && c->tiles[g.tile_begin + e].adapter_lo == t0.adapter_lo &&
-                           c->tiles[g.tile_begin + e].adapter_hi == t0.adapter_hi)
-                        ++e;
-                    // the specialised kernel for this pair, once the work seen for the pair has
-                    // paid for its compile (pc_jit.cpp); until then the generic one
-                    double est_cells = 0;
-                    for (size_t k = i; k < e; ++k)
-                        est_cells += (double)(c->tiles[g.tile_begin + k].count_lo + c->tiles[g.tile_begin + k].count_hi);
-                    est_cells *= (double)max_len * (double)(g.rows ? g.rows : g.gen_max_rows);
-                    pcj::Spec *sp = !linear
-                                        ? pcj::get(c->device, c->adapters[t0.adapter_lo], c->adapters[t0.adapter_hi],
-                                                   c->match, c->mismatch, c->gap_open, c->gap_extend, est_cells)
-                                        : nullptr;
-                    if (sp) {
-                        if ((rc = launch_generic(run_begin, i))) return PC_ERR_NO_DEVICE;
-                        run_begin = e;
-                        const int sub_grid = (int)std::min<size_t>((size_t)grid, (e - i) * (size_t)chunks);
-                        int64_t sub_pairs = 0;
-                        for (size_t k = i; k < e; ++k) sub_pairs += c->tiles[g.tile_begin + k].count_lo + c->tiles[g.tile_begin + k].count_hi;
-                        ScopedTimer tm(c, stream, 3, sub_pairs);
-                        pcj::SpecArgs sa;
-                        memset(&sa, 0, sizeof(sa));
-                        sa.arena = a.arena; sa.win_off = a.win_off; sa.win_len = a.win_len;
-                        sa.tiles = a.tiles + i; sa.ntiles = (int32_t)(e - i);
-                        sa.out = a.out; sa.fin_scratch = c->d_fin.p;
-                        sa.gap_open = c->gap_open; sa.gap_extend = c->gap_extend;
-                        sa.chunks = chunks; sa.chunk_len = a.chunk_len;
-                        sa.span = std::max(c->ad_span[t0.adapter_lo], c->ad_span[t0.adapter_hi]);
-                        sa.err = a.err;
-                        if (pcj::launch(sp, sa, sub_grid, stream)) return PC_ERR_NO_DEVICE;
-                    }
-                    i = e;
+                    b.tiles = a.tiles + L.begin; b.ntiles = (int32_t)L.count;
+                    b.out = c->d_k1.as<int32_t>() + L.k1_ints;
+                    b.chunks = L.chunks; b.chunk_len = chunk_len;
+                    if ((rc = pck::launch_score(b, g.rows, g.pad, grid, stream))) return PC_ERR_NO_DEVICE;
                 }
-                if ((rc = launch_generic(run_begin, g.tile_count))) return PC_ERR_NO_DEVICE;
             }
-            // plan the bounded windows
+            // plan the bounded windows, per launch (the [pair][chunk] layout is the launch's)
             pck::PlanArgs pl;
             memset(&pl, 0, sizeof(pl));
-            pl.win_off = d_win_off; pl.win_len = d_win_len; pl.k1 = c->d_k1.as<int32_t>();
+            pl.win_off = d_win_off; pl.win_len = d_win_len;
             pl.win_off2 = c->d_woff2.as<int64_t>(); pl.win_len2 = c->d_wlen2.as<int32_t>();
             pl.col02 = c->d_col0.as<int32_t>(); pl.ntot2 = c->d_ntot.as<int32_t>();
             pl.force_row2 = c->d_frow.as<int32_t>(); pl.force_score2 = c->d_fscore.as<int32_t>();
-            pl.tiles = a.tiles; pl.ntiles = a.ntiles; pl.chunks = chunks;
             a.chunks = 1;
             pl.ad_window = c->d_ad_window.as<int32_t>();
             pl.score_out = (mode == PC_MODE_SCORE) ? d_out : nullptr;
             {
                 ScopedTimer tm(c, stream, 1, np);
-                if ((rc = pck::launch_plan(pl, stream))) return PC_ERR_NO_DEVICE;
+                for (const ScoreLaunch &L : score_plan[gi]) {
+                    pl.k1 = c->d_k1.as<int32_t>() + L.k1_ints;
+                    pl.tiles = a.tiles + L.begin; pl.ntiles = (int32_t)L.count; pl.chunks = L.chunks;
+                    if ((rc = pck::launch_plan(pl, stream))) return PC_ERR_NO_DEVICE;
+                }
             }
             if (mode == PC_MODE_SCORE) continue;      // no traceback asked for
             // pass 2: traced window ending at the max cell
@@ -549,7 +608,7 @@ int pc_scan_device(pc_ctx *c, const void *d_arena, const int64_t *d_win_off, con
             a.out = d_out;
             a.slab = c->d_slab.as<uint32_t>();
             a.slab_cols = g.max_window + 1;
-            grid = grid_for(c, g, g.tile_count, a.slab_cols, &stride);
+            const int grid = grid_for(c, g, g.tile_count, a.slab_cols, &stride);
             a.slab_stride = (int64_t)stride;
             {
                 ScopedTimer tm(c, stream, 2, np);

@@ -26,3 +26,30 @@ def test_usage_errors():
         runner.run(__file__, output="/tmp/x.fastq", barcode_dir="/tmp/y", aligner=object())
     with pytest.raises(runner.UsageError):
         runner.run(__file__, output="/tmp/x.fastq", options=runner.Options(untrimmed=True), aligner=object())
+
+
+def test_stdout_output(tmp_path):
+    """No -o and no -b: the reads go to stdout (porechop.py:706-711), written by the C++ writer through
+    the process's stdout; a '.gz' format is left alone there and, not being 'fasta', prints FASTQ."""
+    import hashlib
+    import os
+    import subprocess
+    import sys
+    from tests import readgen
+    cases = load_cases()
+    inp = readgen.build_dataset("native", str(tmp_path / "datasets"))
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import sys
+sys.path.insert(0, %r)
+from oracle.oracle import Oracle
+from tests.cpu_aligner import OracleAligner
+from porechop_amd import runner
+opts = runner.Options(format=sys.argv[2])
+runner.run(sys.argv[1], options=opts, aligner=OracleAligner(Oracle(), opts.scoring_scheme))
+''' % repo
+    for fmt, golden in (("auto", "native_default"), ("fasta", "native_to_fasta"), ("fasta.gz", "native_default")):
+        res = subprocess.run([sys.executable, "-c", code, inp, fmt], capture_output=True, timeout=600, cwd=repo)
+        assert res.returncode == 0, res.stderr[-2000:]
+        want = list(cases[golden]["outputs"].values())[0]
+        assert hashlib.md5(res.stdout).hexdigest() == want, (fmt, len(res.stdout))

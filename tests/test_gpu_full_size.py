@@ -110,10 +110,12 @@ def test_config2_end_trim_only_100k(oracle):
 
 
 def test_specialised_score_pass_equals_generic_unchunked():
-    """160 k x 8 kb reads (enough tiles that the score pass is NOT column-chunked) scanned against an
-    adapter pair, once with the run-time specialised kernel (drifting coordinates, renormalised
-    every ~1900 / ~200 columns) and once with the generic ahead-of-time kernel (PC_DISABLE_JIT=1):
-    every output record must be bit-identical.  Two schemes; each variant in a fresh process."""
+    """160 k x 8 kb reads -- 2 500 tiles, more than the 2 048 resident waves, so the specialised
+    score pass runs as a balanced head of whole windows plus a column-chunked tail -- scanned
+    against an adapter pair, once with the run-time specialised kernel (drifting coordinates,
+    renormalised every ~1900 / ~200 columns, two skewed columns per wave) and once with the generic
+    ahead-of-time kernel (PC_DISABLE_JIT=1): every output record must be bit-identical.  Two
+    schemes; each variant in a fresh process."""
     import hashlib
     import os
     import subprocess

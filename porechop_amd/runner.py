@@ -278,9 +278,11 @@ def run(input_path, output=None, barcode_dir=None, options: Options = None, devi
 
         # ---- phase A and the set-level rules ---------------------------------------------
         if R and check_idx.size:
-            # the pruned search: same matching sets and best identities (the table entries of sets
-            # below the threshold are lower bounds, and this runner displays no table)
-            bs, be = pl.phase_a(reads, torch.from_numpy(check_idx).to(dev), prune=True)
+            # the pruned search gives the same matching sets and best identities, but the table
+            # entries of the side of a set that stays below the threshold are only lower bounds; the
+            # barcode-kit choice (porechop.py:343-366) sums BOTH sides of every matching barcode set
+            # in its tie-break, so a binning run needs the exact table
+            bs, be = pl.phase_a(reads, torch.from_numpy(check_idx).to(dev), prune=barcode_dir is None)
         else:
             bs = torch.zeros(len(panel), dtype=torch.float64, device=dev)
             be = torch.zeros(len(panel), dtype=torch.float64, device=dev)

@@ -151,7 +151,7 @@ def record_reference_runs(refdir, tmp):
     return strings, calls, runs, panel
 
 
-def runner_goldens(refdir, tmp):
+def runner_goldens(refdir, tmp, only=None):
     """Whole-run goldens on the seeded synthetic inputs of tests/readgen.py: the unchanged reference
     CLI's output files (md5 of their content) for every case in readgen.RUNNER_CASES."""
     from tests import readgen
@@ -161,6 +161,8 @@ def runner_goldens(refdir, tmp):
     built = {}
     cwd = os.getcwd()
     for name, dataset, mode, extra in readgen.RUNNER_CASES:
+        if only is not None and name not in only:
+            continue
         if dataset not in built:
             built[dataset] = readgen.build_dataset(dataset, os.path.join(tmp, "datasets"))
         inp = built[dataset]
@@ -219,6 +221,16 @@ def main():
     tmp = tempfile.mkdtemp(prefix="pc_golden_")
     try:
         refdir = stage_reference(tmp)
+        if len(sys.argv) > 2 and sys.argv[1] == "--runner-cases":
+            # mint only the named whole-run cases and merge them into runner_goldens.json
+            sys.path.insert(0, refdir)
+            path = os.path.join(HERE, "runner_goldens.json")
+            with open(path) as f:
+                doc = json.load(f)
+            doc["cases"].update(runner_goldens(refdir, tmp, only=set(sys.argv[2:])))
+            with open(path, "w") as f:
+                json.dump(doc, f, indent=1, sort_keys=True)
+            return
         print("recording reference runs ...")
         strings, calls, runs, panel = record_reference_runs(refdir, tmp)
         meta = {"generator": "tests/golden/make_golden.py", "reference": "rrwick/Porechop v0.2.4 "

@@ -174,6 +174,14 @@ def build_dataset(name, root):
                 seq = s5 + body[:500] + end + start + body[500:] + e5          # junction close to both ends
             rr.append(("e%02d" % i, seq, _quals(rng, len(seq))))
         return put("edge.fastq", fastq_text(rr))
+    if name == "bc_tie":
+        # BC01 at one read's start, at the other read's end.  The two orientations tie on the
+        # or-sums; the reference decides on the and-sums, which need the EXACT below-threshold identities
+        rng = random.Random(71)
+        bc = _panel()["Barcode 1 (forward)"]["start"][1]
+        a, b = _body(rng, 900), _body(rng, 1100)
+        rr = [("tie_start", bc + a, "5" * (len(bc) + 900)), ("tie_end", b + bc, "5" * (len(bc) + 1100))]
+        return put("bc_tie.fastq", fastq_text(rr))
     if name == "albacore":
         # workspace/pass/barcodeXX/*.fastq + unclassified, as Albacore lays them out
         reads = native_reads(51, 150, barcodes=(1, 2, 3))
@@ -258,4 +266,5 @@ RUNNER_CASES = [
     ("albacore_bins", "albacore", "b", []),
     ("albacore_bins_check30", "albacore", "b", ["--check_reads", "30"]),
     ("albacore_file_out", "albacore", "o:out.fastq", []),
+    ("bc_tie_bins", "bc_tie", "b", []),
 ]

@@ -5,15 +5,21 @@ One "step" = one pass of the hot path over this rank's batch of reads, inputs al
 HBM: phase A (adapter-set presence over the check reads, 119-set panel, MAX all-reduce across
 ranks -- the only collective), phase B (end windows vs the matching sets -> trim amounts) and
 phase C (whole trimmed reads vs the matching sets' adapters, including the sequential
-mask-and-realign rounds for reads with middle hits).  Workload = BASELINE.json configs[3]
+mask-and-realign rounds for reads with middle hits).  Headline workload = BASELINE.json configs[3]
 ("1M synthetic 8 kb reads with 1% chimeras, middle scan enabled") per GPU; reads are sharded
 over ranks with no data-path collective (weak scaling).
 
-Prints ONE JSON line on rank 0 (see the contract in the task statement) with two extra objects:
+Prints ONE JSON line on rank 0 (see the contract in the task statement) with extra objects:
   roofline     -- the dominant kernel (score-only whole-read scan), timed with HIP events on its
                   launch stream inside the timed region (pc_get_timing)
   cpu_baseline -- the same phases B+C on a bounded sample of the same reads on the host cores,
                   through the compiled reference (oracle/_ref) when present, else the oracle port
+  parity       -- the per-read results of that CPU sample compared with the GPU's for the same reads
+  config.also_measured (N=1 only) -- the two other single-GPU BASELINE configs, each timed the same
+                  way with its own end-scan roofline, CPU sample and parity count:
+                  configs1 = 100 k reads, end-trim only (--no_split): phases A + B
+                  configs2 = 1 M barcoded reads, full panel, end-trim + demultiplexing:
+                             phases A + kit choice + B + barcode calls
 """
 import argparse
 import json
@@ -29,13 +35,21 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
+# VALU issue ceiling (tools/ubench_valu.hip, profiles/r02_ubench_valu.txt): one wave64 VALU instruction
+# per 4 shader cycles per SIMD (16 lanes/clk/SIMD); 1024 SIMDs at the 2.4 GHz peak clock
+VALU_WAVE_INSTR_PER_S = 1024 * 2.4e9 / 4.0
+HBM_PEAK_GBS = 8000.0
+
+
+def load_panel_json():
+    with open(os.path.join(REPO, "tests", "golden", "panel.json")) as f:
+        return json.load(f)
+
 
 def load_panel_sets():
     from porechop_amd.pipeline import AdapterSet
-    with open(os.path.join(REPO, "tests", "golden", "panel.json")) as f:
-        panel = json.load(f)
     return [AdapterSet(a["name"], tuple(a["start"]) if a["start"] else None,
-                       tuple(a["end"]) if a["end"] else None) for a in panel]
+                       tuple(a["end"]) if a["end"] else None) for a in load_panel_json()]
 
 
 def host_cores():
@@ -71,39 +85,249 @@ def one_step(pl, reads, n_check, world, proofs=False):
     return matching, st, et, hits
 
 
-def cpu_baseline(reads, pl, matching, seconds, workers):
-    """Phases B + C of the same reads, the reference's sequential per-read logic
-    (tests/ref_pipeline.py), on all host cores: one spawned worker PROCESS per core (Porechop's own
-    --threads pool is GIL-bound, README.md:355-359; processes are its fair upper bound).
-    Bounded: the sample is sized from a probe so the leg takes ~`seconds`."""
-    import multiprocessing as mp
-    from dataclasses import asdict
-    from oracle.oracle import REF_SO
-    from tests.cpu_worker import run_chunk
+def step_end_trim(pl, reads, n_check):
+    """BASELINE configs[1] (--no_split): phases A + B."""
+    bs, be = pl.phase_a(reads, torch.arange(min(n_check, reads.n), device=reads.off.device))
+    matching = pl.matching_sets(bs, be)
+    st, et = pl.phase_b(reads, matching)
+    return matching, st, et
 
-    kind = "reference" if os.path.isfile(REF_SO) else "port"
-    n_pull = min(reads.n, 16384)
+
+def step_demux(pl, reads, n_check, opts):
+    """BASELINE configs[2] (-b DIR): phase A, the barcode-kit choice (porechop.py:330-371), phase B
+    with the barcode identities, determine_barcode (nanopore_read.py:399-466) for every read."""
+    from porechop_amd import panel as rules
+    from porechop_amd.runner import _bin_names, call_barcodes
+    bs, be = pl.phase_a(reads, torch.arange(min(n_check, reads.n), device=reads.off.device))
+    matching = pl.matching_sets(bs, be)
+    bsh, beh = bs.cpu().numpy(), be.cpu().numpy()
+    index_of = {id(s): i for i, s in enumerate(pl.sets)}
+    orientation = rules.choose_barcoding_kit([pl.sets[i] for i in matching], lambda s: bsh[index_of[id(s)]],
+                                             lambda s: beh[index_of[id(s)]])
+    bc_sets = [i for i in matching if rules.is_barcode(pl.sets[i]) and rules.barcode_direction(pl.sets[i]) == orientation]
+    st, et, fulls = pl.phase_b(reads, matching, full_for=set(bc_sets))
+    names = _bin_names(pl, bc_sets)
+    col = {n: k for k, n in enumerate(names)}
+    zeros = torch.zeros(reads.n, dtype=torch.float64, device=reads.off.device)
+    s_cols, e_cols = [zeros] * len(names), [zeros] * len(names)
+    for i in bc_sets:
+        k = col[rules.barcode_name(pl.sets[i])]
+        if (i, 0) in fulls:
+            s_cols[k] = fulls[(i, 0)]
+        if (i, 1) in fulls:
+            e_cols[k] = fulls[(i, 1)]
+    calls = call_barcodes(names, torch.stack(s_cols, dim=1), torch.stack(e_cols, dim=1), opts)
+    return matching, orientation, names, st, et, calls
+
+
+def host_seqs(reads, n):
     ln = int(reads.length[0].item())
-    host = reads.arena[: n_pull * ln].cpu().numpy().tobytes().decode("ascii")
-    seqs = [host[i * ln:(i + 1) * ln] for i in range(n_pull)]
-    sets = [(s.name, s.start, s.end) for s in pl.sets]
-    params = asdict(pl.p)
-    _, t_probe = run_chunk((seqs[:4], sets, matching, params, True))
-    per_read = t_probe / 4
-    n = int(min(n_pull, max(workers * 2, seconds * workers / max(per_read, 1e-6))))
+    host = reads.arena[: n * ln].cpu().numpy().tobytes().decode("ascii")
+    return [host[i * ln:(i + 1) * ln] for i in range(n)], ln
+
+
+def cpu_sample(worker, make_args, seqs, seconds, workers, probe=4):
+    """Run `worker` (tests/cpu_worker.py) over a bounded sample of `seqs` on `workers` spawned
+    processes, sized from a probe so that the leg takes about `seconds`.
+    -> (reads done, wall seconds, per-read results in read order)."""
+    import multiprocessing as mp
+    _, t_probe, _ = worker(make_args(seqs[:probe]))
+    per_read = t_probe / probe
+    n = int(min(len(seqs), max(workers * 2, seconds * workers / max(per_read, 1e-6))))
     per = max(1, n // workers)
     chunks = [seqs[i:i + per] for i in range(0, n, per)]
     ctx = mp.get_context("spawn")
     with ctx.Pool(workers) as pool:
-        pool.map(run_chunk, [(c[:1], sets, matching, params, True) for c in chunks])   # start-up + import, untimed
+        pool.map(worker, [make_args(c[:1]) for c in chunks])     # start-up + import, untimed
         t0 = time.perf_counter()
-        res = pool.map(run_chunk, [(c, sets, matching, params, True) for c in chunks])
+        res = pool.map(worker, [make_args(c) for c in chunks])
         dt = time.perf_counter() - t0
     done = sum(r[0] for r in res)
-    return {"value": done / dt, "unit": "reads/s", "cores": workers, "kind": kind,
+    per_read_results = [x for r in res for x in r[2]]
+    return done, dt, per_read_results
+
+
+def baseline_kind():
+    from oracle.oracle import REF_SO
+    return "reference" if os.path.isfile(REF_SO) else "port"
+
+
+def kind_text(kind):
+    return ("compiled reference oracle/_ref/cpp_functions.so" if kind == "reference" else "oracle port oracle/pc_oracle.c")
+
+
+def cpu_baseline(reads, pl, matching, st, et, hits, seconds, workers):
+    """Phases B + C of the same reads, the reference's sequential per-read logic
+    (tests/ref_pipeline.py), on all host cores: one spawned worker PROCESS per core over the compiled
+    reference -- BASELINE.md's "B2" (Porechop's own --threads pool is GIL-bound, README.md:355-359;
+    processes are its fair upper bound).  The sample's results are compared with the GPU's."""
+    from dataclasses import asdict
+    from tests.cpu_worker import run_chunk
+    kind = baseline_kind()
+    seqs, ln = host_seqs(reads, min(reads.n, 16384))
+    sets = [(s.name, s.start, s.end) for s in pl.sets]
+    params = asdict(pl.p)
+    done, dt, res = cpu_sample(run_chunk, lambda c: (c, sets, matching, params, True), seqs, seconds, workers)
+    got = {}
+    for r, a, s, e in zip(hits.read.cpu().tolist(), hits.adapter.cpu().tolist(), hits.start.cpu().tolist(), hits.end.cpu().tolist()):
+        if r < done:
+            got.setdefault(r, []).append((a, s, e))
+    stl, etl = st[:done].cpu().tolist(), et[:done].cpu().tolist()
+    bad = [r for r in range(done) if (stl[r], etl[r], got.get(r, [])) != (res[r][0], res[r][1], list(res[r][2]))]
+    base = {"value": done / dt, "unit": "reads/s", "cores": workers, "kind": kind,
+            "label": "%s, process pool (BASELINE.md B2: fair upper bound of the reference's --threads CLI)" % kind_text(kind),
             "sample": "%d of the benchmark's reads (%d bp each), phases B+C, %d worker processes over the %s, %.1f s wall"
-                      % (done, ln, workers, "compiled reference oracle/_ref/cpp_functions.so" if kind == "reference"
-                         else "oracle port oracle/pc_oracle.c", dt)}
+                      % (done, ln, workers, kind_text(kind), dt)}
+    parity = {"checked": done, "mismatches": len(bad), "what": "start trim, end trim, middle hits (adapter, start, end) per read",
+              "first_mismatching_reads": bad[:8]}
+    return base, parity
+
+
+def trace_roofline(timing, n_windows, pairs, cells, steps, ops_per_2_cells):
+    """Roofline object of the traced end-window kernel from the library's per-launch HIP-event timing.
+    Algorithmic bytes: every end window (150 B) in once, 28 B out per (window, adapter)."""
+    ms, launches, tpairs = timing["trace"]
+    if launches <= 0:
+        return None
+    per_launch_s = ms / 1e3 / launches
+    alg_total = (n_windows * 150.0 + 28.0 * pairs) * steps
+    achieved = alg_total / launches / per_launch_s / 1e9
+    gcups = cells * steps / (ms / 1e3) / 1e9
+    peak_gcups = VALU_WAVE_INSTR_PER_S * 64 * 2 / ops_per_2_cells / 1e9
+    return {"bound": "valu", "kernel": "traced end-window scan (trace bits + on-device traceback/digest)",
+            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "launches": int(launches), "avg_launch_ms": per_launch_s * 1e3,
+            "algorithmic_bytes_per_launch": alg_total / launches,
+            "valu": {"achieved_gcups": gcups, "peak_gcups": peak_gcups, "frac": gcups / peak_gcups,
+                     "ops_per_2_cells": ops_per_2_cells},
+            "note": "HBM fraction on ALGORITHMIC bytes (2*150 + 28*2P per read); the kernel is VALU-bound (>= 20 cells per "
+                    "algorithmic byte) and its 4-bit/cell trace slab is implementation traffic (profiles/, DESIGN.md section 4)"}
+
+
+def timed(fn, steps, warmup, sync):
+    for _ in range(warmup):
+        out = fn()
+        sync()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = fn()
+    sync()
+    return out, time.perf_counter() - t0
+
+
+def leg_configs1(dev, args, workers):
+    """BASELINE configs[1]: 100 k synthetic 8 kb reads, SQK-LSK109-style ligation adapters, end-trim only."""
+    from dataclasses import asdict
+    from porechop_amd.pipeline import Pipeline, ScanParams
+    from porechop_amd.synth import make_reads
+    from tests.cpu_worker import run_chunk
+    p = ScanParams()
+    pl = Pipeline(load_panel_sets(), p, device=dev)
+    n = args.reads1
+    reads = make_reads(n, args.read_len, seed=1, start_frac=0.9, end_frac=0.5, chimera_frac=0.0, device=dev)
+
+    def sync():
+        pl.aligner.sync()
+        torch.cuda.synchronize()
+    timed(lambda: step_end_trim(pl, reads, p.check_reads), 0, max(1, args.warmup), sync)
+    pl.aligner.set_timing(True)
+    pl.aligner.get_timing()
+    (matching, st, et), dt = timed(lambda: step_end_trim(pl, reads, p.check_reads), args.steps, 0, sync)
+    timing = pl.aligner.get_timing()
+    pl.aligner.set_timing(False)
+    out = {"workload": "BASELINE configs[1]: %d synthetic %d-bp reads, end-trim only (--no_split): phases A (119-set panel, "
+                       "%d check reads) + B" % (n, args.read_len, p.check_reads),
+           "reads_per_s": n * args.steps / dt, "ms_per_step": dt / args.steps * 1e3,
+           "matching_sets": [pl.sets[i].name for i in matching],
+           "kernel_ms_per_step": {k: v[0] / args.steps for k, v in timing.items()}}
+    # phase B alone (the end-scan kernel of north_star): its own roofline
+    pl.aligner.set_timing(True)
+    pl.aligner.get_timing()
+    _, dtb = timed(lambda: pl.phase_b(reads, matching), args.steps, 0, sync)
+    tb = pl.aligner.get_timing()
+    pl.aligner.set_timing(False)
+    ads = [(pl.sets[i].start, pl.sets[i].end) for i in matching]
+    pairs = n * sum((s is not None) + (e is not None) for s, e in ads)
+    cells = n * 150 * sum((len(s[1]) if s else 0) + (len(e[1]) if e else 0) for s, e in ads)
+    out["phase_b"] = {"reads_per_s": n * args.steps / dtb, "ms_per_step": dtb / args.steps * 1e3, "pairs_per_read": pairs / n}
+    out["roofline"] = trace_roofline(tb, 2 * n, pairs, cells, args.steps, pl.aligner.trace_ops_per_2_cells())
+    if args.cpu_seconds > 0:
+        seqs, ln = host_seqs(reads, min(n, 16384))
+        sets = [(s.name, s.start, s.end) for s in pl.sets]
+        done, dtc, res = cpu_sample(run_chunk, lambda c: (c, sets, matching, asdict(p), True, False), seqs,
+                                    min(args.cpu_seconds, 4.0), workers, probe=64)
+        stl, etl = st[:done].cpu().tolist(), et[:done].cpu().tolist()
+        bad = [r for r in range(done) if (stl[r], etl[r]) != (res[r][0], res[r][1])]
+        out["cpu_baseline"] = {"value": done / dtc, "unit": "reads/s", "cores": workers, "kind": baseline_kind(),
+                               "sample": "%d reads, phase B, %d worker processes, %.2f s wall" % (done, workers, dtc)}
+        out["parity"] = {"checked": done, "mismatches": len(bad), "what": "start trim, end trim per read"}
+        out["speedup_vs_cpu_baseline"] = out["phase_b"]["reads_per_s"] / out["cpu_baseline"]["value"]
+    pl.close()
+    return out
+
+
+def leg_configs2(dev, args, workers):
+    """BASELINE configs[2]: 1 M synthetic 8 kb barcoded reads, full panel incl. the 96 barcodes, end-trim + demux."""
+    from dataclasses import asdict
+    from porechop_amd.pipeline import Pipeline, ScanParams
+    from porechop_amd.runner import Options
+    from porechop_amd.synth import make_reads
+    from tests.cpu_worker import run_chunk_barcodes
+    p = ScanParams()
+    opts = Options()
+    pl = Pipeline(load_panel_sets(), p, device=dev)
+    n = args.reads2
+    fw = [a for a in load_panel_json() if a["name"].startswith("Barcode ") and "(forward)" in a["name"]]
+    reads = make_reads(n, args.read_len, seed=2, start_frac=0.9, end_frac=0.5, chimera_frac=0.0, device=dev,
+                       barcodes_start=[a["start"][1] for a in fw], barcodes_end=[a["end"][1] for a in fw])
+
+    def sync():
+        pl.aligner.sync()
+        torch.cuda.synchronize()
+    timed(lambda: step_demux(pl, reads, p.check_reads, opts), 0, max(1, min(args.warmup, 2)), sync)
+    pl.aligner.set_timing(True)
+    pl.aligner.get_timing()
+    steps = max(1, min(args.steps, 10))
+    (matching, orientation, names, st, et, calls), dt = timed(lambda: step_demux(pl, reads, p.check_reads, opts), steps, 0, sync)
+    timing = pl.aligner.get_timing()
+    pl.aligner.set_timing(False)
+    ads = [(pl.sets[i].start, pl.sets[i].end) for i in matching]
+    pairs = n * sum((s is not None) + (e is not None) for s, e in ads)
+    cells = n * 150 * sum((len(s[1]) if s else 0) + (len(e[1]) if e else 0) for s, e in ads)
+    # phase A's launches are in the timing too: its pairs/cells (check reads x whole panel)
+    nchk = min(p.check_reads, n)
+    pa = [(s.start, s.end) for s in pl.sets if "(full sequence)" not in s.name]
+    pairs_a = nchk * sum((s is not None) + (e is not None) for s, e in pa)
+    cells_a = nchk * 150 * sum((len(s[1]) if s else 0) + (len(e[1]) if e else 0) for s, e in pa)
+    truth = reads.truth_barcode.cpu().numpy()
+    want = np.array([names.index("BC%02d" % (b + 1)) if "BC%02d" % (b + 1) in names else -2 for b in range(len(fw))])[truth]
+    out = {"workload": "BASELINE configs[2]: %d synthetic %d-bp reads, each with barcode b ~ U{1..96} (BCb after the start "
+                       "adapter, BCb_rev before the end adapter), full 119-set panel, end-trim + demultiplexing: phases A + "
+                       "kit choice + B (%d pairs per read) + barcode calls" % (n, args.read_len, pairs // n),
+           "reads_per_s": n * steps / dt, "ms_per_step": dt / steps * 1e3, "steps": steps,
+           "matching_sets": len(matching), "matching_barcode_sets": sum(1 for i in matching if pl.sets[i].name.startswith("Barcode ")),
+           "barcode_orientation": orientation, "pairs_per_read": pairs / n,
+           "reads_binned_to_their_planted_barcode": float((calls == want).mean()), "reads_unassigned": float((calls < 0).mean()),
+           "kernel_ms_per_step": {k: v[0] / steps for k, v in timing.items()},
+           "roofline": trace_roofline(timing, 2 * n + 2 * nchk, pairs + pairs_a, cells + cells_a, steps,
+                                      pl.aligner.trace_ops_per_2_cells())}
+    if args.cpu_seconds > 0:
+        seqs, ln = host_seqs(reads, min(n, 4096))
+        sets = [(s.name, s.start, s.end) for s in pl.sets]
+        mk = lambda c: (c, sets, matching, asdict(p), True, orientation, opts.barcode_threshold, opts.barcode_diff,
+                        opts.require_two_barcodes)
+        done, dtc, res = cpu_sample(run_chunk_barcodes, mk, seqs, min(args.cpu_seconds, 6.0), workers, probe=4)
+        stl, etl = st[:done].cpu().tolist(), et[:done].cpu().tolist()
+        cl = [names[k] if k >= 0 else "none" for k in calls[:done]]
+        bad = [r for r in range(done) if (stl[r], etl[r], cl[r]) != tuple(res[r])]
+        out["cpu_baseline"] = {"value": done / dtc, "unit": "reads/s", "cores": workers, "kind": baseline_kind(),
+                               "sample": "%d reads, phase B + barcode call, %d worker processes, %.2f s wall" % (done, workers, dtc)}
+        out["parity"] = {"checked": done, "mismatches": len(bad), "what": "start trim, end trim, barcode call per read",
+                         "first_mismatching_reads": bad[:8]}
+        out["speedup_vs_cpu_baseline"] = out["reads_per_s"] / out["cpu_baseline"]["value"]
+    pl.close()
+    return out
 
 
 def main():
@@ -111,10 +335,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--reads", type=int, default=1_000_000, help="reads per GPU")
+    ap.add_argument("--reads", type=int, default=1_000_000, help="reads per GPU (headline, configs[3])")
+    ap.add_argument("--reads1", type=int, default=100_000, help="reads of the configs[1] leg")
+    ap.add_argument("--reads2", type=int, default=1_000_000, help="reads of the configs[2] leg")
     ap.add_argument("--read-len", type=int, default=8000)
     ap.add_argument("--chimera", type=float, default=0.01)
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="0 disables the CPU baseline leg")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="0 disables the CPU baseline / parity legs")
+    ap.add_argument("--no-extra", action="store_true", help="headline only (skip the configs[1] / configs[2] legs)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -130,6 +357,9 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
         else:
             dist.init_process_group(backend)
+    if args.gpus != world and rank == 0:
+        print("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run --nproc-per-node %d)"
+              % (args.gpus, world, args.gpus), file=sys.stderr)
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
 
@@ -165,10 +395,12 @@ def main():
     timing = pl.aligner.get_timing()
     pl.aligner.set_timing(False)
 
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    tall = torch.zeros(world, dtype=torch.float64, device=dev)
+    tall[rank] = dt
     if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
+        dist.all_reduce(tall, op=dist.ReduceOp.SUM)
+    rank_s = [float(x) for x in tall.cpu()]
+    dt = max(rank_s)                                    # MAX over ranks
 
     # ---- AFTER the headline measurement: the same steps with the two optional exact prunings
     # (score bound for the identity thresholds: fewer tracebacks, identical sets / trims / hits).
@@ -177,7 +409,8 @@ def main():
     pl.aligner.sync()
     barrier()
     t1 = time.perf_counter()
-    for _ in range(args.steps):
+    psteps = max(1, min(args.steps, 5))
+    for _ in range(psteps):
         _, _, _, hits_p = one_step(pl, reads, n_check, world, proofs=True)
     pl.aligner.sync()
     barrier()
@@ -210,24 +443,25 @@ def main():
             achieved = alg_bytes / per_launch_s / 1e9
             mean_m = float(np.mean([len(a[1]) for a in pl.middle_adapter_list(matching)]))
             cells = pairs_per_launch * mean_trim_len * mean_m
-            # VALU ceiling measured with tools/ubench_valu.hip: one wave64 packed 16-bit op per ~4.3 cycles
-            # per SIMD = 39.3 T lane-ops/s; the specialised score kernel spends 5 packed-fp16 ops per 2
-            # cells (6 in its int16 variant; generic kernel: 9), so its ceiling is 39.3e12 * 2 / 5
-            # cell updates per second.
+            # the specialised score kernel spends 5 packed-fp16 ops per 2 cells (6 in its int16
+            # variant; generic kernel: 9)
             ops_per_pair = (6 if os.environ.get("PC_JIT_INT16", "0") not in ("", "0") else 5) if jit else 9
-            valu_peak_gcups = 39.3e12 * 2 / ops_per_pair / 1e9
-            roof = {"bound": "hbm",
+            valu_peak_gcups = VALU_WAVE_INSTR_PER_S * 64 * 2 / ops_per_pair / 1e9
+            roof = {"bound": "valu",
                     "kernel": ("pc_spec_score (run-time specialised score-only whole-read scan)" if jit
                                else "scan_kernel<R,PAD,false> (generic score-only whole-read scan)"),
-                    "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+                    "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                     "traffic": None, "launches": int(launches), "avg_launch_ms": per_launch_s * 1e3,
                     "algorithmic_bytes_per_launch": alg_bytes,
                     "gcups": cells / per_launch_s / 1e9,
                     "valu": {"achieved_gcups": cells / per_launch_s / 1e9, "peak_gcups": valu_peak_gcups,
-                             "frac": cells / per_launch_s / 1e9 / valu_peak_gcups, "ops_per_2_cells": ops_per_pair},
-                    "note": "integer max-plus DP, >= 50 cells per algorithmic byte: VALU-bound by construction; "
-                            "the launch average includes the small mask-and-realign launches of the same kernel "
-                            "(DESIGN.md section 4)"}
+                             "frac": cells / per_launch_s / 1e9 / valu_peak_gcups, "ops_per_2_cells": ops_per_pair,
+                             "peak_source": "one wave64 VALU instruction per 4 cycles per SIMD x 1024 SIMDs x 2.4 GHz "
+                                            "(tools/ubench_valu.hip, profiles/r02_ubench_valu.txt)"},
+                    "note": "achieved/peak/frac are the HBM roofline on ALGORITHMIC bytes as the contract asks; the kernel is "
+                            "integer max-plus DP with >= 50 cells per algorithmic byte, i.e. VALU-bound by construction "
+                            "(bound: valu) and cannot approach the HBM roofline; the launch average includes the small "
+                            "mask-and-realign launches of the same kernel (DESIGN.md section 4)"}
             # HBM-side traffic of that kernel comes from the separately collected rocprofv3 --pmc passes
             # of this same command (tools/profile_round.sh -> profiles/<round>_summary.json): FETCH_SIZE +
             # WRITE_SIZE of one launch, KB as reported.  (The guide's x2 correction is for wide 16-B/lane
@@ -256,11 +490,14 @@ def main():
                                    "phases A (119-set panel, %d check reads) + B + C (middle scan on)"
                                    % (args.reads, args.read_len, args.chimera * 100, params.check_reads),
                        "reads_per_gpu": args.reads, "read_len": args.read_len, "parallelism": "reads sharded x%d" % world,
+                       "world_size": dist.get_world_size() if world > 1 else 1,
+                       "backend": (dist.get_backend() if world > 1 else "none (single process)"),
+                       "ms_per_step_by_rank": [s / args.steps * 1e3 for s in rank_s],
                        "matching_sets": [pl.sets[i].name for i in matching],
                        "middle_hits_per_step": int(hits.read.numel()), "mask_rounds": hits.rounds,
                        "kernel_ms_per_step": kern_ms,
-                       "optional_exact_pruning": {"reads_per_s": total_reads * args.steps / dt_proofs,
-                                                  "ms_per_step": dt_proofs / args.steps * 1e3, "same_middle_hits": same_hits,
+                       "optional_exact_pruning": {"reads_per_s": total_reads * psteps / dt_proofs,
+                                                  "ms_per_step": dt_proofs / psteps * 1e3, "same_middle_hits": same_hits,
                                                   "note": "not the headline: phase A and the middle scan trace back only "
                                                           "pairs whose score can still reach the identity threshold "
                                                           "(DESIGN.md section 7)"}},
@@ -268,13 +505,25 @@ def main():
         }
         if args.cpu_seconds > 0 and world == 1:
             try:
-                out["cpu_baseline"] = cpu_baseline(reads, pl, matching, args.cpu_seconds, host_cores())
+                out["cpu_baseline"], out["parity"] = cpu_baseline(reads, pl, matching, st, et, hits, args.cpu_seconds, host_cores())
                 out["config"]["speedup_vs_cpu_baseline"] = reads_per_s / out["cpu_baseline"]["value"]
             except Exception as e:   # the baseline leg must never break the bench line
                 out["cpu_baseline"] = {"value": None, "unit": "reads/s", "cores": 0, "kind": "port",
                                        "sample": "failed: %r" % (e,)}
-        print(json.dumps(out))
     pl.close()
+    del reads, pl
+    torch.cuda.empty_cache()
+    if rank == 0:
+        if world == 1 and not args.no_extra:
+            also = {}
+            for name, leg in (("configs1", leg_configs1), ("configs2", leg_configs2)):
+                try:
+                    also[name] = leg(dev, args, host_cores())
+                except Exception as e:   # an extra leg must never break the bench line
+                    also[name] = {"failed": repr(e)}
+                torch.cuda.empty_cache()
+            out["config"]["also_measured"] = also
+        print(json.dumps(out))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

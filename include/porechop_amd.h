@@ -124,6 +124,31 @@ int pc_sync(pc_ctx *ctx, void *stream);
 int pc_set_timing(pc_ctx *ctx, int enabled);
 int pc_get_timing(pc_ctx *ctx, void *stream, double *ms, int64_t *launches, int64_t *pairs);
 
+/* Per-read reduction of end-window records on the device -- what porechop/nanopore_read.py:166-208
+ * (find_start_trim / find_end_trim) and :399-466 (determine_barcode, without the Albacore rule) do per
+ * read, for a whole batch.  d_records: the records pc_scan_device wrote for njobs jobs over the SAME n
+ * reads; job j = one adapter sequence against every read's start (job_side[j] = 0) or end (1) window,
+ * its record for read r at d_records[(job_record_offset[j] + r) * PC_RESULT_INTS].  Writes
+ * d_start_trim[n] / d_end_trim[n]: the largest trim any alignment justifies (aligned identity >
+ * end_threshold, not touching the window's inner edge, at least min_trim_size bases; + extra_end_trim).
+ * nbins > 0 additionally calls barcodes: bin k's start / end entry is job bin_start_job[k] /
+ * bin_end_job[k] (-1 = none, scores 0.0) and d_call[r] becomes the bin index or -1 ('none') by the
+ * reference's rules, ties resolved like Python's stable sort (earlier entry wins; start entries
+ * before end entries).  Identities are the %f-rounded doubles Python parses.  Host arrays are copied
+ * before the call returns; asynchronous on `stream`. */
+int pc_phase_b_reduce(pc_ctx *ctx, const int32_t *d_records, int64_t n, int njobs,
+                      const int64_t *job_record_offset, const int32_t *job_side, int end_size,
+                      int min_trim_size, int extra_end_trim, double end_threshold,
+                      int32_t *d_start_trim, int32_t *d_end_trim, int nbins,
+                      const int32_t *bin_start_job, const int32_t *bin_end_job,
+                      double barcode_threshold, double barcode_diff, int require_two_barcodes,
+                      int32_t *d_call, void *stream);
+
+/* Packed VALU operations per TWO DP cells, times 100, of the traced end-window kernel this context's
+ * scoring scheme selects (2100: packed-int16 kernel; 1325: packed-fp16 kernel) -- the denominator
+ * of the VALU roofline bench.py reports. */
+int pc_trace_ops_x100(pc_ctx *ctx);
+
 /* Run-time specialised score kernels are compiled (hiprtc) once an adapter pair's accumulated work
  * pays for it.  By default the compile happens in place, inside the pc_scan_device call that
  * crosses the threshold; with pc_jit_async(1) it runs on a worker thread and launches keep using

@@ -135,6 +135,10 @@ class Aligner:
         check(self.lib.pc_get_timing(self._ctx, ctypes.c_void_p(s), ms, ln, pr), "pc_get_timing")
         return {k: (ms[i], ln[i], pr[i]) for i, k in enumerate(("score", "plan", "trace", "score_spec"))}
 
+    def trace_ops_per_2_cells(self):
+        """Packed VALU ops the traced end-window kernel spends per two DP cells (roofline reporting)."""
+        return self.lib.pc_trace_ops_x100(self._ctx) / 100.0
+
     def sync(self, stream=None):
         import torch
         s = stream if stream is not None else torch.cuda.current_stream().cuda_stream

@@ -69,6 +69,10 @@ struct pc_ctx {
     DevBuf d_tiles, d_slab, d_fin, d_k1, d_woff2, d_wlen2, d_col0, d_ntot, d_frow, d_fscore, d_err;
     // host-API staging
     DevBuf d_arena, d_woff, d_wlen, d_out;
+    // pc_phase_b_reduce: job / bin tables (host copies stay alive until the next call's upload)
+    DevBuf d_red;
+    std::vector<int64_t> red_off;
+    std::vector<int32_t> red_tab;
     // cached job table (bench loops repeat the same one: skip the re-upload)
     std::vector<pck::Tile> tiles;
     std::vector<Group> groups;
@@ -306,6 +310,37 @@ int grid_for(const pc_ctx *c, const Group &g, size_t ntiles, int slab_cols, size
     return (int)std::max<int64_t>(1, grid);
 }
 
+// The traced scan runs in packed fp16 (pc_kernels.hip trace16_kernel, 13.25 instead of 21 packed ops per
+// two cells) whenever the scheme's values stay exact there for the columns of this launch
+// (pc_bounds.h f16_plan); otherwise -- linear-gap schemes, very large scores, adapters above 72 rows,
+// the LDS-state generic kernel -- in packed int16.  PC_DISABLE_F16=1 forces the int16 kernels.
+bool f16_disabled()
+{
+    static const bool off = [] { const char *e = getenv("PC_DISABLE_F16"); return e && *e && *e != '0'; }();
+    return off;
+}
+
+bool trace16_plan(const pc_ctx *c, int rows, int cols, pcb::F16Plan *out)
+{
+    if (f16_disabled() || rows <= 0 || !pck::trace16_has(rows)) return false;
+    const pcb::F16Plan p = pcb::f16_plan(c->match, c->mismatch, c->gap_open, c->gap_extend, rows);
+    if (!p.ok || cols > p.max_cols) return false;
+    *out = p;
+    return true;
+}
+
+int launch_traced(const pc_ctx *c, pck::ScanArgs &a, const Group &g, int grid, hipStream_t stream)
+{
+    pcb::F16Plan fp;
+    if (trace16_plan(c, g.rows, a.slab_cols, &fp)) {
+        a.f16_cen = fp.cen; a.f16_max_cols = fp.max_cols;
+        static const int dbg = [] { const char *e = getenv("PC_DEBUG_TRACE"); return e ? atoi(e) : 0; }();
+        a.debug = dbg;
+        return pck::launch_trace16(a, g.rows, grid, stream);
+    }
+    return pck::launch_trace(a, g.rows, g.pad, grid, stream);
+}
+
 // One launch of the score pass: a run of tiles, each cut into `chunks` column chunks, writing its
 // [pair][chunk] maxima at k1_ints of the pass-1 buffer; spec = the run-time specialised kernel of
 // the run's adapter pair, or null for the generic kernel (which takes the adapter from each tile).
@@ -347,7 +382,7 @@ std::vector<ScoreLaunch> plan_score_launches(pc_ctx *c, const Group &g, int max_
         } else {
             size_t head = n;
             int tail_chunks = 1;
-            const size_t slots = (size_t)c->ncu * 4 * (size_t)sp->waves;
+            const size_t slots = (size_t)c->ncu * (size_t)sp->blocks_per_cu;
             if (group_chunks == 1 && n > slots && n % slots) {
                 const size_t tail = n % slots;
                 double best = 1.0;                           // in tile-times: one more round of whole tiles
@@ -425,7 +460,7 @@ void pc_destroy(pc_ctx *c)
     (void)hipStreamSynchronize(c->stream);
     DevBuf *bufs[] = {&c->d_ad_codes, &c->d_ad_len, &c->d_ad_window, &c->d_ad_span, &c->d_tiles, &c->d_slab, &c->d_fin, &c->d_k1, &c->d_woff2,
                       &c->d_wlen2, &c->d_col0, &c->d_ntot, &c->d_frow, &c->d_fscore, &c->d_err, &c->d_arena,
-                      &c->d_woff, &c->d_wlen, &c->d_out};
+                      &c->d_woff, &c->d_wlen, &c->d_out, &c->d_red};
     for (DevBuf *b : bufs) b->release();
     (void)hipStreamDestroy(c->stream);
     delete c;
@@ -545,7 +580,7 @@ int pc_scan_device(pc_ctx *c, const void *d_arena, const int64_t *d_win_off, con
             int64_t np = 0;
             for (size_t i = 0; i < g.tile_count; ++i) np += c->tiles[g.tile_begin + i].count_lo + c->tiles[g.tile_begin + i].count_hi;
             ScopedTimer tm(c, stream, 2, np);
-            if ((rc = pck::launch_trace(a, g.rows, g.pad, grid, stream))) return PC_ERR_NO_DEVICE;
+            if ((rc = launch_traced(c, a, g, grid, stream))) return PC_ERR_NO_DEVICE;
         } else {
             int64_t np = 0;
             for (size_t i = 0; i < g.tile_count; ++i) np += c->tiles[g.tile_begin + i].count_lo + c->tiles[g.tile_begin + i].count_hi;
@@ -612,11 +647,58 @@ int pc_scan_device(pc_ctx *c, const void *d_arena, const int64_t *d_win_off, con
             a.slab_stride = (int64_t)stride;
             {
                 ScopedTimer tm(c, stream, 2, np);
-                if ((rc = pck::launch_trace(a, g.rows, g.pad, grid, stream))) return PC_ERR_NO_DEVICE;
+                if ((rc = launch_traced(c, a, g, grid, stream))) return PC_ERR_NO_DEVICE;
             }
         }
     }
     return PC_OK;
+}
+
+int pc_trace_ops_x100(pc_ctx *c)
+{
+    if (!c) return 2100;
+    pcb::F16Plan fp;
+    // the end-window shape: the ligation adapters' row class, 150 columns
+    return trace16_plan(c, 28, 150, &fp) ? 1325 : 2100;
+}
+
+int pc_phase_b_reduce(pc_ctx *c, const int32_t *d_records, int64_t n, int njobs, const int64_t *job_record_offset,
+                      const int32_t *job_side, int end_size, int min_trim_size, int extra_end_trim, double end_threshold,
+                      int32_t *d_start_trim, int32_t *d_end_trim, int nbins, const int32_t *bin_start_job,
+                      const int32_t *bin_end_job, double barcode_threshold, double barcode_diff, int require_two,
+                      int32_t *d_call, void *stream_v)
+{
+    if (!c || n < 0 || njobs < 0 || nbins < 0) return PC_ERR_BAD_ARG;
+    if (n == 0) return PC_OK;
+    if (!d_start_trim || !d_end_trim || (njobs > 0 && (!d_records || !job_record_offset || !job_side))) return PC_ERR_BAD_ARG;
+    if (nbins > 0 && (!bin_start_job || !bin_end_job || !d_call)) return PC_ERR_BAD_ARG;
+    for (int k = 0; k < nbins; ++k)
+        if (bin_start_job[k] >= njobs || bin_end_job[k] >= njobs) return PC_ERR_BAD_ARG;
+    (void)hipSetDevice(c->device);
+    hipStream_t stream = (stream_v == PC_STREAM_CONTEXT) ? c->stream : (hipStream_t)stream_v;
+    // the previous call's tables may still be read by its kernel
+    HIP_TRY(hipStreamSynchronize(stream));
+    c->red_off.assign(job_record_offset, job_record_offset + njobs);
+    c->red_tab.assign(job_side, job_side + njobs);
+    c->red_tab.insert(c->red_tab.end(), bin_start_job, bin_start_job + nbins);
+    c->red_tab.insert(c->red_tab.end(), bin_end_job, bin_end_job + nbins);
+    const size_t off_bytes = ((size_t)std::max(njobs, 1) * 8 + 15) / 16 * 16;
+    int rc = c->d_red.ensure(off_bytes + (c->red_tab.size() + 4) * 4);
+    if (rc) return rc;
+    if (njobs > 0) HIP_TRY(hipMemcpyAsync(c->d_red.p, c->red_off.data(), (size_t)njobs * 8, hipMemcpyHostToDevice, stream));
+    if (!c->red_tab.empty())
+        HIP_TRY(hipMemcpyAsync((char *)c->d_red.p + off_bytes, c->red_tab.data(), c->red_tab.size() * 4, hipMemcpyHostToDevice, stream));
+    pck::ReduceArgs a;
+    memset(&a, 0, sizeof(a));
+    a.records = d_records; a.n = n; a.njobs = njobs;
+    a.job_off = c->d_red.as<int64_t>();
+    a.job_side = (const int32_t *)((char *)c->d_red.p + off_bytes);
+    a.end_size = end_size; a.min_trim_size = min_trim_size; a.extra_end_trim = extra_end_trim; a.end_threshold = end_threshold;
+    a.start_trim = d_start_trim; a.end_trim = d_end_trim;
+    a.nbins = nbins; a.bin_start = a.job_side + njobs; a.bin_end = a.bin_start + nbins;
+    a.barcode_threshold = barcode_threshold; a.barcode_diff = barcode_diff; a.require_two = require_two ? 1 : 0;
+    a.call = d_call;
+    return pck::launch_reduce(a, stream) ? PC_ERR_NO_DEVICE : PC_OK;
 }
 
 void pc_jit_async(int enabled) { pcj::set_async(enabled); }

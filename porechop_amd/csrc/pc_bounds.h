@@ -61,6 +61,36 @@ inline bool scores_supported(int match, int mismatch, int gap_open, int gap_exte
     return true;
 }
 
+// Packed-FP16 traced kernel (pc_kernels.hip, trace16_kernel): every DP value X of register row
+// rho (1..R), jj columns into the window, is held as the fp16 number  X + (rho + jj [+1]) * eps - C,
+// eps = -gap_extend (drifting coordinates: gap extensions cost nothing).  fp16 represents every
+// integer of magnitude <= 2048 exactly and adds them exactly, so the kernel is bit-exact as long as
+// every value ever formed stays within +-kF16Limit.  True values: M <= match*R; the lowest finite
+// value is a T = M + open of a lower-bound start state or a diagonal off it,
+//   low = 3*open + (R-1)*ext + min(mismatch, 0)   (conservative),
+// C puts `low` at -kF16Limit, and the window may then have at most max_cols columns before the
+// drift reaches +kF16Limit.  ok = the scheme and R leave at least 32 columns.
+constexpr int kF16Limit = 2040;
+struct F16Plan { bool ok; int cen; int max_cols; };
+inline F16Plan f16_plan(int match, int mismatch, int gap_open, int gap_extend, int R)
+{
+    F16Plan p = {false, 0, 0};
+    if (is_linear(gap_open, gap_extend)) return p;           // linear mode replaces gap_extend by -12000
+    if (!scores_supported(match, mismatch, gap_open, gap_extend, R)) return p;
+    const long eps = -(long)gap_extend;
+    const long low = 3L * gap_open + (long)(R - 1) * gap_extend + (mismatch < 0 ? mismatch : 0);
+    const long high = (long)match * R;
+    if (-mismatch > 1000 || -gap_open > 1000 || match > 1000 || eps > 500) return p;
+    // the substitution terms sub - open + eps of the kernel's table must be exact fp16 integers too
+    if (match - gap_open + eps > kF16Limit || mismatch - gap_open + eps > kF16Limit || mismatch - gap_open + eps < -kF16Limit) return p;
+    const long cols = (2L * kF16Limit - (high - low)) / eps - R - 2;
+    if (cols < 32) return p;
+    p.ok = true;
+    p.cen = (int)(low + kF16Limit);
+    p.max_cols = (int)(cols > (1 << 20) ? (1 << 20) : cols);
+    return p;
+}
+
 inline bool compute_bounds(int match, int mismatch, int gap_open, int gap_extend, int m, Bounds &b)
 {
     if (!scores_supported(match, mismatch, gap_open, gap_extend, m > 0 ? m : 1)) return false;

@@ -178,20 +178,20 @@ void compile_entry(Entry *e, const Recipe rc)
         }
         r.DestroyProgram(&prog);
     }
-    // S table: [256 read bytes][K letter pairs] of packed (sub_lo - open + eps) | (sub_hi - open + eps) << 16
-    e->table.assign((size_t)256 * K, 0);
+    // S table: [code of the low stream's base * 5 + code of the high stream's base][K letter pairs] of packed
+    // (sub_lo - open + eps) | (sub_hi - open + eps) << 16
+    e->table.assign((size_t)25 * K, 0);
     auto term = [&](int letter, int code) -> int {
         const int sub = letter == 5 ? 0 : (letter == code ? rc.match : rc.mismatch);
         return sub - rc.gap_open + rc.eps;
     };
-    for (int b = 0; b < 256; ++b) {
-        const int code = dna5((unsigned char)b);
-        for (size_t k = 0; k < combos.size(); ++k) {
-            const int l = term(combos[k] / 6, code), h = term(combos[k] % 6, code);
-            e->table[(size_t)b * K + k] = rc.f16 ? (half_bits(l) | (half_bits(h) << 16))
-                                                 : (((uint32_t)l & 0xFFFFu) | ((uint32_t)h << 16));
-        }
-    }
+    for (int cl = 0; cl < 5; ++cl)
+        for (int ch = 0; ch < 5; ++ch)
+            for (size_t k = 0; k < combos.size(); ++k) {
+                const int l = term(combos[k] / 6, cl), h = term(combos[k] % 6, ch);
+                e->table[(size_t)(cl * 5 + ch) * K + k] = rc.f16 ? (half_bits(l) | (half_bits(h) << 16))
+                                                                   : (((uint32_t)l & 0xFFFFu) | ((uint32_t)h << 16));
+            }
     e->compile_done.store(true, std::memory_order_release);
 }
 
@@ -217,6 +217,11 @@ void finalize_entry(Entry *e, bool verbose)
         return;
     }
     sp->module = mod; sp->function = fn;
+    // resident workgroups (= waves) per CU as the runtime sees them -- registers AND LDS -- for the launch
+    // planner's balanced heads (pc_api.cpp plan_score_launches)
+    int nb = 0;
+    if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 64, 0) == hipSuccess && nb > 0) sp->blocks_per_cu = nb;
+    else sp->blocks_per_cu = 4 * e->waves;
     void *d = nullptr;
     if (hipMalloc(&d, e->table.size() * 4) != hipSuccess ||
         hipMemcpy(d, e->table.data(), e->table.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
@@ -224,7 +229,7 @@ void finalize_entry(Entry *e, bool verbose)
         return;
     }
     sp->d_table = d;
-    if (verbose) fprintf(stderr, "porechop_amd: specialised kernel R=%d K=%d f16=%d kren=%ld\n", e->R, e->K, e->f16 ? 1 : 0, e->kren);
+    if (verbose) fprintf(stderr, "porechop_amd: specialised kernel R=%d K=%d f16=%d kren=%ld waves/CU=%d\n", e->R, e->K, e->f16 ? 1 : 0, e->kren, sp->blocks_per_cu);
     e->code.clear(); e->code.shrink_to_fit();
     e->spec = sp;
     e->state = Entry::READY;

@@ -10,10 +10,11 @@ namespace pcj {
 
 struct Spec {
     int R = 0, K = 0, m_lo = 0, m_hi = 0;
-    int waves = 2;               // resident waves per SIMD the register allocation allows
+    int waves = 2;               // resident waves per SIMD the register allocation is asked to allow
+    int blocks_per_cu = 8;       // resident 64-thread workgroups per CU (runtime occupancy query: registers and LDS)
     bool f16 = false;            // packed-fp16 variant (5 ops per cell pair) vs packed-int16 (6)
     void *module = nullptr, *function = nullptr;
-    void *d_table = nullptr;     // device [256][K] substitution-term table
+    void *d_table = nullptr;     // device [25 code pairs][K] substitution-term table
 };
 
 // must match `struct SpecArgs` inside the JIT source

@@ -82,7 +82,7 @@ struct SpecArgs {
     const Tile *tiles; int ntiles;
     int *out;                 // [npairs * chunks][4]: score, I, J, 0
     uint2 *fin_scratch;       // [grid][R*64]
-    const u32 *s_table;       // [256][PC_K]
+    const u32 *s_table;       // [25 = code_lo * 5 + code_hi][PC_K]
     int m_lo, m_hi, gap_open, gap_extend;
     int chunks, chunk_len, span;
     u32 *err;
@@ -97,9 +97,19 @@ typedef u32 u32_unaligned __attribute__((aligned(1)));
 extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PC_WAVES))) void pc_spec_score(SpecArgs a)
 {
     constexpr int R = PC_R, K = PC_K;
-    __shared__ uint4 s_tab[256 * K / 4];
+    // substitution terms by (code of the low stream's base, code of the high stream's base): 25 rows of K
+    // packed terms, 1-4 KB instead of a row per byte value -- LDS no longer limits the waves per CU --
+    // and the two bytes of a column reach their row through two small byte -> row-offset tables
+    __shared__ uint4 s_tab[25 * K / 4];
+    __shared__ unsigned short lut_lo[256], lut_hi[256];      // row offsets in uint4 units
     const int lane = threadIdx.x;
-    for (int i = lane; i < 256 * K / 4; i += 64) s_tab[i] = ((const uint4 *)a.s_table)[i];
+    for (int i = lane; i < 25 * K / 4; i += 64) s_tab[i] = ((const uint4 *)a.s_table)[i];
+    for (int c = lane; c < 256; c += 64) {
+        const int code = (c == 'A' || c == 'a') ? 0 : (c == 'C' || c == 'c') ? 1 : (c == 'G' || c == 'g') ? 2
+                       : (c == 'T' || c == 't' || c == 'U' || c == 'u') ? 3 : 4;
+        lut_lo[c] = (unsigned short)(code * 5 * (K / 4));
+        lut_hi[c] = (unsigned short)(code * (K / 4));
+    }
     __syncthreads();
     const u32 OE2 = pack2(PC_OE), EPS2 = pack2(PC_EPS), NEG2 = PC_NEGBITS;
     const int pad_lo = R - a.m_lo, pad_hi = R - a.m_hi;
@@ -164,20 +174,9 @@ extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P
             return *(const u32_unaligned *)(w + k);
         };
         auto fetch_S = [&](u32 (&S)[K], u32 bl, u32 bh) {
-            const uint4 *row = s_tab + bl * (K / 4);
+            const uint4 *row = s_tab + ((u32)lut_lo[bl] + (u32)lut_hi[one_stream ? bl : bh]);
 #pragma clang loop unroll(full)
             for (int q = 0; q < K / 4; ++q) { const uint4 v = row[q]; S[4*q] = v.x; S[4*q+1] = v.y; S[4*q+2] = v.z; S[4*q+3] = v.w; }
-            if (!one_stream) {
-                const uint4 *rowh = s_tab + bh * (K / 4);
-#pragma clang loop unroll(full)
-                for (int q = 0; q < K / 4; ++q) {
-                    const uint4 v = rowh[q];
-                    S[4*q]   = (S[4*q]   & 0xFFFFu) | (v.x & 0xFFFF0000u);
-                    S[4*q+1] = (S[4*q+1] & 0xFFFFu) | (v.y & 0xFFFF0000u);
-                    S[4*q+2] = (S[4*q+2] & 0xFFFFu) | (v.z & 0xFFFF0000u);
-                    S[4*q+3] = (S[4*q+3] & 0xFFFFu) | (v.w & 0xFFFF0000u);
-                }
-            }
         };
         // One column.  Returns the tracked last-row term T~(R,j) - top(j) = M(R,j) + R*eps.
         // FastT: every stream of the tile tracks this column and none ends in it (the caller
@@ -293,7 +292,7 @@ extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P
 #pragma unroll 1
                     for (int r = 0; r < R; ++r) {
                         const uint2 old = (fin_lo || fin_hi) ? fin[lane * R + r] : make_uint2(0u, 0u);
-                        const u32 s = (srow[bl * K + COMBO[r]] & 0xFFFFu) | (srow[bh * K + COMBO[r]] & 0xFFFF0000u);
+                        const u32 s = srow[4 * ((u32)lut_lo[bl] + (u32)lut_hi[bh]) + COMBO[r]];
                         const u32 d = pk_add(diag, s);
                         const u32 Hs = pk_max(old.y, old.x);
                         const u32 Vs = pk_max(Vprev, Tup);

@@ -47,6 +47,8 @@ struct ScanArgs {
     int32_t chunks, chunk_len;       // score-only pass: column chunks per tile (1 = whole window) and their length
     const int32_t *ad_span;          // [nadapters] warm-up columns (SPAN) for chunked passes
     const int32_t *ad_window;        // [nadapters] W + SPAN + 1 (pass-2 windows; W = window - SPAN - 1)
+    int32_t debug;                   // timing experiments only (PC_DEBUG_TRACE): 1 = no traceback, 2 = no slab stores
+    int32_t f16_cen, f16_max_cols;   // packed-fp16 traced kernel: centring constant C and the columns it may run (pc_bounds.h f16_plan)
 };
 
 // pass-2 planner: from the score-only pass's (score, I, J) build the bounded windows
@@ -60,6 +62,24 @@ struct PlanArgs {
     int32_t *score_out;                                 // PC_MODE_SCORE: [npairs][8] records (-2, J, I, 0, score, 0, 0, 0)
 };
 
+// per-read reduction of the end-window records (pc_reduce.hip)
+struct ReduceArgs {
+    const int32_t *records;          // TRACE_OUT_INTS per record
+    int64_t n;                       // reads
+    int32_t njobs;
+    const int64_t *job_off;          // [njobs] first record of the job (device)
+    const int32_t *job_side;         // [njobs] 0 = start window, 1 = end window (device)
+    int32_t end_size, min_trim_size, extra_end_trim;
+    double end_threshold;
+    int32_t *start_trim, *end_trim;  // [n]
+    int32_t nbins;                   // barcode bins (0 = no barcode calling)
+    const int32_t *bin_start, *bin_end;   // [nbins] job of the bin's start / end entry, or -1 (device)
+    double barcode_threshold, barcode_diff;
+    int32_t require_two;
+    int32_t *call;                   // [n] bin index or -1
+};
+int launch_reduce(const ReduceArgs &a, void *stream);
+
 constexpr int TRACE_OUT_INTS = 8;
 constexpr int SCORE_OUT_INTS = 4;
 
@@ -69,6 +89,8 @@ constexpr int SCORE_OUT_INTS = 4;
 static const int kExactRows[] = {22, 24, 28, 32};
 static const int kPaddedRows[] = {16, 20, 24, 26, 28, 30, 32, 34, 36, 38, 40, 48, 56, 64, 68, 72, 112, 128};
 constexpr int kMaxRows = 128;
+// row classes of the packed-fp16 traced kernel (every class of the lists above up to 72 rows)
+static const int kTrace16Rows[] = {16, 20, 22, 24, 26, 28, 30, 32, 34, 36, 38, 40, 48, 56, 64, 68, 72};
 
 // m_lo/m_hi: adapter lengths of the two halves.  -> rows, *pad; 0 = no register variant fits: use
 // the generic LDS-state kernel (rows = max length at run time)
@@ -85,6 +107,8 @@ inline int pick_rows(int m_lo, int m_hi, bool *pad)
 // launchers (pc_kernels.hip); stream is a hipStream_t passed as void*
 int launch_trace(const ScanArgs &a, int rows, bool pad, int grid, void *stream);
 int launch_score(const ScanArgs &a, int rows, bool pad, int grid, void *stream);
+bool trace16_has(int rows);
+int launch_trace16(const ScanArgs &a, int rows, int grid, void *stream);   // packed-fp16 traced scan (needs a.f16_*)
 int launch_plan(const PlanArgs &a, void *stream);
 int trace_words_per_col(int rows);   // NW
 

@@ -174,6 +174,78 @@ __device__ __forceinline__ void column_step(u32 (&T)[R], u32 (&U)[R], u32 h2,
 }
 
 // ---------------------------------------------------------------------------------------------
+// Traceback + digest of a lane's two pairs from the trace slab, SIDE BY SIDE: each walk is a chain
+// of dependent loads (trace word -> next cell), so the two are advanced in one loop and their loads
+// are in flight together (pc_walk.h: Walk::consume takes one cell's nibble).  Shared by the int16
+// and the fp16 traced kernels (same slab layout: [column][word][lane], 16 bits per 4 rows per half,
+// first row of a group in the highest nibble).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void traceback_pairs(const ScanArgs &a, const u32 *slab, const int rows, const int NW, const int lane,
+                                                const Best b_lo, const Best b_hi, const int pad_lo, const int pad_hi,
+                                                const uint8_t *w_lo, const uint8_t *w_hi, const u32 *codes_lo, const u32 *codes_hi,
+                                                const bool have_lo, const bool have_hi, const int n_lo, const int n_hi,
+                                                const int c0_lo, const int c0_hi, const int m_lo, const int m_hi,
+                                                const int64_t p_lo, const int64_t p_hi, const int notrace_upto)
+{
+    auto fetch = [&](int hf, int pad, const uint8_t *w, const u32 *codes, int col, int row, int &nib, bool &eq) {
+        const int r = pad + row - 1;
+        const int wq = r >> 2;
+        const int rows_in_group = (rows - 4 * wq) < 4 ? (rows - 4 * wq) : 4;
+        const int pos = rows_in_group - 1 - (r & 3);
+        const u32 dw = slab[((int64_t)(col - 1) * NW + wq) * 64 + lane];
+        nib = (int)((dw >> (16 * hf + 4 * pos)) & 0xFu);
+        eq = dna5_code(w[col - 1]) == (int)codes[row - 1];
+    };
+    pcw::Walk wk_lo, wk_hi;
+    const int nt_lo = a.n_total ? (have_lo ? a.n_total[p_lo] : 0) : n_lo;
+    const int nt_hi = a.n_total ? (have_hi ? a.n_total[p_hi] : 0) : n_hi;
+    // _correctTraceValue needs the end cell's nibble before the walk starts
+    auto tie_fix_of = [&](int hf, bool have, const Best &b, int pad, const uint8_t *w, const u32 *codes) -> int {
+        if (!have || !(b.J > 0 && b.I > 0) || a.linear) return 0;
+        int nb; bool eq;
+        fetch(hf, pad, w, codes, b.J, b.I, nb, eq);
+        return ((nb & pcw::NIB_NOTDIAG) || b.tie) ? ((nb & pcw::NIB_FROMH) ? 2 : 1) : 0;
+    };
+    const int tiefix_lo = tie_fix_of(0, have_lo, b_lo, pad_lo, w_lo, codes_lo);
+    const int tiefix_hi = tie_fix_of(1, have_hi, b_hi, pad_hi, w_hi, codes_hi);
+    wk_lo.start(b_lo.I, b_lo.J, m_lo, c0_lo, nt_lo, b_lo.score, tiefix_lo);
+    wk_hi.start(b_hi.I, b_hi.J, m_hi, c0_hi, nt_hi, b_hi.score, tiefix_hi);
+    if (!have_lo) wk_lo.done = 1;
+    if (!have_hi) wk_hi.done = 1;
+    bool left_trace = false;
+    while (!wk_lo.done || !wk_hi.done) {
+        int nb_lo = 0, nb_hi = 0;
+        bool eq_lo = false, eq_hi = false;
+        const bool go_lo = !wk_lo.done, go_hi = !wk_hi.done;
+        // a walk that leaves the traced columns of a pass-2 window is stopped and flagged
+        // (never expected: the bound of pc_bounds.h)
+        if (go_lo && wk_lo.col <= notrace_upto) { left_trace = true; wk_lo.done = 1; }
+        else if (go_lo) fetch(0, pad_lo, w_lo, codes_lo, wk_lo.col, wk_lo.row, nb_lo, eq_lo);
+        if (go_hi && wk_hi.col <= notrace_upto) { left_trace = true; wk_hi.done = 1; }
+        else if (go_hi) fetch(1, pad_hi, w_hi, codes_hi, wk_hi.col, wk_hi.row, nb_hi, eq_hi);
+        if (go_lo && !wk_lo.done) wk_lo.consume(nb_lo, eq_lo);
+        if (go_hi && !wk_hi.done) wk_hi.consume(nb_hi, eq_hi);
+    }
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+        const bool have = hf ? have_hi : have_lo;
+        if (!have) continue;
+        pcw::Walk &wk = hf ? wk_hi : wk_lo;
+        const Best b = hf ? b_hi : b_lo;
+        const int64_t p = hf ? p_hi : p_lo;
+        pcw::Digest dg;
+        int err = wk.finish(dg);
+        if (a.force_score && a.force_score[p] != b.score) err = 1;
+        if (left_trace) err = 1;
+        if (err) atomicAdd(a.err, 1u);
+        int4 o0 = {dg.read_start, dg.read_end, dg.adapter_start, dg.adapter_end};
+        int4 o1 = {dg.score, dg.matches, dg.aligned_len, dg.full_len};
+        int4 *op = (int4 *)(a.out + p * TRACE_OUT_INTS);
+        op[0] = o0; op[1] = o1;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // The scan kernel.  TRACE=true : full alignment (trace slab, traceback, digest) -> 8 ints/pair
 //                   TRACE=false: score-only forward pass -> (score, I, J) per pair
 // R > 0 : DP column in VGPRs, R rows fully unrolled (the fast path; PAD as in column_step).
@@ -486,68 +558,356 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((R > 0 && R 
             if (have_lo) { int4 o = {b_lo.score, b_lo.I, b_lo.J + c0_lo, 0}; *(int4 *)(a.out + (p_lo * nchunks + chunk) * SCORE_OUT_INTS) = o; }
             if (have_hi) { int4 o = {b_hi.score, b_hi.I, b_hi.J + c0_hi, 0}; *(int4 *)(a.out + (p_hi * nchunks + chunk) * SCORE_OUT_INTS) = o; }
         } else {
-            // Traceback + digest of the lane's two pairs, SIDE BY SIDE: each walk is a chain of
-            // dependent loads (trace word -> next cell), so the two are advanced in one loop and
-            // their loads are in flight together (pc_walk.h: Walk::consume takes one cell's nibble).
-            auto fetch = [&](int hf, int pad, const uint8_t *w, const u32 *codes, int col, int row, int &nib, bool &eq) {
-                const int r = pad + row - 1;
-                const int wq = r >> 2;
-                const int rows_in_group = (rows - 4 * wq) < 4 ? (rows - 4 * wq) : 4;
-                const int pos = rows_in_group - 1 - (r & 3);
-                const u32 dw = slab[((int64_t)(col - 1) * NW + wq) * 64 + lane];
-                nib = (int)((dw >> (16 * hf + 4 * pos)) & 0xFu);
-                eq = dna5_code(w[col - 1]) == (int)codes[row - 1];
-            };
-            pcw::Walk wk_lo, wk_hi;
-            const int nt_lo = a.n_total ? (have_lo ? a.n_total[p_lo] : 0) : n_lo;
-            const int nt_hi = a.n_total ? (have_hi ? a.n_total[p_hi] : 0) : n_hi;
-            // _correctTraceValue needs the end cell's nibble before the walk starts
-            auto tie_fix_of = [&](int hf, bool have, const Best &b, int pad, const uint8_t *w, const u32 *codes) -> int {
-                if (!have || !(b.J > 0 && b.I > 0) || a.linear) return 0;
-                int nb; bool eq;
-                fetch(hf, pad, w, codes, b.J, b.I, nb, eq);
-                return ((nb & pcw::NIB_NOTDIAG) || b.tie) ? ((nb & pcw::NIB_FROMH) ? 2 : 1) : 0;
-            };
-            const int tiefix_lo = tie_fix_of(0, have_lo, b_lo, pad_lo, w_lo, codes_lo);
-            const int tiefix_hi = tie_fix_of(1, have_hi, b_hi, pad_hi, w_hi, codes_hi);
-            wk_lo.start(b_lo.I, b_lo.J, m_lo, c0_lo, nt_lo, b_lo.score, tiefix_lo);
-            wk_hi.start(b_hi.I, b_hi.J, m_hi, c0_hi, nt_hi, b_hi.score, tiefix_hi);
-            if (!have_lo) wk_lo.done = 1;
-            if (!have_hi) wk_hi.done = 1;
-            bool left_trace = false;
-            while (!wk_lo.done || !wk_hi.done) {
-                int nb_lo = 0, nb_hi = 0;
-                bool eq_lo = false, eq_hi = false;
-                const bool go_lo = !wk_lo.done, go_hi = !wk_hi.done;
-                // a walk that leaves the traced columns of a pass-2 window is stopped and flagged
-                // (never expected: the bound of pc_bounds.h)
-                if (go_lo && wk_lo.col <= notrace_upto) { left_trace = true; wk_lo.done = 1; }
-                else if (go_lo) fetch(0, pad_lo, w_lo, codes_lo, wk_lo.col, wk_lo.row, nb_lo, eq_lo);
-                if (go_hi && wk_hi.col <= notrace_upto) { left_trace = true; wk_hi.done = 1; }
-                else if (go_hi) fetch(1, pad_hi, w_hi, codes_hi, wk_hi.col, wk_hi.row, nb_hi, eq_hi);
-                if (go_lo && !wk_lo.done) wk_lo.consume(nb_lo, eq_lo);
-                if (go_hi && !wk_hi.done) wk_hi.consume(nb_hi, eq_hi);
-            }
-#pragma unroll
-            for (int hf = 0; hf < 2; ++hf) {
-                const bool have = hf ? have_hi : have_lo;
-                if (!have) continue;
-                pcw::Walk &wk = hf ? wk_hi : wk_lo;
-                const Best b = hf ? b_hi : b_lo;
-                const int64_t p = hf ? p_hi : p_lo;
-                pcw::Digest dg;
-                int err = wk.finish(dg);
-                if (a.force_score && a.force_score[p] != b.score) err = 1;
-                if (left_trace) err = 1;
-                if (err) atomicAdd(a.err, 1u);
-                int4 o0 = {dg.read_start, dg.read_end, dg.adapter_start, dg.adapter_end};
-                int4 o1 = {dg.score, dg.matches, dg.aligned_len, dg.full_len};
-                int4 *op = (int4 *)(a.out + p * TRACE_OUT_INTS);
-                op[0] = o0; op[1] = o1;
-            }
+            traceback_pairs(a, slab, rows, NW, lane, b_lo, b_hi, pad_lo, pad_hi, w_lo, w_hi, codes_lo, codes_hi,
+                            have_lo, have_hi, n_lo, n_hi, c0_lo, c0_hi, m_lo, m_hi, p_lo, p_hi, notrace_upto);
         }
     }
 }
+
+// ---------------------------------------------------------------------------------------------
+// The traced scan in PACKED FP16 (the fast path of the end windows and of pass-2 windows).
+//
+// Same recurrence, same drifting coordinates, same trace slab and traceback as scan_kernel<R,*,true>,
+// but 13.25 instead of 21 packed VALU ops per two cells:
+//   * the DP values are the reference's integers held as fp16 numbers X + (rho + jj [+1])*eps - C
+//     (pc_bounds.h f16_plan: every value ever formed is an integer of magnitude <= 2040, which
+//     fp16 holds and adds exactly), so  M = v_pk_maximum3_f16(d, H, V)  is one op;
+//   * the diagonal term is ONE op,  d = T_diag + S,  with the substitution terms S of this tile's
+//     adapter pair fetched from an LDS table [25 letter pairs of the two streams][R rows] by one
+//     ds_read_b128 per four rows (scan_kernel builds it from run-time adapter codes in 4 ops);
+//   * each trace bit is ONE op,  b = v_pk_add_f16(x, -y) clamp  = min(max(x - y, 0), 1)  exactly
+//     1.0 or 0.0 for integers, and joins the byte of its row pair by ONE fma,  acc = 2*acc + b:
+//     started at 4.0, two rows (8 bits) later acc = 1024 + byte, whose fp16 bit pattern is
+//     0x6400 | byte -- the integer appears in the mantissa without a conversion; v_perm_b32 joins
+//     two such bytes per half into the slab's 16 bits per four rows.
+// Rows are issued as one hand-interleaved asm statement each (independent half of row r+2, the
+// serial V -> M -> T chain of row r, the trace bits of row r, the byte accumulation of row r-1):
+// no two dependent packed ops are adjacent.
+// ---------------------------------------------------------------------------------------------
+typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ h16x2 HV(u32 x) { return __builtin_bit_cast(h16x2, x); }
+__device__ __forceinline__ u32 WH(h16x2 x) { return __builtin_bit_cast(u32, x); }
+__device__ __forceinline__ u32 hk_add(u32 a, u32 b) { return WH(HV(a) + HV(b)); }
+__device__ __forceinline__ u32 hk_sub(u32 a, u32 b) { return WH(HV(a) - HV(b)); }
+__device__ __forceinline__ u32 hk_max(u32 a, u32 b) { return WH(__builtin_elementwise_max(HV(a), HV(b))); }
+__device__ __forceinline__ u32 hk_min(u32 a, u32 b) { return WH(__builtin_elementwise_min(HV(a), HV(b))); }
+__device__ __forceinline__ u32 hpack2x(int l, int h) { const h16x2 v = {(_Float16)l, (_Float16)h}; return WH(v); }
+__device__ __forceinline__ u32 hpack2(int v) { return hpack2x(v, v); }
+__device__ __forceinline__ int hlo(u32 x) { return (int)(float)HV(x).x; }
+__device__ __forceinline__ int hhi(u32 x) { return (int)(float)HV(x).y; }
+constexpr u32 H_NEGINF2 = 0xFC00FC00u, H_POSINF2 = 0x7C007C00u;
+
+#define PC_HMAX "v_pk_max_f16 "
+#define PC_HADD "v_pk_add_f16 "
+#define PC_HMAX3 "v_pk_maximum3_f16 "
+#define PC_HFMA "v_pk_fma_f16 "
+#define PC_BIT " neg_lo:[0,1] neg_hi:[0,1] clamp\n\t"
+// byte accumulation of the previous row's four bits: an even row starts a byte (acc = 2*4 + b3)
+#define PC_ACC3_EVEN PC_HADD "%[acc], %[pb3], %[eight]\n\t"
+#define PC_ACC3_ODD PC_HFMA "%[acc], %[acc], %[two], %[pb3]\n\t"
+#define PC_ACC2 PC_HFMA "%[acc], %[acc], %[two], %[pb2]\n\t"
+#define PC_ACC1 PC_HFMA "%[acc], %[acc], %[two], %[pb1]\n\t"
+#define PC_ACC0 PC_HFMA "%[acc], %[acc], %[two], %[pb0]\n\t"
+// full row: ind(q = r+2) | chain(r) | bits(r) | acc(r-1)
+#define PC_ROW16_FULL(ACC3)                                         \
+    PC_HADD "%[b0q], %[tq], %[uq]" PC_BIT                           \
+    ACC3                                                            \
+    PC_HMAX "%[vs], %[vp], %[tu]\n\t"                               \
+    PC_HADD "%[dq], %[dg], %[sq]\n\t"                               \
+    PC_ACC2                                                         \
+    PC_HMAX3 "%[mn], %[dr], %[hr], %[vs]\n\t"                       \
+    PC_HMAX "%[uq], %[uq], %[tq]\n\t"                               \
+    PC_ACC1                                                         \
+    PC_HADD "%[tn], %[mn], %[oe]\n\t"                               \
+    PC_HADD "%[b1], %[vs], %[vp]" PC_BIT                            \
+    PC_ACC0                                                         \
+    PC_HADD "%[b2], %[hr], %[vs]" PC_BIT                            \
+    PC_HADD "%[b3], %[mn], %[dr] neg_lo:[0,1] neg_hi:[0,1] clamp"
+// first row: nothing to accumulate yet
+#define PC_ROW16_FIRST                                              \
+    PC_HADD "%[b0q], %[tq], %[uq]" PC_BIT                           \
+    PC_HMAX "%[vs], %[vp], %[tu]\n\t"                               \
+    PC_HADD "%[dq], %[dg], %[sq]\n\t"                               \
+    PC_HMAX "%[uq], %[uq], %[tq]\n\t"                               \
+    PC_HMAX3 "%[mn], %[dr], %[hr], %[vs]\n\t"                       \
+    PC_HADD "%[b1], %[vs], %[vp]" PC_BIT                            \
+    PC_HADD "%[b2], %[hr], %[vs]" PC_BIT                            \
+    PC_HADD "%[tn], %[mn], %[oe]\n\t"                               \
+    PC_HADD "%[b3], %[mn], %[dr] neg_lo:[0,1] neg_hi:[0,1] clamp"
+// last two rows: no row r+2
+#define PC_ROW16_NOIND(ACC3)                                        \
+    ACC3                                                            \
+    PC_HMAX "%[vs], %[vp], %[tu]\n\t"                               \
+    PC_ACC2                                                         \
+    PC_HADD "%[b1], %[vs], %[vp]" PC_BIT                            \
+    PC_HMAX3 "%[mn], %[dr], %[hr], %[vs]\n\t"                       \
+    PC_ACC1                                                         \
+    PC_HADD "%[b2], %[hr], %[vs]" PC_BIT                            \
+    PC_HADD "%[tn], %[mn], %[oe]\n\t"                               \
+    PC_ACC0                                                         \
+    PC_HADD "%[b3], %[mn], %[dr] neg_lo:[0,1] neg_hi:[0,1] clamp"
+
+template <int R>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(R <= 22 ? 4 : R <= 44 ? 3 : 2))) void trace16_kernel(ScanArgs a)
+{
+    static_assert(R >= 4 && R % 2 == 0, "row classes are even");
+    constexpr int RP = (R + 3) & ~3;         // table row padded to whole b128 groups
+    constexpr int STRIDE = RP + 4;           // dwords per table row (+16 B: rows start in different banks)
+    constexpr int NW = (R + 3) / 4;          // trace dwords per column per lane
+    __shared__ uint16_t lut_lo[256], lut_hi[256];             // byte -> table row offset (dwords) of the lo / hi stream
+    __shared__ __attribute__((aligned(16))) u32 s_tab[25 * STRIDE];
+    uint2 *fin = (uint2 *)a.fin_scratch + (int64_t)blockIdx.x * R * 64;
+    const int lane = threadIdx.x;
+    for (int c = lane; c < 256; c += 64) {
+        const int code = dna5_code(c);
+        lut_lo[c] = (uint16_t)(code * 5 * STRIDE);
+        lut_hi[c] = (uint16_t)(code * STRIDE);
+    }
+    const int eps = -a.gap_extend, CEN = a.f16_cen;
+    const u32 OE2 = __builtin_amdgcn_readfirstlane(hpack2(a.gap_open + eps)), EPS2 = hpack2(eps), NEG2 = H_NEGINF2;
+    const u32 TWO2 = 0x40004000u, EIGHT2 = 0x48004800u;
+    u32 *slab = a.slab + (int64_t)blockIdx.x * a.slab_stride;
+
+    for (int t = blockIdx.x; t < a.ntiles; t += gridDim.x) {
+        const Tile tile = a.tiles[t];
+        const int m_lo = a.ad_len[tile.adapter_lo];
+        const int m_hi = a.ad_len[tile.adapter_hi];
+        const u32 *codes_lo = a.ad_codes + (int64_t)tile.adapter_lo * pcb::MAX_ADAPTER;
+        const u32 *codes_hi = a.ad_codes + (int64_t)tile.adapter_hi * pcb::MAX_ADAPTER;
+        const int pad_lo = R - m_lo, pad_hi = R - m_hi;           // top padding rows of each half
+        if (pad_lo < 0 || pad_hi < 0) {                           // host bug
+            if (lane == 0) atomicAdd(a.err, 1u);
+            continue;
+        }
+        // ---- substitution table of this adapter pair: s_tab[(c_lo*5 + c_hi)][row] = packed
+        // (sub_lo - open + eps | sub_hi - open + eps); a padding row scores 0, which keeps its
+        // M = 0 and re-opens V exactly like the true row 0 (DESIGN.md "top padding")
+        __syncthreads();
+        for (int e = lane; e < 25 * RP; e += 64) {
+            const int pair = e / RP, r = e - pair * RP;
+            const int cl = pair / 5, ch = pair - cl * 5;
+            int sl = 0, sh = 0;
+            if (r < R) {
+                const int il = r - pad_lo, ih = r - pad_hi;
+                if (il >= 0) sl = ((int)codes_lo[il] == cl) ? a.match : a.mismatch;
+                if (ih >= 0) sh = ((int)codes_hi[ih] == ch) ? a.match : a.mismatch;
+            }
+            s_tab[pair * STRIDE + r] = hpack2x(sl - a.gap_open + eps, sh - a.gap_open + eps);
+        }
+        __syncthreads();
+
+        // ---- this lane's two pairs -----------------------------------------------------
+        const int64_t p_lo = tile.out_lo + lane, p_hi = tile.out_hi + lane;
+        const int64_t wi_lo = a.win_by_out ? p_lo : tile.win_lo + lane;
+        const int64_t wi_hi = a.win_by_out ? p_hi : tile.win_hi + lane;
+        const bool have_lo = lane < tile.count_lo, have_hi = lane < tile.count_hi;
+        const bool one_stream = !a.win_by_out && tile.win_lo == tile.win_hi;
+        const uint8_t *w_lo = a.arena + (have_lo ? a.win_off[wi_lo] : 0);
+        const uint8_t *w_hi = a.arena + (have_hi ? a.win_off[wi_hi] : 0);
+        const int n_lo = have_lo ? a.win_len[wi_lo] : 0;
+        const int n_hi = have_hi ? a.win_len[wi_hi] : 0;
+        const int c0_lo = (have_lo && a.col0) ? a.col0[p_lo] : 0;
+        const int c0_hi = (have_hi && a.col0) ? a.col0[p_hi] : 0;
+        const int fr_lo = (have_lo && a.force_row) ? a.force_row[p_lo] : -1;
+        const int fr_hi = (have_hi && a.force_row) ? a.force_row[p_hi] : -1;
+
+        // column 0 (see scan_kernel): M = 0, or the lower-bound state of an interior window start
+        u32 T[R], U[R];
+#pragma clang loop unroll(full)
+        for (int r = 0; r < R; ++r) {
+            const int vl = (c0_lo > 0 && r >= pad_lo) ? 2 * a.gap_open + (r - pad_lo) * a.init_extend : a.gap_open;
+            const int vh = (c0_hi > 0 && r >= pad_hi) ? 2 * a.gap_open + (r - pad_hi) * a.init_extend : a.gap_open;
+            T[r] = hpack2x(vl + (r + 2) * eps - CEN, vh + (r + 2) * eps - CEN);
+            U[r] = NEG2;
+        }
+        u32 top = hpack2(a.gap_open + eps - CEN);                 // T~(0, j-1) entering column j
+        Best b_lo = {0, m_lo, 0, 0}, b_hi = {0, m_hi, 0, 0};
+        // packed running maxima of the tracked last-row term  M(R,j) + R*eps  (what the fast check compares)
+        u32 best2 = hpack2(R * eps);
+
+        int nmax = n_lo > n_hi ? n_lo : n_hi;
+#pragma unroll
+        for (int s = 32; s >= 1; s >>= 1) { const int o = __shfl_xor(nmax, s); nmax = o > nmax ? o : nmax; }
+        if (nmax > a.slab_cols || nmax > a.f16_max_cols) {        // host sized the slab / chose this kernel from a wrong bound
+            if (lane == 0) atomicAdd(a.err, 1u);
+            nmax = 0;
+        }
+        int notrace_upto = 0;
+        if (a.force_row && a.ad_window) {
+            const int wl = a.ad_window[tile.adapter_lo] - a.ad_span[tile.adapter_lo] - 1;
+            const int wh = a.ad_window[tile.adapter_hi] - a.ad_span[tile.adapter_hi] - 1;
+            int t0 = 1 << 30;
+            if (have_lo) t0 = n_lo - wl - 2;
+            if (have_hi && n_hi - wh - 2 < t0) t0 = n_hi - wh - 2;
+#pragma unroll
+            for (int s = 32; s >= 1; s >>= 1) { const int o = __shfl_xor(t0, s); t0 = o < t0 ? o : t0; }
+            notrace_upto = __builtin_amdgcn_readfirstlane(t0 > 0 ? t0 : 0);
+        }
+        // last-row cells are tracked in columns 1..n-1 of pairs that scout (no forced end cell):
+        // +inf lets a half's candidate through, -inf blanks it
+        auto track_limit = [&](int j) -> u32 {
+            const bool tl = fr_lo < 0 && j < n_lo, th = fr_hi < 0 && j < n_hi;
+            return (tl ? (H_POSINF2 & 0xFFFFu) : (H_NEGINF2 & 0xFFFFu)) | (th ? (H_POSINF2 & 0xFFFF0000u) : (H_NEGINF2 & 0xFFFF0000u));
+        };
+        auto scan_row = [&](int r, int j, u32 Tn, bool tie_l, bool tie_h, bool fin_lo, bool fin_hi) {
+            const int il = r - pad_lo + 1, ih = r - pad_hi + 1;
+            const int off = a.gap_open + (r + 1 + j + 1) * eps - CEN;                  // T~ -> true M of this row
+            const int cl = hlo(Tn) - off, ch = hhi(Tn) - off;
+            if (fin_lo && il >= 1 && (fr_lo >= 0 ? (il == fr_lo) : (cl > b_lo.score))) { b_lo.score = cl; b_lo.I = il; b_lo.J = j; b_lo.tie = tie_l; }
+            if (fin_hi && ih >= 1 && (fr_hi >= 0 ? (ih == fr_hi) : (ch > b_hi.score))) { b_hi.score = ch; b_hi.I = ih; b_hi.J = j; b_hi.tie = tie_h; }
+        };
+        auto load_dw = [&](const uint8_t *w, int n, int col) -> u32 {   // dword holding 0-based columns col..col+3
+            const int k = (col < n) ? col : (n > 0 ? ((n - 1) & ~3) : 0);
+            return load_u32_unaligned(w + k);
+        };
+        auto row_of = [&](u32 bl, u32 bh) -> int {                      // table row (dword offset) of a column's byte pair
+            return one_stream ? (int)lut_lo[bl] + (int)lut_hi[bl] : (int)lut_lo[bl] + (int)lut_hi[bh];
+        };
+
+        u32 cur_lo = load_dw(w_lo, n_lo, 0), cur_hi = one_stream ? 0u : load_dw(w_hi, n_hi, 0);
+        int trow = row_of(cur_lo & 0xFF, cur_hi & 0xFF);
+        for (int j = 1; j <= nmax; ++j) {
+            const int trow_j = trow;
+            // next column's bytes / table row, one column ahead of their use
+            cur_lo >>= 8; cur_hi >>= 8;
+            if ((j & 3) == 0) { cur_lo = load_dw(w_lo, n_lo, j); if (!one_stream) cur_hi = load_dw(w_hi, n_hi, j); }
+            trow = row_of(cur_lo & 0xFF, cur_hi & 0xFF);
+
+            const bool fin_lo = (j == n_lo), fin_hi = (j == n_hi);
+            const bool any_fin = __any(fin_lo || fin_hi);
+            if (any_fin && (fin_lo || fin_hi)) {
+#pragma clang loop unroll(full)
+                for (int r = 0; r < R; ++r) fin[lane * R + r] = make_uint2(T[r], U[r]);
+            }
+            const u32 topn = hk_add(top, EPS2);                   // T~(0, j)
+            const uint4 *srow = (const uint4 *)(s_tab + trow_j);
+            // (columns up to notrace_upto are written too: the walk never reads them, and a branch per
+            // word would cut the row sequence into basic blocks)
+            u32 *trace_dst = slab + ((int64_t)((a.debug & 2) ? 0 : (j - 1)) * NW) * 64 + lane;
+
+            // ---- the column ------------------------------------------------------------------
+            u32 S[RP];
+            auto load_group = [&](int g) { const uint4 v = srow[g]; S[4 * g] = v.x; S[4 * g + 1] = v.y; S[4 * g + 2] = v.z; S[4 * g + 3] = v.w; };
+            load_group(0);
+            if (RP > 4) load_group(1);
+            u32 dh[R], b0[R];                    // d and HOPEN of the rows in flight (a window of 3 is ever live)
+            // independent halves of rows 0 and 1
+            {
+                asm volatile(PC_HADD "%[b00], %[t0], %[u0]" PC_BIT
+                             PC_HADD "%[b01], %[t1], %[u1]" PC_BIT
+                             PC_HADD "%[d0], %[top], %[s0]\n\t"
+                             PC_HADD "%[d1], %[t0], %[s1]\n\t"
+                             PC_HMAX "%[u0], %[u0], %[t0]\n\t"
+                             PC_HMAX "%[u1], %[u1], %[t1]"
+                             : [u0] "+v"(U[0]), [u1] "+v"(U[1]), [d0] "=&v"(dh[0]), [d1] "=&v"(dh[1]), [b00] "=&v"(b0[0]), [b01] "=&v"(b0[1])
+                             : [t0] "v"(T[0]), [t1] "v"(T[1]), [top] "v"(top), [s0] "v"(S[0]), [s1] "v"(S[1]));
+            }
+            u32 Tup = topn, Vp = NEG2, acc = 0, accA = 0;
+            u32 pb1 = 0, pb2 = 0, pb3 = 0;       // bits of the previous row (its HOPEN bit is b0[r-1])
+            u32 d_last = 0, h_last = 0, v_last = 0;
+#pragma clang loop unroll(full)
+            for (int r = 0; r < R; ++r) {
+                // table terms one group ahead of the row that needs them (row r+2 is fetched now)
+                if (((r + 6) & 3) == 0 && (r + 6) < RP) load_group((r + 6) >> 2);
+                u32 vs, mn, tn, b1, b2, b3;
+                if (r + 2 < R) {
+                    const int q = r + 2;
+                    if (r == 0) {
+                        asm volatile(PC_ROW16_FIRST
+                                     : [uq] "+v"(U[q]), [vs] "=&v"(vs), [dq] "=&v"(dh[q]), [b0q] "=&v"(b0[q]), [mn] "=&v"(mn), [tn] "=&v"(tn),
+                                       [b1] "=&v"(b1), [b2] "=&v"(b2), [b3] "=&v"(b3)
+                                     : [tq] "v"(T[q]), [vp] "v"(Vp), [tu] "v"(Tup), [dg] "v"(T[q - 1]), [sq] "v"(S[q]),
+                                       [dr] "v"(dh[r]), [hr] "v"(U[r]), [oe] "s"(OE2));
+                    } else if ((r - 1) & 1) {
+                        asm volatile(PC_ROW16_FULL(PC_ACC3_ODD)
+                                     : [uq] "+v"(U[q]), [vs] "=&v"(vs), [dq] "=&v"(dh[q]), [b0q] "=&v"(b0[q]), [mn] "=&v"(mn), [tn] "=&v"(tn),
+                                       [b1] "=&v"(b1), [b2] "=&v"(b2), [b3] "=&v"(b3), [acc] "+v"(acc)
+                                     : [tq] "v"(T[q]), [vp] "v"(Vp), [tu] "v"(Tup), [dg] "v"(T[q - 1]), [sq] "v"(S[q]),
+                                       [dr] "v"(dh[r]), [hr] "v"(U[r]), [oe] "s"(OE2), [two] "s"(TWO2),
+                                       [pb0] "v"(b0[r - 1]), [pb1] "v"(pb1), [pb2] "v"(pb2), [pb3] "v"(pb3));
+                    } else {
+                        asm volatile(PC_ROW16_FULL(PC_ACC3_EVEN)
+                                     : [uq] "+v"(U[q]), [vs] "=&v"(vs), [dq] "=&v"(dh[q]), [b0q] "=&v"(b0[q]), [mn] "=&v"(mn), [tn] "=&v"(tn),
+                                       [b1] "=&v"(b1), [b2] "=&v"(b2), [b3] "=&v"(b3), [acc] "=&v"(acc)
+                                     : [tq] "v"(T[q]), [vp] "v"(Vp), [tu] "v"(Tup), [dg] "v"(T[q - 1]), [sq] "v"(S[q]),
+                                       [dr] "v"(dh[r]), [hr] "v"(U[r]), [oe] "s"(OE2), [two] "s"(TWO2), [eight] "s"(EIGHT2),
+                                       [pb0] "v"(b0[r - 1]), [pb1] "v"(pb1), [pb2] "v"(pb2), [pb3] "v"(pb3));
+                    }
+                } else if ((r - 1) & 1) {
+                    asm volatile(PC_ROW16_NOIND(PC_ACC3_ODD)
+                                 : [vs] "=&v"(vs), [mn] "=&v"(mn), [tn] "=&v"(tn), [b1] "=&v"(b1), [b2] "=&v"(b2), [b3] "=&v"(b3), [acc] "+v"(acc)
+                                 : [vp] "v"(Vp), [tu] "v"(Tup), [dr] "v"(dh[r]), [hr] "v"(U[r]), [oe] "s"(OE2), [two] "s"(TWO2),
+                                   [pb0] "v"(b0[r - 1]), [pb1] "v"(pb1), [pb2] "v"(pb2), [pb3] "v"(pb3));
+                } else {
+                    asm volatile(PC_ROW16_NOIND(PC_ACC3_EVEN)
+                                 : [vs] "=&v"(vs), [mn] "=&v"(mn), [tn] "=&v"(tn), [b1] "=&v"(b1), [b2] "=&v"(b2), [b3] "=&v"(b3), [acc] "=&v"(acc)
+                                 : [vp] "v"(Vp), [tu] "v"(Tup), [dr] "v"(dh[r]), [hr] "v"(U[r]), [oe] "s"(OE2), [two] "s"(TWO2), [eight] "s"(EIGHT2),
+                                   [pb0] "v"(b0[r - 1]), [pb1] "v"(pb1), [pb2] "v"(pb2), [pb3] "v"(pb3));
+                }
+                // row r-1's byte half is complete now: every second row a byte, every fourth a slab word
+                if (r >= 1) {
+                    const int pr = r - 1;
+                    if ((pr & 3) == 1) accA = acc;
+                    if ((pr & 3) == 3) { const u32 wd = __builtin_amdgcn_perm(accA, acc, 0x06020400u); trace_dst[(pr >> 2) * 64] = wd; }
+                }
+                if (r == R - 1) { d_last = dh[r]; h_last = U[r]; v_last = vs; }
+                T[r] = tn; Tup = tn; Vp = vs; pb1 = b1; pb2 = b2; pb3 = b3;
+            }
+            // the last row's bits (R is even, so this row completes a byte)
+            asm volatile(PC_ACC3_ODD "s_nop 0\n\t" PC_ACC2 "s_nop 0\n\t" PC_ACC1 "s_nop 0\n\t"
+                         PC_HFMA "%[acc], %[acc], %[two], %[pb0]"
+                         : [acc] "+v"(acc)
+                         : [two] "s"(TWO2), [pb0] "v"(b0[R - 1]), [pb1] "v"(pb1), [pb2] "v"(pb2), [pb3] "v"(pb3));
+            {
+                constexpr int pr = R - 1;
+                const u32 wd = ((pr & 3) == 3) ? __builtin_amdgcn_perm(accA, acc, 0x06020400u)     // rows 4g..4g+3
+                                               : __builtin_amdgcn_perm(acc, 0u, 0x0c060c04u);     // a last group of two rows
+                trace_dst[(pr >> 2) * 64] = wd;
+            }
+
+            // ---- tracked cells ---------------------------------------------------------------
+            const u32 cand = hk_min(hk_sub(T[R - 1], topn), track_limit(j));     // M(R,j) + R*eps where tracked, else -inf
+            const u32 nb = hk_max(best2, cand);
+            if (__any(nb != best2)) {
+                const int cl = hlo(hk_sub(T[R - 1], topn)) - R * eps, ch = hhi(hk_sub(T[R - 1], topn)) - R * eps;
+                const u32 g = hk_max(h_last, v_last);
+                const bool tie_l = HV(d_last).x == HV(g).x, tie_h = HV(d_last).y == HV(g).y;      // d == max(H,V)
+                if (fr_lo < 0 && j < n_lo && cl > b_lo.score) { b_lo.score = cl; b_lo.I = m_lo; b_lo.J = j; b_lo.tie = tie_l; }
+                if (fr_hi < 0 && j < n_hi && ch > b_hi.score) { b_hi.score = ch; b_hi.I = m_hi; b_hi.J = j; b_hi.tie = tie_h; }
+                best2 = hpack2x(b_lo.score + R * eps, b_hi.score + R * eps);
+            }
+            if (any_fin) {
+                // a pair's last column: rolled re-run from the saved previous column, tracked cells top
+                // to bottom with strict '>' (dp_scout.h:165-179), plus every row's d == max(H,V) flag
+                u32 dq = top, Tu2 = topn, Vp2 = NEG2;
+#pragma unroll 1
+                for (int r = 0; r < R; ++r) {
+                    const uint2 old = (fin_lo || fin_hi) ? fin[lane * R + r] : make_uint2(0u, 0u);
+                    const u32 sv = s_tab[trow_j + r];
+                    const u32 d = hk_add(dq, sv);
+                    const u32 Hs = hk_max(old.y, old.x);
+                    const u32 Vs = hk_max(Vp2, Tu2);
+                    const u32 g = hk_max(Hs, Vs);
+                    const u32 Tn = hk_add(hk_max(d, g), OE2);
+                    dq = old.x; Tu2 = Tn; Vp2 = Vs;
+                    scan_row(r, j, Tn, HV(d).x == HV(g).x, HV(d).y == HV(g).y, fin_lo, fin_hi);
+                }
+                best2 = hpack2x(b_lo.score + R * eps, b_hi.score + R * eps);
+            }
+            top = topn;
+        }
+        if (a.debug & 1) {
+            if (have_lo) a.out[p_lo * TRACE_OUT_INTS + 4] = b_lo.score;
+            if (have_hi) a.out[p_hi * TRACE_OUT_INTS + 4] = b_hi.score;
+            continue;
+        }
+        traceback_pairs(a, slab, R, NW, lane, b_lo, b_hi, pad_lo, pad_hi, w_lo, w_hi, codes_lo, codes_hi,
+                        have_lo, have_hi, n_lo, n_hi, c0_lo, c0_hi, m_lo, m_hi, p_lo, p_hi, notrace_upto);
+    }
+}
+#undef PC_ROW16_FULL
+#undef PC_ROW16_FIRST
+#undef PC_ROW16_NOIND
 
 // ---------------------------------------------------------------------------------------------
 // Planner between the two passes of a whole-read scan: bounded window ending at the max cell.
@@ -619,6 +979,25 @@ static int launch_scan(const ScanArgs &a0, int rows, bool pad, int grid, void *s
 }
 
 int launch_trace(const ScanArgs &a, int rows, bool pad, int grid, void *stream) { return launch_scan<true>(a, rows, pad, grid, stream); }
+
+bool trace16_has(int rows)
+{
+    for (int r : kTrace16Rows) if (r == rows) return true;
+    return false;
+}
+
+int launch_trace16(const ScanArgs &a, int rows, int grid, void *stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+#define PC_T16(RR) case RR: hipLaunchKernelGGL((trace16_kernel<RR>), dim3(grid), dim3(64), 0, s, a); break;
+    switch (rows) {
+        PC_T16(16) PC_T16(20) PC_T16(22) PC_T16(24) PC_T16(26) PC_T16(28) PC_T16(30) PC_T16(32) PC_T16(34) PC_T16(36)
+        PC_T16(38) PC_T16(40) PC_T16(48) PC_T16(56) PC_T16(64) PC_T16(68) PC_T16(72)
+        default: return -1;
+    }
+#undef PC_T16
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
 int launch_score(const ScanArgs &a, int rows, bool pad, int grid, void *stream) { return launch_scan<false>(a, rows, pad, grid, stream); }
 
 int launch_plan(const PlanArgs &a, void *stream)

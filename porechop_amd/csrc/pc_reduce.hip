@@ -1,0 +1,117 @@
+// pc_reduce.hip -- per-read reduction of the end-window records on the device.
+//
+// What porechop/nanopore_read.py does per read with the alignments of phase B, for a whole batch:
+//   find_start_trim / find_end_trim   nanopore_read.py:166-208   (trim amounts)
+//   determine_barcode                 nanopore_read.py:399-466   (barcode call; without the Albacore rule)
+// Input: the records pc_scan_device wrote for J jobs over the same n reads (job j's records are
+// contiguous, read r of job j at rec[job_off[j] + r]), each job being one adapter sequence
+// against the start (side 0) or the end (side 1) window of every read.  HBM-bound integer work:
+// one thread per read, adjacent threads read adjacent 32-byte records (coalesced per job).
+//
+// Identities are the doubles Python sees: (100.0 * matches) / length printed with %f and parsed
+// back, i.e. rounded half-to-even at 6 decimals (porechop/src/alignment.cpp:113-121,
+// nanopore_read.py:476-491); a failed alignment (field 0 == -1) scores 0.0.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "pc_kernels.h"
+
+namespace pck {
+
+namespace {
+
+struct Rec { int32_t rs, re, as, ae, score, matches, aligned_len, full_len; };
+
+__device__ __forceinline__ Rec load_rec(const int32_t *base, int64_t idx)
+{
+    const int4 a = ((const int4 *)(base + idx * TRACE_OUT_INTS))[0];
+    const int4 b = ((const int4 *)(base + idx * TRACE_OUT_INTS))[1];
+    return {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+}
+
+__device__ __forceinline__ double identity(int matches, int len)
+{
+    const double x = (100.0 * (double)matches) / (double)len;      // 0/0 -> NaN: compares false, like Python's nan
+    return rint(x * 1e6) / 1e6;
+}
+
+__device__ __forceinline__ double full_identity(const Rec &r)
+{
+    return r.rs == -1 ? 0.0 : identity(r.matches, r.full_len);
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(256) void reduce_kernel(ReduceArgs a)
+{
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= a.n) return;
+    // ---- trims: every job, in job order (the order is irrelevant to a max) -----------------
+    int start_trim = 0, end_trim = 0;
+    for (int j = 0; j < a.njobs; ++j) {
+        const Rec rec = load_rec(a.records, a.job_off[j] + r);
+        if (rec.rs == -1) continue;
+        const double partial = identity(rec.matches, rec.aligned_len);
+        const int rs = rec.rs, re = rec.re + 1;
+        if (!(partial > a.end_threshold) || re - rs < a.min_trim_size) continue;
+        if (a.job_side[j] == 0) {
+            if (re != a.end_size) { const int t = re + a.extra_end_trim; start_trim = t > start_trim ? t : start_trim; }
+        } else {
+            if (rs != 0) { const int t = (a.end_size - rs) + a.extra_end_trim; end_trim = t > end_trim ? t : end_trim; }
+        }
+    }
+    a.start_trim[r] = start_trim;
+    a.end_trim[r] = end_trim;
+    if (a.nbins <= 0 || !a.call) return;
+
+    // ---- barcode call ------------------------------------------------------------------------
+    // bin k has a start entry (job bin_start[k]) and an end entry (job bin_end[k]); a missing entry
+    // scores 0.0.  Python sorts (name, score) lists with a stable descending sort: among equal
+    // scores the entry inserted first wins -- start entries before end entries, bins in order.
+    auto score_of = [&](const int32_t *jobs, int k) -> double {
+        const int j = jobs[k];
+        return j < 0 ? 0.0 : full_identity(load_rec(a.records, a.job_off[j] + r));
+    };
+    int call = -1;
+    if (a.require_two) {
+        // best and second best (the next entry of the sorted list) of each side
+        auto best_two = [&](const int32_t *jobs, int &bi, double &bv, double &second) {
+            bi = 0; bv = score_of(jobs, 0); second = -1.0;
+            for (int k = 1; k < a.nbins; ++k) {
+                const double v = score_of(jobs, k);
+                if (v > bv) { second = bv; bv = v; bi = k; }
+                else if (v > second) second = v;
+            }
+            if (a.nbins < 2) second = 0.0;
+        };
+        int si, ei; double sv, s2, ev, e2;
+        best_two(a.bin_start, si, sv, s2);
+        best_two(a.bin_end, ei, ev, e2);
+        if (sv >= a.barcode_threshold && ev >= a.barcode_threshold && sv >= s2 + a.barcode_diff && ev >= e2 + a.barcode_diff && si == ei)
+            call = si;
+    } else {
+        int bk = 0; double bv = score_of(a.bin_start, 0);
+        for (int k = 1; k < a.nbins; ++k) { const double v = score_of(a.bin_start, k); if (v > bv) { bv = v; bk = k; } }
+        for (int k = 0; k < a.nbins; ++k) { const double v = score_of(a.bin_end, k); if (v > bv) { bv = v; bk = k; } }
+        // second best: the best score among the OTHER bins (a bin keeps the better of its two entries)
+        double second = 0.0;
+        for (int k = 0; k < a.nbins; ++k) {
+            if (k == bk) continue;
+            const double s = score_of(a.bin_start, k), e = score_of(a.bin_end, k);
+            const double v = s > e ? s : e;
+            second = v > second ? v : second;
+        }
+        if (bv >= a.barcode_threshold && bv >= second + a.barcode_diff) call = bk;
+    }
+    a.call[r] = call;
+}
+
+int launch_reduce(const ReduceArgs &a, void *stream)
+{
+    if (a.n <= 0) return 0;
+    const unsigned grid = (unsigned)((a.n + 255) / 256);
+    hipLaunchKernelGGL(reduce_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+}  // namespace pck

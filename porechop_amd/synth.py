@@ -38,6 +38,7 @@ def _mutate(rng, seq, rate):
 
 
 def _pool(rng, seq, n, rate, trunc_side, width):
+    """n mutated (and, for adapters, sometimes outer-truncated) copies of seq, left-aligned in [n, width]."""
     arr = np.full((n, width), ord("A"), dtype=np.uint8)
     lens = np.zeros(n, dtype=np.int64)
     for i in range(n):
@@ -52,7 +53,13 @@ def _pool(rng, seq, n, rate, trunc_side, width):
 
 
 def make_reads(n_reads, read_len=8000, seed=1, start_frac=0.9, end_frac=0.5, chimera_frac=0.0,
-               start_adapter=Y_TOP, end_adapter=Y_BOTTOM, device="cuda", pool=4096):
+               start_adapter=Y_TOP, end_adapter=Y_BOTTOM, device="cuda", pool=4096,
+               barcodes_start=None, barcodes_end=None, barcode_rate=0.10):
+    """barcodes_start / barcodes_end: lists of equally many
+    sequences (the panel's BCb / BCb_rev, porechop/adapters.py:176-463).  Every read then draws
+    b ~ U{0..B-1} and carries a mutated copy of barcodes_start[b] between the start adapter (if it
+    has one) and the body, and of barcodes_end[b] between the body and the end adapter;
+    the drawn b is returned as `reads.truth_barcode` (int64 [n_reads])."""
     dev = torch.device(device)
     rng = random.Random(seed)
     g = torch.Generator(device=dev)
@@ -67,42 +74,68 @@ def make_reads(n_reads, read_len=8000, seed=1, start_frac=0.9, end_frac=0.5, chi
         arena[s:e] = acgt[r.long()]
     arena[total:] = ord("N")
     view = arena[:total].view(n_reads, read_len)
-    col = None
 
-    def paste(mask_frac, seq, rate, trunc_side, at_end):
-        nonlocal col
-        if mask_frac <= 0 or seq is None:
-            return
+    def instances(seq, rate, trunc_side, count=pool):
         width = len(seq) + 8
-        inst, lens = _pool(rng, seq, pool, rate, trunc_side, width)
-        inst = torch.from_numpy(inst).to(dev)
-        lens = torch.from_numpy(lens).to(dev)
-        sel = torch.nonzero(torch.rand(n_reads, device=dev, generator=g) < mask_frac).flatten()
-        k = torch.randint(0, pool, (sel.numel(),), device=dev, generator=g)
-        L = lens[k]
-        c = torch.arange(width, device=dev)
-        if not at_end:
-            rows = view[sel, :width]
-            m = c[None, :] < L[:, None]
-            rows[m] = inst[k][m]
-            view[sel, :width] = rows
-        else:
-            rows = view[sel, read_len - width:]
-            # right-aligned: instance byte i goes to column width - L + i
-            src = c[None, :] - (width - L)[:, None]
-            m = src >= 0
-            vals = torch.gather(inst[k], 1, torch.clamp(src, min=0))
-            rows[m] = vals[m]
-            view[sel, read_len - width:] = rows
+        inst, lens = _pool(rng, seq, count, rate, trunc_side, width)
+        return torch.from_numpy(inst).to(dev), torch.from_numpy(lens).to(dev), width
 
-    paste(start_frac, start_adapter, 0.10, "front", False)
-    paste(end_frac, end_adapter, 0.10, "back", True)
+    def paste(sel, inst_rows, L, dist, width, region, at_end):
+        """Write instance bytes into the first (at_end=False) / last (True) `region` columns of the
+        reads `sel`: instance row i occupies columns [dist_i, dist_i + L_i) counted from the read's
+        start, or -- at_end -- ends dist_i bases before the read's last base."""
+        if sel.numel() == 0:
+            return
+        c = torch.arange(region, device=dev)
+        rows = view[sel, read_len - region:] if at_end else view[sel, :region]
+        first = (region - dist - L) if at_end else dist
+        src = c[None, :] - first[:, None]
+        m = (src >= 0) & (src < L[:, None])
+        vals = torch.gather(inst_rows, 1, torch.clamp(src, min=0, max=width - 1))
+        rows[m] = vals[m]
+        if at_end:
+            view[sel, read_len - region:] = rows
+        else:
+            view[sel, :region] = rows
+
+    truth = None
+    for at_end, frac, seq, trunc, bcs in ((False, start_frac, start_adapter, "front", barcodes_start),
+                                          (True, end_frac, end_adapter, "back", barcodes_end)):
+        has_ad = torch.zeros(n_reads, dtype=torch.bool, device=dev)
+        La = torch.zeros(n_reads, dtype=torch.int64, device=dev)
+        ad = None
+        if frac > 0 and seq is not None:
+            inst, lens, width = instances(seq, 0.10, trunc)
+            has_ad = torch.rand(n_reads, device=dev, generator=g) < frac
+            k = torch.randint(0, pool, (n_reads,), device=dev, generator=g)
+            La = torch.where(has_ad, lens[k], La)
+            ad = (inst, lens, width, k)
+        if bcs:
+            nb = len(bcs)
+            per = 64                                        # mutated instances per barcode
+            if truth is None:
+                truth = torch.randint(0, nb, (n_reads,), device=dev, generator=g)
+            wb = max(len(b) for b in bcs) + 8
+            binst = torch.full((nb * per, wb), ord("A"), dtype=torch.uint8, device=dev)
+            blens = torch.zeros(nb * per, dtype=torch.int64, device=dev)
+            for b, bseq in enumerate(bcs):
+                i_, l_, w_ = instances(bseq, barcode_rate, None, per)
+                binst[b * per:(b + 1) * per, :w_] = i_
+                blens[b * per:(b + 1) * per] = l_
+            kb = truth * per + torch.randint(0, per, (n_reads,), device=dev, generator=g)
+            region = wb + (ad[2] if ad is not None else 0)
+            for s0 in range(0, n_reads, 1 << 18):           # bounded temporaries
+                sel = torch.arange(s0, min(n_reads, s0 + (1 << 18)), device=dev)
+                paste(sel, binst[kb[sel]], blens[kb[sel]], La[sel], wb, region, at_end)
+        if ad is not None:
+            inst, lens, width, k = ad
+            sel = torch.nonzero(has_ad).flatten()
+            for s0 in range(0, int(sel.numel()), 1 << 18):
+                ss = sel[s0:s0 + (1 << 18)]
+                paste(ss, inst[k[ss]], lens[k[ss]], torch.zeros_like(ss), width, width, at_end)
     if chimera_frac > 0 and start_adapter and end_adapter:
         junction = end_adapter + start_adapter
-        width = len(junction) + 8
-        inst, lens = _pool(rng, junction, pool, 0.05, None, width)
-        inst = torch.from_numpy(inst).to(dev)
-        lens = torch.from_numpy(lens).to(dev)
+        inst, lens, width = instances(junction, 0.05, None)
         sel = torch.nonzero(torch.rand(n_reads, device=dev, generator=g) < chimera_frac).flatten()
         k = torch.randint(0, pool, (sel.numel(),), device=dev, generator=g)
         lo, hi = read_len // 8, 7 * read_len // 8 - width
@@ -117,7 +150,9 @@ def make_reads(n_reads, read_len=8000, seed=1, start_frac=0.9, end_frac=0.5, chi
         view[sel] = tmp
     off = torch.arange(n_reads, device=dev, dtype=torch.int64) * read_len
     length = torch.full((n_reads,), read_len, dtype=torch.int32, device=dev)
-    return DeviceReads(arena, off, length)
+    reads = DeviceReads(arena, off, length)
+    reads.truth_barcode = truth
+    return reads
 
 
 def reads_from_strings(seqs, device="cuda"):

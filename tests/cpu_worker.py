@@ -20,12 +20,19 @@ class _Params:
         self.__dict__.update(d)
 
 
-def run_chunk(args):
-    seqs, sets, matching, params, want_ref = args
+def _backend(want_ref):
     from oracle.oracle import Oracle, Reference, REF_SO
+    return Reference() if (want_ref and os.path.isfile(REF_SO)) else Oracle()
+
+
+def run_chunk(args):
+    """Phases B + C of a chunk of reads -> (reads done, seconds, per-read results): one
+    (start_trim, end_trim, [(adapter, start, end), ...]) per read, so that the caller can compare
+    them with what the GPU produced for the same reads."""
+    seqs, sets, matching, params, want_ref = args[:5]
+    middle = args[5] if len(args) > 5 else True
     from tests import ref_pipeline
-    backend = Reference() if (want_ref and os.path.isfile(REF_SO)) else Oracle()
-    fn = backend.adapter_alignment
+    fn = _backend(want_ref).adapter_alignment
     sets = [_Set(*s) for s in sets]
     p = _Params(params)
     adapters = []
@@ -35,8 +42,26 @@ def run_chunk(args):
             adapters.append(s.start)
         if s.end is not None and (s.start is None or s.end[1] != s.start[1]):
             adapters.append(s.end)
+    out = []
     t0 = time.perf_counter()
     for seq in seqs:
         st, et = ref_pipeline.phase_b(fn, seq, sets, matching, p)
-        ref_pipeline.phase_c(fn, seq, st, et, adapters, p)
-    return len(seqs), time.perf_counter() - t0
+        hits = ref_pipeline.phase_c(fn, seq, st, et, adapters, p) if middle else []
+        out.append((st, et, [(a, rs, re) for a, rs, re, _ in hits]))
+    return len(seqs), time.perf_counter() - t0, out
+
+
+def run_chunk_barcodes(args):
+    """Phase B with barcode scores + the barcode call of a chunk of reads (demultiplexing run)
+    -> (reads done, seconds, [(start_trim, end_trim, bin name), ...])."""
+    seqs, sets, matching, params, want_ref, orientation, thr, diff, two = args
+    from tests import ref_pipeline
+    fn = _backend(want_ref).adapter_alignment
+    sets = [_Set(*s) for s in sets]
+    p = _Params(params)
+    out = []
+    t0 = time.perf_counter()
+    for seq in seqs:
+        st, et, ss, es = ref_pipeline.phase_b_barcodes(fn, seq, sets, matching, p, orientation)
+        out.append((st, et, ref_pipeline.determine_barcode(ss, es, thr, diff, two)))
+    return len(seqs), time.perf_counter() - t0, out

@@ -292,3 +292,77 @@ print("SPEC_OK")
     assert "SPEC_OK" in res.stdout, res.stdout[-2000:] + res.stderr[-3000:]
     assert "hiprtc" not in res.stderr, res.stderr[-2000:]
     assert res.stderr.count("specialised kernel R=") >= 6, res.stderr[-2000:]      # most schemes do specialise
+
+
+def test_fp16_and_int16_traced_kernels_agree(pa, oracle):
+    """The traced scan has two implementations of the same recurrence: packed fp16 (trace16_kernel,
+    the default wherever pc_bounds.h f16_plan says every value stays exact) and packed int16
+    (scan_kernel<R,PAD,true>, PC_DISABLE_F16=1).  The same batch -- end windows of every length and
+    alphabet against adapters of 1..72 bases under seven schemes, ragged dual-adapter tiles,
+    pass-2 windows of whole reads -- through both, each in a fresh process: identical digests, and
+    the fp16 run equal to the oracle."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import hashlib, random, sys
+sys.path.insert(0, ".")
+import numpy as np, torch
+import porechop_amd
+from oracle.oracle import Oracle
+from tests.golden_io import comparable
+from tests.pairgen import SCHEMES, random_case
+check = sys.argv[1] == "check"
+o = Oracle()
+rng = random.Random(20260925)
+h = hashlib.sha1()
+for sc in SCHEMES + [(20, -30, -25, -12)]:
+    cases = [random_case(rng, m=rng.choice([1, 7, 16, 22, 24, 24, 28, 28, 30, 33, 40, 47, 56, 63, 68, 72])) for _ in range(2500)]
+    cases += [random_case(rng, n=rng.choice([160, 200, 412, 700, 3000]), m=rng.choice([22, 24, 28, 33, 50, 68])) for _ in range(60)]
+    ads, idx, pairs = [], {}, []
+    for rd, ad in cases:
+        if ad not in idx:
+            idx[ad] = len(ads); ads.append(ad)
+        pairs.append((rd, idx[ad]))
+    al = porechop_amd.Aligner(ads, sc)
+    recs = al.align_pairs(pairs)
+    al.close()
+    h.update(recs.tobytes())
+    if check:
+        for (rd, ad), r in zip(cases, recs):
+            want = o.adapter_alignment(rd, ad, sc)
+            assert comparable(porechop_amd.format_result(r)) == comparable(want), (sc, rd, ad, want, porechop_amd.format_result(r))
+# dual-adapter one-stream tiles with ragged windows (device API), the phase-B shape
+ads = ["AATGTACTTCGTTCAGTTACGTATTGCT", "GCAATACGTAACTGAACGAAGT", "GGTTGTTTCTGTTGGTGCTGATATTGCTGGCGTCTGCTT", "AAGAAAGTTGTCGGTGTCTTTGTG"]
+reads = [random_case(rng, n=rng.choice([3, 40, 149, 150, 150, 150]), m=28)[0] for _ in range(1000)]
+for i in range(0, 1000, 2):
+    a = ads[(i // 2) % 4]
+    reads[i] = (a + reads[i])[:150] if i % 4 == 0 else (reads[i] + a)[-150:]
+arena = torch.from_numpy(np.frombuffer(("".join(reads)).encode() + b"N" * 64, dtype=np.uint8).copy()).cuda()
+lens = np.array([len(r) for r in reads], dtype=np.int32)
+offs = np.concatenate([[0], np.cumsum(lens[:-1].astype(np.int64))]).astype(np.int64)
+woff, wlen = torch.from_numpy(offs).cuda(), torch.from_numpy(lens).cuda()
+n = len(reads)
+al = porechop_amd.Aligner(ads)
+for (a, b) in [(0, 1), (2, 3), (1, -1)]:
+    out = torch.zeros((n * (2 if b >= 0 else 1), 8), dtype=torch.int32, device="cuda")
+    al.scan_device(arena, woff, wlen, [a], [0, n], 150, out, porechop_amd.MODE_TRACE, job_adapter_b=[b])
+    al.sync()
+    rec = out.cpu().numpy()
+    h.update(rec.tobytes())
+    if check:
+        for i, r in enumerate(reads):
+            assert porechop_amd.format_result(rec[i]) == o.adapter_alignment(r, ads[a]), (a, i)
+            if b >= 0:
+                assert porechop_amd.format_result(rec[n + i]) == o.adapter_alignment(r, ads[b]), (b, i)
+print("DIGEST", h.hexdigest(), porechop_amd.load_library().pc_trace_ops_x100(al._ctx))
+'''
+    outs = []
+    for extra, arg in (({}, "check"), ({"PC_DISABLE_F16": "1"}, "nocheck")):
+        res = subprocess.run([sys.executable, "-c", code, arg], capture_output=True, text=True, timeout=1200,
+                             env=dict(os.environ, **extra), cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        lines = [l for l in res.stdout.splitlines() if l.startswith("DIGEST")]
+        assert len(lines) == 1, res.stdout[-2000:] + res.stderr[-3000:]
+        outs.append(lines[0].split())
+    assert outs[0][1] == outs[1][1]
+    assert (outs[0][2], outs[1][2]) == ("1325", "2100")          # the two runs really took different kernels

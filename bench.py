@@ -97,7 +97,7 @@ def step_demux(pl, reads, n_check, opts):
     """BASELINE configs[2] (-b DIR): phase A, the barcode-kit choice (porechop.py:330-371), phase B
     with the barcode identities, determine_barcode (nanopore_read.py:399-466) for every read."""
     from porechop_amd import panel as rules
-    from porechop_amd.runner import _bin_names, call_barcodes
+    from porechop_amd.runner import barcode_bins
     bs, be = pl.phase_a(reads, torch.arange(min(n_check, reads.n), device=reads.off.device))
     matching = pl.matching_sets(bs, be)
     bsh, beh = bs.cpu().numpy(), be.cpu().numpy()
@@ -105,18 +105,8 @@ def step_demux(pl, reads, n_check, opts):
     orientation = rules.choose_barcoding_kit([pl.sets[i] for i in matching], lambda s: bsh[index_of[id(s)]],
                                              lambda s: beh[index_of[id(s)]])
     bc_sets = [i for i in matching if rules.is_barcode(pl.sets[i]) and rules.barcode_direction(pl.sets[i]) == orientation]
-    st, et, fulls = pl.phase_b(reads, matching, full_for=set(bc_sets))
-    names = _bin_names(pl, bc_sets)
-    col = {n: k for k, n in enumerate(names)}
-    zeros = torch.zeros(reads.n, dtype=torch.float64, device=reads.off.device)
-    s_cols, e_cols = [zeros] * len(names), [zeros] * len(names)
-    for i in bc_sets:
-        k = col[rules.barcode_name(pl.sets[i])]
-        if (i, 0) in fulls:
-            s_cols[k] = fulls[(i, 0)]
-        if (i, 1) in fulls:
-            e_cols[k] = fulls[(i, 1)]
-    calls = call_barcodes(names, torch.stack(s_cols, dim=1), torch.stack(e_cols, dim=1), opts)
+    names, bins = barcode_bins(pl, bc_sets)
+    st, et, calls = pl.phase_b_demux(reads, matching, bins, opts.barcode_threshold, opts.barcode_diff, opts.require_two_barcodes)
     return matching, orientation, names, st, et, calls
 
 
@@ -330,6 +320,49 @@ def leg_configs2(dev, args, workers):
     return out
 
 
+def leg_ragged(dev, args, workers, uniform_bp_per_s):
+    """The headline workload (configs[3] shape: phases A + B + C, 1 % chimeras) on a realistic length
+    distribution instead of exactly 8 000 bases per read: log-normal, mean 8 kb, sigma 0.6."""
+    from dataclasses import asdict
+    from porechop_amd.pipeline import Pipeline, ScanParams
+    from porechop_amd.synth import make_ragged_reads
+    from tests.cpu_worker import run_chunk
+    p = ScanParams()
+    pl = Pipeline(load_panel_sets(), p, device=dev)
+    n = args.reads
+    reads = make_ragged_reads(n, mean_len=args.read_len, sigma=0.6, min_len=20, seed=5, start_frac=0.9, end_frac=0.5,
+                              chimera_frac=args.chimera, device=dev)
+    bases = int(reads.length.to(torch.int64).sum().item())
+
+    def sync():
+        pl.aligner.sync()
+        torch.cuda.synchronize()
+    steps = max(1, min(args.steps, 5))
+    (matching, st, et, hits), dt = timed(lambda: one_step(pl, reads, p.check_reads, 1), steps, max(1, min(args.warmup, 2)), sync)
+    out = {"workload": "configs[3] shape on log-normal read lengths: %d reads, mean %d bp, sigma 0.6 (min %d, max %d bp), %.0f%% chimeras, "
+                       "phases A + B + C" % (n, args.read_len, int(reads.length.min()), int(reads.length.max()), args.chimera * 100),
+           "reads_per_s": n * steps / dt, "read_bp_per_s": bases * steps / dt, "ms_per_step": dt / steps * 1e3,
+           "bp_per_s_vs_uniform_lengths": bases * steps / dt / uniform_bp_per_s,
+           "middle_hits_per_step": int(hits.read.numel()), "matching_sets": [pl.sets[i].name for i in matching]}
+    if args.cpu_seconds > 0:
+        k = min(n, 512)
+        host = reads.arena[: int(reads.off[k - 1]) + int(reads.length[k - 1])].cpu().numpy().tobytes().decode("ascii")
+        offs, lens = reads.off[:k].cpu().tolist(), reads.length[:k].cpu().tolist()
+        seqs = [host[o:o + l] for o, l in zip(offs, lens)]
+        sets = [(s.name, s.start, s.end) for s in pl.sets]
+        done, dtc, res = cpu_sample(run_chunk, lambda c: (c, sets, matching, asdict(p), True), seqs, 1e9, workers)
+        got = {}
+        for r, a, s_, e_ in zip(hits.read.cpu().tolist(), hits.adapter.cpu().tolist(), hits.start.cpu().tolist(), hits.end.cpu().tolist()):
+            if r < done:
+                got.setdefault(r, []).append((a, s_, e_))
+        stl, etl = st[:done].cpu().tolist(), et[:done].cpu().tolist()
+        bad = [r for r in range(done) if (stl[r], etl[r], got.get(r, [])) != (res[r][0], res[r][1], list(res[r][2]))]
+        out["parity"] = {"checked": done, "mismatches": len(bad), "what": "start trim, end trim, middle hits per read",
+                         "first_mismatching_reads": bad[:8]}
+    pl.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -516,9 +549,12 @@ def main():
     if rank == 0:
         if world == 1 and not args.no_extra:
             also = {}
-            for name, leg in (("configs1", leg_configs1), ("configs2", leg_configs2)):
+            legs = (("configs1", lambda: leg_configs1(dev, args, host_cores())),
+                    ("configs2", lambda: leg_configs2(dev, args, host_cores())),
+                    ("ragged_lengths", lambda: leg_ragged(dev, args, host_cores(), out["read_bp_per_s"])))
+            for name, leg in legs:
                 try:
-                    also[name] = leg(dev, args, host_cores())
+                    also[name] = leg()
                 except Exception as e:   # an extra leg must never break the bench line
                     also[name] = {"failed": repr(e)}
                 torch.cuda.empty_cache()

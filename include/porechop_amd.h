@@ -144,6 +144,12 @@ int pc_phase_b_reduce(pc_ctx *ctx, const int32_t *d_records, int64_t n, int njob
                       double barcode_threshold, double barcode_diff, int require_two_barcodes,
                       int32_t *d_call, void *stream);
 
+/* Debug builds of the 16-bit kernels (PC_CHECK_RANGE=1: packed-fp16 traced kernel, row classes 24/28/30/40;
+ * PC_JIT_CHECK_RANGE=1: the run-time specialised score kernel) record the extremes of every DP value they
+ * hold, in the kernel's own offset coordinates; this returns them since the last call and resets.  The
+ * exactness argument needs |value| <= 2040 in the fp16 kernels and <= 32000 in the int16 ones. */
+int pc_debug_value_range(pc_ctx *ctx, int32_t *lo, int32_t *hi);
+
 /* Packed VALU operations per TWO DP cells, times 100, of the traced end-window kernel this context's
  * scoring scheme selects (2100: packed-int16 kernel; 1325: packed-fp16 kernel) -- the denominator
  * of the VALU roofline bench.py reports. */

@@ -135,6 +135,35 @@ class Aligner:
         check(self.lib.pc_get_timing(self._ctx, ctypes.c_void_p(s), ms, ln, pr), "pc_get_timing")
         return {k: (ms[i], ln[i], pr[i]) for i, k in enumerate(("score", "plan", "trace", "score_spec"))}
 
+    def phase_b_reduce(self, records, n, job_record_offset, job_side, end_size, min_trim_size, extra_end_trim,
+                       end_threshold, start_trim, end_trim, bins=None, barcode_threshold=0.0, barcode_diff=0.0,
+                       require_two=False, call=None, stream=None):
+        """Per-read reduction of end-window records on the device (pc_phase_b_reduce): records int32[*,8]
+        written by scan_device for len(job_side) jobs over the same n reads; start_trim / end_trim (and call,
+        when bins = [(start job or -1, end job or -1), ...] is given) are int32[n] CUDA tensors."""
+        import torch
+        assert records.is_cuda and start_trim.is_cuda and end_trim.is_cuda
+        assert records.dtype == torch.int32 and start_trim.dtype == torch.int32 and end_trim.dtype == torch.int32
+        off = np.ascontiguousarray(job_record_offset, dtype=np.int64)
+        side = np.ascontiguousarray(job_side, dtype=np.int32)
+        nb = 0 if bins is None else len(bins)
+        bs = np.ascontiguousarray([b[0] for b in bins] if nb else [0], dtype=np.int32)
+        be = np.ascontiguousarray([b[1] for b in bins] if nb else [0], dtype=np.int32)
+        if nb:
+            assert call is not None and call.is_cuda and call.dtype == torch.int32
+        s = stream if stream is not None else torch.cuda.current_stream().cuda_stream
+        check(self.lib.pc_phase_b_reduce(self._ctx, records.data_ptr(), int(n), len(side), off.ctypes.data, side.ctypes.data,
+                                         int(end_size), int(min_trim_size), int(extra_end_trim), float(end_threshold),
+                                         start_trim.data_ptr(), end_trim.data_ptr(), nb, bs.ctypes.data, be.ctypes.data,
+                                         float(barcode_threshold), float(barcode_diff), 1 if require_two else 0,
+                                         call.data_ptr() if nb else None, ctypes.c_void_p(s)), "pc_phase_b_reduce")
+
+    def debug_value_range(self):
+        """(lo, hi) of the DP values the range-checking kernel builds have held since the last call."""
+        lo, hi = ctypes.c_int32(), ctypes.c_int32()
+        check(self.lib.pc_debug_value_range(self._ctx, ctypes.byref(lo), ctypes.byref(hi)), "pc_debug_value_range")
+        return lo.value, hi.value
+
     def trace_ops_per_2_cells(self):
         """Packed VALU ops the traced end-window kernel spends per two DP cells (roofline reporting)."""
         return self.lib.pc_trace_ops_x100(self._ctx) / 100.0

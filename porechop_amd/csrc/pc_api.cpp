@@ -181,20 +181,50 @@ int build_tiles(pc_ctx *c, const int32_t *job_adapter, const int32_t *job_adapte
         const int m = c->ad_len[ad], mb = adb >= 0 ? c->ad_len[adb] : m;
         if (m <= 0 || mb <= 0) return PC_ERR_BAD_ARG;
         if (m > pcb::MAX_ADAPTER || mb > pcb::MAX_ADAPTER) return PC_ERR_ADAPTER_TOO_LONG;
-        bool pad = false;
-        int rows = pck::pick_rows(m, mb, &pad);           // 0 => generic LDS-state kernel
+        const int64_t ws = job_start[k], n = job_start[k + 1] - job_start[k];
+        if (n < 0) return PC_ERR_BAD_ARG;
         // the register variants run in drifting coordinates: linear-gap schemes (extension made
         // impossible, pc_bounds.h) and schemes whose gap extension is too large to drift in int16 take
         // the generic kernel
-        if (drift_period(c) < 64) { rows = 0; pad = true; }
+        const bool no_drift = drift_period(c) < 64;
+        auto group_of = [&](int ma, int mbb, int window, int *rows_out) -> std::vector<pck::Tile> & {
+            bool pad = false;
+            int rows = pck::pick_rows(ma, mbb, &pad);         // 0 => generic LDS-state kernel
+            if (no_drift) { rows = 0; pad = true; }
+            const bool two = (mode == PC_MODE_TWO_PASS) || (mode == PC_MODE_SCORE) || (mode == PC_MODE_AUTO && max_len > 2 * window + 64);
+            auto key = std::make_pair(rows * 2 + (pad ? 1 : 0), two ? 1 : 0);
+            group_window[key] = std::max(group_window[key], window);
+            *rows_out = rows;
+            return by_group[key];
+        };
+        // one adapter, two windows per lane (the halves read different streams)
+        auto emit_single = [&](int a1, int64_t out_base) {
+            const int m1 = c->ad_len[a1];
+            int rows;
+            auto &v = group_of(m1, m1, c->ad_window[a1], &rows);
+            for (int64_t s = 0; s < n; s += 128) {
+                pck::Tile t;
+                t.win_lo = ws + s; t.win_hi = ws + s + 64;
+                t.out_lo = out_base + s; t.out_hi = out_base + s + 64;
+                t.count_lo = (int32_t)std::min<int64_t>(64, n - s);
+                t.count_hi = (int32_t)std::max<int64_t>(0, std::min<int64_t>(64, n - s - 64));
+                t.adapter_lo = a1; t.adapter_hi = a1; t.rows = rows ? rows : m1; t.pad_ = 0;
+                v.push_back(t);
+            }
+        };
         const int window = std::max(c->ad_window[ad], adb >= 0 ? c->ad_window[adb] : 0);
-        bool two = (mode == PC_MODE_TWO_PASS) || (mode == PC_MODE_SCORE) || (mode == PC_MODE_AUTO && max_len > 2 * window + 64);
-        auto key = std::make_pair(rows * 2 + (pad ? 1 : 0), two ? 1 : 0);
-        auto &v = by_group[key];
-        group_window[key] = std::max(group_window[key], window);
-        const int64_t ws = job_start[k], n = job_start[k + 1] - job_start[k];
-        if (n < 0) return PC_ERR_BAD_ARG;
-        if (adb >= 0) {
+        const bool two_pass_job = (mode == PC_MODE_TWO_PASS) || (mode == PC_MODE_SCORE) || (mode == PC_MODE_AUTO && max_len > 2 * window + 64);
+        // A dual tile runs both halves with the longer adapter's rows and saves nothing but the second
+        // read stream -- which matters for whole reads (8 kB per window), not for 150-byte end windows:
+        // there, two adapters of different row classes cost fewer rows as two single-adapter jobs
+        // (same tile count, same output layout).
+        bool pa_ = false, pb_ = false;
+        static const bool no_split = [] { const char *e = getenv("PC_NO_SPLIT_DUAL"); return e && *e && *e != '0'; }();
+        const bool split_dual = adb >= 0 && !two_pass_job && !no_drift && !no_split &&
+                                pck::pick_rows(m, m, &pa_) != pck::pick_rows(mb, mb, &pb_);
+        if (adb >= 0 && !split_dual) {
+            int rows;
+            auto &v = group_of(m, mb, window, &rows);
             for (int64_t s = 0; s < n; s += 64) {
                 pck::Tile t;
                 t.win_lo = ws + s; t.win_hi = ws + s;
@@ -204,16 +234,12 @@ int build_tiles(pc_ctx *c, const int32_t *job_adapter, const int32_t *job_adapte
                 v.push_back(t);
             }
             out_pos += 2 * n;
+        } else if (adb >= 0) {
+            emit_single(ad, out_pos);
+            emit_single(adb, out_pos + n);
+            out_pos += 2 * n;
         } else {
-            for (int64_t s = 0; s < n; s += 128) {
-                pck::Tile t;
-                t.win_lo = ws + s; t.win_hi = ws + s + 64;
-                t.out_lo = out_pos + s; t.out_hi = out_pos + s + 64;
-                t.count_lo = (int32_t)std::min<int64_t>(64, n - s);
-                t.count_hi = (int32_t)std::max<int64_t>(0, std::min<int64_t>(64, n - s - 64));
-                t.adapter_lo = ad; t.adapter_hi = ad; t.rows = rows ? rows : m; t.pad_ = 0;
-                v.push_back(t);
-            }
+            emit_single(ad, out_pos);
             out_pos += n;
         }
     }
@@ -334,7 +360,10 @@ int launch_traced(const pc_ctx *c, pck::ScanArgs &a, const Group &g, int grid, h
     pcb::F16Plan fp;
     if (trace16_plan(c, g.rows, a.slab_cols, &fp)) {
         a.f16_cen = fp.cen; a.f16_max_cols = fp.max_cols;
-        static const int dbg = [] { const char *e = getenv("PC_DEBUG_TRACE"); return e ? atoi(e) : 0; }();
+        static const int dbg = [] {
+            const char *e = getenv("PC_DEBUG_TRACE"), *r = getenv("PC_CHECK_RANGE");
+            return (e ? atoi(e) : 0) | ((r && *r && *r != '0') ? 4 : 0);
+        }();
         a.debug = dbg;
         return pck::launch_trace16(a, g.rows, grid, stream);
     }
@@ -654,6 +683,18 @@ int pc_scan_device(pc_ctx *c, const void *d_arena, const int64_t *d_win_off, con
     return PC_OK;
 }
 
+int pc_debug_value_range(pc_ctx *c, int32_t *lo, int32_t *hi)
+{
+    if (!c || !lo || !hi) return PC_ERR_BAD_ARG;
+    (void)hipSetDevice(c->device);
+    HIP_TRY(hipDeviceSynchronize());
+    int32_t v[2] = {0, 0};
+    HIP_TRY(hipMemcpy(v, (char *)c->d_err.p + 16, 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemset((char *)c->d_err.p + 16, 0, 8));
+    *hi = v[0]; *lo = -v[1];
+    return PC_OK;
+}
+
 int pc_trace_ops_x100(pc_ctx *c)
 {
     if (!c) return 2100;
@@ -850,44 +891,80 @@ struct MemoKey {
     bool operator==(const MemoKey &o) const { return h1 == o.h1 && h2 == o.h2; }
 };
 struct MemoHash { size_t operator()(const MemoKey &k) const { return (size_t)(k.h1 ^ (k.h2 * 0x9E3779B97F4A7C15ull)); } };
-struct MemoVal { int32_t r[PC_RESULT_INTS]; };
+// A hit is only a hit if the entry's own record of what it was computed for agrees: both lengths and a
+// third, independently seeded 64-bit digest of (read bytes, adapter bytes, scores).  A collision of the
+// 128-bit map key alone therefore cannot hand back another pair's alignment: it is treated as a miss.
+struct MemoVal { int32_t r[PC_RESULT_INTS]; uint32_t n, m; uint64_t check; };
+struct FullKey { MemoKey key; uint32_t n, m; uint64_t check; };
 
 inline uint64_t mix64(uint64_t x) { x ^= x >> 33; x *= 0xff51afd7ed558ccdull; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull; x ^= x >> 33; return x; }
 
-MemoKey make_key(const char *rd, size_t n, const char *ad, size_t m, int a, int b, int o, int e)
+FullKey make_key(const char *rd, size_t n, const char *ad, size_t m, int a, int b, int o, int e)
 {
-    // two independent 64-bit hashes over (len, read bytes, adapter bytes, scores)
-    uint64_t h1 = 0xcbf29ce484222325ull ^ n, h2 = 0x9ae16a3b2f90404full + m;
+    // three independent 64-bit hashes over (len, read bytes, adapter bytes, scores)
+    uint64_t h1 = 0xcbf29ce484222325ull ^ n, h2 = 0x9ae16a3b2f90404full + m, h3 = 0x2545F4914F6CDD1Dull ^ (n * 0x9E3779B97F4A7C15ull) ^ m;
     auto feed = [&](const unsigned char *p, size_t len) {
         size_t i = 0;
         for (; i + 8 <= len; i += 8) {
             uint64_t w; memcpy(&w, p + i, 8);
             h1 = (h1 ^ w) * 0x100000001b3ull; h1 ^= h1 >> 29;
             h2 = mix64(h2 + w * 0x9E3779B97F4A7C15ull);
+            h3 = (h3 ^ (w * 0xD6E8FEB86659FD93ull)) * 0xA0761D6478BD642Full; h3 ^= h3 >> 32;
         }
         uint64_t w = 0; memcpy(&w, p + i, len - i);
         w |= (uint64_t)(len - i) << 56;
         h1 = (h1 ^ w) * 0x100000001b3ull; h1 ^= h1 >> 29;
         h2 = mix64(h2 + w * 0x9E3779B97F4A7C15ull);
+        h3 = (h3 ^ (w * 0xD6E8FEB86659FD93ull)) * 0xA0761D6478BD642Full; h3 ^= h3 >> 32;
     };
     feed((const unsigned char *)rd, n);
     feed((const unsigned char *)ad, m);
-    const uint64_t sc = ((uint64_t)(uint16_t)a << 48) | ((uint64_t)(uint16_t)b << 32) | ((uint64_t)(uint16_t)o << 16) | (uint16_t)e;
-    h1 = mix64(h1 ^ sc); h2 = mix64(h2 + sc);
-    return {h1, h2};
+    // the four scores in full (int32 each), not truncated
+    const uint64_t s1 = ((uint64_t)(uint32_t)a << 32) | (uint32_t)b, s2 = ((uint64_t)(uint32_t)o << 32) | (uint32_t)e;
+    h1 = mix64(mix64(h1 ^ s1) + s2); h2 = mix64(mix64(h2 + s1) ^ s2); h3 = mix64(mix64(h3 ^ s2) + s1);
+    return {{h1, h2}, (uint32_t)n, (uint32_t)m, h3};
 }
 
 struct Global {
-    std::mutex mu;
+    std::mutex mu;        // the memo and the adapter interning tables
+    std::mutex gpu_mu;    // the default context (scores, panel, launches); always taken BEFORE mu, never after
     pc_ctx *ctx = nullptr;
     std::unordered_map<std::string, int> ad_index;
     std::vector<std::string> ad_list;
     std::unordered_map<MemoKey, MemoVal, MemoHash> memo;
-    int64_t hits = 0, misses = 0;
+    int64_t hits = 0, misses = 0, rejected = 0;
+    size_t max_entries = 0;
 };
-Global &G() { static Global g; return g; }
+Global &G()
+{
+    static Global g;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        // bounded: ~100 B per entry; when the bound is reached the memo starts over (an epoch clear --
+        // Porechop's phases query each (window, adapter) pair at most a few times, close together)
+        const char *e = getenv("PC_MEMO_MAX_ENTRIES");
+        g.max_entries = e ? (size_t)atoll(e) : (size_t)4 << 20;
+    });
+    return g;
+}
 
-// with G().mu held
+bool memo_lookup(Global &g, const FullKey &k, int32_t *rec)      // with g.mu held
+{
+    auto it = g.memo.find(k.key);
+    if (it == g.memo.end()) return false;
+    if (it->second.n != k.n || it->second.m != k.m || it->second.check != k.check) { ++g.rejected; return false; }
+    memcpy(rec, it->second.r, sizeof(it->second.r));
+    return true;
+}
+
+void memo_insert(Global &g, const FullKey &k, const int32_t *rec)   // with g.mu held
+{
+    if (g.max_entries && g.memo.size() >= g.max_entries) g.memo.clear();
+    MemoVal v; memcpy(v.r, rec, sizeof(v.r)); v.n = k.n; v.m = k.m; v.check = k.check;
+    g.memo[k.key] = v;
+}
+
+// with g.gpu_mu held
 int default_ctx(int a, int b, int o, int e, pc_ctx **out)
 {
     Global &g = G();
@@ -898,17 +975,21 @@ int default_ctx(int a, int b, int o, int e, pc_ctx **out)
     return PC_OK;
 }
 
+// with g.gpu_mu held
 int intern_adapters(const char *const *seqs, int n, std::vector<int> &idx)
 {
     Global &g = G();
     bool grew = false;
     idx.resize(n);
-    for (int i = 0; i < n; ++i) {
-        std::string s(seqs[i]);
-        if (s.size() > (size_t)PC_MAX_ADAPTER) return PC_ERR_ADAPTER_TOO_LONG;
-        auto it = g.ad_index.find(s);
-        if (it == g.ad_index.end()) { it = g.ad_index.emplace(s, (int)g.ad_list.size()).first; g.ad_list.push_back(s); grew = true; }
-        idx[i] = it->second;
+    {
+        std::lock_guard<std::mutex> lk(g.mu);
+        for (int i = 0; i < n; ++i) {
+            std::string s(seqs[i]);
+            if (s.size() > (size_t)PC_MAX_ADAPTER) return PC_ERR_ADAPTER_TOO_LONG;
+            auto it = g.ad_index.find(s);
+            if (it == g.ad_index.end()) { it = g.ad_index.emplace(s, (int)g.ad_list.size()).first; g.ad_list.push_back(s); grew = true; }
+            idx[i] = it->second;
+        }
     }
     if (grew || g.ctx->adapters.size() != g.ad_list.size()) {
         std::vector<const char *> ptrs;
@@ -929,7 +1010,7 @@ int pc_prefetch(const char *read_arena, int64_t arena_bytes, const int64_t *win_
     if (npairs <= 0) return PC_OK;
     if (!read_arena || !win_off || !win_len || !adapters || !adapter_idx) return PC_ERR_BAD_ARG;
     Global &g = G();
-    std::lock_guard<std::mutex> lk(g.mu);
+    std::lock_guard<std::mutex> gpu(g.gpu_mu);
     pc_ctx *c;
     int rc = default_ctx(match, mismatch, gap_open, gap_extend, &c);
     if (rc) return rc;
@@ -939,11 +1020,18 @@ int pc_prefetch(const char *read_arena, int64_t arena_bytes, const int64_t *win_
     if ((rc = intern_adapters(adapters, nad, gidx))) return rc;
     // skip what is already known
     std::vector<int64_t> todo;
-    std::vector<MemoKey> keys((size_t)npairs);
+    std::vector<FullKey> keys((size_t)npairs);
+    std::vector<size_t> ad_len((size_t)nad);
+    for (int i = 0; i < nad; ++i) ad_len[i] = strlen(adapters[i]);
     for (int64_t p = 0; p < npairs; ++p) {
         const char *ad = adapters[adapter_idx[p]];
-        keys[p] = make_key(read_arena + win_off[p], (size_t)win_len[p], ad, strlen(ad), match, mismatch, gap_open, gap_extend);
-        if (g.memo.find(keys[p]) == g.memo.end()) todo.push_back(p);
+        keys[p] = make_key(read_arena + win_off[p], (size_t)win_len[p], ad, ad_len[adapter_idx[p]], match, mismatch, gap_open, gap_extend);
+    }
+    {
+        std::lock_guard<std::mutex> lk(g.mu);
+        int32_t tmp[PC_RESULT_INTS];
+        for (int64_t p = 0; p < npairs; ++p)
+            if (!memo_lookup(g, keys[p], tmp)) todo.push_back(p);
     }
     if (todo.empty()) return PC_OK;
     std::vector<int64_t> off(todo.size());
@@ -952,10 +1040,8 @@ int pc_prefetch(const char *read_arena, int64_t arena_bytes, const int64_t *win_
     std::vector<int32_t> res(todo.size() * PC_RESULT_INTS);
     rc = pc_align_batch_host(c, read_arena, arena_bytes, off.data(), len.data(), aidx.data(), (int64_t)todo.size(), PC_MODE_AUTO, res.data());
     if (rc) return rc;
-    for (size_t i = 0; i < todo.size(); ++i) {
-        MemoVal v; memcpy(v.r, res.data() + i * PC_RESULT_INTS, sizeof(v.r));
-        g.memo[keys[todo[i]]] = v;
-    }
+    std::lock_guard<std::mutex> lk(g.mu);
+    for (size_t i = 0; i < todo.size(); ++i) memo_insert(g, keys[todo[i]], res.data() + i * PC_RESULT_INTS);
     return PC_OK;
 }
 
@@ -963,7 +1049,7 @@ void pc_memo_clear(void)
 {
     Global &g = G();
     std::lock_guard<std::mutex> lk(g.mu);
-    g.memo.clear(); g.hits = g.misses = 0;
+    g.memo.clear(); g.hits = g.misses = g.rejected = 0;
 }
 
 void pc_memo_stats(int64_t *hits, int64_t *misses, int64_t *entries)
@@ -982,34 +1068,41 @@ char *adapterAlignment(char *readSeq, char *adapterSeq, int matchScore, int mism
     const size_t n = strlen(readSeq), m = strlen(adapterSeq);
     int32_t rec[PC_RESULT_INTS];
     Global &g = G();
+    const FullKey key = make_key(readSeq, n, adapterSeq, m, matchScore, mismatchScore, gapOpenScore, gapExtensionScore);
+    bool hit;
     {
+        // hits never wait for the GPU: Porechop calls this from --threads Python threads at once
+        // (porechop.py:309-322) and only the memo lookup is under the shared lock
         std::lock_guard<std::mutex> lk(g.mu);
-        const MemoKey key = make_key(readSeq, n, adapterSeq, m, matchScore, mismatchScore, gapOpenScore, gapExtensionScore);
-        auto it = g.memo.find(key);
-        if (it != g.memo.end()) {
-            ++g.hits;
-            memcpy(rec, it->second.r, sizeof(rec));
+        hit = memo_lookup(g, key, rec);
+        if (hit) ++g.hits; else ++g.misses;
+    }
+    if (!hit) {
+        if (n == 0 || m == 0) {
+            rec[0] = -1; rec[1] = 0; rec[2] = -1; rec[3] = 0; rec[4] = INT_MIN; rec[5] = rec[6] = rec[7] = 0;
         } else {
-            ++g.misses;
-            if (n == 0 || m == 0) {
-                rec[0] = -1; rec[1] = 0; rec[2] = -1; rec[3] = 0; rec[4] = INT_MIN; rec[5] = rec[6] = rec[7] = 0;
-            } else {
-                pc_ctx *c;
-                int rc = default_ctx(matchScore, mismatchScore, gapOpenScore, gapExtensionScore, &c);
-                std::vector<int> gidx;
-                const char *ads[1] = {adapterSeq};
-                if (!rc) rc = intern_adapters(ads, 1, gidx);
-                const int64_t off = 0; const int32_t len = (int32_t)n, aidx = rc ? 0 : gidx[0];
-                if (!rc) rc = pc_align_batch_host(c, readSeq, (int64_t)n, &off, &len, &aidx, 1, PC_MODE_AUTO, rec);
-                if (rc) {
-                    fprintf(stderr, "porechop_amd: adapterAlignment failed: %s (scores %d,%d,%d,%d)\n", pc_strerror(rc),
-                            matchScore, mismatchScore, gapOpenScore, gapExtensionScore);
-                    return nullptr;
-                }
+            // a single-pair launch; misses queue up behind one another on the context, not behind hits
+            std::lock_guard<std::mutex> gpu(g.gpu_mu);
+            pc_ctx *c;
+            int rc = default_ctx(matchScore, mismatchScore, gapOpenScore, gapExtensionScore, &c);
+            std::vector<int> gidx;
+            const char *ads[1] = {adapterSeq};
+            if (!rc) rc = intern_adapters(ads, 1, gidx);
+            const int64_t off = 0; const int32_t len = (int32_t)n, aidx = rc ? 0 : gidx[0];
+            if (!rc) rc = pc_align_batch_host(c, readSeq, (int64_t)n, &off, &len, &aidx, 1, PC_MODE_AUTO, rec);
+            if (rc) {
+                // The reference accepts any scheme and any adapter length; this library refuses what it
+                // cannot compute exactly.  The unchanged Python wrapper dereferences the NULL below
+                // (cpp_function_wrappers.py:56-63), so say clearly why before it does.
+                fprintf(stderr, "porechop_amd: adapterAlignment cannot be computed on the GPU: %s (scores %d,%d,%d,%d; adapter of %zu bases, "
+                                "limit %d).  Supported: match > 0, match > mismatch, negative gap scores within the 16-bit range "
+                                "(pc_scores_supported), adapters up to %d bases, a visible MI355X.  Returning NULL.\n",
+                        pc_strerror(rc), matchScore, mismatchScore, gapOpenScore, gapExtensionScore, m, PC_MAX_ADAPTER, PC_MAX_ADAPTER);
+                return nullptr;
             }
-            MemoVal v; memcpy(v.r, rec, sizeof(rec));
-            g.memo[key] = v;
         }
+        std::lock_guard<std::mutex> lk(g.mu);
+        memo_insert(g, key, rec);
     }
     char *buf = (char *)malloc(160);
     if (!buf) return nullptr;

@@ -38,7 +38,7 @@ namespace pcj {
 
 // defines prepended by pc_jit.cpp: PC_R, PC_K (multiple of 4), PC_COMBO_INIT (R comma-separated
 // ints), PC_F16, PC_EPS (= -gap_extend), PC_OE (= gap_open + PC_EPS), PC_CEN (C), PC_KREN,
-// PC_WAVES (resident waves per SIMD the register allocation must allow)
+// PC_WAVES (resident waves per SIMD the register allocation must allow), PC_CHECK_RANGE (0/1)
 static const char *kSpecSource = R"PCJIT(
 typedef unsigned int u32;
 typedef long long i64;
@@ -52,6 +52,7 @@ __device__ __forceinline__ u32 pack2x(int l, int h) { const h16x2 v = {(_Float16
 __device__ __forceinline__ int lo16(u32 x) { return (int)(float)SV(x).x; }
 __device__ __forceinline__ int hi16(u32 x) { return (int)(float)SV(x).y; }
 #define PC_NEGBITS 0xFC00FC00u
+#define PC_POSBITS 0x7C007C00u
 #define PC_ADD "v_pk_add_f16"
 #define PC_MAX "v_pk_max_f16"
 #else
@@ -62,12 +63,14 @@ __device__ __forceinline__ u32 pack2x(int l, int h) { return ((u32)l & 0xFFFFu) 
 __device__ __forceinline__ int lo16(u32 x) { return (int)(short)(x & 0xFFFFu); }
 __device__ __forceinline__ int hi16(u32 x) { return (int)(short)(x >> 16); }
 #define PC_NEGBITS 0x80008000u
+#define PC_POSBITS 0x7FFF7FFFu
 #define PC_ADD "v_pk_add_u16"
 #define PC_MAX "v_pk_max_i16"
 #endif
 __device__ __forceinline__ u32 pk_add(u32 a, u32 b) { return WV(SV(a) + SV(b)); }
 __device__ __forceinline__ u32 pk_sub(u32 a, u32 b) { return WV(SV(a) - SV(b)); }
 __device__ __forceinline__ u32 pk_max(u32 a, u32 b) { return WV(__builtin_elementwise_max(SV(a), SV(b))); }
+__device__ __forceinline__ u32 pk_min(u32 a, u32 b) { return WV(__builtin_elementwise_min(SV(a), SV(b))); }
 __device__ __forceinline__ u32 pack2(int v) { return pack2x(v, v); }
 // packed "best so far" in the tracked-score domain (score + R*eps); the chunk>0 sentinel maps to -inf
 __device__ __forceinline__ u32 packbest(int l, int h)
@@ -445,6 +448,15 @@ extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P
 #undef PC_PAIR_FULL
 #undef PC_PAIR_ATAIL
         };
+#if PC_CHECK_RANGE
+        // debug build (PC_JIT_CHECK_RANGE=1): every column takes the one-column path and the extremes of
+        // every T / U held after it are recorded -- the host-side range gate (pc_jit.cpp) asserted on the device
+        u32 vmax = PC_NEGBITS, vmin = PC_POSBITS;
+        auto note_range = [&]() {
+#pragma clang loop unroll(full)
+            for (int r = 0; r < R; ++r) { vmax = pk_max(vmax, pk_max(T[r], U[r])); vmin = pk_min(vmin, T[r]); }
+        };
+#endif
         u32 cur_lo = load_dw(w_lo, n_lo, 0), cur_hi = one_stream ? 0u : load_dw(w_hi, n_hi, 0);
         u32 nxt_lo = load_dw(w_lo, n_lo, 4), nxt_hi = one_stream ? 0u : load_dw(w_hi, n_hi, 4);
         u32 SA[K], SB[K], SC[K], SD[K];
@@ -458,7 +470,7 @@ extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P
                 top = pk_sub(top, DK);
                 jj = 0;
             }
-            if (j0 > tfmax && j0 + 3 < nmin) {
+            if (!PC_CHECK_RANGE && j0 > tfmax && j0 + 3 < nmin) {
                 u32 c0, c1, c2, c3;
                 fetch_S(SB, (cur_lo >> 8) & 0xFF, (cur_hi >> 8) & 0xFF);
                 fetch_S(SC, (cur_lo >> 16) & 0xFF, (cur_hi >> 16) & 0xFF);
@@ -479,14 +491,19 @@ extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P
                     best2 = nb;
                 }
             } else {
+#if PC_CHECK_RANGE
+#define PC_NOTE note_range();
+#else
+#define PC_NOTE
+#endif
                 fetch_S(SB, (cur_lo >> 8) & 0xFF, (cur_hi >> 8) & 0xFF);
-                column(SlowT{}, j0, SA);
+                column(SlowT{}, j0, SA); PC_NOTE
                 fetch_S(SA, (cur_lo >> 16) & 0xFF, (cur_hi >> 16) & 0xFF);
-                column(SlowT{}, j0 + 1, SB);
+                column(SlowT{}, j0 + 1, SB); PC_NOTE
                 fetch_S(SB, cur_lo >> 24, cur_hi >> 24);
-                column(SlowT{}, j0 + 2, SA);
+                column(SlowT{}, j0 + 2, SA); PC_NOTE
                 fetch_S(SA, nxt_lo & 0xFF, nxt_hi & 0xFF);
-                column(SlowT{}, j0 + 3, SB);
+                column(SlowT{}, j0 + 3, SB); PC_NOTE
                 best2 = packbest(bs_lo, bs_hi);
             }
             jj += 4;
@@ -494,6 +511,17 @@ extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P
             nxt_lo = load_dw(w_lo, n_lo, j0 + 7);
             if (!one_stream) nxt_hi = load_dw(w_hi, n_hi, j0 + 7);
         }
+#if PC_CHECK_RANGE
+        {
+            const int hi = lo16(vmax) > hi16(vmax) ? lo16(vmax) : hi16(vmax);
+            const int lo = lo16(vmin) < hi16(vmin) ? lo16(vmin) : hi16(vmin);
+            if (have_lo || have_hi) {
+                atomicMax((int *)a.err + 4, hi); atomicMax((int *)a.err + 5, -lo);
+                // the on-device assertion: outside what the lane type holds exactly -> the launch is reported as failed
+                if (hi > (PC_F16 ? 2040 : 32000) || -lo > (PC_F16 ? 2040 : 32000)) atomicAdd(a.err, 1u);
+            }
+        }
+#endif
         if (have_lo) { int4 o = {bs_lo, bi_lo, bj_lo + c0_lo, 0}; *(int4 *)(a.out + (p_lo * nchunks + chunk) * 4) = o; }
         if (have_hi) { int4 o = {bs_hi, bi_hi, bj_hi + c0_hi, 0}; *(int4 *)(a.out + (p_hi * nchunks + chunk) * 4) = o; }
     }

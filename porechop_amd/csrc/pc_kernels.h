@@ -47,7 +47,7 @@ struct ScanArgs {
     int32_t chunks, chunk_len;       // score-only pass: column chunks per tile (1 = whole window) and their length
     const int32_t *ad_span;          // [nadapters] warm-up columns (SPAN) for chunked passes
     const int32_t *ad_window;        // [nadapters] W + SPAN + 1 (pass-2 windows; W = window - SPAN - 1)
-    int32_t debug;                   // timing experiments only (PC_DEBUG_TRACE): 1 = no traceback, 2 = no slab stores
+    int32_t debug;                   // PC_DEBUG_TRACE (timing experiments): 1 = no traceback, 2 = no slab stores; 4 = range-checking build (PC_CHECK_RANGE)
     int32_t f16_cen, f16_max_cols;   // packed-fp16 traced kernel: centring constant C and the columns it may run (pc_bounds.h f16_plan)
 };
 

@@ -182,49 +182,49 @@ __device__ __forceinline__ void column_step(u32 (&T)[R], u32 (&U)[R], u32 h2,
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ void traceback_pairs(const ScanArgs &a, const u32 *slab, const int rows, const int NW, const int lane,
                                                 const Best b_lo, const Best b_hi, const int pad_lo, const int pad_hi,
-                                                const uint8_t *w_lo, const uint8_t *w_hi, const u32 *codes_lo, const u32 *codes_hi,
                                                 const bool have_lo, const bool have_hi, const int n_lo, const int n_hi,
                                                 const int c0_lo, const int c0_hi, const int m_lo, const int m_hi,
                                                 const int64_t p_lo, const int64_t p_hi, const int notrace_upto)
 {
-    auto fetch = [&](int hf, int pad, const uint8_t *w, const u32 *codes, int col, int row, int &nib, bool &eq) {
+    // trace nibble of cell (col, adapter row) of half hf; the bases themselves are never needed
+    // (pc_walk.h derives the match count from the score)
+    auto fetch = [&](int hf, int pad, int col, int row) -> int {
         const int r = pad + row - 1;
         const int wq = r >> 2;
         const int rows_in_group = (rows - 4 * wq) < 4 ? (rows - 4 * wq) : 4;
         const int pos = rows_in_group - 1 - (r & 3);
         const u32 dw = slab[((int64_t)(col - 1) * NW + wq) * 64 + lane];
-        nib = (int)((dw >> (16 * hf + 4 * pos)) & 0xFu);
-        eq = dna5_code(w[col - 1]) == (int)codes[row - 1];
+        return (int)((dw >> (16 * hf + 4 * pos)) & 0xFu);
     };
     pcw::Walk wk_lo, wk_hi;
     const int nt_lo = a.n_total ? (have_lo ? a.n_total[p_lo] : 0) : n_lo;
     const int nt_hi = a.n_total ? (have_hi ? a.n_total[p_hi] : 0) : n_hi;
     // _correctTraceValue needs the end cell's nibble before the walk starts
-    auto tie_fix_of = [&](int hf, bool have, const Best &b, int pad, const uint8_t *w, const u32 *codes) -> int {
+    auto tie_fix_of = [&](int hf, bool have, const Best &b, int pad) -> int {
         if (!have || !(b.J > 0 && b.I > 0) || a.linear) return 0;
-        int nb; bool eq;
-        fetch(hf, pad, w, codes, b.J, b.I, nb, eq);
+        const int nb = fetch(hf, pad, b.J, b.I);
         return ((nb & pcw::NIB_NOTDIAG) || b.tie) ? ((nb & pcw::NIB_FROMH) ? 2 : 1) : 0;
     };
-    const int tiefix_lo = tie_fix_of(0, have_lo, b_lo, pad_lo, w_lo, codes_lo);
-    const int tiefix_hi = tie_fix_of(1, have_hi, b_hi, pad_hi, w_hi, codes_hi);
+    const int tiefix_lo = tie_fix_of(0, have_lo, b_lo, pad_lo);
+    const int tiefix_hi = tie_fix_of(1, have_hi, b_hi, pad_hi);
     wk_lo.start(b_lo.I, b_lo.J, m_lo, c0_lo, nt_lo, b_lo.score, tiefix_lo);
     wk_hi.start(b_hi.I, b_hi.J, m_hi, c0_hi, nt_hi, b_hi.score, tiefix_hi);
     if (!have_lo) wk_lo.done = 1;
     if (!have_hi) wk_hi.done = 1;
-    bool left_trace = false;
-    while (!wk_lo.done || !wk_hi.done) {
-        int nb_lo = 0, nb_hi = 0;
-        bool eq_lo = false, eq_hi = false;
-        const bool go_lo = !wk_lo.done, go_hi = !wk_hi.done;
-        // a walk that leaves the traced columns of a pass-2 window is stopped and flagged
-        // (never expected: the bound of pc_bounds.h)
-        if (go_lo && wk_lo.col <= notrace_upto) { left_trace = true; wk_lo.done = 1; }
-        else if (go_lo) fetch(0, pad_lo, w_lo, codes_lo, wk_lo.col, wk_lo.row, nb_lo, eq_lo);
-        if (go_hi && wk_hi.col <= notrace_upto) { left_trace = true; wk_hi.done = 1; }
-        else if (go_hi) fetch(1, pad_hi, w_hi, codes_hi, wk_hi.col, wk_hi.row, nb_hi, eq_hi);
-        if (go_lo && !wk_lo.done) wk_lo.consume(nb_lo, eq_lo);
-        if (go_hi && !wk_hi.done) wk_hi.consume(nb_hi, eq_hi);
+    int left_trace = 0;
+    while (!(wk_lo.done & wk_hi.done)) {
+        // a walk that leaves the traced columns of a pass-2 window is stopped and flagged (never
+        // expected: the bound of pc_bounds.h).  Both walks fetch every round -- a finished one from
+        // a clamped, valid cell -- and step under a predicate: no divergent branches in the loop.
+        int go_lo = wk_lo.done ^ 1, go_hi = wk_hi.done ^ 1;
+        const int out_lo = go_lo & (wk_lo.col <= notrace_upto ? 1 : 0), out_hi = go_hi & (wk_hi.col <= notrace_upto ? 1 : 0);
+        left_trace |= out_lo | out_hi;
+        wk_lo.done |= out_lo; wk_hi.done |= out_hi;
+        go_lo &= out_lo ^ 1; go_hi &= out_hi ^ 1;
+        const int nb_lo = fetch(0, pad_lo, wk_lo.col > 1 ? wk_lo.col : 1, wk_lo.row > 1 ? wk_lo.row : 1);
+        const int nb_hi = fetch(1, pad_hi, wk_hi.col > 1 ? wk_hi.col : 1, wk_hi.row > 1 ? wk_hi.row : 1);
+        wk_lo.step(nb_lo, go_lo);
+        wk_hi.step(nb_hi, go_hi);
     }
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf) {
@@ -234,7 +234,7 @@ __device__ __forceinline__ void traceback_pairs(const ScanArgs &a, const u32 *sl
         const Best b = hf ? b_hi : b_lo;
         const int64_t p = hf ? p_hi : p_lo;
         pcw::Digest dg;
-        int err = wk.finish(dg);
+        int err = wk.finish(dg, a.match, a.mismatch, a.gap_open, a.init_extend);
         if (a.force_score && a.force_score[p] != b.score) err = 1;
         if (left_trace) err = 1;
         if (err) atomicAdd(a.err, 1u);
@@ -558,7 +558,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((R > 0 && R 
             if (have_lo) { int4 o = {b_lo.score, b_lo.I, b_lo.J + c0_lo, 0}; *(int4 *)(a.out + (p_lo * nchunks + chunk) * SCORE_OUT_INTS) = o; }
             if (have_hi) { int4 o = {b_hi.score, b_hi.I, b_hi.J + c0_hi, 0}; *(int4 *)(a.out + (p_hi * nchunks + chunk) * SCORE_OUT_INTS) = o; }
         } else {
-            traceback_pairs(a, slab, rows, NW, lane, b_lo, b_hi, pad_lo, pad_hi, w_lo, w_hi, codes_lo, codes_hi,
+            traceback_pairs(a, slab, rows, NW, lane, b_lo, b_hi, pad_lo, pad_hi,
                             have_lo, have_hi, n_lo, n_hi, c0_lo, c0_hi, m_lo, m_hi, p_lo, p_hi, notrace_upto);
         }
     }
@@ -647,8 +647,11 @@ constexpr u32 H_NEGINF2 = 0xFC00FC00u, H_POSINF2 = 0x7C007C00u;
     PC_ACC0                                                         \
     PC_HADD "%[b3], %[mn], %[dr] neg_lo:[0,1] neg_hi:[0,1] clamp"
 
-template <int R>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(R <= 22 ? 4 : R <= 44 ? 3 : 2))) void trace16_kernel(ScanArgs a)
+// CHECK: debug build (PC_CHECK_RANGE=1, a few row classes): records the extremes of every T / U held after a
+// column into err[4] (max) and err[5] (-min) -- the host-side range gate (pc_bounds.h f16_plan) asserted on
+// the device; read with pc_debug_value_range.
+template <int R, bool CHECK = false>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(R <= 30 ? 4 : R <= 44 ? 3 : 2))) void trace16_kernel(ScanArgs a)
 {
     static_assert(R >= 4 && R % 2 == 0, "row classes are even");
     constexpr int RP = (R + 3) & ~3;         // table row padded to whole b128 groups
@@ -656,6 +659,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(R <= 22 ? 4 
     constexpr int NW = (R + 3) / 4;          // trace dwords per column per lane
     __shared__ uint16_t lut_lo[256], lut_hi[256];             // byte -> table row offset (dwords) of the lo / hi stream
     __shared__ __attribute__((aligned(16))) u32 s_tab[25 * STRIDE];
+    // per-lane state that only the rare paths touch (a new maximum, a pair's last column) lives in LDS
+    // during the column loop instead of in a dozen VGPRs: scout cells (score, I, J, tie) of both halves
+    // and the forced end rows
+    __shared__ int st_best[8][64], st_fr[2][64];
     uint2 *fin = (uint2 *)a.fin_scratch + (int64_t)blockIdx.x * R * 64;
     const int lane = threadIdx.x;
     for (int c = lane; c < 256; c += 64) {
@@ -708,8 +715,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(R <= 22 ? 4 
         const int n_hi = have_hi ? a.win_len[wi_hi] : 0;
         const int c0_lo = (have_lo && a.col0) ? a.col0[p_lo] : 0;
         const int c0_hi = (have_hi && a.col0) ? a.col0[p_hi] : 0;
-        const int fr_lo = (have_lo && a.force_row) ? a.force_row[p_lo] : -1;
-        const int fr_hi = (have_hi && a.force_row) ? a.force_row[p_hi] : -1;
+        {
+            const int fl = (have_lo && a.force_row) ? a.force_row[p_lo] : -1;
+            const int fh = (have_hi && a.force_row) ? a.force_row[p_hi] : -1;
+            st_fr[0][lane] = fl; st_fr[1][lane] = fh;
+            st_best[0][lane] = 0; st_best[1][lane] = m_lo; st_best[2][lane] = 0; st_best[3][lane] = 0;
+            st_best[4][lane] = 0; st_best[5][lane] = m_hi; st_best[6][lane] = 0; st_best[7][lane] = 0;
+        }
 
         // column 0 (see scan_kernel): M = 0, or the lower-bound state of an interior window start
         u32 T[R], U[R];
@@ -721,7 +733,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(R <= 22 ? 4 
             U[r] = NEG2;
         }
         u32 top = hpack2(a.gap_open + eps - CEN);                 // T~(0, j-1) entering column j
-        Best b_lo = {0, m_lo, 0, 0}, b_hi = {0, m_hi, 0, 0};
         // packed running maxima of the tracked last-row term  M(R,j) + R*eps  (what the fast check compares)
         u32 best2 = hpack2(R * eps);
 
@@ -746,15 +757,25 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(R <= 22 ? 4 
         // last-row cells are tracked in columns 1..n-1 of pairs that scout (no forced end cell):
         // +inf lets a half's candidate through, -inf blanks it
         auto track_limit = [&](int j) -> u32 {
-            const bool tl = fr_lo < 0 && j < n_lo, th = fr_hi < 0 && j < n_hi;
+            const bool tl = st_fr[0][lane] < 0 && j < n_lo, th = st_fr[1][lane] < 0 && j < n_hi;
             return (tl ? (H_POSINF2 & 0xFFFFu) : (H_NEGINF2 & 0xFFFFu)) | (th ? (H_POSINF2 & 0xFFFF0000u) : (H_NEGINF2 & 0xFFFF0000u));
         };
-        auto scan_row = [&](int r, int j, u32 Tn, bool tie_l, bool tie_h, bool fin_lo, bool fin_hi) {
+        u32 limit2 = track_limit(1);          // changes only in a column where some pair ends (any_fin below)
+        auto scan_row = [&](int r, int j, u32 Tn, bool tie_l, bool tie_h, bool fin_lo, bool fin_hi, Best &b_lo, Best &b_hi,
+                            int fr_lo, int fr_hi) {
             const int il = r - pad_lo + 1, ih = r - pad_hi + 1;
             const int off = a.gap_open + (r + 1 + j + 1) * eps - CEN;                  // T~ -> true M of this row
             const int cl = hlo(Tn) - off, ch = hhi(Tn) - off;
             if (fin_lo && il >= 1 && (fr_lo >= 0 ? (il == fr_lo) : (cl > b_lo.score))) { b_lo.score = cl; b_lo.I = il; b_lo.J = j; b_lo.tie = tie_l; }
             if (fin_hi && ih >= 1 && (fr_hi >= 0 ? (ih == fr_hi) : (ch > b_hi.score))) { b_hi.score = ch; b_hi.I = ih; b_hi.J = j; b_hi.tie = tie_h; }
+        };
+        auto load_best = [&](Best &b_lo, Best &b_hi) {
+            b_lo = {st_best[0][lane], st_best[1][lane], st_best[2][lane], st_best[3][lane]};
+            b_hi = {st_best[4][lane], st_best[5][lane], st_best[6][lane], st_best[7][lane]};
+        };
+        auto store_best = [&](const Best &b_lo, const Best &b_hi) {
+            st_best[0][lane] = b_lo.score; st_best[1][lane] = b_lo.I; st_best[2][lane] = b_lo.J; st_best[3][lane] = b_lo.tie;
+            st_best[4][lane] = b_hi.score; st_best[5][lane] = b_hi.I; st_best[6][lane] = b_hi.J; st_best[7][lane] = b_hi.tie;
         };
         auto load_dw = [&](const uint8_t *w, int n, int col) -> u32 {   // dword holding 0-based columns col..col+3
             const int k = (col < n) ? col : (n > 0 ? ((n - 1) & ~3) : 0);
@@ -766,6 +787,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(R <= 22 ? 4 
 
         u32 cur_lo = load_dw(w_lo, n_lo, 0), cur_hi = one_stream ? 0u : load_dw(w_hi, n_hi, 0);
         int trow = row_of(cur_lo & 0xFF, cur_hi & 0xFF);
+        u32 vmax = H_NEGINF2, vmin = H_POSINF2;
         for (int j = 1; j <= nmax; ++j) {
             const int trow_j = trow;
             // next column's bytes / table row, one column ahead of their use
@@ -775,6 +797,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(R <= 22 ? 4 
 
             const bool fin_lo = (j == n_lo), fin_hi = (j == n_hi);
             const bool any_fin = __any(fin_lo || fin_hi);
+            if (any_fin) limit2 = track_limit(j);
             if (any_fin && (fin_lo || fin_hi)) {
 #pragma clang loop unroll(full)
                 for (int r = 0; r < R; ++r) fin[lane * R + r] = make_uint2(T[r], U[r]);
@@ -865,18 +888,32 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(R <= 22 ? 4 
                 trace_dst[(pr >> 2) * 64] = wd;
             }
 
+            if constexpr (CHECK) {
+                // only while a pair still runs: a finished stream re-reads its last bytes and its state is never used
+                if (j <= (n_lo > n_hi ? n_lo : n_hi)) {
+#pragma clang loop unroll(full)
+                    for (int r = 0; r < R; ++r) { vmax = hk_max(vmax, hk_max(T[r], U[r])); vmin = hk_min(vmin, T[r]); }
+                }
+            }
             // ---- tracked cells ---------------------------------------------------------------
-            const u32 cand = hk_min(hk_sub(T[R - 1], topn), track_limit(j));     // M(R,j) + R*eps where tracked, else -inf
+            const u32 cand = hk_min(hk_sub(T[R - 1], topn), limit2);     // M(R,j) + R*eps where tracked, else -inf
             const u32 nb = hk_max(best2, cand);
             if (__any(nb != best2)) {
+                Best b_lo, b_hi;
+                load_best(b_lo, b_hi);
+                const int fr_lo = st_fr[0][lane], fr_hi = st_fr[1][lane];
                 const int cl = hlo(hk_sub(T[R - 1], topn)) - R * eps, ch = hhi(hk_sub(T[R - 1], topn)) - R * eps;
                 const u32 g = hk_max(h_last, v_last);
                 const bool tie_l = HV(d_last).x == HV(g).x, tie_h = HV(d_last).y == HV(g).y;      // d == max(H,V)
                 if (fr_lo < 0 && j < n_lo && cl > b_lo.score) { b_lo.score = cl; b_lo.I = m_lo; b_lo.J = j; b_lo.tie = tie_l; }
                 if (fr_hi < 0 && j < n_hi && ch > b_hi.score) { b_hi.score = ch; b_hi.I = m_hi; b_hi.J = j; b_hi.tie = tie_h; }
                 best2 = hpack2x(b_lo.score + R * eps, b_hi.score + R * eps);
+                store_best(b_lo, b_hi);
             }
             if (any_fin) {
+                Best b_lo, b_hi;
+                load_best(b_lo, b_hi);
+                const int fr_lo = st_fr[0][lane], fr_hi = st_fr[1][lane];
                 // a pair's last column: rolled re-run from the saved previous column, tracked cells top
                 // to bottom with strict '>' (dp_scout.h:165-179), plus every row's d == max(H,V) flag
                 u32 dq = top, Tu2 = topn, Vp2 = NEG2;
@@ -890,18 +927,28 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(R <= 22 ? 4 
                     const u32 g = hk_max(Hs, Vs);
                     const u32 Tn = hk_add(hk_max(d, g), OE2);
                     dq = old.x; Tu2 = Tn; Vp2 = Vs;
-                    scan_row(r, j, Tn, HV(d).x == HV(g).x, HV(d).y == HV(g).y, fin_lo, fin_hi);
+                    scan_row(r, j, Tn, HV(d).x == HV(g).x, HV(d).y == HV(g).y, fin_lo, fin_hi, b_lo, b_hi, fr_lo, fr_hi);
                 }
                 best2 = hpack2x(b_lo.score + R * eps, b_hi.score + R * eps);
+                store_best(b_lo, b_hi);
             }
             top = topn;
         }
+        if constexpr (CHECK) {
+            const int hi = hlo(vmax) > hhi(vmax) ? hlo(vmax) : hhi(vmax), lo = hlo(vmin) < hhi(vmin) ? hlo(vmin) : hhi(vmin);
+            if ((have_lo || have_hi) && nmax > 0) {
+                atomicMax((int *)a.err + 4, hi); atomicMax((int *)a.err + 5, -lo);
+                if (hi > pcb::kF16Limit || -lo > pcb::kF16Limit) atomicAdd(a.err, 1u);   // the on-device assertion
+            }
+        }
+        Best b_lo, b_hi;
+        load_best(b_lo, b_hi);
         if (a.debug & 1) {
             if (have_lo) a.out[p_lo * TRACE_OUT_INTS + 4] = b_lo.score;
             if (have_hi) a.out[p_hi * TRACE_OUT_INTS + 4] = b_hi.score;
             continue;
         }
-        traceback_pairs(a, slab, R, NW, lane, b_lo, b_hi, pad_lo, pad_hi, w_lo, w_hi, codes_lo, codes_hi,
+        traceback_pairs(a, slab, R, NW, lane, b_lo, b_hi, pad_lo, pad_hi,
                         have_lo, have_hi, n_lo, n_hi, c0_lo, c0_hi, m_lo, m_hi, p_lo, p_hi, notrace_upto);
     }
 }
@@ -989,6 +1036,11 @@ bool trace16_has(int rows)
 int launch_trace16(const ScanArgs &a, int rows, int grid, void *stream)
 {
     hipStream_t s = (hipStream_t)stream;
+    if (a.debug & 4) {      // range-checking build, where instantiated
+#define PC_T16C(RR) case RR: hipLaunchKernelGGL((trace16_kernel<RR, true>), dim3(grid), dim3(64), 0, s, a); return hipGetLastError() == hipSuccess ? 0 : -2;
+        switch (rows) { PC_T16C(24) PC_T16C(28) PC_T16C(30) PC_T16C(40) default: break; }
+#undef PC_T16C
+    }
 #define PC_T16(RR) case RR: hipLaunchKernelGGL((trace16_kernel<RR>), dim3(grid), dim3(64), 0, s, a); break;
     switch (rows) {
         PC_T16(16) PC_T16(20) PC_T16(22) PC_T16(24) PC_T16(26) PC_T16(28) PC_T16(30) PC_T16(32) PC_T16(34) PC_T16(36)

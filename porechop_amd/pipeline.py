@@ -96,6 +96,48 @@ def trimmed_interval(length, start_trim, end_trim):
     return s_pos, e_pos
 
 
+def call_barcodes(nbins: int, start_scores: torch.Tensor, end_scores: torch.Tensor, barcode_threshold: float,
+                  barcode_diff: float, require_two_barcodes: bool) -> np.ndarray:
+    """nanopore_read.py:399-466 for every read at once (torch formulation; the GPU product path runs
+    the same rules in pc_phase_b_reduce).
+
+    start_scores / end_scores are float64 [R, K]: the full-adapter identity of bin k's start / end
+    sequence (the reference's two dicts, in insertion order; bin names are distinct).
+    -> int64 [R] bin index, or -1 for 'none'.
+
+    Ties are resolved as Python's stable sorted(..., reverse=True) resolves them there: among equal
+    scores the entry inserted first wins, start entries before end entries."""
+    R, K = start_scores.shape
+    dev = start_scores.device
+    none = torch.full((R,), -1, dtype=torch.int64, device=dev)
+    if K == 0:
+        return none.cpu().numpy()       # best = ('none', 0.0): the call is 'none' whatever the thresholds
+
+    def best_two(x):
+        order = torch.sort(x, dim=1, descending=True, stable=True)
+        second = order.values[:, 1] if x.shape[1] >= 2 else torch.zeros(R, dtype=x.dtype, device=dev)
+        return order.indices[:, 0], order.values[:, 0], second
+
+    if require_two_barcodes:
+        si, sv, s2 = best_two(start_scores)
+        ei, ev, e2 = best_two(end_scores)
+        ok = (sv >= barcode_threshold) & (ev >= barcode_threshold) & \
+             (sv >= s2 + barcode_diff) & (ev >= e2 + barcode_diff)
+        ok &= si == ei                                             # start_end_match compares NAMES (distinct per bin)
+        call = torch.where(ok, si, none)
+    else:
+        both = torch.cat([start_scores, end_scores], dim=1)            # start entries first
+        bi, bv, _ = best_two(both)
+        bk = bi % K
+        # second best = best score among the OTHER names (each name keeps its best of start/end)
+        per_name = torch.maximum(start_scores, end_scores)
+        other = per_name.masked_fill(torch.arange(K, device=dev)[None, :] == bk[:, None], -1.0)
+        second = torch.clamp(other.max(dim=1).values, min=0.0)
+        ok = (bv >= barcode_threshold) & (bv >= second + barcode_diff)
+        call = torch.where(ok, bk, none)
+    return call.cpu().numpy()
+
+
 class Pipeline:
     def __init__(self, sets: List[AdapterSet], params: ScanParams = None, device=None, aligner=None):
         """aligner: an object with the Aligner interface.  The default -- and the only product
@@ -143,11 +185,27 @@ class Pipeline:
             return off, wl
         return off + (ln - wl).to(torch.int64), wl
 
-    def _scan_jobs(self, arena, jobs, mode, max_len):
+    def _scan_jobs(self, arena, jobs, mode, max_len, with_layout=False, sort_lengths=False):
         """jobs: list of (adapter_index, win_off int64[n], win_len int32[n]) -> list of [n,8] views.
 
         Jobs that scan the very same windows (same tensors) are fused two adapters at a time
-        (similar lengths together), so each window is streamed from HBM once per adapter PAIR."""
+        (similar lengths together), so each window is streamed from HBM once per adapter PAIR.
+
+        sort_lengths: whole-read scans of reads of different lengths.  A tile (64 or 128 consecutive
+        windows) runs as many columns as its longest window, so the windows of every job are handed
+        over longest first -- a tile then holds windows of nearly one length, and the specialised score
+        kernel stays on its block-resolved path -- and the records are put back in the caller's order."""
+        order_of = {}
+        if sort_lengths:
+            sorted_jobs = []
+            for j in jobs:
+                key = (id(j[1]), id(j[2]))
+                if key not in order_of:
+                    order = torch.argsort(j[2], descending=True, stable=True)
+                    order_of[key] = (order, j[1][order], j[2][order], j[1], j[2])   # keeps the originals alive (ids stay unique)
+                sorted_jobs.append((j[0], order_of[key][1], order_of[key][2]))
+            orders = [order_of[(id(j[1]), id(j[2]))][0] for j in jobs]
+            jobs = sorted_jobs
         groups = {}
         for k, j in enumerate(jobs):
             groups.setdefault((id(j[1]), id(j[2])), []).append(k)
@@ -173,12 +231,23 @@ class Pipeline:
                                      job_adapter_b=np.array([jobs[b][0] if b is not None else -1 for _, b in fused],
                                                             dtype=np.int32))
         res = [None] * len(jobs)
+        rec_off = [0] * len(jobs)
         for k, (a, b) in enumerate(fused):
             n = jobs[a][1].shape[0]
             o = int(ostarts[k])
-            res[a] = out[o:o + n]
+            res[a] = out[o:o + n]; rec_off[a] = o
             if b is not None:
-                res[b] = out[o + n:o + 2 * n]
+                res[b] = out[o + n:o + 2 * n]; rec_off[b] = o + n
+        if sort_lengths:
+            assert not with_layout
+            back = []
+            for r, order in zip(res, orders):
+                u = torch.empty_like(r)
+                u[order] = r
+                back.append(u)
+            return back
+        if with_layout:
+            return res, out, rec_off          # + the one tensor behind the views and each job's first record
         return res
 
     # ------------------------------------------------------------------------------------------
@@ -277,14 +346,7 @@ class Pipeline:
                 if "(full sequence)" not in s.name and best[i] >= self.p.adapter_threshold]
 
     # ------------------------------------------------------------------------------------------
-    def phase_b(self, reads: DeviceReads, matching: List[int], full_for=()):
-        """-> (start_trim[R], end_trim[R]) int32: nanopore_read.py:166-208 for every read.
-        full_for: set indices whose full-adapter identities are wanted too (barcode calling,
-        nanopore_read.py:185-187,206-208) -> third result {(set, side): float64[R]}, side 0 = start."""
-        R = reads.n
-        p = self.p
-        start_trim = torch.zeros(R, dtype=torch.int32, device=self.device)
-        end_trim = torch.zeros(R, dtype=torch.int32, device=self.device)
+    def _phase_b_jobs(self, reads, matching):
         so, sl = self._end_windows(reads, None, "start")
         eo, el = self._end_windows(reads, None, "end")
         jobs, where = [], []
@@ -294,9 +356,65 @@ class Pipeline:
                 jobs.append((self.seq_index[s.start[1]], so, sl)); where.append((0, si))
             if s.end is not None:
                 jobs.append((self.seq_index[s.end[1]], eo, el)); where.append((1, si))
+        return jobs, where
+
+    @property
+    def native_reduce(self):
+        """The per-read reduction of phase B runs as a library kernel (pc_phase_b_reduce) on the GPU;
+        an injected test aligner without it takes the equivalent torch formulation below."""
+        return hasattr(self.aligner, "phase_b_reduce")
+
+    def phase_b_demux(self, reads: DeviceReads, matching: List[int], bins, barcode_threshold, barcode_diff, require_two):
+        """Phase B of a demultiplexing run: trims + the barcode call of every read.
+        bins: one (start set index or None, end set index or None) per barcode bin, in the order the
+        reference inserts the names into its score dicts (nanopore_read.py:185-187,206-208)
+        -> (start_trim, end_trim int32[R], call: numpy int64[R], bin index or -1 = 'none')."""
+        R = reads.n
+        p = self.p
+        if not self.native_reduce:
+            full_for = {i for b in bins for i in b if i is not None}
+            out = self.phase_b(reads, matching, full_for=full_for)
+            fulls = out[2] if full_for else {}
+            zeros = torch.zeros(R, dtype=torch.float64, device=self.device)
+            S = [fulls.get((b[0], 0), zeros) if b[0] is not None else zeros for b in bins]
+            E = [fulls.get((b[1], 1), zeros) if b[1] is not None else zeros for b in bins]
+            S = torch.stack(S, dim=1) if bins else torch.zeros((R, 0), dtype=torch.float64, device=self.device)
+            E = torch.stack(E, dim=1) if bins else torch.zeros((R, 0), dtype=torch.float64, device=self.device)
+            return out[0], out[1], call_barcodes(len(bins), S, E, barcode_threshold, barcode_diff, require_two)
+        start_trim = torch.zeros(R, dtype=torch.int32, device=self.device)
+        end_trim = torch.zeros(R, dtype=torch.int32, device=self.device)
+        call = torch.full((R,), -1, dtype=torch.int32, device=self.device)
+        jobs, where = self._phase_b_jobs(reads, matching)
+        if jobs and R:
+            _, out, rec_off = self._scan_jobs(reads.arena, jobs, MODE_TRACE, p.end_size, with_layout=True)
+            job_of = {(si, side): k for k, (side, si) in enumerate(where)}
+            jb = [(job_of.get((b[0], 0), -1) if b[0] is not None else -1,
+                   job_of.get((b[1], 1), -1) if b[1] is not None else -1) for b in bins]
+            self.aligner.phase_b_reduce(out, R, rec_off, [w[0] for w in where], p.end_size, p.min_trim_size, p.extra_end_trim,
+                                        p.end_threshold, start_trim, end_trim, bins=jb if bins else None,
+                                        barcode_threshold=barcode_threshold, barcode_diff=barcode_diff,
+                                        require_two=require_two, call=call)
+            self.stats["pairs_end"] += sum(int(j[1].shape[0]) for j in jobs)
+        return start_trim, end_trim, call.to(torch.int64).cpu().numpy()
+
+    def phase_b(self, reads: DeviceReads, matching: List[int], full_for=()):
+        """-> (start_trim[R], end_trim[R]) int32: nanopore_read.py:166-208 for every read.
+        full_for: set indices whose full-adapter identities are wanted too (barcode calling,
+        nanopore_read.py:185-187,206-208) -> third result {(set, side): float64[R]}, side 0 = start."""
+        R = reads.n
+        p = self.p
+        start_trim = torch.zeros(R, dtype=torch.int32, device=self.device)
+        end_trim = torch.zeros(R, dtype=torch.int32, device=self.device)
+        jobs, where = self._phase_b_jobs(reads, matching)
         fulls = {}
         if not jobs:
             return (start_trim, end_trim, fulls) if full_for else (start_trim, end_trim)
+        if self.native_reduce and not full_for and R:
+            _, out, rec_off = self._scan_jobs(reads.arena, jobs, MODE_TRACE, p.end_size, with_layout=True)
+            self.aligner.phase_b_reduce(out, R, rec_off, [w[0] for w in where], p.end_size, p.min_trim_size, p.extra_end_trim,
+                                        p.end_threshold, start_trim, end_trim)
+            self.stats["pairs_end"] += sum(int(j[1].shape[0]) for j in jobs)
+            return start_trim, end_trim
         outs = self._scan_jobs(reads.arena, jobs, MODE_TRACE, p.end_size)
         for (side, si), rec in zip(where, outs):
             full, partial = _identities(rec)
@@ -363,7 +481,8 @@ class Pipeline:
         if live.numel() == 0:
             return empty
         loff, llen = toff[live], tlen[live]
-        max_len = int(llen.max().item())
+        mm = torch.stack([llen.max(), llen.min()]).cpu()
+        max_len, ragged = int(mm[0]), bool(mm[0] != mm[1])
         aidx = [self.seq_index[a[1]] for a in ads]
 
         def identity_of(rec):
@@ -374,7 +493,7 @@ class Pipeline:
         jobs0 = [(ai, loff, llen) for ai in aidx]
         bounds = [self.identity_score_bound(len(self.seqs[ai]), p.middle_threshold) for ai in aidx] if prove else None
         if prove and all(b is not None for b in bounds):
-            score = torch.stack(self._scan_jobs(reads.arena, jobs0, MODE_SCORE, max_len))[:, :, 4]      # [A, L]
+            score = torch.stack(self._scan_jobs(reads.arena, jobs0, MODE_SCORE, max_len, sort_lengths=ragged))[:, :, 4]      # [A, L]
             cand = torch.nonzero(score >= torch.tensor(bounds, device=dev)[:, None])                     # adapter-major
             counts = torch.bincount(cand[:, 0], minlength=A).cpu().numpy()
             L = int(live.numel())
@@ -386,14 +505,14 @@ class Pipeline:
                     pos += int(counts[a])
                     cjobs.append((aidx[a], loff[sel], llen[sel])); csel.append((a, sel))
             if cjobs:
-                for (a, sel), o in zip(csel, self._scan_jobs(reads.arena, cjobs, MODE_TWO_PASS, max_len)):
+                for (a, sel), o in zip(csel, self._scan_jobs(reads.arena, cjobs, MODE_TWO_PASS, max_len, sort_lengths=ragged)):
                     recs[a, sel] = o
             outs = [recs[a] for a in range(A)]
             # an all-zero record (rs = 0, lengths 0) is "not a hit" below: 0/0 identities are masked
             fulls = torch.stack([torch.nan_to_num(identity_of(rec), nan=0.0) for rec in outs])
             self.stats["pairs_middle_traced_after_proof"] = self.stats.get("pairs_middle_traced_after_proof", 0) + int(counts.sum())
         else:
-            outs = self._scan_jobs(reads.arena, jobs0, MODE_TWO_PASS, max_len)
+            outs = self._scan_jobs(reads.arena, jobs0, MODE_TWO_PASS, max_len, sort_lengths=ragged)
             fulls = torch.stack([identity_of(rec) for rec in outs])  # [A, L]
         hit0 = (fulls >= p.middle_threshold) & torch.stack([rec[:, 0] != -1 for rec in outs])
         d_sel = torch.nonzero(hit0.any(dim=0)).flatten()             # dirty reads (indices into live)
@@ -445,7 +564,8 @@ class Pipeline:
                 rounds += 1
                 a0 = int(ah.min().item())
                 o_act, l_act = d_off[act], dlen[act]
-                outs_r = self._scan_jobs(dirty.view(-1), [(aidx[a], o_act, l_act) for a in range(a0, A)], MODE_TWO_PASS, dmax)
+                outs_r = self._scan_jobs(dirty.view(-1), [(aidx[a], o_act, l_act) for a in range(a0, A)], MODE_TWO_PASS, dmax,
+                                         sort_lengths=ragged)
                 scheduled = (A - a0) * int(act.numel())
                 for a, o in zip(range(a0, A), outs_r):
                     rec_all[a, act] = o

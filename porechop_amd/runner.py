@@ -33,6 +33,7 @@ from . import panel as panel_rules
 from .distributed import gather_in_order, reduce_presence, shard_by_bases
 from .io import ReadSet
 from .pipeline import AdapterSet, DeviceReads, Pipeline, ScanParams, trimmed_interval
+from .pipeline import call_barcodes as _call_barcodes
 
 
 @dataclass
@@ -112,48 +113,24 @@ def _load(input_path, check_read_count):
 
 
 def call_barcodes(names: List[str], start_scores: torch.Tensor, end_scores: torch.Tensor, opts: Options) -> np.ndarray:
-    """nanopore_read.py:399-466 for every read at once.
+    """nanopore_read.py:399-466 for every read at once: see pipeline.call_barcodes (names[k] is bin k's name)."""
+    return _call_barcodes(len(names), start_scores, end_scores, opts.barcode_threshold, opts.barcode_diff,
+                          opts.require_two_barcodes)
 
-    names[k] is barcode k's bin name; start_scores / end_scores are float64 [R, K]: the full-adapter
-    identity of barcode k's start / end sequence (the reference's two dicts, in insertion order).
-    -> int64 [R] index into names, or -1 for 'none'.
 
-    Ties are resolved as Python's stable sorted(..., reverse=True) resolves them there: among equal
-    scores the entry inserted first wins, start entries before end entries."""
-    R, K = start_scores.shape
-    dev = start_scores.device
-    none = torch.full((R,), -1, dtype=torch.int64, device=dev)
-    if K == 0:
-        return none.cpu().numpy()       # best = ('none', 0.0): the call is 'none' whatever the thresholds
-
-    def best_two(x):
-        order = torch.sort(x, dim=1, descending=True, stable=True)
-        second = order.values[:, 1] if x.shape[1] >= 2 else torch.zeros(R, dtype=x.dtype, device=dev)
-        return order.indices[:, 0], order.values[:, 0], second
-
-    if opts.require_two_barcodes:
-        si, sv, s2 = best_two(start_scores)
-        ei, ev, e2 = best_two(end_scores)
-        ok = (sv >= opts.barcode_threshold) & (ev >= opts.barcode_threshold) & \
-             (sv >= s2 + opts.barcode_diff) & (ev >= e2 + opts.barcode_diff)
-        # start_end_match compares NAMES
-        name_id = {}
-        ids = torch.tensor([name_id.setdefault(n, len(name_id)) for n in names], device=dev)
-        ok &= ids[si] == ids[ei]
-        call = torch.where(ok, si, none)
-    else:
-        both = torch.cat([start_scores, end_scores], dim=1)            # start entries first
-        bi, bv, _ = best_two(both)
-        bk = bi % K
-        # second best = best score among the OTHER names (each name keeps its best of start/end)
-        name_id = {}
-        ids = torch.tensor([name_id.setdefault(n, len(name_id)) for n in names], device=dev)
-        per_name = torch.maximum(start_scores, end_scores)
-        other = per_name.masked_fill(ids[None, :] == ids[bk][:, None], -1.0)
-        second = torch.clamp(other.max(dim=1).values, min=0.0)
-        ok = (bv >= opts.barcode_threshold) & (bv >= second + opts.barcode_diff)
-        call = torch.where(ok, bk, none)
-    return call.cpu().numpy()
+def barcode_bins(pl, bc_sets):
+    """-> (bin names, [(start set, end set)] per bin).  The reference's two score dicts are keyed by bin
+    name: a later set with the same name overwrites the value but keeps the first insertion's position."""
+    names = _bin_names(pl, bc_sets)
+    col = {n: k for k, n in enumerate(names)}
+    bins = [[None, None] for _ in names]
+    for i in bc_sets:
+        k = col[panel_rules.barcode_name(pl.sets[i])]
+        if pl.sets[i].start is not None:
+            bins[k][0] = i
+        if pl.sets[i].end is not None:
+            bins[k][1] = i
+    return names, [tuple(b) for b in bins]
 
 
 def _bin_names(pl, bc_sets):
@@ -320,25 +297,12 @@ def run(input_path, output=None, barcode_dir=None, options: Options = None, devi
             check_barcodes = barcode_dir is not None
             bc_sets = [i for i in match_idx if check_barcodes and panel_rules.is_barcode(pl.sets[i])
                        and panel_rules.barcode_direction(pl.sets[i]) == orientation]
-            out_b = pl.phase_b(reads, match_idx, full_for=set(bc_sets))
-            start_trim, end_trim = out_b[0], out_b[1]
             if check_barcodes:
-                fulls = out_b[2] if bc_sets else {}
-                # the reference's two dicts are keyed by bin name: a later set with the same name
-                # overwrites the value but keeps the first insertion's position
-                names = _bin_names(pl, bc_sets)
-                col = {n: k for k, n in enumerate(names)}
-                zeros = torch.zeros(R, dtype=torch.float64, device=dev)
-                s_cols, e_cols = [zeros] * len(names), [zeros] * len(names)
-                for i in bc_sets:
-                    k = col[panel_rules.barcode_name(pl.sets[i])]
-                    if (i, 0) in fulls:
-                        s_cols[k] = fulls[(i, 0)]
-                    if (i, 1) in fulls:
-                        e_cols[k] = fulls[(i, 1)]
-                S = torch.stack(s_cols, dim=1) if names else torch.zeros((R, 0), dtype=torch.float64, device=dev)
-                E = torch.stack(e_cols, dim=1) if names else torch.zeros((R, 0), dtype=torch.float64, device=dev)
-                ci = call_barcodes(names, S, E, opts)
+                names, bins = barcode_bins(pl, bc_sets)
+                start_trim, end_trim, ci = pl.phase_b_demux(reads, match_idx, bins, opts.barcode_threshold, opts.barcode_diff,
+                                                            opts.require_two_barcodes)
+            else:
+                start_trim, end_trim = pl.phase_b(reads, match_idx)
             lap("phase_b", sync=True)
             # ---- phase C -------------------------------------------------------------------
             if not opts.no_split:

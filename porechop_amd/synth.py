@@ -155,6 +155,61 @@ def make_reads(n_reads, read_len=8000, seed=1, start_frac=0.9, end_frac=0.5, chi
     return reads
 
 
+def make_ragged_reads(n_reads, mean_len=8000, sigma=0.6, min_len=20, seed=1, start_frac=0.9, end_frac=0.5, chimera_frac=0.0,
+                      start_adapter=Y_TOP, end_adapter=Y_BOTTOM, device="cuda", pool=4096):
+    """Like make_reads, but with log-normal read lengths (mean mean_len, shape sigma, floor min_len): the
+    length distribution of a real nanopore run instead of exactly read_len bases per read.  Reads lie
+    back to back in one arena; adapter copies overwrite the first / last bases of reads long enough to
+    hold them, junctions go to a uniform position inside reads of at least 2 000 bases."""
+    dev = torch.device(device)
+    rng = random.Random(seed)
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    z = torch.randn(n_reads, device=dev, generator=g, dtype=torch.float64)
+    length = torch.clamp(torch.round(mean_len * torch.exp(sigma * z - 0.5 * sigma * sigma)), min=min_len).to(torch.int64)
+    off = torch.cumsum(length, 0) - length
+    total = int(length.sum().item())
+    arena = torch.empty(total + 64, dtype=torch.uint8, device=dev)
+    acgt = torch.tensor([65, 67, 71, 84], dtype=torch.uint8, device=dev)
+    chunk = 1 << 26
+    for s0 in range(0, total, chunk):
+        e0 = min(total, s0 + chunk)
+        arena[s0:e0] = acgt[torch.randint(0, 4, (e0 - s0,), dtype=torch.uint8, device=dev, generator=g).long()]
+    arena[total:] = ord("N")
+
+    def paste(frac, seq, rate, trunc, where):
+        if frac <= 0 or not seq:
+            return
+        width = len(seq) + 8
+        inst, lens = _pool(rng, seq, pool, rate, trunc, width)
+        inst, lens = torch.from_numpy(inst).to(dev), torch.from_numpy(lens).to(dev)
+        need = width if where != "middle" else 2000
+        sel = torch.nonzero((torch.rand(n_reads, device=dev, generator=g) < frac) & (length >= need)).flatten()
+        if sel.numel() == 0:
+            return
+        k = torch.randint(0, pool, (sel.numel(),), device=dev, generator=g)
+        L = lens[k]
+        if where == "start":
+            first = off[sel]
+        elif where == "end":
+            first = off[sel] + length[sel] - L
+        else:
+            u = torch.rand(sel.numel(), device=dev, generator=g, dtype=torch.float64)
+            lo = length[sel] // 8
+            hi = torch.clamp(7 * length[sel] // 8 - width, min=1)
+            first = off[sel] + lo + (u * torch.clamp(hi - lo, min=1).to(torch.float64)).to(torch.int64)
+        c = torch.arange(width, device=dev)
+        m = c[None, :] < L[:, None]
+        idx = first[:, None] + c[None, :]
+        arena[idx[m]] = inst[k][m]
+
+    paste(start_frac, start_adapter, 0.10, "front", "start")
+    paste(end_frac, end_adapter, 0.10, "back", "end")
+    if chimera_frac > 0 and start_adapter and end_adapter:
+        paste(chimera_frac, end_adapter + start_adapter, 0.05, None, "middle")
+    return DeviceReads(arena, off, length.to(torch.int32))
+
+
 def reads_from_strings(seqs, device="cuda"):
     """Upload Python strings the way NanoporeRead.__init__ normalises them
     (porechop/nanopore_read.py:26-31): upper-case, and U->T when U's outnumber T's."""

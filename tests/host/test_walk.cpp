@@ -94,7 +94,7 @@ static bool check(const std::string &rd, const std::string &ad, int a, int b, in
     };
     pcw::Digest dg;
     auto f = mk(dp, 0);
-    int err = pcw::walk(f.first, f.second, dp.bestI, dp.bestJ, m, 0, n, dp.bestM, tie_fix_of(dp, dp.bestI, dp.bestJ), dg);
+    int err = pcw::walk(f.first, f.second, dp.bestI, dp.bestJ, m, 0, n, dp.bestM, tie_fix_of(dp, dp.bestI, dp.bestJ), a, b, o, e, dg);
     auto same = [&](const pcw::Digest &x) {
         return x.read_start == R.read_start && x.read_end == R.read_end && x.adapter_start == R.adapter_start &&
                x.adapter_end == R.adapter_end && x.score == R.score && x.matches == R.aligned_matches &&
@@ -120,7 +120,7 @@ static bool check(const std::string &rd, const std::string &ad, int a, int b, in
         auto fw = mk(wd, c0);
         pcw::Digest dw;
         err = pcw::walk(fw.first, fw.second, dp.bestI, dp.bestJ - c0, m, c0, n, dp.bestM,
-                        tie_fix_of(wd, dp.bestI, dp.bestJ - c0), dw);
+                        tie_fix_of(wd, dp.bestI, dp.bestJ - c0), a, b, o, e, dw);
         if (err || !same(dw)) {
             printf("WINDOW MISMATCH err=%d c0=%d J=%d n=%d m=%d scores=%d,%d,%d,%d\n", err, c0, dp.bestJ, n, m, a, b, o, e);
             return false;

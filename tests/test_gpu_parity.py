@@ -282,16 +282,22 @@ while done < 10:
             assert porechop_amd.format_result(rec[i]) == o.adapter_alignment(r, ads[a], scores), (scores, a, i)
             if b >= 0:
                 assert porechop_amd.format_result(rec[n + i]) == o.adapter_alignment(r, ads[b], scores), (scores, b, i)
+    lo, hi = al.debug_value_range()
     al.close()
-    print("SCHEME", scores)
+    print("SCHEME", scores, "RANGE", lo, hi)
 print("SPEC_OK")
 '''
-    env = dict(os.environ, PC_JIT_MIN_CELLS="1", PC_JIT_VERBOSE="1")
+    # PC_JIT_CHECK_RANGE=1: the kernels are built with the on-device range assertion (every T / U held must
+    # stay within what fp16 / int16 represent exactly, else the launch fails); al.sync() above would raise
+    env = dict(os.environ, PC_JIT_MIN_CELLS="1", PC_JIT_VERBOSE="1", PC_JIT_CHECK_RANGE="1")
     res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=900,
                          cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert "SPEC_OK" in res.stdout, res.stdout[-2000:] + res.stderr[-3000:]
     assert "hiprtc" not in res.stderr, res.stderr[-2000:]
     assert res.stderr.count("specialised kernel R=") >= 6, res.stderr[-2000:]      # most schemes do specialise
+    ranges = [l.split("RANGE")[1].split() for l in res.stdout.splitlines() if l.startswith("SCHEME")]
+    assert len(ranges) == 10 and any(int(hi) > 500 for _, hi in ranges)           # the recorder really ran
+    assert all(-32000 <= int(lo) and int(hi) <= 32000 for lo, hi in ranges), ranges
 
 
 def test_fp16_and_int16_traced_kernels_agree(pa, oracle):
@@ -358,7 +364,8 @@ for (a, b) in [(0, 1), (2, 3), (1, -1)]:
 print("DIGEST", h.hexdigest(), porechop_amd.load_library().pc_trace_ops_x100(al._ctx))
 '''
     outs = []
-    for extra, arg in (({}, "check"), ({"PC_DISABLE_F16": "1"}, "nocheck")):
+    # PC_CHECK_RANGE=1: row classes 24/28/30/40 run the build with the on-device assertion |value| <= 2040
+    for extra, arg in (({"PC_CHECK_RANGE": "1"}, "check"), ({"PC_DISABLE_F16": "1"}, "nocheck")):
         res = subprocess.run([sys.executable, "-c", code, arg], capture_output=True, text=True, timeout=1200,
                              env=dict(os.environ, **extra), cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
         lines = [l for l in res.stdout.splitlines() if l.startswith("DIGEST")]

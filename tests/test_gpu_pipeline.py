@@ -138,3 +138,72 @@ def test_proven_middle_scan_on_gpu():
     assert (h0.rounds, h0.alignments) == (h1.rounds, h1.alignments)
     assert pl.stats["pairs_middle_traced_after_proof"] < 0.05 * 200_000 * len(pl.middle_adapters)
     pl.close()
+
+
+def test_ragged_lengths_and_demux_reduce_vs_reference_logic(oracle):
+    """A realistic length distribution (log-normal, 20 bp .. several kb, reads shorter than the end
+    windows included): whole-read scans run length-sorted and un-permuted (Pipeline._scan_jobs),
+    phase B is reduced by the library kernel (pc_phase_b_reduce) -- trims, and barcode calls under both
+    calling rules -- and everything must equal the reference's sequential per-read logic on the oracle."""
+    import torch
+    from porechop_amd.pipeline import DeviceReads, Pipeline, ScanParams
+    from porechop_amd.runner import barcode_bins
+    from porechop_amd import panel as rules
+    from porechop_amd.synth import make_ragged_reads
+
+    p = ScanParams()
+    pl = Pipeline(panel_sets(None), p)
+    assert pl.native_reduce
+    reads = make_ragged_reads(640, mean_len=1500, sigma=0.8, min_len=20, seed=12, start_frac=0.8, end_frac=0.6, chimera_frac=0.1,
+                              pool=128)
+    n = reads.n
+    assert int(reads.length.min()) < 150 and int(reads.length.max()) > 4000
+    host = reads.arena.cpu().numpy().tobytes().decode()
+    offs, lens = reads.off.cpu().tolist(), reads.length.cpu().tolist()
+    seqs = [host[o:o + l] for o, l in zip(offs, lens)]
+    bs, be = pl.phase_a(reads)
+    matching = pl.matching_sets(bs, be)
+    assert "SQK-NSK007" in [pl.sets[i].name for i in matching]
+    st, et = pl.phase_b(reads, matching)
+    hits = pl.phase_c(reads, st, et, matching)
+    pl.aligner.sync()
+    stl, etl = st.cpu().tolist(), et.cpu().tolist()
+    got = {}
+    for r, a, s, e in zip(hits.read.cpu().tolist(), hits.adapter.cpu().tolist(), hits.start.cpu().tolist(), hits.end.cpu().tolist()):
+        got.setdefault(r, []).append((a, s, e))
+    nh = 0
+    for r, seq in enumerate(seqs):
+        assert (stl[r], etl[r]) == ref_pipeline.phase_b(oracle.adapter_alignment, seq, pl.sets, matching, p), r
+        want = [(a, s, e) for a, s, e, _ in ref_pipeline.phase_c(oracle.adapter_alignment, seq, stl[r], etl[r], pl.middle_adapters, p)]
+        assert got.get(r, []) == want, r
+        nh += len(want)
+    assert nh >= 20
+
+    # demultiplexing reduce: plant forward barcodes on a subset, call with both rule sets
+    panel = load_panel()
+    fw = [i for i, s in enumerate(pl.sets) if s.name.startswith("Barcode ") and "(forward)" in s.name][:12]
+    rng = random.Random(3)
+    seqs2 = []
+    for i in range(320):
+        body = "".join(rng.choice("ACGT") for _ in range(rng.choice([30, 100, 400, 900])))
+        k = rng.randrange(len(fw))
+        k2 = k if rng.random() < 0.7 else rng.randrange(len(fw))
+        s5 = mutate(rng, pl.sets[fw[k]].start[1], rng.choice([0.0, 0.1, 0.2])) if rng.random() < 0.8 else ""
+        s3 = mutate(rng, pl.sets[fw[k2]].end[1], rng.choice([0.0, 0.1, 0.2])) if rng.random() < 0.8 else ""
+        seqs2.append(s5 + body + s3)
+    from porechop_amd.synth import reads_from_strings
+    dreads, norm = reads_from_strings(seqs2)
+    names, bins = barcode_bins(pl, fw)
+    for two in (False, True):
+        st2, et2, calls = pl.phase_b_demux(dreads, fw, bins, 75.0, 5.0, two)
+        pl.aligner.sync()
+        s2l, e2l = st2.cpu().tolist(), et2.cpu().tolist()
+        n_called = 0
+        for r, seq in enumerate(norm):
+            ws, we, ss, es = ref_pipeline.phase_b_barcodes(oracle.adapter_alignment, seq, pl.sets, fw, p, "forward")
+            want = ref_pipeline.determine_barcode(ss, es, 75.0, 5.0, two)
+            g = names[calls[r]] if calls[r] >= 0 else "none"
+            assert (s2l[r], e2l[r], g) == (ws, we, want), (two, r)
+            n_called += g != "none"
+        assert n_called >= 40
+    pl.close()

@@ -110,6 +110,14 @@ int pc_scan_device(pc_ctx *ctx, const void *d_arena, const int64_t *d_win_off,
                    const int32_t *job_adapter_b, const int64_t *job_start, int njobs, int max_len,
                    int mode, int32_t *d_out, void *stream);
 
+/* Load-balancing hint for the whole-read scans of the following pc_scan_device calls: the typical
+ * (mean) window length, when max_len is far above it -- real read sets are log-normal, the longest read
+ * tens of times the mean.  The score pass then cuts every window into column chunks about that long,
+ * hands them to the chip longest window first and lets workgroups draw further chunks as they finish,
+ * so a launch no longer lasts as long as its longest read.  0 (the default) = lengths are about uniform.
+ * Affects scheduling only, never results (the chunked pass is exact, pc_bounds.h). */
+int pc_set_length_hint(pc_ctx *ctx, int typical_len);
+
 /* Waits for `stream` and returns PC_ERR_INTERNAL if any kernel since the last pc_sync reported
  * an inconsistency. */
 int pc_sync(pc_ctx *ctx, void *stream);

@@ -121,6 +121,11 @@ class Aligner:
                                       int(max_len), mode, out.data_ptr(), ctypes.c_void_p(s)),
               "pc_scan_device")
 
+    def set_length_hint(self, typical_len):
+        """Typical window length of the following whole-read scans (0 = about uniform): load balancing of the
+        score pass only, never results (pc_set_length_hint)."""
+        check(self.lib.pc_set_length_hint(self._ctx, int(max(0, typical_len))), "pc_set_length_hint")
+
     def set_timing(self, enabled=True):
         check(self.lib.pc_set_timing(self._ctx, 1 if enabled else 0), "pc_set_timing")
 

@@ -53,7 +53,28 @@ struct Group {            // tiles that run in one launch
     bool two_pass;
     size_t tile_begin, tile_count;
     int max_window;       // for two-pass groups: slab columns needed by the traced window
+    std::vector<pck::TileRun> runs;   // the group's tiles, run by run (tile0 relative to tile_begin)
 };
+
+inline int64_t run_tiles(const pck::TileRun &r) { return r.dual ? (r.n + 63) / 64 : (r.n + 127) / 128; }
+// pairs in tiles [b, e) of a run
+inline int64_t run_pairs(const pck::TileRun &r, int64_t b, int64_t e)
+{
+    const int64_t w = r.dual ? 64 : 128;
+    const int64_t windows = std::min<int64_t>(r.n, w * e) - w * b;
+    return windows <= 0 ? 0 : (r.dual ? 2 * windows : windows);
+}
+// pairs in tiles [b, e) of a group
+inline int64_t group_pairs(const Group &g, size_t b, size_t e)
+{
+    int64_t np = 0;
+    for (const pck::TileRun &r : g.runs) {
+        const int64_t t0 = r.tile0, t1 = r.tile0 + run_tiles(r);
+        const int64_t lo = std::max<int64_t>(t0, (int64_t)b), hi = std::min<int64_t>(t1, (int64_t)e);
+        if (lo < hi) np += run_pairs(r, lo - t0, hi - t0);
+    }
+    return np;
+}
 
 }  // namespace
 
@@ -71,11 +92,15 @@ struct pc_ctx {
     DevBuf d_arena, d_woff, d_wlen, d_out;
     // pc_phase_b_reduce: job / bin tables (host copies stay alive until the next call's upload)
     DevBuf d_red;
+    // score pass: one work counter per launch (units beyond the grid are drawn from it)
+    DevBuf d_work;
+    int len_hint = 0;            // pc_set_length_hint
     std::vector<int64_t> red_off;
     std::vector<int32_t> red_tab;
-    // cached job table (bench loops repeat the same one: skip the re-upload)
-    std::vector<pck::Tile> tiles;
+    // cached job table (bench loops repeat the same one: skip the re-upload).  The tile table itself only
+    // exists on the device: it is expanded there from the groups' runs (one per job and shape).
     std::vector<Group> groups;
+    DevBuf d_runs;
     std::vector<int32_t> last_job_adapter, last_job_adapter_b;
     std::vector<int64_t> last_job_start;
     int last_max_len = -1, last_mode = -1;
@@ -171,7 +196,7 @@ int build_tiles(pc_ctx *c, const int32_t *job_adapter, const int32_t *job_adapte
                       std::equal(job_start, job_start + njobs + 1, c->last_job_start.begin());
     if (same) return PC_OK;
 
-    std::map<std::pair<int, int>, std::vector<pck::Tile>> by_group;   // (rows*2+pad, two_pass) -> tiles
+    std::map<std::pair<int, int>, std::vector<pck::TileRun>> by_group;   // (rows*2+pad, two_pass) -> runs
     std::map<std::pair<int, int>, int> group_window;
     int64_t out_pos = 0;
     for (int k = 0; k < njobs; ++k) {
@@ -187,7 +212,7 @@ int build_tiles(pc_ctx *c, const int32_t *job_adapter, const int32_t *job_adapte
         // impossible, pc_bounds.h) and schemes whose gap extension is too large to drift in int16 take
         // the generic kernel
         const bool no_drift = drift_period(c) < 64;
-        auto group_of = [&](int ma, int mbb, int window, int *rows_out) -> std::vector<pck::Tile> & {
+        auto group_of = [&](int ma, int mbb, int window, int *rows_out) -> std::vector<pck::TileRun> & {
             bool pad = false;
             int rows = pck::pick_rows(ma, mbb, &pad);         // 0 => generic LDS-state kernel
             if (no_drift) { rows = 0; pad = true; }
@@ -197,20 +222,12 @@ int build_tiles(pc_ctx *c, const int32_t *job_adapter, const int32_t *job_adapte
             *rows_out = rows;
             return by_group[key];
         };
-        // one adapter, two windows per lane (the halves read different streams)
+        // one adapter, two windows per lane (the halves read different streams): tiles of 128 windows
         auto emit_single = [&](int a1, int64_t out_base) {
             const int m1 = c->ad_len[a1];
             int rows;
             auto &v = group_of(m1, m1, c->ad_window[a1], &rows);
-            for (int64_t s = 0; s < n; s += 128) {
-                pck::Tile t;
-                t.win_lo = ws + s; t.win_hi = ws + s + 64;
-                t.out_lo = out_base + s; t.out_hi = out_base + s + 64;
-                t.count_lo = (int32_t)std::min<int64_t>(64, n - s);
-                t.count_hi = (int32_t)std::max<int64_t>(0, std::min<int64_t>(64, n - s - 64));
-                t.adapter_lo = a1; t.adapter_hi = a1; t.rows = rows ? rows : m1; t.pad_ = 0;
-                v.push_back(t);
-            }
+            if (n > 0) v.push_back(pck::TileRun{ws, out_base, n, 0, a1, a1, rows ? rows : m1, 0});
         };
         const int window = std::max(c->ad_window[ad], adb >= 0 ? c->ad_window[adb] : 0);
         const bool two_pass_job = (mode == PC_MODE_TWO_PASS) || (mode == PC_MODE_SCORE) || (mode == PC_MODE_AUTO && max_len > 2 * window + 64);
@@ -223,16 +240,10 @@ int build_tiles(pc_ctx *c, const int32_t *job_adapter, const int32_t *job_adapte
         const bool split_dual = adb >= 0 && !two_pass_job && !no_drift && !no_split &&
                                 pck::pick_rows(m, m, &pa_) != pck::pick_rows(mb, mb, &pb_);
         if (adb >= 0 && !split_dual) {
+            // both halves of a lane scan the same 64 windows: adapter A's records first, then B's
             int rows;
             auto &v = group_of(m, mb, window, &rows);
-            for (int64_t s = 0; s < n; s += 64) {
-                pck::Tile t;
-                t.win_lo = ws + s; t.win_hi = ws + s;
-                t.out_lo = out_pos + s; t.out_hi = out_pos + n + s;
-                t.count_lo = t.count_hi = (int32_t)std::min<int64_t>(64, n - s);
-                t.adapter_lo = ad; t.adapter_hi = adb; t.rows = rows ? rows : std::max(m, mb); t.pad_ = 0;
-                v.push_back(t);
-            }
+            if (n > 0) v.push_back(pck::TileRun{ws, out_pos, n, 0, ad, adb, rows ? rows : std::max(m, mb), 1});
             out_pos += 2 * n;
         } else if (adb >= 0) {
             emit_single(ad, out_pos);
@@ -243,24 +254,41 @@ int build_tiles(pc_ctx *c, const int32_t *job_adapter, const int32_t *job_adapte
             out_pos += n;
         }
     }
-    c->tiles.clear();
     c->groups.clear();
+    std::vector<pck::TileRun> all_runs;
+    size_t ntiles = 0;
     for (auto &kv : by_group) {
         Group g;
         g.rows = kv.first.first / 2; g.pad = (kv.first.first & 1) != 0; g.two_pass = kv.first.second != 0;
-        g.tile_begin = c->tiles.size(); g.tile_count = kv.second.size();
+        g.tile_begin = ntiles;
         g.max_window = group_window[kv.first];
         g.gen_max_rows = 1;
-        for (const pck::Tile &t : kv.second) g.gen_max_rows = std::max(g.gen_max_rows, (int)t.rows);
-        c->tiles.insert(c->tiles.end(), kv.second.begin(), kv.second.end());
-        c->groups.push_back(g);
+        int64_t t = 0;
+        for (pck::TileRun &r : kv.second) {
+            g.gen_max_rows = std::max(g.gen_max_rows, (int)r.rows);
+            r.tile0 = t;
+            t += run_tiles(r);
+            all_runs.push_back(r);
+            all_runs.back().tile0 += (int64_t)g.tile_begin;     // the device table is indexed over all groups
+        }
+        g.tile_count = (size_t)t;
+        g.runs.swap(kv.second);
+        ntiles += g.tile_count;
+        if (g.tile_count) c->groups.push_back(std::move(g));
     }
+    if (ntiles > (size_t)INT32_MAX) return PC_ERR_BAD_ARG;
     // the previous table may still be in use by launches in flight
     HIP_TRY(hipDeviceSynchronize());
-    int rc = c->d_tiles.ensure(std::max<size_t>(1, c->tiles.size()) * sizeof(pck::Tile));
+    int rc = c->d_tiles.ensure(std::max<size_t>(1, ntiles) * sizeof(pck::Tile));
     if (rc) return rc;
-    if (!c->tiles.empty())
-        HIP_TRY(hipMemcpy(c->d_tiles.p, c->tiles.data(), c->tiles.size() * sizeof(pck::Tile), hipMemcpyHostToDevice));
+    if ((rc = c->d_runs.ensure(std::max<size_t>(1, all_runs.size()) * sizeof(pck::TileRun)))) return rc;
+    if (ntiles) {
+        // a few hundred bytes per job cross PCIe; the tiles (56 B per 64..128 windows) are written by the GPU
+        HIP_TRY(hipMemcpy(c->d_runs.p, all_runs.data(), all_runs.size() * sizeof(pck::TileRun), hipMemcpyHostToDevice));
+        if (pck::launch_expand_tiles(c->d_runs.as<pck::TileRun>(), (int)all_runs.size(), c->d_tiles.as<pck::Tile>(), (int64_t)ntiles, nullptr))
+            return PC_ERR_NO_DEVICE;
+        HIP_TRY(hipDeviceSynchronize());
+    }
     c->last_job_adapter.assign(job_adapter, job_adapter + njobs);
     c->last_job_adapter_b = jb;
     c->last_job_start.assign(job_start, job_start + njobs + 1);
@@ -315,6 +343,22 @@ int resident_waves(const pc_ctx *c, const Group &g)
     int per_simd = g.rows ? 512 / (2 * rows + 48) : (int)((160 * 1024) / ((size_t)rows * 520 + 1024)) / 4;
     per_simd = std::max(1, std::min(8, per_simd));
     return c->ncu * 4 * per_simd;
+}
+
+// Column chunks of a two-pass group's score pass: the under-filled rule above, or -- reads of very
+// different lengths (the caller's typical length is far below the longest, pc_set_length_hint) -- chunks
+// about as long as a typical read, so that no unit of work is much longer than the others: a launch
+// otherwise lasts as long as its longest read (measured on log-normal lengths, mean 8 kb, longest
+// 113 kb: 3.4 times the balanced duration).  The windows come longest first, units are drawn in
+// that order (work_counter), and chunks beyond a window's end cost a few microseconds.
+int group_chunks_for(const pc_ctx *c, const Group &g, int max_len)
+{
+    int chunks = chunks_for((int64_t)g.tile_count, resident_waves(c, g), max_len, g.max_window);
+    if (c->len_hint > 0 && (int64_t)max_len * 2 > (int64_t)c->len_hint * 3) {
+        const int unit = std::max(c->len_hint, std::max(512, 4 * g.max_window));
+        chunks = std::max(chunks, std::min(kMaxChunks, (max_len + unit - 1) / unit));
+    }
+    return chunks;
 }
 
 // Workgroups to launch for `ntiles` tiles.  Measured on MI355X (tools/time_score.py, time_trace.py):
@@ -373,7 +417,7 @@ int launch_traced(const pc_ctx *c, pck::ScanArgs &a, const Group &g, int grid, h
 // One launch of the score pass: a run of tiles, each cut into `chunks` column chunks, writing its
 // [pair][chunk] maxima at k1_ints of the pass-1 buffer; spec = the run-time specialised kernel of
 // the run's adapter pair, or null for the generic kernel (which takes the adapter from each tile).
-struct ScoreLaunch { size_t begin, count; int chunks; size_t k1_ints; pcj::Spec *spec; };
+struct ScoreLaunch { size_t begin, count; int chunks; size_t k1_ints; pcj::Spec *spec; int adapter_lo, adapter_hi; };
 
 // Launch plan of a two-pass group.  Tiles of one job (= one adapter pair) are contiguous.  A job
 // with a specialised kernel and more tiles than resident waves is launched as a balanced head (a
@@ -386,20 +430,18 @@ std::vector<ScoreLaunch> plan_score_launches(pc_ctx *c, const Group &g, int max_
 {
     std::vector<ScoreLaunch> out;
     size_t k1 = (size_t)npairs * 4 * (size_t)group_chunks;
-    size_t i = 0;
-    while (i < g.tile_count) {
-        const pck::Tile &t0 = c->tiles[g.tile_begin + i];
-        size_t e = i + 1;
-        while (e < g.tile_count && c->tiles[g.tile_begin + e].adapter_lo == t0.adapter_lo &&
-               c->tiles[g.tile_begin + e].adapter_hi == t0.adapter_hi)
-            ++e;
+    size_t ri = 0;
+    while (ri < g.runs.size()) {
+        // consecutive runs of one adapter pair share their launches
+        const pck::TileRun &r0 = g.runs[ri];
+        size_t re = ri + 1;
+        while (re < g.runs.size() && g.runs[re].adapter_lo == r0.adapter_lo && g.runs[re].adapter_hi == r0.adapter_hi) ++re;
+        const size_t i = (size_t)r0.tile0;
+        const size_t e = (size_t)(g.runs[re - 1].tile0 + run_tiles(g.runs[re - 1]));
         // the specialised kernel for this pair, once the work seen for the pair has paid for its
         // compile (pc_jit.cpp); until then the generic one
-        double est_cells = 0;
-        for (size_t k = i; k < e; ++k)
-            est_cells += (double)(c->tiles[g.tile_begin + k].count_lo + c->tiles[g.tile_begin + k].count_hi);
-        est_cells *= (double)max_len * (double)(g.rows ? g.rows : g.gen_max_rows);
-        pcj::Spec *sp = !linear ? pcj::get(c->device, c->adapters[t0.adapter_lo], c->adapters[t0.adapter_hi], c->match,
+        const double est_cells = (double)group_pairs(g, i, e) * (double)max_len * (double)(g.rows ? g.rows : g.gen_max_rows);
+        pcj::Spec *sp = !linear ? pcj::get(c->device, c->adapters[r0.adapter_lo], c->adapters[r0.adapter_hi], c->match,
                                            c->mismatch, c->gap_open, c->gap_extend, est_cells)
                                 : nullptr;
         const size_t n = e - i;
@@ -407,7 +449,7 @@ std::vector<ScoreLaunch> plan_score_launches(pc_ctx *c, const Group &g, int max_
             if (!out.empty() && !out.back().spec && out.back().begin + out.back().count == i && out.back().chunks == group_chunks)
                 out.back().count += n;                       // runs of pairs without a kernel share a launch
             else
-                out.push_back({i, n, group_chunks, 0, nullptr});
+                out.push_back({i, n, group_chunks, 0, nullptr, r0.adapter_lo, r0.adapter_hi});
         } else {
             size_t head = n;
             int tail_chunks = 1;
@@ -424,13 +466,13 @@ std::vector<ScoreLaunch> plan_score_launches(pc_ctx *c, const Group &g, int max_
                 }
                 if (tail_chunks > 1) head = n - tail;
             }
-            out.push_back({i, head, group_chunks, 0, sp});
+            out.push_back({i, head, group_chunks, 0, sp, r0.adapter_lo, r0.adapter_hi});
             if (head < n) {
-                out.push_back({i + head, n - head, tail_chunks, k1, sp});
+                out.push_back({i + head, n - head, tail_chunks, k1, sp, r0.adapter_lo, r0.adapter_hi});
                 k1 += (size_t)npairs * 4 * (size_t)tail_chunks;
             }
         }
-        i = e;
+        ri = re;
     }
     if (k1_ints_needed) *k1_ints_needed = k1;
     return out;
@@ -489,7 +531,7 @@ void pc_destroy(pc_ctx *c)
     (void)hipStreamSynchronize(c->stream);
     DevBuf *bufs[] = {&c->d_ad_codes, &c->d_ad_len, &c->d_ad_window, &c->d_ad_span, &c->d_tiles, &c->d_slab, &c->d_fin, &c->d_k1, &c->d_woff2,
                       &c->d_wlen2, &c->d_col0, &c->d_ntot, &c->d_frow, &c->d_fscore, &c->d_err, &c->d_arena,
-                      &c->d_woff, &c->d_wlen, &c->d_out, &c->d_red};
+                      &c->d_woff, &c->d_wlen, &c->d_out, &c->d_red, &c->d_work, &c->d_runs};
     for (DevBuf *b : bufs) b->release();
     (void)hipStreamDestroy(c->stream);
     delete c;
@@ -503,6 +545,13 @@ int pc_set_scores(pc_ctx *c, int match, int mismatch, int gap_open, int gap_exte
         c->match = match; c->mismatch = mismatch; c->gap_open = gap_open; c->gap_extend = gap_extend;
         c->panel_dirty = true;
     }
+    return PC_OK;
+}
+
+int pc_set_length_hint(pc_ctx *c, int typical_len)
+{
+    if (!c || typical_len < 0) return PC_ERR_BAD_ARG;
+    c->len_hint = typical_len;
     return PC_OK;
 }
 
@@ -545,7 +594,7 @@ int pc_scan_device(pc_ctx *c, const void *d_arena, const int64_t *d_win_off, con
         const int cols = g.two_pass ? g.max_window + 1 : max_len;
         const int grid = grid_for(c, g, g.tile_count, cols, &stride);
         slab_bytes = std::max(slab_bytes, (size_t)grid * stride * 4);
-        const int chunks = g.two_pass ? chunks_for((int64_t)g.tile_count, resident_waves(c, g), max_len, g.max_window) : 1;
+        const int chunks = g.two_pass ? group_chunks_for(c, g, max_len) : 1;
         max_chunks = std::max(max_chunks, chunks);
         // score pass: chunked launches, and the chunked tails of big jobs (at most 8 chunks x resident waves)
         const int grid1 = grid_for(c, g, std::max<size_t>(g.tile_count * (size_t)chunks, (size_t)c->ncu * 64), 1, nullptr);
@@ -558,18 +607,24 @@ int pc_scan_device(pc_ctx *c, const void *d_arena, const int64_t *d_win_off, con
     // kernels already in flight
     std::vector<std::vector<ScoreLaunch>> score_plan(c->groups.size());
     std::vector<int> group_chunks(c->groups.size(), 1);
-    size_t k1_ints = 0;
+    size_t k1_ints = 0, n_score_launches = 0;
     {
         const bool lin = pcb::is_linear(c->gap_open, c->gap_extend);
         for (size_t gi = 0; gi < c->groups.size(); ++gi) {
             const Group &g = c->groups[gi];
             if (!g.two_pass) continue;
-            group_chunks[gi] = chunks_for((int64_t)g.tile_count, resident_waves(c, g), max_len, g.max_window);
+            group_chunks[gi] = group_chunks_for(c, g, max_len);
             size_t need = 0;
             score_plan[gi] = plan_score_launches(c, g, max_len, npairs, lin, group_chunks[gi], &need);
             k1_ints = std::max(k1_ints, need);
+            n_score_launches += score_plan[gi].size();
         }
     }
+    if (n_score_launches) {
+        if ((rc = c->d_work.ensure(n_score_launches * 4 + 256))) return rc;
+        HIP_TRY(hipMemsetAsync(c->d_work.p, 0, n_score_launches * 4, stream));
+    }
+    size_t score_launch_no = 0;
     (void)max_chunks;
     if (any_two) {
         const size_t n = (size_t)npairs;
@@ -606,13 +661,11 @@ int pc_scan_device(pc_ctx *c, const void *d_arena, const int64_t *d_win_off, con
             a.slab_cols = max_len;
             const int grid = grid_for(c, g, g.tile_count, max_len, &stride);
             a.slab_stride = (int64_t)stride;
-            int64_t np = 0;
-            for (size_t i = 0; i < g.tile_count; ++i) np += c->tiles[g.tile_begin + i].count_lo + c->tiles[g.tile_begin + i].count_hi;
+            const int64_t np = group_pairs(g, 0, g.tile_count);
             ScopedTimer tm(c, stream, 2, np);
             if ((rc = launch_traced(c, a, g, grid, stream))) return PC_ERR_NO_DEVICE;
         } else {
-            int64_t np = 0;
-            for (size_t i = 0; i < g.tile_count; ++i) np += c->tiles[g.tile_begin + i].count_lo + c->tiles[g.tile_begin + i].count_hi;
+            const int64_t np = group_pairs(g, 0, g.tile_count);
             // pass 1: score only, whole window
             a.win_off = d_win_off; a.win_len = d_win_len;
             a.out = c->d_k1.as<int32_t>();
@@ -620,12 +673,9 @@ int pc_scan_device(pc_ctx *c, const void *d_arena, const int64_t *d_win_off, con
             a.ad_span = c->d_ad_span.as<int32_t>();
             const size_t gi = (size_t)(&g - &c->groups[0]);
             for (const ScoreLaunch &L : score_plan[gi]) {
-                const pck::Tile &t0 = c->tiles[g.tile_begin + L.begin];
                 const int chunk_len = (max_len + L.chunks - 1) / L.chunks;
                 const int grid = grid_for(c, g, L.count * (size_t)L.chunks, 1, nullptr);
-                int64_t sub_pairs = 0;
-                for (size_t k = 0; k < L.count; ++k)
-                    sub_pairs += c->tiles[g.tile_begin + L.begin + k].count_lo + c->tiles[g.tile_begin + L.begin + k].count_hi;
+                const int64_t sub_pairs = group_pairs(g, L.begin, L.begin + L.count);
                 ScopedTimer tm(c, stream, L.spec ? 3 : 0, sub_pairs);       // one timed region per kernel launch
                 if (L.spec) {
                     pcj::SpecArgs sa;
@@ -635,14 +685,16 @@ int pc_scan_device(pc_ctx *c, const void *d_arena, const int64_t *d_win_off, con
                     sa.out = c->d_k1.as<int32_t>() + L.k1_ints; sa.fin_scratch = c->d_fin.p;
                     sa.gap_open = c->gap_open; sa.gap_extend = c->gap_extend;
                     sa.chunks = L.chunks; sa.chunk_len = chunk_len;
-                    sa.span = std::max(c->ad_span[t0.adapter_lo], c->ad_span[t0.adapter_hi]);
+                    sa.span = std::max(c->ad_span[L.adapter_lo], c->ad_span[L.adapter_hi]);
                     sa.err = a.err;
+                    sa.work_counter = c->d_work.as<uint32_t>() + score_launch_no++;
                     if (pcj::launch(L.spec, sa, grid, stream)) return PC_ERR_NO_DEVICE;
                 } else {
                     pck::ScanArgs b = a;
                     b.tiles = a.tiles + L.begin; b.ntiles = (int32_t)L.count;
                     b.out = c->d_k1.as<int32_t>() + L.k1_ints;
                     b.chunks = L.chunks; b.chunk_len = chunk_len;
+                    b.work_counter = c->d_work.as<uint32_t>() + score_launch_no++;
                     if ((rc = pck::launch_score(b, g.rows, g.pad, grid, stream))) return PC_ERR_NO_DEVICE;
                 }
             }

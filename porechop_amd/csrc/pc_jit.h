@@ -27,6 +27,7 @@ struct SpecArgs {
     int32_t m_lo, m_hi, gap_open, gap_extend;
     int32_t chunks, chunk_len, span;
     uint32_t *err;
+    uint32_t *work_counter;      // units beyond the grid are handed out by this counter (zeroed by the host); null = fixed stride
 };
 
 bool disabled();

@@ -89,6 +89,7 @@ struct SpecArgs {
     int m_lo, m_hi, gap_open, gap_extend;
     int chunks, chunk_len, span;
     u32 *err;
+    u32 *work_counter;
 };
 struct FastT { static constexpr bool fast = true; };
 struct SlowT { static constexpr bool fast = false; };
@@ -119,7 +120,16 @@ extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P
     uint2 *fin = a.fin_scratch + (i64)blockIdx.x * R * 64;
     const int nchunks = a.chunks > 1 ? a.chunks : 1;
 
-    for (int vt = blockIdx.x; vt < a.ntiles * nchunks; vt += gridDim.x) {
+    // Units (tile x column chunk) are taken in launch order -- the host hands tiles over longest first -- the
+    // first gridDim.x by the hardware dispatcher, the rest from a counter: a workgroup that drew short units
+    // simply draws more of them, so reads of very different lengths still fill the chip to the end.
+    auto next_unit = [&](int vt) -> int {
+        if (!a.work_counter) return vt + (int)gridDim.x;
+        u32 v = 0;
+        if (lane == 0) v = atomicAdd(a.work_counter, 1u);
+        return (int)gridDim.x + (int)__builtin_amdgcn_readfirstlane(v);
+    };
+    for (int vt = blockIdx.x; vt < a.ntiles * nchunks; vt = next_unit(vt)) {
         const int t = vt / nchunks, chunk = vt - t * nchunks;
         const Tile tile = a.tiles[t];
         const bool one_stream = tile.win_lo == tile.win_hi;

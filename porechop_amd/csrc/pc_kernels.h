@@ -19,6 +19,17 @@ struct Tile {
     int32_t pad_;
 };
 
+// A run of consecutive tiles of one job: n windows from win0 against one adapter (tiles of 128 windows,
+// the high half 64 windows after the low one) or -- dual -- against two adapters on the same windows
+// (tiles of 64 windows, the second adapter's records n after the first's).  The host describes a scan by
+// a handful of runs; the tile table is expanded from them on the device (pc_reduce.hip).
+struct TileRun {
+    int64_t win0, out0, n;
+    int64_t tile0;               // index of the run's first tile
+    int32_t adapter_lo, adapter_hi, rows, dual;
+};
+int launch_expand_tiles(const TileRun *d_runs, int nruns, Tile *d_tiles, int64_t ntiles, void *stream);
+
 struct ScanArgs {
     const uint8_t *arena;        // read bytes, 1 B/base, as delivered by the caller
     const int64_t *win_off;      // [nwindows] byte offset of the window's first column
@@ -49,6 +60,8 @@ struct ScanArgs {
     const int32_t *ad_window;        // [nadapters] W + SPAN + 1 (pass-2 windows; W = window - SPAN - 1)
     int32_t debug;                   // PC_DEBUG_TRACE (timing experiments): 1 = no traceback, 2 = no slab stores; 4 = range-checking build (PC_CHECK_RANGE)
     int32_t f16_cen, f16_max_cols;   // packed-fp16 traced kernel: centring constant C and the columns it may run (pc_bounds.h f16_plan)
+    uint32_t *work_counter;          // score pass: units beyond the grid are handed out by this counter (zeroed by the host) in
+                                     // launch order -- longest tiles first -- instead of a fixed stride; null = fixed stride
 };
 
 // pass-2 planner: from the score-only pass's (score, I, J) build the bounded windows

@@ -291,7 +291,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((R > 0 && R 
     // columns (c*L, (c+1)*L] after a warm-up of SPAN columns that makes its values exact
     // (pc_bounds.h); the planner kernel then merges the per-chunk maxima in visiting order.
     const int nchunks = (!TRACE && a.chunks > 1) ? a.chunks : 1;
-    for (int vt = blockIdx.x; vt < a.ntiles * nchunks; vt += gridDim.x) {
+    // units beyond the grid come from a counter in launch order (see pc_spec_score, pc_jit_source.h)
+    auto next_unit = [&](int vt) -> int {
+        if (TRACE || !a.work_counter) return vt + (int)gridDim.x;
+        u32 v = 0;
+        if (lane == 0) v = atomicAdd(a.work_counter, 1u);
+        return (int)gridDim.x + (int)__builtin_amdgcn_readfirstlane(v);
+    };
+    for (int vt = blockIdx.x; vt < a.ntiles * nchunks; vt = next_unit(vt)) {
         const int t = vt / nchunks, chunk = vt - t * nchunks;
         const Tile tile = a.tiles[t];
         const int rows = GEN ? tile.rows : R;

@@ -185,7 +185,7 @@ class Pipeline:
             return off, wl
         return off + (ln - wl).to(torch.int64), wl
 
-    def _scan_jobs(self, arena, jobs, mode, max_len, with_layout=False, sort_lengths=False):
+    def _scan_jobs(self, arena, jobs, mode, max_len, with_layout=False, sort_lengths=False, typ_len=0):
         """jobs: list of (adapter_index, win_off int64[n], win_len int32[n]) -> list of [n,8] views.
 
         Jobs that scan the very same windows (same tensors) are fused two adapters at a time
@@ -194,7 +194,9 @@ class Pipeline:
         sort_lengths: whole-read scans of reads of different lengths.  A tile (64 or 128 consecutive
         windows) runs as many columns as its longest window, so the windows of every job are handed
         over longest first -- a tile then holds windows of nearly one length, and the specialised score
-        kernel stays on its block-resolved path -- and the records are put back in the caller's order."""
+        kernel stays on its block-resolved path -- and the records are put back in the caller's order.
+        typ_len: their typical (mean) length, which lets the library cut the longest reads into chunks of
+        about that many columns (pc_set_length_hint) so that a launch does not last as long as its longest read."""
         order_of = {}
         if sort_lengths:
             sorted_jobs = []
@@ -226,6 +228,7 @@ class Pipeline:
             ostarts[k + 1] = ostarts[k] + n * (2 if b is not None else 1)
         out = torch.empty((int(ostarts[-1]), RESULT_INTS), dtype=torch.int32, device=self.device)
         if starts[-1] > 0:
+            self.aligner.set_length_hint(typ_len if sort_lengths else 0)
             self.aligner.scan_device(arena, woff, wlen, np.array([jobs[a][0] for a, _ in fused], dtype=np.int32),
                                      starts, max_len, out, mode,
                                      job_adapter_b=np.array([jobs[b][0] if b is not None else -1 for _, b in fused],
@@ -481,8 +484,8 @@ class Pipeline:
         if live.numel() == 0:
             return empty
         loff, llen = toff[live], tlen[live]
-        mm = torch.stack([llen.max(), llen.min()]).cpu()
-        max_len, ragged = int(mm[0]), bool(mm[0] != mm[1])
+        mm = torch.stack([llen.max(), llen.min(), llen.sum(dtype=torch.int64) // llen.numel()]).cpu()
+        max_len, ragged, typ_len = int(mm[0]), bool(mm[0] != mm[1]), int(mm[2])
         aidx = [self.seq_index[a[1]] for a in ads]
 
         def identity_of(rec):
@@ -493,7 +496,7 @@ class Pipeline:
         jobs0 = [(ai, loff, llen) for ai in aidx]
         bounds = [self.identity_score_bound(len(self.seqs[ai]), p.middle_threshold) for ai in aidx] if prove else None
         if prove and all(b is not None for b in bounds):
-            score = torch.stack(self._scan_jobs(reads.arena, jobs0, MODE_SCORE, max_len, sort_lengths=ragged))[:, :, 4]      # [A, L]
+            score = torch.stack(self._scan_jobs(reads.arena, jobs0, MODE_SCORE, max_len, sort_lengths=ragged, typ_len=typ_len))[:, :, 4]      # [A, L]
             cand = torch.nonzero(score >= torch.tensor(bounds, device=dev)[:, None])                     # adapter-major
             counts = torch.bincount(cand[:, 0], minlength=A).cpu().numpy()
             L = int(live.numel())
@@ -505,14 +508,14 @@ class Pipeline:
                     pos += int(counts[a])
                     cjobs.append((aidx[a], loff[sel], llen[sel])); csel.append((a, sel))
             if cjobs:
-                for (a, sel), o in zip(csel, self._scan_jobs(reads.arena, cjobs, MODE_TWO_PASS, max_len, sort_lengths=ragged)):
+                for (a, sel), o in zip(csel, self._scan_jobs(reads.arena, cjobs, MODE_TWO_PASS, max_len, sort_lengths=ragged, typ_len=typ_len)):
                     recs[a, sel] = o
             outs = [recs[a] for a in range(A)]
             # an all-zero record (rs = 0, lengths 0) is "not a hit" below: 0/0 identities are masked
             fulls = torch.stack([torch.nan_to_num(identity_of(rec), nan=0.0) for rec in outs])
             self.stats["pairs_middle_traced_after_proof"] = self.stats.get("pairs_middle_traced_after_proof", 0) + int(counts.sum())
         else:
-            outs = self._scan_jobs(reads.arena, jobs0, MODE_TWO_PASS, max_len, sort_lengths=ragged)
+            outs = self._scan_jobs(reads.arena, jobs0, MODE_TWO_PASS, max_len, sort_lengths=ragged, typ_len=typ_len)
             fulls = torch.stack([identity_of(rec) for rec in outs])  # [A, L]
         hit0 = (fulls >= p.middle_threshold) & torch.stack([rec[:, 0] != -1 for rec in outs])
         d_sel = torch.nonzero(hit0.any(dim=0)).flatten()             # dirty reads (indices into live)
@@ -565,7 +568,7 @@ class Pipeline:
                 a0 = int(ah.min().item())
                 o_act, l_act = d_off[act], dlen[act]
                 outs_r = self._scan_jobs(dirty.view(-1), [(aidx[a], o_act, l_act) for a in range(a0, A)], MODE_TWO_PASS, dmax,
-                                         sort_lengths=ragged)
+                                         sort_lengths=ragged, typ_len=typ_len)
                 scheduled = (A - a0) * int(act.numel())
                 for a, o in zip(range(a0, A), outs_r):
                     rec_all[a, act] = o

@@ -71,6 +71,9 @@ class OracleAligner:
     def sync(self, stream=None):
         pass
 
+    def set_length_hint(self, typical_len):
+        pass
+
     def set_timing(self, enabled=True):
         pass
 

@@ -3,7 +3,7 @@
 #   1. --kernel-trace --stats of the bench (smaller batch so the trace stays small)
 #   2. FETCH_SIZE and WRITE_SIZE in their own passes (never together with trace domains)
 # Only the summaries are kept under gpurun_out/prof_<tag>/ ; copy them into profiles/ afterwards.
-TAG=${1:-r01}
+TAG=${1:-r02}
 READS=${2:-400000}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
@@ -15,12 +15,16 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $W/trace -o trace -- $CM
 find $W/trace -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats.csv \;
 # per-dispatch durations of our kernels only (start/end timestamps -> ns)
 KT=$(find $W/trace -name "*kernel_trace.csv" | head -1)
-if [ -n "$KT" ]; then head -1 $KT > $OUT/kernel_trace_scan.csv; grep -E "scan_kernel|plan_kernel|pc_spec" $KT >> $OUT/kernel_trace_scan.csv; fi
+if [ -n "$KT" ]; then head -1 $KT > $OUT/kernel_trace_scan.csv; grep -E "pck::|pc_spec" $KT >> $OUT/kernel_trace_scan.csv; fi
 for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $C --output-format csv -d $W/$C -o pmc -- $CMD > $OUT/bench_$C.log 2>&1
   CC=$(find $W/$C -name "*counter_collection.csv" | head -1)
-  if [ -n "$CC" ]; then head -1 $CC > $OUT/pmc_$C.csv; grep -E "scan_kernel|plan_kernel|pc_spec" $CC >> $OUT/pmc_$C.csv; fi
+  if [ -n "$CC" ]; then head -1 $CC > $OUT/pmc_$C.csv; grep -E "pck::|pc_spec" $CC >> $OUT/pmc_$C.csv; fi
 done
+# VALU activity of the kernels (own pass, headline only): busy/issued VALU cycles, wave cycles, GPU clock ticks
+rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $W/VALU -o pmc -- $CMD --no-extra > $OUT/bench_VALU.log 2>&1
+CC=$(find $W/VALU -name "*counter_collection.csv" | head -1)
+if [ -n "$CC" ]; then head -1 $CC > $OUT/pmc_VALU.csv; grep -E "pck::|pc_spec" $CC >> $OUT/pmc_VALU.csv; fi
 for f in $OUT/bench_*.log; do tail -1 $f > $f.json; grep -v "^W2\|^I2\|^E2" $f | tail -5 > $f.tail; rm $f; done
 ls -la $OUT; du -sh $OUT
 head -12 $OUT/kernel_stats.csv

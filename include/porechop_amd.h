@@ -152,6 +152,14 @@ int pc_phase_b_reduce(pc_ctx *ctx, const int32_t *d_records, int64_t n, int njob
                       double barcode_threshold, double barcode_diff, int require_two_barcodes,
                       int32_t *d_call, void *stream);
 
+/* Packed private copies of n windows on the device: window i of d_arena (d_src_off[i], d_len[i]) is copied
+ * to d_dst + d_dst_off[i], and the bytes from its end up to d_dst_off[i+1] are set to `pad` (d_dst_off has
+ * n + 1 entries).  Porechop masks every middle hit in a copy of the read and aligns again
+ * (nanopore_read.py:212-243); the batch pipeline keeps such copies only for the reads that had a hit,
+ * back to back whatever their lengths.  Asynchronous on `stream`. */
+int pc_copy_windows(pc_ctx *ctx, const void *d_arena, const int64_t *d_src_off, const int32_t *d_len,
+                    int64_t n, void *d_dst, const int64_t *d_dst_off, int pad, void *stream);
+
 /* Debug builds of the 16-bit kernels (PC_CHECK_RANGE=1: packed-fp16 traced kernel, row classes 24/28/30/40;
  * PC_JIT_CHECK_RANGE=1: the run-time specialised score kernel) record the extremes of every DP value they
  * hold, in the kernel's own offset coordinates; this returns them since the last call and resets.  The

@@ -163,6 +163,18 @@ class Aligner:
                                          float(barcode_threshold), float(barcode_diff), 1 if require_two else 0,
                                          call.data_ptr() if nb else None, ctypes.c_void_p(s)), "pc_phase_b_reduce")
 
+    def copy_windows(self, arena, src_off, length, dst, dst_off, pad, stream=None):
+        """Packed private copies on the device (pc_copy_windows): window i of `arena` -> dst[dst_off[i]:], padded
+        with `pad` up to dst_off[i+1]; src_off int64[n], length int32[n], dst_off int64[n+1], all CUDA tensors."""
+        import torch
+        n = int(src_off.shape[0])
+        assert arena.is_cuda and dst.is_cuda and src_off.dtype == torch.int64 and length.dtype == torch.int32
+        assert dst_off.dtype == torch.int64 and int(dst_off.shape[0]) == n + 1
+        assert src_off.is_contiguous() and length.is_contiguous() and dst_off.is_contiguous()
+        s = stream if stream is not None else torch.cuda.current_stream().cuda_stream
+        check(self.lib.pc_copy_windows(self._ctx, arena.data_ptr(), src_off.data_ptr(), length.data_ptr(), n, dst.data_ptr(),
+                                       dst_off.data_ptr(), int(pad), ctypes.c_void_p(s)), "pc_copy_windows")
+
     def debug_value_range(self):
         """(lo, hi) of the DP values the range-checking kernel builds have held since the last call."""
         lo, hi = ctypes.c_int32(), ctypes.c_int32()

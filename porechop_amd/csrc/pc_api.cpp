@@ -351,10 +351,12 @@ int resident_waves(const pc_ctx *c, const Group &g)
 // otherwise lasts as long as its longest read (measured on log-normal lengths, mean 8 kb, longest
 // 113 kb: 3.4 times the balanced duration).  The windows come longest first, units are drawn in
 // that order (work_counter), and chunks beyond a window's end cost a few microseconds.
+bool ragged_lengths(const pc_ctx *c, int max_len) { return c->len_hint > 0 && (int64_t)max_len * 2 > (int64_t)c->len_hint * 3; }
+
 int group_chunks_for(const pc_ctx *c, const Group &g, int max_len)
 {
     int chunks = chunks_for((int64_t)g.tile_count, resident_waves(c, g), max_len, g.max_window);
-    if (c->len_hint > 0 && (int64_t)max_len * 2 > (int64_t)c->len_hint * 3) {
+    if (ragged_lengths(c, max_len)) {
         const int unit = std::max(c->len_hint, std::max(512, 4 * g.max_window));
         chunks = std::max(chunks, std::min(kMaxChunks, (max_len + unit - 1) / unit));
     }
@@ -674,7 +676,13 @@ int pc_scan_device(pc_ctx *c, const void *d_arena, const int64_t *d_win_off, con
             const size_t gi = (size_t)(&g - &c->groups[0]);
             for (const ScoreLaunch &L : score_plan[gi]) {
                 const int chunk_len = (max_len + L.chunks - 1) / L.chunks;
-                const int grid = grid_for(c, g, L.count * (size_t)L.chunks, 1, nullptr);
+                int grid = grid_for(c, g, L.count * (size_t)L.chunks, 1, nullptr);
+                // windows of very different lengths: exactly the resident workgroups, every further unit drawn from
+                // the counter in launch order -- longest first.  (With a larger grid the first workgroups would stay
+                // resident drawing the short units while the long ones waited for a slot until the very end.)
+                if (ragged_lengths(c, max_len))
+                    grid = (int)std::min<size_t>((size_t)grid, L.spec ? (size_t)c->ncu * (size_t)L.spec->blocks_per_cu
+                                                                      : (size_t)resident_waves(c, g));
                 const int64_t sub_pairs = group_pairs(g, L.begin, L.begin + L.count);
                 ScopedTimer tm(c, stream, L.spec ? 3 : 0, sub_pairs);       // one timed region per kernel launch
                 if (L.spec) {
@@ -792,6 +800,17 @@ int pc_phase_b_reduce(pc_ctx *c, const int32_t *d_records, int64_t n, int njobs,
     a.barcode_threshold = barcode_threshold; a.barcode_diff = barcode_diff; a.require_two = require_two ? 1 : 0;
     a.call = d_call;
     return pck::launch_reduce(a, stream) ? PC_ERR_NO_DEVICE : PC_OK;
+}
+
+int pc_copy_windows(pc_ctx *c, const void *d_arena, const int64_t *d_src_off, const int32_t *d_len, int64_t n,
+                    void *d_dst, const int64_t *d_dst_off, int pad, void *stream_v)
+{
+    if (!c || n < 0) return PC_ERR_BAD_ARG;
+    if (n == 0) return PC_OK;
+    if (!d_arena || !d_src_off || !d_len || !d_dst || !d_dst_off || n > (int64_t)INT32_MAX) return PC_ERR_BAD_ARG;
+    (void)hipSetDevice(c->device);
+    hipStream_t stream = (stream_v == PC_STREAM_CONTEXT) ? c->stream : (hipStream_t)stream_v;
+    return pck::launch_copy_windows((const uint8_t *)d_arena, d_src_off, d_len, n, (uint8_t *)d_dst, d_dst_off, pad, stream) ? PC_ERR_NO_DEVICE : PC_OK;
 }
 
 void pc_jit_async(int enabled) { pcj::set_async(enabled); }

@@ -92,6 +92,8 @@ struct ReduceArgs {
     int32_t *call;                   // [n] bin index or -1
 };
 int launch_reduce(const ReduceArgs &a, void *stream);
+int launch_copy_windows(const uint8_t *arena, const int64_t *src_off, const int32_t *len, int64_t n, uint8_t *dst,
+                        const int64_t *dst_off, int pad, void *stream);
 
 constexpr int TRACE_OUT_INTS = 8;
 constexpr int SCORE_OUT_INTS = 4;

@@ -156,4 +156,26 @@ int launch_expand_tiles(const TileRun *d_runs, int nruns, Tile *d_tiles, int64_t
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Packed private copies of windows (the maskable copies of reads with middle hits): one workgroup per
+// window copies its bytes and pads up to the next copy's start.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void copy_windows_kernel(const uint8_t *arena, const int64_t *src_off, const int32_t *len,
+                                                           uint8_t *dst, const int64_t *dst_off, int pad)
+{
+    const int64_t i = blockIdx.x;
+    const uint8_t *s = arena + src_off[i];
+    uint8_t *d = dst + dst_off[i];
+    const int64_t n = len[i], total = dst_off[i + 1] - dst_off[i];
+    for (int64_t b = threadIdx.x; b < total; b += blockDim.x) d[b] = b < n ? s[b] : (uint8_t)pad;
+}
+
+int launch_copy_windows(const uint8_t *arena, const int64_t *src_off, const int32_t *len, int64_t n, uint8_t *dst,
+                        const int64_t *dst_off, int pad, void *stream)
+{
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(copy_windows_kernel, dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, arena, src_off, len, dst, dst_off, pad);
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+
 }  // namespace pck

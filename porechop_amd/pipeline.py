@@ -525,17 +525,27 @@ class Pipeline:
         rounds = 0
         H_read, H_ad, H_s, H_e, H_id = [], [], [], [], []
         if Dn > 0:
-            rec_all = torch.stack(outs)[:, d_sel]                    # [A, Dn, 8] for the current masked state
+            rec_all = torch.stack([o[d_sel] for o in outs])          # [A, Dn, 8] for the current masked state
             full_all = fulls[:, d_sel]
-            # private, maskable copies of the dirty reads: [Dn, stride]
-            dlen = llen[d_sel]
-            dmax = int(dlen.max().item())
-            stride = (dmax + 8 + 15) // 16 * 16
-            col = torch.arange(stride, device=dev, dtype=torch.int64)
-            src = loff[d_sel][:, None] + torch.clamp(col[None, :], max=(dlen.to(torch.int64) - 1)[:, None])
-            dirty = reads.arena[src]
-            dirty[col[None, :] >= dlen[:, None]] = ord("N")
-            d_off = torch.arange(Dn, device=dev, dtype=torch.int64) * stride
+            # private, maskable copies of the dirty reads, back to back whatever their lengths (each padded
+            # with N to a multiple of 16 bytes plus slack: the kernels read whole dwords)
+            dlen = llen[d_sel].contiguous()
+            dstride = (dlen.to(torch.int64) + (8 + 15)) // 16 * 16
+            d_ends = torch.zeros(Dn + 1, dtype=torch.int64, device=dev)
+            d_ends[1:] = torch.cumsum(dstride, 0)
+            mm2 = torch.stack([dlen.max().to(torch.int64), d_ends[-1], dlen.sum(dtype=torch.int64) // Dn]).cpu()
+            dmax, dtotal, dtyp = int(mm2[0]), int(mm2[1]), int(mm2[2])
+            dirty = torch.empty(dtotal + 64, dtype=torch.uint8, device=dev)
+            dirty[dtotal:] = ord("N")
+            d_off = d_ends[:-1]
+            if hasattr(self.aligner, "copy_windows"):
+                self.aligner.copy_windows(reads.arena, loff[d_sel].contiguous(), dlen, dirty, d_ends, ord("N"))
+            else:                                                    # injected test aligner: the same copy in torch
+                seg = torch.repeat_interleave(torch.arange(Dn, device=dev), dstride)
+                pos = torch.arange(dtotal, device=dev, dtype=torch.int64) - d_off[seg]
+                inside = pos < dlen[seg]
+                src = loff[d_sel][seg] + torch.clamp(pos, max=(dlen.to(torch.int64) - 1)[seg])
+                dirty[:dtotal] = torch.where(inside, reads.arena[src], torch.full_like(src, ord("N"), dtype=torch.uint8))
             arow = torch.arange(A, device=dev)[:, None]
             cur = torch.zeros(Dn, dtype=torch.int64, device=dev)     # adapter each dirty read is at
             act = torch.arange(Dn, device=dev)
@@ -559,16 +569,18 @@ class Pipeline:
                 rs, re = r[:, 0], r[:, 1] + 1
                 H_read.append(live[d_sel[hsel]]); H_ad.append(ah.to(torch.int32))
                 H_s.append(rs); H_e.append(re); H_id.append(full_all[ah, hsel])
-                rows = dirty[hsel]
-                rows[(col[None, :] >= rs[:, None]) & (col[None, :] < re[:, None])] = ord("-")   # masked_seq[rs:re] = '-' * n
-                dirty[hsel] = rows
+                # masked_seq[rs:re] = '-' * n: the masked positions of all hits as one index list
+                cnt = torch.clamp(re - rs, min=0).to(torch.int64)
+                first = torch.cumsum(cnt, 0) - cnt
+                run = torch.repeat_interleave(d_off[hsel] + rs.to(torch.int64) - first, cnt)
+                dirty[run + torch.arange(int(run.shape[0]), device=dev, dtype=torch.int64)] = ord("-")
                 cur[hsel] = ah                                       # the reference re-aligns the adapter that hit
                 act = hsel
                 rounds += 1
                 a0 = int(ah.min().item())
                 o_act, l_act = d_off[act], dlen[act]
-                outs_r = self._scan_jobs(dirty.view(-1), [(aidx[a], o_act, l_act) for a in range(a0, A)], MODE_TWO_PASS, dmax,
-                                         sort_lengths=ragged, typ_len=typ_len)
+                outs_r = self._scan_jobs(dirty, [(aidx[a], o_act, l_act) for a in range(a0, A)], MODE_TWO_PASS, dmax,
+                                         sort_lengths=ragged, typ_len=dtyp)
                 scheduled = (A - a0) * int(act.numel())
                 for a, o in zip(range(a0, A), outs_r):
                     rec_all[a, act] = o

@@ -194,14 +194,25 @@ def trace_roofline(timing, n_windows, pairs, cells, steps, ops_per_2_cells):
                     "algorithmic byte) and its 4-bit/cell trace slab is implementation traffic (profiles/, DESIGN.md section 4)"}
 
 
+VERBOSE = os.environ.get("PC_BENCH_VERBOSE", "0") not in ("", "0")
+
+
+def note(msg):
+    if VERBOSE:
+        print("[bench %.3f] %s" % (time.perf_counter(), msg), file=sys.stderr, flush=True)
+
+
 def timed(fn, steps, warmup, sync):
     for _ in range(warmup):
         out = fn()
         sync()
     sync()
     t0 = time.perf_counter()
-    for _ in range(steps):
+    for k in range(steps):
         out = fn()
+        if VERBOSE:
+            sync()
+            note("step %d done at +%.1f ms" % (k, (time.perf_counter() - t0) * 1e3))
     sync()
     return out, time.perf_counter() - t0
 
@@ -316,6 +327,89 @@ def leg_configs2(dev, args, workers):
         out["parity"] = {"checked": done, "mismatches": len(bad), "what": "start trim, end trim, barcode call per read",
                          "first_mismatching_reads": bad[:8]}
         out["speedup_vs_cpu_baseline"] = out["reads_per_s"] / out["cpu_baseline"]["value"]
+    pl.close()
+    return out
+
+
+def leg_host_buffers(dev, args):
+    """The headline workload with the reads starting in (pinned) HOST memory: every step uploads all read bytes
+    over PCIe again.  Reads go up in batches on a copy stream into two device buffers while the previous batch
+    is being scanned on the compute stream (phase A runs on the first batch, which holds the check reads).
+    This is the PCIe-inclusive rate of DESIGN.md section 6 -- never `value`, which is measured HBM-resident."""
+    from porechop_amd.pipeline import Pipeline, ScanParams, DeviceReads
+    from porechop_amd.synth import make_reads
+    p = ScanParams()
+    pl = Pipeline(load_panel_sets(), p, device=dev)
+    n, nb = args.reads, 8
+    reads = make_reads(n, args.read_len, seed=3, start_frac=0.9, end_frac=0.5, chimera_frac=args.chimera, device=dev)
+    total = int(reads.arena.shape[0])
+    h_arena = torch.empty(total, dtype=torch.uint8, pin_memory=True)
+    h_arena.copy_(reads.arena)
+    h_off, h_len = reads.off.cpu().pin_memory(), reads.length.cpu().pin_memory()
+    del reads
+    torch.cuda.empty_cache()
+    per = (n + nb - 1) // nb
+    bounds = [(i, min(n, i + per)) for i in range(0, n, per)]
+    first = [int(h_off[a]) for a, _ in bounds] + [int(h_off[n - 1]) + int(h_len[n - 1])]
+    cap = max(first[k + 1] - first[k] for k in range(len(bounds))) + 64
+    bufs = [torch.empty(cap, dtype=torch.uint8, device=dev) for _ in range(2)]
+    offs = [torch.empty(per, dtype=torch.int64, device=dev) for _ in range(2)]
+    lens = [torch.empty(per, dtype=torch.int32, device=dev) for _ in range(2)]
+    copy_stream = torch.cuda.Stream(device=dev)
+    main = torch.cuda.current_stream(dev)
+    uploaded = [torch.cuda.Event() for _ in range(2)]
+    scanned = [torch.cuda.Event() for _ in range(2)]
+
+    def upload(k):
+        a, b = bounds[k]
+        s = k & 1
+        with torch.cuda.stream(copy_stream):
+            copy_stream.wait_event(scanned[s])                      # the scan of batch k-2 is done with this buffer
+            nbytes = first[k + 1] - first[k]
+            bufs[s][:nbytes].copy_(h_arena[first[k]:first[k + 1]], non_blocking=True)
+            bufs[s][nbytes:nbytes + 64].fill_(ord("N"))
+            offs[s][:b - a].copy_(h_off[a:b], non_blocking=True)
+            lens[s][:b - a].copy_(h_len[a:b], non_blocking=True)
+            uploaded[s].record(copy_stream)
+
+    def step():
+        matching, hits_n = None, 0
+        upload(0)
+        for k, (a, b) in enumerate(bounds):
+            s = k & 1
+            if k + 1 < len(bounds):
+                upload(k + 1)                                       # in flight while batch k is scanned
+            main.wait_event(uploaded[s])
+            batch = DeviceReads(bufs[s], offs[s][:b - a] - first[k], lens[s][:b - a])
+            if k == 0:
+                bs, be = pl.phase_a(batch, torch.arange(min(p.check_reads, b - a), device=dev))
+                matching = pl.matching_sets(bs, be)
+            st, et = pl.phase_b(batch, matching)
+            hits = pl.phase_c(batch, st, et, matching)
+            hits_n += int(hits.read.numel())
+            scanned[s].record(main)
+        return matching, hits_n
+
+    def sync():
+        pl.aligner.sync()
+        torch.cuda.synchronize()
+    for e in scanned:
+        e.record(main)
+    steps = max(1, min(args.steps, 5))
+    (matching, hits_n), dt = timed(step, steps, max(1, min(args.warmup, 2)), sync)
+    # the upload alone, for reference
+    sync()
+    t0 = time.perf_counter()
+    with torch.cuda.stream(copy_stream):
+        for k in range(len(bounds)):
+            bufs[k & 1][:first[k + 1] - first[k]].copy_(h_arena[first[k]:first[k + 1]], non_blocking=True)
+    torch.cuda.synchronize()
+    dt_up = time.perf_counter() - t0
+    out = {"workload": "BASELINE configs[3] from pinned host memory: %d reads x %d bp uploaded every step in %d batches, upload of "
+                       "batch k+1 overlapping the scan of batch k (two device buffers, two streams)" % (n, args.read_len, len(bounds)),
+           "reads_per_s": n * steps / dt, "ms_per_step": dt / steps * 1e3, "steps": steps,
+           "h2d_gb_per_s_alone": total / dt_up / 1e9, "h2d_ms_alone": dt_up * 1e3,
+           "middle_hits_per_step": hits_n, "matching_sets": [pl.sets[i].name for i in matching]}
     pl.close()
     return out
 
@@ -551,14 +645,18 @@ def main():
             also = {}
             legs = (("configs1", lambda: leg_configs1(dev, args, host_cores())),
                     ("configs2", lambda: leg_configs2(dev, args, host_cores())),
-                    ("ragged_lengths", lambda: leg_ragged(dev, args, host_cores(), out["read_bp_per_s"])))
+                    ("ragged_lengths", lambda: leg_ragged(dev, args, host_cores(), out["read_bp_per_s"])),
+                    ("from_host_memory", lambda: leg_host_buffers(dev, args)))
             for name, leg in legs:
+                note("leg " + name)
                 try:
                     also[name] = leg()
                 except Exception as e:   # an extra leg must never break the bench line
                     also[name] = {"failed": repr(e)}
                 torch.cuda.empty_cache()
             out["config"]["also_measured"] = also
+            if "reads_per_s" in also.get("from_host_memory", {}):
+                out["value_incl_h2d"] = also["from_host_memory"]["reads_per_s"]
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

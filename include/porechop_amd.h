@@ -173,8 +173,10 @@ int pc_trace_ops_x100(pc_ctx *ctx);
 
 /* Run-time specialised score kernels are compiled (hiprtc) once an adapter pair's accumulated work
  * pays for it.  By default the compile happens in place, inside the pc_scan_device call that
- * crosses the threshold; with pc_jit_async(1) it runs on a worker thread and launches keep using
- * the generic kernels until the kernel is ready -- no stall for one-shot runs.  Process-wide. */
+ * crosses the threshold -- provided that call alone is large enough to be worth the stall; a small
+ * launch that merely tips the running total over never waits.  With pc_jit_async(1) every compile
+ * runs on a worker thread and launches keep using the generic kernels until the kernel is ready --
+ * no stall for one-shot runs.  Process-wide. */
 void pc_jit_async(int enabled);
 /* With asynchronous specialisation on, call this before the process exits: it drops compiles that
  * have not started and waits for the one in flight (a worker thread must not be inside hiprtc while

@@ -87,7 +87,13 @@ struct pc_ctx {
     std::vector<int> ad_len, ad_window, ad_span;
     bool panel_dirty = true;
     DevBuf d_ad_codes, d_ad_len, d_ad_window, d_ad_span;
-    DevBuf d_tiles, d_slab, d_fin, d_k1, d_woff2, d_wlen2, d_col0, d_ntot, d_frow, d_fscore, d_err;
+    DevBuf d_slab, d_fin, d_k1, d_woff2, d_wlen2, d_col0, d_ntot, d_frow, d_fscore, d_err;
+    // the tile table lives in one of two slots: a new table is built (on the context's own stream) in the slot
+    // the scans two tables ago used, so building never waits for the scans in flight on the current one
+    DevBuf d_tiles_slot[2], d_runs_slot[2];
+    hipEvent_t slot_free[2] = {nullptr, nullptr};    // recorded on the caller's stream after the last launch that reads the slot
+    hipEvent_t table_ready = nullptr;                // recorded on the context's stream after the expansion kernel
+    int slot = 0;
     // host-API staging
     DevBuf d_arena, d_woff, d_wlen, d_out;
     // pc_phase_b_reduce: job / bin tables (host copies stay alive until the next call's upload)
@@ -100,7 +106,6 @@ struct pc_ctx {
     // cached job table (bench loops repeat the same one: skip the re-upload).  The tile table itself only
     // exists on the device: it is expanded there from the groups' runs (one per job and shape).
     std::vector<Group> groups;
-    DevBuf d_runs;
     std::vector<int32_t> last_job_adapter, last_job_adapter_b;
     std::vector<int64_t> last_job_start;
     int last_max_len = -1, last_mode = -1;
@@ -162,7 +167,9 @@ int upload_panel(pc_ctx *c)
         c->ad_span[i] = b.SPAN;
     }
     // stream-ordered: earlier launches may still read the old tables
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    // the tables below may be in use by scans in flight on ANY stream (callers pass their own): drain the device.
+    // (Only when the panel or the scores change.)
+    HIP_TRY(hipDeviceSynchronize());
     int rc;
     if ((rc = c->d_ad_codes.ensure(codes.size() * 4)) || (rc = c->d_ad_len.ensure(c->ad_len.size() * 4)) ||
         (rc = c->d_ad_window.ensure(c->ad_window.size() * 4)) || (rc = c->d_ad_span.ensure(c->ad_span.size() * 4)))
@@ -277,17 +284,23 @@ int build_tiles(pc_ctx *c, const int32_t *job_adapter, const int32_t *job_adapte
         if (g.tile_count) c->groups.push_back(std::move(g));
     }
     if (ntiles > (size_t)INT32_MAX) return PC_ERR_BAD_ARG;
-    // the previous table may still be in use by launches in flight
-    HIP_TRY(hipDeviceSynchronize());
-    int rc = c->d_tiles.ensure(std::max<size_t>(1, ntiles) * sizeof(pck::Tile));
+    // Build in the other slot: the scans that read it were enqueued two tables ago (their end is marked by
+    // slot_free); the scans in flight on the current slot are not waited for.  No device-wide synchronisation:
+    // a caller's upload of the next batch on another stream keeps running.
+    c->slot ^= 1;
+    const int sl = c->slot;
+    HIP_TRY(hipEventSynchronize(c->slot_free[sl]));
+    int rc = c->d_tiles_slot[sl].ensure(std::max<size_t>(1, ntiles) * sizeof(pck::Tile));
     if (rc) return rc;
-    if ((rc = c->d_runs.ensure(std::max<size_t>(1, all_runs.size()) * sizeof(pck::TileRun)))) return rc;
+    if ((rc = c->d_runs_slot[sl].ensure(std::max<size_t>(1, all_runs.size()) * sizeof(pck::TileRun)))) return rc;
     if (ntiles) {
         // a few hundred bytes per job cross PCIe; the tiles (56 B per 64..128 windows) are written by the GPU
-        HIP_TRY(hipMemcpy(c->d_runs.p, all_runs.data(), all_runs.size() * sizeof(pck::TileRun), hipMemcpyHostToDevice));
-        if (pck::launch_expand_tiles(c->d_runs.as<pck::TileRun>(), (int)all_runs.size(), c->d_tiles.as<pck::Tile>(), (int64_t)ntiles, nullptr))
+        HIP_TRY(hipMemcpyAsync(c->d_runs_slot[sl].p, all_runs.data(), all_runs.size() * sizeof(pck::TileRun), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));        // all_runs is a local: the copy must have left it
+        if (pck::launch_expand_tiles(c->d_runs_slot[sl].as<pck::TileRun>(), (int)all_runs.size(), c->d_tiles_slot[sl].as<pck::Tile>(),
+                                     (int64_t)ntiles, c->stream))
             return PC_ERR_NO_DEVICE;
-        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipEventRecord(c->table_ready, c->stream));
     }
     c->last_job_adapter.assign(job_adapter, job_adapter + njobs);
     c->last_job_adapter_b = jb;
@@ -442,7 +455,9 @@ std::vector<ScoreLaunch> plan_score_launches(pc_ctx *c, const Group &g, int max_
         const size_t e = (size_t)(g.runs[re - 1].tile0 + run_tiles(g.runs[re - 1]));
         // the specialised kernel for this pair, once the work seen for the pair has paid for its
         // compile (pc_jit.cpp); until then the generic one
-        const double est_cells = (double)group_pairs(g, i, e) * (double)max_len * (double)(g.rows ? g.rows : g.gen_max_rows);
+        // (windows of very different lengths: their typical length, not the longest, is what the launch costs)
+        const double est_len = ragged_lengths(c, max_len) ? (double)c->len_hint : (double)max_len;
+        const double est_cells = (double)group_pairs(g, i, e) * est_len * (double)(g.rows ? g.rows : g.gen_max_rows);
         pcj::Spec *sp = !linear ? pcj::get(c->device, c->adapters[r0.adapter_lo], c->adapters[r0.adapter_hi], c->match,
                                            c->mismatch, c->gap_open, c->gap_extend, est_cells)
                                 : nullptr;
@@ -522,6 +537,9 @@ int pc_create(pc_ctx **out, int device)
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->ncu = prop.multiProcessorCount;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return PC_ERR_NO_DEVICE; }
     if (c->d_err.ensure(256) != PC_OK || hipMemset(c->d_err.p, 0, 256) != hipSuccess) { delete c; return PC_ERR_NO_DEVICE; }
+    for (int i = 0; i < 2; ++i)
+        if (hipEventCreateWithFlags(&c->slot_free[i], hipEventDisableTiming) != hipSuccess) { delete c; return PC_ERR_NO_DEVICE; }
+    if (hipEventCreateWithFlags(&c->table_ready, hipEventDisableTiming) != hipSuccess) { delete c; return PC_ERR_NO_DEVICE; }
     *out = c;
     return PC_OK;
 }
@@ -531,9 +549,13 @@ void pc_destroy(pc_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    DevBuf *bufs[] = {&c->d_ad_codes, &c->d_ad_len, &c->d_ad_window, &c->d_ad_span, &c->d_tiles, &c->d_slab, &c->d_fin, &c->d_k1, &c->d_woff2,
+    (void)hipDeviceSynchronize();
+    for (int i = 0; i < 2; ++i) if (c->slot_free[i]) (void)hipEventDestroy(c->slot_free[i]);
+    if (c->table_ready) (void)hipEventDestroy(c->table_ready);
+    DevBuf *bufs[] = {&c->d_ad_codes, &c->d_ad_len, &c->d_ad_window, &c->d_ad_span, &c->d_tiles_slot[0], &c->d_tiles_slot[1],
+                      &c->d_runs_slot[0], &c->d_runs_slot[1], &c->d_slab, &c->d_fin, &c->d_k1, &c->d_woff2,
                       &c->d_wlen2, &c->d_col0, &c->d_ntot, &c->d_frow, &c->d_fscore, &c->d_err, &c->d_arena,
-                      &c->d_woff, &c->d_wlen, &c->d_out, &c->d_red, &c->d_work, &c->d_runs};
+                      &c->d_woff, &c->d_wlen, &c->d_out, &c->d_red, &c->d_work};
     for (DevBuf *b : bufs) b->release();
     (void)hipStreamDestroy(c->stream);
     delete c;
@@ -586,6 +608,7 @@ int pc_scan_device(pc_ctx *c, const void *d_arena, const int64_t *d_win_off, con
     int64_t npairs = 0;
     if ((rc = build_tiles(c, job_adapter, job_adapter_b, job_start, njobs, max_len, mode, &npairs))) return rc;
     hipStream_t stream = (stream_v == PC_STREAM_CONTEXT) ? c->stream : (hipStream_t)stream_v;
+    if (stream != c->stream) HIP_TRY(hipStreamWaitEvent(stream, c->table_ready, 0));   // the table is built on the context's stream
 
     // scratch sizing over all groups
     size_t slab_bytes = 0, fin_bytes = 0;
@@ -642,7 +665,7 @@ int pc_scan_device(pc_ctx *c, const void *d_arena, const int64_t *d_win_off, con
         a.arena = (const uint8_t *)d_arena;
         a.ad_codes = c->d_ad_codes.as<uint32_t>();
         a.ad_len = c->d_ad_len.as<int32_t>();
-        a.tiles = c->d_tiles.as<pck::Tile>() + g.tile_begin;
+        a.tiles = c->d_tiles_slot[c->slot].as<pck::Tile>() + g.tile_begin;
         a.ntiles = (int32_t)g.tile_count;
         const bool linear = pcb::is_linear(c->gap_open, c->gap_extend);
         a.match = c->match; a.mismatch = c->mismatch; a.gap_open = c->gap_open;
@@ -740,6 +763,7 @@ int pc_scan_device(pc_ctx *c, const void *d_arena, const int64_t *d_win_off, con
             }
         }
     }
+    HIP_TRY(hipEventRecord(c->slot_free[c->slot], stream));      // the last launch that reads this table slot
     return PC_OK;
 }
 

@@ -261,6 +261,11 @@ void wait_idle(bool cancel_queued)
     for (Entry *e : es) if (e->worker.joinable()) e->worker.join();
 }
 
+namespace {
+// a worker thread must not be inside hiprtc while the process image is torn down, whoever loaded the library
+struct JoinAtExit { ~JoinAtExit() { wait_idle(true); } } g_join_at_exit;
+}  // namespace
+
 Spec *get(int device, const std::string &ad_lo, const std::string &ad_hi, int match, int mismatch, int gap_open,
           int gap_extend, double cells)
 {
@@ -319,8 +324,11 @@ Spec *get(int device, const std::string &ad_lo, const std::string &ad_hi, int ma
     if (e->seen < min_cells) return nullptr;
     const Recipe rc{ad_lo, ad_hi, match, mismatch, gap_open, gap_extend, R, m_lo, m_hi, eps, 2, f16, kren, cen};
     e->state = Entry::COMPILING;
-    if (g_async.load()) {
-        // the caller does not wait: this launch and the next ones use the generic kernel
+    // Compile in place only when THIS launch alone is worth the stall; a small launch that merely tipped
+    // the pair's running total over the threshold (the mask-and-realign rounds: a millisecond of work)
+    // never waits 0.3 s for a compile -- the worker thread builds the kernel, this launch and the next
+    // ones use the generic kernel, a later one picks the result up.
+    if (g_async.load() || cells < min_cells) {
         e->worker = std::thread(compile_entry, e, rc);
         return nullptr;
     }

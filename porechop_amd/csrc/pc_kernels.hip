@@ -604,6 +604,12 @@ __device__ __forceinline__ int hlo(u32 x) { return (int)(float)HV(x).x; }
 __device__ __forceinline__ int hhi(u32 x) { return (int)(float)HV(x).y; }
 constexpr u32 H_NEGINF2 = 0xFC00FC00u, H_POSINF2 = 0x7C007C00u;
 
+// the trace slab is written once and read back only along the path, long after it has left the caches
+#ifndef PC_SLAB_TEMPORAL
+#define SLAB_STORE(p, v) __builtin_nontemporal_store((v), (p))
+#else
+#define SLAB_STORE(p, v) (*(p) = (v))
+#endif
 #define PC_HMAX "v_pk_max_f16 "
 #define PC_HADD "v_pk_add_f16 "
 #define PC_HMAX3 "v_pk_maximum3_f16 "
@@ -878,7 +884,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(R <= 30 ? 4 
                 if (r >= 1) {
                     const int pr = r - 1;
                     if ((pr & 3) == 1) accA = acc;
-                    if ((pr & 3) == 3) { const u32 wd = __builtin_amdgcn_perm(accA, acc, 0x06020400u); trace_dst[(pr >> 2) * 64] = wd; }
+                    if ((pr & 3) == 3) { const u32 wd = __builtin_amdgcn_perm(accA, acc, 0x06020400u); SLAB_STORE(&trace_dst[(pr >> 2) * 64], wd); }
                 }
                 if (r == R - 1) { d_last = dh[r]; h_last = U[r]; v_last = vs; }
                 T[r] = tn; Tup = tn; Vp = vs; pb1 = b1; pb2 = b2; pb3 = b3;
@@ -892,7 +898,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(R <= 30 ? 4 
                 constexpr int pr = R - 1;
                 const u32 wd = ((pr & 3) == 3) ? __builtin_amdgcn_perm(accA, acc, 0x06020400u)     // rows 4g..4g+3
                                                : __builtin_amdgcn_perm(acc, 0u, 0x0c060c04u);     // a last group of two rows
-                trace_dst[(pr >> 2) * 64] = wd;
+                SLAB_STORE(&trace_dst[(pr >> 2) * 64], wd);
             }
 
             if constexpr (CHECK) {

@@ -29,6 +29,32 @@ for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             out["kernels"][k][counter + "_KB_largest_launch"] = max(v)
             out["kernels"][k][counter + "_KB_mean_launch"] = sum(v) / len(v)
             out["kernels"][k][counter + "_launches"] = len(v)
+# VALU activity pass (headline legs only): per kernel, over its launches -- wave64 VALU instructions, the cycles the
+# VALU was busy with them (SQ_ACTIVE_INST_VALU counts quad-cycles: x4), and the effective clock
+# GRBM_GUI_ACTIVE / 8 XCDs / launch duration (the chip clocks to its power budget, MI355X_MICROARCH.md "DVFS give-back")
+valu_csv = os.path.join(src, "pmc_VALU.csv")
+if os.path.isfile(valu_csv):
+    disp = collections.defaultdict(dict)
+    for r in csv.DictReader(open(valu_csv)):
+        k = (r["Dispatch_Id"], r["Kernel_Name"])
+        disp[k][r["Counter_Name"]] = float(r["Counter_Value"])
+        disp[k]["ns"] = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+    per = collections.defaultdict(lambda: collections.defaultdict(float))
+    for (_, name), v in disp.items():
+        if name in out["kernels"] and v.get("GRBM_GUI_ACTIVE", 0) > 0:
+            for c in ("SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "ns"):
+                per[name][c] += v.get(c, 0.0)
+            per[name]["launches"] += 1
+    for name, v in per.items():
+        gui = v["GRBM_GUI_ACTIVE"] / 8.0                       # cycles of one XCD's clock
+        out["kernels"][name]["valu_pass"] = {
+            "launches": int(v["launches"]), "total_ms": v["ns"] / 1e6,
+            "effective_clock_ghz": gui / v["ns"],
+            "valu_wave_instructions": v["SQ_INSTS_VALU"],
+            "valu_instr_per_s_per_simd": v["SQ_INSTS_VALU"] / 1024.0 / (v["ns"] / 1e9),
+            "valu_busy_frac": v["SQ_ACTIVE_INST_VALU"] * 4.0 / 1024.0 / gui,
+            "resident_waves_per_simd": v["SQ_WAVE_CYCLES"] * 4.0 / 1024.0 / gui}
+    shutil.copy(valu_csv, os.path.join("profiles", "%s_pmc_VALU.csv" % rnd))
 for f in ("kernel_stats.csv", "kernel_trace_scan.csv", "pmc_FETCH_SIZE.csv", "pmc_WRITE_SIZE.csv"):
     shutil.copy(os.path.join(src, f), os.path.join("profiles", "%s_%s" % (rnd, f)))
 with open(os.path.join("profiles", rnd + "_summary.json"), "w") as f:

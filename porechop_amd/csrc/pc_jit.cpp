@@ -146,10 +146,13 @@ void compile_entry(Entry *e, const Recipe rc)
     }
     const int K = ((int)combos.size() + 3) / 4 * 4;
     // Register budget: T, U and four sets of substitution terms (two columns in flight, two being
-    // fetched).  Up to 2R + 4K = 140 the kernel fits 256 VGPRs (two waves per SIMD); longer adapters (full barcode sequences, 63-111 bases) get the
-    // whole register file of a SIMD -- one wave, the rows beyond 256 VGPRs parked in AGPRs -- which
-    // is still several times faster than the generic kernel's column in LDS.
-    const int waves = (2 * R + 4 * K <= 140) ? 2 : 1;
+    // fetched) = 2R + 4K, plus ~50 of bookkeeping.  Up to 120 the column loop fits 168 VGPRs -- three waves
+    // per SIMD, the few values the allocator then spills are touched only outside the loop (measured: -5 %
+    // on the 28+22-base pair, -4 % on 33+30; a 39+34-base pair, 142, spills inside the loop and loses 10 %).
+    // Up to 140: 256 VGPRs, two waves.  Longer adapters (full barcode sequences, 63-111 bases) get the whole
+    // register file of a SIMD -- one wave, the rows beyond 256 VGPRs parked in AGPRs -- which is still
+    // several times faster than the generic kernel's column in LDS.
+    const int waves = (2 * R + 4 * K <= 120) ? 3 : (2 * R + 4 * K <= 140) ? 2 : 1;
     e->R = R; e->K = K; e->m_lo = rc.m_lo; e->m_hi = rc.m_hi; e->f16 = rc.f16; e->waves = waves; e->kren = rc.kren;
 
     std::string init;

@@ -148,3 +148,54 @@ for scores in [(3, -6, -5, -2), (20, -30, -25, -12)]:
         outs.append(lines)
     assert outs[0] == outs[1]
     assert int(outs[0][0].split()[-1]) > 1000        # the planted adapters were found
+
+
+def test_ragged_score_pass_chunked_and_drawn_from_the_counter_equals_plain():
+    """120 k log-normal reads (mean 4 kb, longest > 40 kb), handed over longest first with the length hint set:
+    the score pass cuts every window into typical-length chunks and a persistent grid draws the units from the
+    work counter (pc_set_length_hint) -- with the run-time specialised kernel and with the generic one.  Both
+    must produce, record for record, what the plain one-window-per-workgroup pass (no hint) produces, and a
+    sample of the records must equal the oracle's.  Each variant in a fresh process."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import hashlib, os, sys
+sys.path.insert(0, ".")
+import torch
+import porechop_amd
+from porechop_amd.synth import make_ragged_reads
+from oracle.oracle import Oracle
+ads = ["AATGTACTTCGTTCAGTTACGTATTGCT", "GCAATACGTAACTGAACGAAGT"]
+reads = make_ragged_reads(120_000, mean_len=4000, sigma=0.7, min_len=20, seed=21, start_frac=0.3, end_frac=0.3, chimera_frac=0.05)
+n = reads.n
+order = torch.argsort(reads.length, descending=True, stable=True)
+off, ln = reads.off[order].contiguous(), reads.length[order].contiguous()
+assert int(ln[0]) > 40000
+al = porechop_amd.Aligner(ads)
+if os.environ.get("PC_TEST_HINT") == "1":
+    al.set_length_hint(int(ln.sum().item()) // n)
+out = torch.zeros((2 * n, 8), dtype=torch.int32, device="cuda")
+al.scan_device(reads.arena, off, ln, [0], [0, n], int(ln[0]), out, porechop_amd.MODE_TWO_PASS, job_adapter_b=[1])
+al.sync()
+host = reads.arena.cpu().numpy().tobytes().decode()
+ora = Oracle()
+for k in list(range(0, 40)) + list(range(n // 2, n // 2 + 40)) + list(range(n - 40, n)):
+    seq = host[int(off[k]):int(off[k]) + int(ln[k])]
+    for a in range(2):
+        assert porechop_amd.format_result(out[a * n + k].cpu().numpy()) == ora.adapter_alignment(seq, ads[a]), (k, a)
+print("DIGEST", hashlib.sha1(out.cpu().numpy().tobytes()).hexdigest(), int((out[:, 4] > 40).sum()))
+'''
+    outs = []
+    for env_extra in ({"PC_JIT_MIN_CELLS": "1", "PC_JIT_VERBOSE": "1", "PC_TEST_HINT": "1"}, {"PC_DISABLE_JIT": "1", "PC_TEST_HINT": "1"},
+                      {"PC_JIT_MIN_CELLS": "1", "PC_TEST_HINT": "0"}):
+        res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900,
+                             env=dict(os.environ, **env_extra),
+                             cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        lines = [l for l in res.stdout.splitlines() if l.startswith("DIGEST")]
+        assert len(lines) == 1, res.stdout[-2000:] + res.stderr[-3000:]
+        if "PC_JIT_VERBOSE" in env_extra:
+            assert "specialised kernel R=28" in res.stderr, res.stderr[-2000:]
+        outs.append(lines[0])
+    assert outs[0] == outs[1] == outs[2]
+    assert int(outs[0].split()[-1]) > 1000

@@ -207,3 +207,30 @@ def test_ragged_lengths_and_demux_reduce_vs_reference_logic(oracle):
             n_called += g != "none"
         assert n_called >= 40
     pl.close()
+
+
+def test_copy_windows_packs_and_pads():
+    """pc_copy_windows: windows of any length and alignment copied back to back, the gap up to the next
+    copy's start filled with the pad byte (the maskable copies of reads with middle hits)."""
+    import torch
+    from porechop_amd.batch import Aligner
+    al = Aligner(["ACGT"])
+    g = torch.Generator(device="cuda")
+    g.manual_seed(5)
+    arena = torch.randint(65, 91, (200_000,), dtype=torch.uint8, device="cuda", generator=g)
+    n = 500
+    ln = torch.randint(1, 3000, (n,), device="cuda", generator=g).to(torch.int32)
+    ln[7], ln[8] = 1, 70_000                       # one byte; longer than a workgroup's stride many times over
+    off = torch.randint(0, 200_000 - 70_000, (n,), device="cuda", generator=g).to(torch.int64)
+    stride = (ln.to(torch.int64) + 23) // 16 * 16
+    ends = torch.zeros(n + 1, dtype=torch.int64, device="cuda")
+    ends[1:] = torch.cumsum(stride, 0)
+    dst = torch.full((int(ends[-1]) + 64,), 7, dtype=torch.uint8, device="cuda")
+    al.copy_windows(arena, off, ln, dst, ends, ord("N"))
+    al.sync()
+    a, d = arena.cpu().numpy(), dst.cpu().numpy()
+    for i, (o, l, s, e) in enumerate(zip(off.tolist(), ln.tolist(), ends[:-1].tolist(), ends[1:].tolist())):
+        assert (d[s:s + l] == a[o:o + l]).all(), i
+        assert (d[s + l:e] == ord("N")).all(), i
+    assert (d[int(ends[-1]):] == 7).all()          # nothing written past the last copy
+    al.close()

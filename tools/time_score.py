@@ -6,10 +6,10 @@ sys.path.insert(0, ".")
 import torch
 import porechop_amd
 from porechop_amd.synth import make_reads
-ads = ["AATGTACTTCGTTCAGTTACGTATTGCT", "GCAATACGTAACTGAACGAAGT"]
+ads = sys.argv[1:3] if len(sys.argv) > 2 else ["AATGTACTTCGTTCAGTTACGTATTGCT", "GCAATACGTAACTGAACGAAGT"]
 al = porechop_amd.Aligner(ads)
 al.set_timing(True)
-for n in (2048 * 7 * 64, 1_000_000, 2048 * 8 * 64, 2048 * 4 * 64 + 64 * 100):
+for n in ((1_000_000,) if len(sys.argv) > 2 else (2048 * 7 * 64, 1_000_000, 2048 * 8 * 64, 2048 * 4 * 64 + 64 * 100)):
     reads = make_reads(n, 8000, seed=5, start_frac=0.9, end_frac=0.5, chimera_frac=0.01)
     out = torch.zeros((2 * n, 8), dtype=torch.int32, device="cuda")
     for rep in range(3):

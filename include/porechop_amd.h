@@ -104,7 +104,11 @@ int pc_align_batch_host(pc_ctx *ctx, const char *read_arena, int64_t arena_bytes
  * order: for job k first its n_k records for job_adapter[k], then (if any) its n_k records for
  * job_adapter_b[k].  max_len is an upper bound on every win_len (checked on the device).  The
  * arena must be readable 8 bytes past its last window.  Asynchronous on `stream`; call pc_sync()
- * (or otherwise order your reads after it on the same stream) before reading d_out. */
+ * (or otherwise order your reads after it on the same stream) before reading d_out.
+ * A context is used from ONE host thread and ONE stream at a time: its scratch (trace slab, pass-1
+ * buffer, work counters) is shared by successive calls and ordered only by that stream.  Other streams
+ * of the process (an upload of the next batch, say) are never synchronised with: the tile table of a call
+ * is built on the context's own stream in the table slot the call before last used. */
 int pc_scan_device(pc_ctx *ctx, const void *d_arena, const int64_t *d_win_off,
                    const int32_t *d_win_len, int64_t nwindows, const int32_t *job_adapter,
                    const int32_t *job_adapter_b, const int64_t *job_start, int njobs, int max_len,

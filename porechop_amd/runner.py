@@ -75,6 +75,11 @@ class RunResult:
     seconds: Dict[str, float] = field(default_factory=dict)      # wall-clock per stage
 
 
+# (read, adapter) pairs one block of phases B / C may hold at a time: 8 ints each, a few copies -> a few GB of HBM
+READ_BLOCK_PAIRS = 64_000_000
+MIN_READ_BLOCK = 4096
+
+
 class UsageError(ValueError):
     """What the reference reports with sys.exit('Error: ...')."""
 
@@ -297,17 +302,43 @@ def run(input_path, output=None, barcode_dir=None, options: Options = None, devi
             check_barcodes = barcode_dir is not None
             bc_sets = [i for i in match_idx if check_barcodes and panel_rules.is_barcode(pl.sets[i])
                        and panel_rules.barcode_direction(pl.sets[i]) == orientation]
+            # Phases B and C are per read: they run over blocks of reads so that the scratch of a run
+            # (8 ints per (read, adapter) pair, all middle adapters at once) is bounded by the block, not by
+            # the input -- the reference holds one read's alignments at a time (nanopore_read.py:149-243).
             if check_barcodes:
                 names, bins = barcode_bins(pl, bc_sets)
-                start_trim, end_trim, ci = pl.phase_b_demux(reads, match_idx, bins, opts.barcode_threshold, opts.barcode_diff,
-                                                            opts.require_two_barcodes)
-            else:
-                start_trim, end_trim = pl.phase_b(reads, match_idx)
-            lap("phase_b", sync=True)
-            # ---- phase C -------------------------------------------------------------------
+            n_mid = max(1, len(pl.middle_adapter_list(match_idx)))
+            n_end = max(1, 2 * len(match_idx))
+            block = max(MIN_READ_BLOCK, int(READ_BLOCK_PAIRS // max(n_mid, n_end)))
+            st_parts, et_parts, ci_parts, hit_parts = [], [], [], []
+            for b0 in range(0, R, block):
+                b1 = min(R, b0 + block)
+                sub = reads if (b0 == 0 and b1 == R) else DeviceReads(reads.arena, reads.off[b0:b1], reads.length[b0:b1])
+                if check_barcodes:
+                    st_b, et_b, ci_b = pl.phase_b_demux(sub, match_idx, bins, opts.barcode_threshold, opts.barcode_diff,
+                                                        opts.require_two_barcodes)
+                    ci_parts.append(ci_b)
+                else:
+                    st_b, et_b = pl.phase_b(sub, match_idx)
+                lap("phase_b", sync=True)
+                if not opts.no_split:
+                    hb = pl.phase_c(sub, st_b, et_b, match_idx, prove=True)   # identical hits, fewer tracebacks
+                    if hb.read.numel():
+                        hb.read = hb.read + b0
+                        hit_parts.append(hb)
+                    lap("phase_c", sync=True)
+                st_parts.append(st_b); et_parts.append(et_b)
+            start_trim, end_trim = torch.cat(st_parts), torch.cat(et_parts)
+            if check_barcodes:
+                ci = np.concatenate(ci_parts)
             if not opts.no_split:
-                hits = pl.phase_c(reads, start_trim, end_trim, match_idx, prove=True)   # identical hits, fewer tracebacks
-                lap("phase_c", sync=True)
+                from .pipeline import MiddleHits
+                if hit_parts:
+                    hits = MiddleHits(*(torch.cat([getattr(h_, f) for h_ in hit_parts]) for f in ("read", "adapter", "start", "end", "identity")),
+                                      max(h_.rounds for h_ in hit_parts), sum(h_.alignments for h_ in hit_parts))
+                else:
+                    hits = MiddleHits(*(torch.empty(0, dtype=dt, device=dev) for dt in
+                                        (torch.int64, torch.int32, torch.int32, torch.int32, torch.float64)))
         if hasattr(pl.aligner, "sync"):
             pl.aligner.sync()
 

@@ -53,3 +53,24 @@ runner.run(sys.argv[1], options=opts, aligner=OracleAligner(Oracle(), opts.scori
         assert res.returncode == 0, res.stderr[-2000:]
         want = list(cases[golden]["outputs"].values())[0]
         assert hashlib.md5(res.stdout).hexdigest() == want, (fmt, len(res.stdout))
+
+
+def test_read_blocks_do_not_change_the_outputs(oracle, tmp_path, monkeypatch):
+    """Phases B and C run over blocks of reads (bounded scratch); with blocks of 7 reads instead of one
+    block the output files must still be the reference CLI's (a native-barcoding run with chimeras, a
+    plain run with middle splits)."""
+    from porechop_amd import runner
+    monkeypatch.setattr(runner, "MIN_READ_BLOCK", 7)
+    monkeypatch.setattr(runner, "READ_BLOCK_PAIRS", 1)
+    cases = load_cases()
+    datasets = {}
+    done = 0
+    for name, case in sorted(cases.items()):
+        if name in GPU_ONLY or not (name.startswith("native_") or name.startswith("chimera")):
+            continue
+        got = run_case(name, case, str(tmp_path), datasets, make_aligner=lambda sc: OracleAligner(oracle, sc))
+        assert got == case["outputs"], (name, got, case["outputs"])
+        done += 1
+        if done >= 6:
+            break
+    assert done >= 3

@@ -623,7 +623,8 @@ int pc_scan_device(pc_ctx *c, const void *d_arena, const int64_t *d_win_off, con
         max_chunks = std::max(max_chunks, chunks);
         // score pass: chunked launches, and the chunked tails of big jobs (at most 8 chunks x resident waves)
         const int grid1 = grid_for(c, g, std::max<size_t>(g.tile_count * (size_t)chunks, (size_t)c->ncu * 64), 1, nullptr);
-        fin_bytes = std::max(fin_bytes, (size_t)std::max(grid, grid1) * (size_t)std::max(1, g.rows ? g.rows : g.gen_max_rows) * 64 * 8);
+        // (x2: the specialised score kernel parks the two halves of a lane separately)
+        fin_bytes = std::max(fin_bytes, (size_t)std::max(grid, grid1) * (size_t)std::max(1, g.rows ? g.rows : g.gen_max_rows) * 64 * 8 * 2);
         any_two |= g.two_pass;
     }
     if ((rc = c->d_slab.ensure(slab_bytes + 256)) || (rc = c->d_fin.ensure(fin_bytes + 256))) return rc;

@@ -164,11 +164,12 @@ void compile_entry(Entry *e, const Recipe rc)
                       dW = std::string("-DPC_WAVES=") + (getenv("PC_JIT_WAVES") ? getenv("PC_JIT_WAVES") : std::to_string(waves));
     const char *chk = getenv("PC_JIT_CHECK_RANGE");
     const std::string dG = std::string("-DPC_CHECK_RANGE=") + ((chk && *chk && *chk != '0') ? "1" : "0");
+    const std::string dD = std::string("-DPC_DUAL=") + (rc.ad_lo != rc.ad_hi ? "1" : "0");
     const char *opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", dR.c_str(), dK.c_str(), dC.c_str(), dF.c_str(),
-                          dE.c_str(), dO.c_str(), dN.c_str(), dP.c_str(), dW.c_str(), dG.c_str()};
+                          dE.c_str(), dO.c_str(), dN.c_str(), dP.c_str(), dW.c_str(), dG.c_str(), dD.c_str()};
     hiprtcProgram prog = nullptr;
     if (r.CreateProgram(&prog, kSpecSource, "pc_spec_score.hip", 0, nullptr, nullptr) == 0) {
-        const hiprtcResult rcode = r.CompileProgram(prog, 13, opts);
+        const hiprtcResult rcode = r.CompileProgram(prog, (int)(sizeof(opts) / sizeof(opts[0])), opts);
         if (rcode != 0) {
             size_t n = 0;
             r.GetProgramLogSize(prog, &n);

@@ -36,7 +36,7 @@
 
 namespace pcj {
 
-// defines prepended by pc_jit.cpp: PC_R, PC_K (multiple of 4), PC_COMBO_INIT (R comma-separated
+// defines prepended by pc_jit.cpp: PC_DUAL (1: the two adapters differ), PC_R, PC_K (multiple of 4), PC_COMBO_INIT (R comma-separated
 // ints), PC_F16, PC_EPS (= -gap_extend), PC_OE (= gap_open + PC_EPS), PC_CEN (C), PC_KREN,
 // PC_WAVES (resident waves per SIMD the register allocation must allow), PC_CHECK_RANGE (0/1)
 static const char *kSpecSource = R"PCJIT(
@@ -106,6 +106,11 @@ extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P
     // and the two bytes of a column reach their row through two small byte -> row-offset tables
     __shared__ uint4 s_tab[25 * K / 4];
     __shared__ unsigned short lut_lo[256], lut_hi[256];      // row offsets in uint4 units
+#if PC_DUAL
+    // two DIFFERENT adapters only ever share a tile whose halves read the same windows (pc_api.cpp
+    // build_tiles): one byte stream per lane, and the byte -> table row lookup is a single read
+    __shared__ unsigned short lut_one[256];
+#endif
     const int lane = threadIdx.x;
     for (int i = lane; i < 25 * K / 4; i += 64) s_tab[i] = ((const uint4 *)a.s_table)[i];
     for (int c = lane; c < 256; c += 64) {
@@ -113,11 +118,17 @@ extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P
                        : (c == 'T' || c == 't' || c == 'U' || c == 'u') ? 3 : 4;
         lut_lo[c] = (unsigned short)(code * 5 * (K / 4));
         lut_hi[c] = (unsigned short)(code * (K / 4));
+#if PC_DUAL
+        lut_one[c] = (unsigned short)(code * 6 * (K / 4));
+#endif
     }
     __syncthreads();
     const u32 OE2 = pack2(PC_OE), EPS2 = pack2(PC_EPS), NEG2 = PC_NEGBITS;
     const int pad_lo = R - a.m_lo, pad_hi = R - a.m_hi;
-    uint2 *fin = a.fin_scratch + (i64)blockIdx.x * R * 64;
+    // previous-column state of the lanes whose read ends (one region per half: in a tile of two read
+    // streams the halves of a lane end in different columns)
+    uint2 *fin = a.fin_scratch + (i64)blockIdx.x * 2 * R * 64;
+    uint2 *fin_hi_buf = fin + (PC_DUAL ? 0 : R * 64);
     const int nchunks = a.chunks > 1 ? a.chunks : 1;
 
     // Units (tile x column chunk) are taken in launch order -- the host hands tiles over longest first -- the
@@ -132,7 +143,15 @@ extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P
     for (int vt = blockIdx.x; vt < a.ntiles * nchunks; vt = next_unit(vt)) {
         const int t = vt / nchunks, chunk = vt - t * nchunks;
         const Tile tile = a.tiles[t];
+#if PC_DUAL
+        constexpr bool one_stream = true;
+        if (tile.win_lo != tile.win_hi) {                        // host bug
+            if (lane == 0) atomicAdd(a.err, 1u);
+            continue;
+        }
+#else
         const bool one_stream = tile.win_lo == tile.win_hi;
+#endif
         const i64 p_lo = tile.out_lo + lane, p_hi = tile.out_hi + lane;
         const bool have_lo = lane < tile.count_lo, have_hi = lane < tile.count_hi;
         const unsigned char *w_lo = a.arena + (have_lo ? a.win_off[tile.win_lo + lane] : 0);
@@ -166,6 +185,7 @@ extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P
         int bs_lo = 0, bi_lo = a.m_lo, bj_lo = 0, bs_hi = 0, bi_hi = a.m_hi, bj_hi = 0;
         if (chunk > 0) { bs_lo = -32768; bj_lo = -1; bs_hi = -32768; bj_hi = -1; }   // (m,0) belongs to chunk 0
         u32 best2 = packbest(bs_lo, bs_hi);
+        u32 ftop = 0;                                       // T~(0, n-1) of each half when its read ended
         // wave-uniform extents: columns in (tfmax, nmin) are tracked by every stream of the tile
         int nmax = n_lo > n_hi ? n_lo : n_hi;
         int nmin = have_lo ? n_lo : 0x7FFFFFFF;
@@ -187,7 +207,11 @@ extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P
             return *(const u32_unaligned *)(w + k);
         };
         auto fetch_S = [&](u32 (&S)[K], u32 bl, u32 bh) {
+#if PC_DUAL
+            const uint4 *row = s_tab + (u32)lut_one[bl];
+#else
             const uint4 *row = s_tab + ((u32)lut_lo[bl] + (u32)lut_hi[one_stream ? bl : bh]);
+#endif
 #pragma clang loop unroll(full)
             for (int q = 0; q < K / 4; ++q) { const uint4 v = row[q]; S[4*q] = v.x; S[4*q+1] = v.y; S[4*q+2] = v.z; S[4*q+3] = v.w; }
         };
@@ -198,11 +222,23 @@ extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P
             constexpr bool FAST = decltype(tag)::fast;
             bool fin_lo = false, fin_hi = false, any_fin = false;
             if constexpr (!FAST) {
+                // A read's LAST column is scanned row by row (every cell of it is an end candidate,
+                // dp_scout.h:165-179) -- after the column loop, for all lanes of the tile at once: here the
+                // lanes that end in this column only park the state the column starts from.
                 fin_lo = (j == n_lo) && tail_lo; fin_hi = (j == n_hi) && tail_hi;
                 any_fin = __any(fin_lo || fin_hi);
-                if (any_fin && (fin_lo || fin_hi)) {
+                if (any_fin) {
+                    if (fin_lo) {
 #pragma clang loop unroll(full)
-                    for (int r = 0; r < R; ++r) fin[lane * R + r] = make_uint2(T[r], U[r]);
+                        for (int r = 0; r < R; ++r) fin[lane * R + r] = make_uint2(T[r], U[r]);
+                    }
+#if !PC_DUAL
+                    if (fin_hi) {
+#pragma clang loop unroll(full)
+                        for (int r = 0; r < R; ++r) fin_hi_buf[lane * R + r] = make_uint2(T[r], U[r]);
+                    }
+#endif
+                    ftop = (fin_lo ? (top & 0xFFFFu) : (ftop & 0xFFFFu)) | (fin_hi ? (top & 0xFFFF0000u) : (ftop & 0xFFFF0000u));
                 }
             }
             const u32 topn = pk_add(top, EPS2);               // T~(0, j)
@@ -294,30 +330,6 @@ extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P
             }
             const u32 cand = pk_sub(T[R - 1], topn);
             if constexpr (!FAST) {
-                if (any_fin) {
-                    // last column of a pair: rolled re-run from the saved previous column, tracked
-                    // cells visited top to bottom with strict '>' (dp_scout.h:165-179)
-                    u32 diag = top, Tup = topn, Vprev = NEG2;
-                    const u32 *srow = (const u32 *)s_tab;
-                    // the bytes of THIS column were consumed above: recover them from the streams
-                    const int bl = (j - 1 < n_lo && n_lo > 0) ? w_lo[j - 1] : 0;
-                    const int bh = one_stream ? bl : ((j - 1 < n_hi && n_hi > 0) ? w_hi[j - 1] : 0);
-#pragma unroll 1
-                    for (int r = 0; r < R; ++r) {
-                        const uint2 old = (fin_lo || fin_hi) ? fin[lane * R + r] : make_uint2(0u, 0u);
-                        const u32 s = srow[4 * ((u32)lut_lo[bl] + (u32)lut_hi[bh]) + COMBO[r]];
-                        const u32 d = pk_add(diag, s);
-                        const u32 Hs = pk_max(old.y, old.x);
-                        const u32 Vs = pk_max(Vprev, Tup);
-                        const u32 Tn = pk_add(pk_max(pk_max(d, Hs), Vs), OE2);
-                        diag = old.x; Tup = Tn; Vprev = Vs;
-                        const u32 c = pk_sub(Tn, topn);                  // M(rho, j) + rho*eps, rho = r+1
-                        const int il = r - pad_lo + 1, ih = r - pad_hi + 1;
-                        const int cl = lo16(c) - (r + 1) * PC_EPS, ch = hi16(c) - (r + 1) * PC_EPS;
-                        if (fin_lo && il >= 1 && cl > bs_lo) { bs_lo = cl; bi_lo = il; bj_lo = j; }
-                        if (fin_hi && ih >= 1 && ch > bs_hi) { bs_hi = ch; bi_hi = ih; bj_hi = j; }
-                    }
-                }
                 const int cl = lo16(cand) - R * PC_EPS, ch = hi16(cand) - R * PC_EPS;
                 const bool tr_lo = j > tf_lo && (tail_lo ? j < n_lo : j <= n_lo);
                 const bool tr_hi = j > tf_hi && (tail_hi ? j < n_hi : j <= n_hi);
@@ -520,6 +532,41 @@ extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P
             cur_lo = nxt_lo; cur_hi = nxt_hi;
             nxt_lo = load_dw(w_lo, n_lo, j0 + 7);
             if (!one_stream) nxt_hi = load_dw(w_hi, n_hi, j0 + 7);
+        }
+        // ---- the reads' last columns, all lanes at once: rolled re-run of the column from the parked
+        // state, cells visited top to bottom with strict '>' (dp_scout.h:165-179).  The last column is the
+        // last one the reference visits, so doing it after the loop keeps the visiting order.
+        {
+            const bool ev_lo = have_lo && tail_lo && n_lo > 0, ev_hi = have_hi && tail_hi && n_hi > 0;
+            if (__any(ev_lo || ev_hi)) {
+                const u32 topn = pk_add(ftop, EPS2);
+                u32 diag = ftop, Tup = topn, Vprev = NEG2;
+                const u32 *srow = (const u32 *)s_tab;
+                const int bl = ev_lo ? w_lo[n_lo - 1] : 0;
+                const int bh = one_stream ? bl : (ev_hi ? w_hi[n_hi - 1] : 0);
+                const u32 rowbase = 4 * ((u32)lut_lo[bl] + (u32)lut_hi[bh]);
+#pragma unroll 1
+                for (int r = 0; r < R; ++r) {
+                    const uint2 ol = ev_lo ? fin[lane * R + r] : make_uint2(0u, 0u);
+#if PC_DUAL
+                    const uint2 old = ol;
+#else
+                    const uint2 oh = ev_hi ? fin_hi_buf[lane * R + r] : make_uint2(0u, 0u);
+                    const uint2 old = make_uint2((ol.x & 0xFFFFu) | (oh.x & 0xFFFF0000u), (ol.y & 0xFFFFu) | (oh.y & 0xFFFF0000u));
+#endif
+                    const u32 s = srow[rowbase + COMBO[r]];
+                    const u32 d = pk_add(diag, s);
+                    const u32 Hs = pk_max(old.y, old.x);
+                    const u32 Vs = pk_max(Vprev, Tup);
+                    const u32 Tn = pk_add(pk_max(pk_max(d, Hs), Vs), OE2);
+                    diag = old.x; Tup = Tn; Vprev = Vs;
+                    const u32 c = pk_sub(Tn, topn);                  // M(rho, n) + rho*eps, rho = r+1
+                    const int il = r - pad_lo + 1, ih = r - pad_hi + 1;
+                    const int cl = lo16(c) - (r + 1) * PC_EPS, ch = hi16(c) - (r + 1) * PC_EPS;
+                    if (ev_lo && il >= 1 && cl > bs_lo) { bs_lo = cl; bi_lo = il; bj_lo = n_lo; }
+                    if (ev_hi && ih >= 1 && ch > bs_hi) { bs_hi = ch; bi_hi = ih; bj_hi = n_hi; }
+                }
+            }
         }
 #if PC_CHECK_RANGE
         {

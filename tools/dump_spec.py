@@ -25,7 +25,7 @@ high = match * R
 lim = 2040 if f16 else 32000
 kren = min((2 * lim - (high - low) - (R + 6) * eps) // eps // 4 * 4, 1 << 20)
 defs = ["-DPC_R=%d" % R, "-DPC_K=%d" % K, "-DPC_COMBO_INIT=" + ",".join(map(str, rows)), "-DPC_F16=%d" % f16,
-        "-DPC_EPS=%d" % eps, "-DPC_OE=(%d)" % (go + eps), "-DPC_CEN=(%d)" % (low + lim), "-DPC_KREN=%d" % kren, "-DPC_WAVES=%s" % __import__("os").environ.get("PC_JIT_WAVES", "2"), "-DPC_CHECK_RANGE=%d" % ("--check" in sys.argv)]
+        "-DPC_EPS=%d" % eps, "-DPC_OE=(%d)" % (go + eps), "-DPC_CEN=(%d)" % (low + lim), "-DPC_KREN=%d" % kren, "-DPC_WAVES=%s" % __import__("os").environ.get("PC_JIT_WAVES", "2"), "-DPC_CHECK_RANGE=%d" % ("--check" in sys.argv), "-DPC_DUAL=%d" % (lo != hi)]
 with tempfile.TemporaryDirectory() as d:
     p = os.path.join(d, "k.hip")
     open(p, "w").write("#include <hip/hip_runtime.h>\n" + src)

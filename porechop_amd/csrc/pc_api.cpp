@@ -94,6 +94,11 @@ struct pc_ctx {
     hipEvent_t slot_free[2] = {nullptr, nullptr};    // recorded on the caller's stream after the last launch that reads the slot
     hipEvent_t table_ready = nullptr;                // recorded on the context's stream after the expansion kernel
     int slot = 0;
+    // single-pass traced groups of one call (the row classes of phase A / phase B) run two at a time, every
+    // other one on the context's own stream, each with its own region of the slab: the tail of one launch
+    // is filled by the next.  (No further streams: HIP maps streams onto four hardware queues, and a fifth
+    // stream would share a queue with -- and serialise behind -- a caller's upload stream; measured.)
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // host-API staging
     DevBuf d_arena, d_woff, d_wlen, d_out;
     // pc_phase_b_reduce: job / bin tables (host copies stay alive until the next call's upload)
@@ -540,6 +545,8 @@ int pc_create(pc_ctx **out, int device)
     for (int i = 0; i < 2; ++i)
         if (hipEventCreateWithFlags(&c->slot_free[i], hipEventDisableTiming) != hipSuccess) { delete c; return PC_ERR_NO_DEVICE; }
     if (hipEventCreateWithFlags(&c->table_ready, hipEventDisableTiming) != hipSuccess) { delete c; return PC_ERR_NO_DEVICE; }
+    if (hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) { delete c; return PC_ERR_NO_DEVICE; }
     *out = c;
     return PC_OK;
 }
@@ -552,6 +559,8 @@ void pc_destroy(pc_ctx *c)
     (void)hipDeviceSynchronize();
     for (int i = 0; i < 2; ++i) if (c->slot_free[i]) (void)hipEventDestroy(c->slot_free[i]);
     if (c->table_ready) (void)hipEventDestroy(c->table_ready);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     DevBuf *bufs[] = {&c->d_ad_codes, &c->d_ad_len, &c->d_ad_window, &c->d_ad_span, &c->d_tiles_slot[0], &c->d_tiles_slot[1],
                       &c->d_runs_slot[0], &c->d_runs_slot[1], &c->d_slab, &c->d_fin, &c->d_k1, &c->d_woff2,
                       &c->d_wlen2, &c->d_col0, &c->d_ntot, &c->d_frow, &c->d_fscore, &c->d_err, &c->d_arena,
@@ -611,13 +620,24 @@ int pc_scan_device(pc_ctx *c, const void *d_arena, const int64_t *d_win_off, con
     if (stream != c->stream) HIP_TRY(hipStreamWaitEvent(stream, c->table_ready, 0));   // the table is built on the context's stream
 
     // scratch sizing over all groups
-    size_t slab_bytes = 0, fin_bytes = 0;
+    // single-pass groups get slab / last-column regions of their own (they run concurrently); two-pass groups
+    // run one after the other and share the region behind them
+    size_t slab_bytes = 0, fin_bytes = 0, slab_single = 0, fin_single = 0;
+    std::vector<size_t> slab_off(c->groups.size(), 0), fin_off(c->groups.size(), 0);
     bool any_two = false;
-    int max_chunks = 1;
+    int max_chunks = 1, n_single = 0;
     for (const Group &g : c->groups) {
         size_t stride;
         const int cols = g.two_pass ? g.max_window + 1 : max_len;
         const int grid = grid_for(c, g, g.tile_count, cols, &stride);
+        if (!g.two_pass) {
+            const size_t gi = (size_t)(&g - &c->groups[0]);
+            slab_off[gi] = slab_single; fin_off[gi] = fin_single;
+            slab_single += ((size_t)grid * stride * 4 + 255) & ~(size_t)255;
+            fin_single += ((size_t)grid * (size_t)std::max(1, g.rows ? g.rows : g.gen_max_rows) * 64 * 8 + 255) & ~(size_t)255;
+            ++n_single;
+            continue;
+        }
         slab_bytes = std::max(slab_bytes, (size_t)grid * stride * 4);
         const int chunks = g.two_pass ? group_chunks_for(c, g, max_len) : 1;
         max_chunks = std::max(max_chunks, chunks);
@@ -627,7 +647,23 @@ int pc_scan_device(pc_ctx *c, const void *d_arena, const int64_t *d_win_off, con
         fin_bytes = std::max(fin_bytes, (size_t)std::max(grid, grid1) * (size_t)std::max(1, g.rows ? g.rows : g.gen_max_rows) * 64 * 8 * 2);
         any_two |= g.two_pass;
     }
+    for (size_t gi = 0; gi < c->groups.size(); ++gi)
+        if (c->groups[gi].two_pass) { slab_off[gi] = slab_single; fin_off[gi] = fin_single; }
+    slab_bytes += slab_single; fin_bytes += fin_single;
     if ((rc = c->d_slab.ensure(slab_bytes + 256)) || (rc = c->d_fin.ensure(fin_bytes + 256))) return rc;
+    const bool fork = n_single >= 2 && stream != c->stream;
+    int forked = 0;
+    pc_ctx::Timed fork_timer;
+    bool fork_timed = false;
+    if (fork) {
+        int64_t np_all = 0;
+        for (const Group &g : c->groups) if (!g.two_pass) np_all += group_pairs(g, 0, g.tile_count);
+        if (c->timing && hipEventCreate(&fork_timer.e0) == hipSuccess && hipEventCreate(&fork_timer.e1) == hipSuccess) {
+            fork_timer.kind = 2; fork_timer.pairs = np_all; fork_timed = true;
+            (void)hipEventRecord(fork_timer.e0, stream);            // the concurrent launches are timed as ONE region
+        }
+        HIP_TRY(hipEventRecord(c->ev_fork, stream));
+    }
     // launch plans of the score pass of every two-pass group, made BEFORE anything is enqueued: they
     // decide how large the pass-1 buffer must be, and growing it later would pull it from under
     // kernels already in flight
@@ -674,9 +710,10 @@ int pc_scan_device(pc_ctx *c, const void *d_arena, const int64_t *d_win_off, con
         a.init_extend = c->gap_extend; a.linear = linear ? 1 : 0;
         a.kren = std::max(1, drift_period(c));
         a.err = c->d_err.as<uint32_t>();
-        a.slab = c->d_slab.as<uint32_t>();
+        const size_t gidx = (size_t)(&g - &c->groups[0]);
+        a.slab = (uint32_t *)((char *)c->d_slab.p + slab_off[gidx]);
         a.gen_max_rows = g.gen_max_rows;
-        a.fin_scratch = c->d_fin.as<uint32_t>();
+        a.fin_scratch = (uint32_t *)((char *)c->d_fin.p + fin_off[gidx]);
         a.ad_span = c->d_ad_span.as<int32_t>();
         a.ad_window = c->d_ad_window.as<int32_t>();
         a.win_by_out = 0;
@@ -688,8 +725,15 @@ int pc_scan_device(pc_ctx *c, const void *d_arena, const int64_t *d_win_off, con
             const int grid = grid_for(c, g, g.tile_count, max_len, &stride);
             a.slab_stride = (int64_t)stride;
             const int64_t np = group_pairs(g, 0, g.tile_count);
-            ScopedTimer tm(c, stream, 2, np);
-            if ((rc = launch_traced(c, a, g, grid, stream))) return PC_ERR_NO_DEVICE;
+            if (fork) {
+                hipStream_t ps = (forked & 1) ? c->stream : stream;
+                if (forked == 1) HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_fork, 0));
+                ++forked;
+                if ((rc = launch_traced(c, a, g, grid, ps))) return PC_ERR_NO_DEVICE;
+            } else {
+                ScopedTimer tm(c, stream, 2, np);
+                if ((rc = launch_traced(c, a, g, grid, stream))) return PC_ERR_NO_DEVICE;
+            }
         } else {
             const int64_t np = group_pairs(g, 0, g.tile_count);
             // pass 1: score only, whole window
@@ -714,7 +758,7 @@ int pc_scan_device(pc_ctx *c, const void *d_arena, const int64_t *d_win_off, con
                     memset(&sa, 0, sizeof(sa));
                     sa.arena = a.arena; sa.win_off = a.win_off; sa.win_len = a.win_len;
                     sa.tiles = a.tiles + L.begin; sa.ntiles = (int32_t)L.count;
-                    sa.out = c->d_k1.as<int32_t>() + L.k1_ints; sa.fin_scratch = c->d_fin.p;
+                    sa.out = c->d_k1.as<int32_t>() + L.k1_ints; sa.fin_scratch = a.fin_scratch;
                     sa.gap_open = c->gap_open; sa.gap_extend = c->gap_extend;
                     sa.chunks = L.chunks; sa.chunk_len = chunk_len;
                     sa.span = std::max(c->ad_span[L.adapter_lo], c->ad_span[L.adapter_hi]);
@@ -754,7 +798,7 @@ int pc_scan_device(pc_ctx *c, const void *d_arena, const int64_t *d_win_off, con
             a.win_by_out = 1;
             a.force_row = pl.force_row2; a.force_score = pl.force_score2;
             a.out = d_out;
-            a.slab = c->d_slab.as<uint32_t>();
+            a.slab = (uint32_t *)((char *)c->d_slab.p + slab_off[gidx]);
             a.slab_cols = g.max_window + 1;
             const int grid = grid_for(c, g, g.tile_count, a.slab_cols, &stride);
             a.slab_stride = (int64_t)stride;
@@ -763,6 +807,13 @@ int pc_scan_device(pc_ctx *c, const void *d_arena, const int64_t *d_win_off, con
                 if ((rc = launch_traced(c, a, g, grid, stream))) return PC_ERR_NO_DEVICE;
             }
         }
+    }
+    if (fork) {
+        if (forked >= 2) {
+            HIP_TRY(hipEventRecord(c->ev_join, c->stream));
+            HIP_TRY(hipStreamWaitEvent(stream, c->ev_join, 0));
+        }
+        if (fork_timed) { (void)hipEventRecord(fork_timer.e1, stream); c->timed.push_back(fork_timer); }
     }
     HIP_TRY(hipEventRecord(c->slot_free[c->slot], stream));      // the last launch that reads this table slot
     return PC_OK;

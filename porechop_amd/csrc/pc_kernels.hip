@@ -597,6 +597,9 @@ __device__ __forceinline__ u32 WH(h16x2 x) { return __builtin_bit_cast(u32, x); 
 __device__ __forceinline__ u32 hk_add(u32 a, u32 b) { return WH(HV(a) + HV(b)); }
 __device__ __forceinline__ u32 hk_sub(u32 a, u32 b) { return WH(HV(a) - HV(b)); }
 __device__ __forceinline__ u32 hk_max(u32 a, u32 b) { return WH(__builtin_elementwise_max(HV(a), HV(b))); }
+// IEEE-754-2019 maximum: lowers to v_pk_maximum3_f16 (two nested ones fuse into ONE three-input op) and, unlike
+// maxnum, needs no canonicalisation of operands the compiler cannot prove quiet (values here are never NaN)
+__device__ __forceinline__ u32 hk_maximum(u32 a, u32 b) { return WH(__builtin_elementwise_maximum(HV(a), HV(b))); }
 __device__ __forceinline__ u32 hk_min(u32 a, u32 b) { return WH(__builtin_elementwise_min(HV(a), HV(b))); }
 __device__ __forceinline__ u32 hpack2x(int l, int h) { const h16x2 v = {(_Float16)l, (_Float16)h}; return WH(v); }
 __device__ __forceinline__ u32 hpack2(int v) { return hpack2x(v, v); }
@@ -801,7 +804,37 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(R <= 30 ? 4 
         u32 cur_lo = load_dw(w_lo, n_lo, 0), cur_hi = one_stream ? 0u : load_dw(w_hi, n_hi, 0);
         int trow = row_of(cur_lo & 0xFF, cur_hi & 0xFF);
         u32 vmax = H_NEGINF2, vmin = H_POSINF2;
-        for (int j = 1; j <= nmax; ++j) {
+        // ---- warm-up columns of pass-2 windows: the traced path provably cannot reach them (pc_bounds.h),
+        // every pair's end cell is forced and no window ends here, so they run the bare recurrence -- five
+        // ops per two cells, no trace bits, no slab stores, no scout -- left to the compiler's scheduler
+        int j_first = 1;
+        for (; j_first <= notrace_upto; ++j_first) {
+            const int trow_j = trow;
+            cur_lo >>= 8; cur_hi >>= 8;
+            if ((j_first & 3) == 0) { cur_lo = load_dw(w_lo, n_lo, j_first); if (!one_stream) cur_hi = load_dw(w_hi, n_hi, j_first); }
+            trow = row_of(cur_lo & 0xFF, cur_hi & 0xFF);
+            const u32 topn = hk_add(top, EPS2);
+            const uint4 *srow = (const uint4 *)(s_tab + trow_j);
+            u32 dq = top, Tup = topn, Vp = NEG2;
+#pragma clang loop unroll(full)
+            for (int g = 0; g < RP / 4; ++g) {
+                const uint4 v = srow[g];
+                const u32 Sg[4] = {v.x, v.y, v.z, v.w};
+#pragma clang loop unroll(full)
+                for (int k = 0; k < 4; ++k) {
+                    const int r = 4 * g + k;
+                    if (r < R) {
+                        const u32 Hs = hk_maximum(U[r], T[r]);
+                        const u32 d = hk_add(dq, Sg[k]);
+                        const u32 Vs = hk_maximum(Vp, Tup);
+                        const u32 Tn = hk_add(hk_maximum(hk_maximum(d, Hs), Vs), OE2);
+                        dq = T[r]; U[r] = Hs; T[r] = Tn; Tup = Tn; Vp = Vs;
+                    }
+                }
+            }
+            top = topn;
+        }
+        for (int j = j_first; j <= nmax; ++j) {
             const int trow_j = trow;
             // next column's bytes / table row, one column ahead of their use
             cur_lo >>= 8; cur_hi >>= 8;
@@ -817,8 +850,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(R <= 30 ? 4 
             }
             const u32 topn = hk_add(top, EPS2);                   // T~(0, j)
             const uint4 *srow = (const uint4 *)(s_tab + trow_j);
-            // (columns up to notrace_upto are written too: the walk never reads them, and a branch per
-            // word would cut the row sequence into basic blocks)
             u32 *trace_dst = slab + ((int64_t)((a.debug & 2) ? 0 : (j - 1)) * NW) * 64 + lane;
 
             // ---- the column ------------------------------------------------------------------

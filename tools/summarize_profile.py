@@ -13,7 +13,7 @@ import sys
 
 tag, rnd, reads = sys.argv[1], sys.argv[2], int(sys.argv[3])
 src = os.path.join("gpurun_out", "prof_" + tag)
-out = {"command": "python bench.py --reads %d --steps 2 --warmup 1 --cpu-seconds 0" % reads, "reads_per_gpu": reads,
+out = {"command": "python bench.py --reads %d --steps 2 --warmup 1 --cpu-seconds 0 --no-extra" % reads, "reads_per_gpu": reads,
        "kernels": {}}
 for r in csv.DictReader(open(os.path.join(src, "kernel_stats.csv"))):
     name = r["Name"]
@@ -57,6 +57,15 @@ if os.path.isfile(valu_csv):
     shutil.copy(valu_csv, os.path.join("profiles", "%s_pmc_VALU.csv" % rnd))
 for f in ("kernel_stats.csv", "kernel_trace_scan.csv", "pmc_FETCH_SIZE.csv", "pmc_WRITE_SIZE.csv"):
     shutil.copy(os.path.join(src, f), os.path.join("profiles", "%s_%s" % (rnd, f)))
+# the full default run (all legs): per-kernel stats only
+legs = os.path.join(src, "kernel_stats_all_legs.csv")
+if os.path.isfile(legs):
+    out["all_legs"] = {"command": "python bench.py --steps 2 --warmup 1 --cpu-seconds 0", "kernels": {}}
+    for r in csv.DictReader(open(legs)):
+        if "pck::" in r["Name"] or "pc_spec" in r["Name"]:
+            out["all_legs"]["kernels"][r["Name"]] = {"calls": int(r["Calls"]), "avg_ms": float(r["AverageNs"]) / 1e6,
+                                                     "max_ms": int(r["MaxNs"]) / 1e6, "total_ms": int(r["TotalDurationNs"]) / 1e6}
+    shutil.copy(legs, os.path.join("profiles", "%s_kernel_stats_all_legs.csv" % rnd))
 with open(os.path.join("profiles", rnd + "_summary.json"), "w") as f:
     json.dump(out, f, indent=1)
 print(json.dumps({k: v for k, v in out["kernels"].items() if v.get("max_ms", 0) > 5}, indent=1))

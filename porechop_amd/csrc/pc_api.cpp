@@ -784,6 +784,10 @@ int pc_scan_device(pc_ctx *c, const void *d_arena, const int64_t *d_win_off, con
             a.chunks = 1;
             pl.ad_window = c->d_ad_window.as<int32_t>();
             pl.score_out = (mode == PC_MODE_SCORE) ? d_out : nullptr;
+            {   // end-aligned windows only for the packed-fp16 traced kernel (it is the one that knows lead-ins)
+                pcb::F16Plan fp_;
+                pl.end_align = trace16_plan(c, g.rows, g.max_window + 1, &fp_) ? 1 : 0;
+            }
             {
                 ScopedTimer tm(c, stream, 1, np);
                 for (const ScoreLaunch &L : score_plan[gi]) {

@@ -73,6 +73,10 @@ struct PlanArgs {
     int32_t chunks;                                     // chunk results per pair in k1 (>= 1)
     const int32_t *ad_window;                           // [nadapters] W+SPAN+1 for that adapter length
     int32_t *score_out;                                 // PC_MODE_SCORE: [npairs][8] records (-2, J, I, 0, score, 0, 0, 0)
+    int32_t end_align;                                  // 1: every window of a tile gets the same length (the larger of the two
+                                                        // adapters' windows), a window that would start before the read's column 0
+                                                        // by a lead-in of the bytes before the read (col0 < 0): all windows then END
+                                                        // in the same local column and share their trace-free warm-up (trace16_kernel)
 };
 
 // per-read reduction of the end-window records (pc_reduce.hip)

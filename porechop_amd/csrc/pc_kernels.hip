@@ -186,6 +186,8 @@ __device__ __forceinline__ void traceback_pairs(const ScanArgs &a, const u32 *sl
                                                 const int c0_lo, const int c0_hi, const int m_lo, const int m_hi,
                                                 const int64_t p_lo, const int64_t p_hi, const int notrace_upto)
 {
+    // end-aligned windows: a negative col0 is the lead-in before the read's column 0
+    const int cmin_lo = c0_lo < 0 ? -c0_lo : 0, cmin_hi = c0_hi < 0 ? -c0_hi : 0;
     // trace nibble of cell (col, adapter row) of half hf; the bases themselves are never needed
     // (pc_walk.h derives the match count from the score)
     auto fetch = [&](int hf, int pad, int col, int row) -> int {
@@ -207,12 +209,15 @@ __device__ __forceinline__ void traceback_pairs(const ScanArgs &a, const u32 *sl
     };
     const int tiefix_lo = tie_fix_of(0, have_lo, b_lo, pad_lo);
     const int tiefix_hi = tie_fix_of(1, have_hi, b_hi, pad_hi);
-    wk_lo.start(b_lo.I, b_lo.J, m_lo, c0_lo, nt_lo, b_lo.score, tiefix_lo);
-    wk_hi.start(b_hi.I, b_hi.J, m_hi, c0_hi, nt_hi, b_hi.score, tiefix_hi);
+    wk_lo.start(b_lo.I, b_lo.J, m_lo, c0_lo, nt_lo, b_lo.score, tiefix_lo, cmin_lo);
+    wk_hi.start(b_hi.I, b_hi.J, m_hi, c0_hi, nt_hi, b_hi.score, tiefix_hi, cmin_hi);
     if (!have_lo) wk_lo.done = 1;
     if (!have_hi) wk_hi.done = 1;
     int left_trace = 0;
+    // (a path has at most rows + columns steps: the cap turns a corrupted trace into a reported error, not a hang)
+    int steps_left = 2 * (rows + (n_lo > n_hi ? n_lo : n_hi)) + 8;
     while (!(wk_lo.done & wk_hi.done)) {
+        if (--steps_left < 0) { left_trace = 1; break; }
         // a walk that leaves the traced columns of a pass-2 window is stopped and flagged (never
         // expected: the bound of pc_bounds.h).  Both walks fetch every round -- a finished one from
         // a clamped, valid cell -- and step under a predicate: no divergent branches in the loop.
@@ -223,6 +228,7 @@ __device__ __forceinline__ void traceback_pairs(const ScanArgs &a, const u32 *sl
         go_lo &= out_lo ^ 1; go_hi &= out_hi ^ 1;
         const int nb_lo = fetch(0, pad_lo, wk_lo.col > 1 ? wk_lo.col : 1, wk_lo.row > 1 ? wk_lo.row : 1);
         const int nb_hi = fetch(1, pad_hi, wk_hi.col > 1 ? wk_hi.col : 1, wk_hi.row > 1 ? wk_hi.row : 1);
+        (void)cmin_lo; (void)cmin_hi;
         wk_lo.step(nb_lo, go_lo);
         wk_hi.step(nb_hi, go_hi);
     }
@@ -431,7 +437,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((R > 0 && R 
             if (have_hi && n_hi - w_hi - 2 < t0) t0 = n_hi - w_hi - 2;
 #pragma unroll
             for (int s = 32; s >= 1; s >>= 1) { const int o = __shfl_xor(t0, s); t0 = o < t0 ? o : t0; }
-            notrace_upto = __builtin_amdgcn_readfirstlane(t0 > 0 ? t0 : 0);   // wave-uniform: a scalar branch below
+            notrace_upto = __builtin_amdgcn_readfirstlane((t0 > 0 && t0 < nmax) ? t0 : 0);   // (a tile of empty windows has no t0)   // wave-uniform: a scalar branch below
         }
 
         u32 cur_lo = 0, cur_hi = 0;
@@ -764,11 +770,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(R <= 30 ? 4 
             const int wl = a.ad_window[tile.adapter_lo] - a.ad_span[tile.adapter_lo] - 1;
             const int wh = a.ad_window[tile.adapter_hi] - a.ad_span[tile.adapter_hi] - 1;
             int t0 = 1 << 30;
-            if (have_lo) t0 = n_lo - wl - 2;
-            if (have_hi && n_hi - wh - 2 < t0) t0 = n_hi - wh - 2;
+            if (have_lo && n_lo > 0) t0 = n_lo - wl - 2;
+            if (have_hi && n_hi > 0 && n_hi - wh - 2 < t0) t0 = n_hi - wh - 2;
 #pragma unroll
             for (int s = 32; s >= 1; s >>= 1) { const int o = __shfl_xor(t0, s); t0 = o < t0 ? o : t0; }
-            notrace_upto = __builtin_amdgcn_readfirstlane(t0 > 0 ? t0 : 0);
+            notrace_upto = __builtin_amdgcn_readfirstlane((t0 > 0 && t0 < nmax) ? t0 : 0);   // (a tile of empty windows has no t0)
         }
         // last-row cells are tracked in columns 1..n-1 of pairs that scout (no forced end cell):
         // +inf lets a half's candidate through, -inf blanks it
@@ -801,6 +807,26 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(R <= 30 ? 4 
             return one_stream ? (int)lut_lo[bl] + (int)lut_hi[bl] : (int)lut_lo[bl] + (int)lut_hi[bh];
         };
 
+        // End-aligned pass-2 windows (plan_kernel, end_align): a window that would start before its read's column 0
+        // carries a lead-in of -col0 columns instead, so that every window of the tile ends in the same column and
+        // the tile keeps its trace-free warm-up.  The lead-in is garbage: when a half reaches the read's column 0
+        // its state is set to what column 0 is (M = 0 everywhere), in the drifted frame of that column.
+        const int sh_lo = c0_lo < 0 ? -c0_lo : 0, sh_hi = c0_hi < 0 ? -c0_hi : 0;
+        int shmax = sh_lo > sh_hi ? sh_lo : sh_hi;
+#pragma unroll
+        for (int s_ = 32; s_ >= 1; s_ >>= 1) { const int o = __shfl_xor(shmax, s_); shmax = o > shmax ? o : shmax; }
+        shmax = __builtin_amdgcn_readfirstlane(shmax);
+        auto reach_column0 = [&](int j) {
+            const bool rl = sh_lo > 0 && j == sh_lo, rh = sh_hi > 0 && j == sh_hi;
+            if (!__any(rl || rh)) return;
+            const u32 ml = rl ? 0xFFFFu : 0u, mh = rh ? 0xFFFF0000u : 0u, keep = ~(ml | mh);
+#pragma clang loop unroll(full)
+            for (int r = 0; r < R; ++r) {
+                const u32 init = hpack2(a.gap_open + (r + 2 + j) * eps - CEN);
+                T[r] = (T[r] & keep) | (init & (ml | mh));
+                U[r] = (U[r] & keep) | (NEG2 & (ml | mh));
+            }
+        };
         u32 cur_lo = load_dw(w_lo, n_lo, 0), cur_hi = one_stream ? 0u : load_dw(w_hi, n_hi, 0);
         int trow = row_of(cur_lo & 0xFF, cur_hi & 0xFF);
         u32 vmax = H_NEGINF2, vmin = H_POSINF2;
@@ -833,6 +859,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(R <= 30 ? 4 
                 }
             }
             top = topn;
+            if (j_first <= shmax) reach_column0(j_first);
         }
         for (int j = j_first; j <= nmax; ++j) {
             const int trow_j = trow;
@@ -977,6 +1004,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(R <= 30 ? 4 
                 store_best(b_lo, b_hi);
             }
             top = topn;
+            if (j <= shmax) reach_column0(j);
         }
         if constexpr (CHECK) {
             const int hi = hlo(vmax) > hhi(vmax) ? hlo(vmax) : hhi(vmax), lo = hlo(vmin) < hhi(vmin) ? hlo(vmin) : hhi(vmin);
@@ -1023,9 +1051,17 @@ __global__ void plan_kernel(PlanArgs a)
         o[1] = make_int4(score, 0, 0, 0);
         return;
     }
-    const int window = a.ad_window[hi ? tile.adapter_hi : tile.adapter_lo];
+    int window = a.ad_window[hi ? tile.adapter_hi : tile.adapter_lo];
     int c0 = J - window;
-    if (c0 < 0) c0 = 0;
+    if (a.end_align && J > 0) {             // (J == 0: the end cell is the corner (m, 0) -- nothing to run, nothing to align)
+        // (a longer warm-up is still exact; the lead-in columns are garbage the kernel discards when it reaches
+        // the read's column 0 -- they only have to be readable: not before the arena's first byte)
+        const int wl = a.ad_window[tile.adapter_lo], wh = a.ad_window[tile.adapter_hi];
+        window = wl > wh ? wl : wh;
+        c0 = J - window;
+        const int64_t room = a.win_off[w];
+        if (c0 < 0 && (int64_t)(-c0) > room) c0 = -(int)room;
+    } else if (c0 < 0) c0 = 0;
     a.win_off2[p] = a.win_off[w] + c0;
     a.win_len2[p] = J - c0;
     a.col02[p] = c0;

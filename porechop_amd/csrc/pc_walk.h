@@ -67,17 +67,20 @@ struct Digest {
 struct Walk {
     enum : int { DISPATCH = 0, VRUN = 1, HRUN = 2 };
     int col, row, mode, first, tie_fix, done, err;
+    int cmin;                                     // local column of the read's column 0 (0, or the lead-in of an end-aligned window)
     int m, col0, n_total, score, I, J;
     int ndiag, nopen, nsteps;                     // diagonal steps, gap steps that OPENED their gap, all steps
     int matches_seen;                             // host cross-check only (consume())
     int cur_type, cur_len, changed;               // the run being walked, until it first changes
     int first_type, first_len, second_type;       // the first run seen from the end, and what follows it
 
-    PC_HD void start(int I_, int J_, int m_, int col0_, int n_total_, int score_, int tie_fix_) {
-        col = J_; row = I_; I = I_; J = J_; mode = DISPATCH; first = 1; tie_fix = tie_fix_; err = 0;
+    // cmin_ > 0: the window was given a lead-in of cmin_ columns before the read's column 0 (col0_ = -cmin_) so
+    // that it ends where the other windows of its tile end; the path stops at local column cmin_
+    PC_HD void start(int I_, int J_, int m_, int col0_, int n_total_, int score_, int tie_fix_, int cmin_ = 0) {
+        col = J_; row = I_; I = I_; J = J_; mode = DISPATCH; first = 1; tie_fix = tie_fix_; err = 0; cmin = cmin_;
         m = m_; col0 = col0_; n_total = n_total_; score = score_;
         ndiag = 0; nopen = 0; nsteps = 0; matches_seen = 0; cur_type = 0; cur_len = 0; changed = 0; first_type = 0; first_len = 0; second_type = 0;
-        done = !(col > 0 && row > 0);
+        done = !(col > cmin && row > 0);
     }
     // nib: trace nibble of cell (col,row); eq: read base (col-1) == adapter base (row-1)
     PC_HD void consume(int nib, bool eq) {
@@ -127,15 +130,15 @@ struct Walk {
         // a gap run goes on while the cell being left extended its gap (its open bit is clear) and the
         // run has not reached row / column 0; after its opening step the dispatch restarts (GapsLeft)
         const int go_v = (t == T_V ? 1 : 0) & (vopen ^ 1) & (row >= 1 ? 1 : 0);
-        const int go_h = (t == T_H ? 1 : 0) & (hopen ^ 1) & (col >= 1 ? 1 : 0);
+        const int go_h = (t == T_H ? 1 : 0) & (hopen ^ 1) & (col >= cmin + 1 ? 1 : 0);
         const int nmode = go_v ? VRUN : (go_h ? HRUN : DISPATCH);
         mode = active ? nmode : mode;
-        const int ndone = (nmode == DISPATCH ? 1 : 0) & ((col > 0 && row > 0) ? 0 : 1);
+        const int ndone = (nmode == DISPATCH ? 1 : 0) & ((col > cmin && row > 0) ? 0 : 1);
         done = active ? ndone : done;
     }
     // match, mismatch, gap_open, gap_extend: the scheme's real scores (linear mode: gap_extend = gap_open)
     PC_HD int finish(Digest &out, int match, int mismatch, int gap_open, int gap_extend) {
-        if (row > 0 && col == 0 && col0 > 0) err = 1;   // left the window: bound violated
+        if (row > 0 && col == cmin && col0 + cmin > 0) err = 1;   // left the window: bound violated
         const int gaps = nsteps - ndiag;
         const int num = score - mismatch * ndiag - nopen * gap_open - (gaps - nopen) * gap_extend;
         const int matches = num / (match - mismatch);

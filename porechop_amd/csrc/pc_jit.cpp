@@ -346,6 +346,7 @@ int launch(const Spec *sp, const SpecArgs &a, int grid, void *stream)
     SpecArgs args = a;
     args.s_table = (const uint32_t *)sp->d_table;
     args.m_lo = sp->m_lo; args.m_hi = sp->m_hi;
+    args.one2 = 0x00010001u;
     void *params[] = {&args};
     const hipError_t e = hipModuleLaunchKernel((hipFunction_t)sp->function, (unsigned)grid, 1, 1, 64, 1, 1, 0,
                                                (hipStream_t)stream, params, nullptr);

@@ -28,6 +28,7 @@ struct SpecArgs {
     int32_t chunks, chunk_len, span;
     uint32_t *err;
     uint32_t *work_counter;      // units beyond the grid are handed out by this counter (zeroed by the host); null = fixed stride
+    uint32_t one2;               // 0x00010001 (set by launch())
 };
 
 bool disabled();

@@ -72,6 +72,18 @@ __device__ __forceinline__ u32 pk_sub(u32 a, u32 b) { return WV(SV(a) - SV(b)); 
 __device__ __forceinline__ u32 pk_max(u32 a, u32 b) { return WV(__builtin_elementwise_max(SV(a), SV(b))); }
 __device__ __forceinline__ u32 pk_min(u32 a, u32 b) { return WV(__builtin_elementwise_min(SV(a), SV(b))); }
 __device__ __forceinline__ u32 pack2(int v) { return pack2x(v, v); }
+#if PC_F16
+// IEEE-754-2019 maximum = v_pk_maximum3_f16: no canonicalising op on operands the compiler cannot prove quiet (never NaN here)
+__device__ __forceinline__ u32 pk_maxq(u32 a, u32 b) { return WV(__builtin_elementwise_maximum(SV(a), SV(b))); }
+#else
+__device__ __forceinline__ u32 pk_maxq(u32 a, u32 b) { return pk_max(a, b); }
+#endif
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ u16x2 UV16(u32 x) { return __builtin_bit_cast(u16x2, x); }
+__device__ __forceinline__ u32 WV16(u16x2 x) { return __builtin_bit_cast(u32, x); }
+__device__ __forceinline__ u32 pk_minu(u32 a, u32 b) { return WV16(__builtin_elementwise_min(UV16(a), UV16(b))); }
+__device__ __forceinline__ u32 pk_subu(u32 a, u32 b) { return WV16(UV16(a) - UV16(b)); }
+__device__ __forceinline__ u32 pk_madu(u32 a, u32 k, u32 c) { return WV16(UV16(a) * UV16(k) + UV16(c)); }
 // packed "best so far" in the tracked-score domain (score + R*eps); the chunk>0 sentinel maps to -inf
 __device__ __forceinline__ u32 packbest(int l, int h)
 {
@@ -90,6 +102,7 @@ struct SpecArgs {
     int chunks, chunk_len, span;
     u32 *err;
     u32 *work_counter;
+    u32 one2;                 // 0x00010001, kept opaque to the compiler (with a literal it turns min_u16(x, 1) into compare / select chains)
 };
 struct FastT { static constexpr bool fast = true; };
 struct SlowT { static constexpr bool fast = false; };
@@ -186,6 +199,21 @@ extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P
         if (chunk > 0) { bs_lo = -32768; bj_lo = -1; bs_hi = -32768; bj_hi = -1; }   // (m,0) belongs to chunk 0
         u32 best2 = packbest(bs_lo, bs_hi);
         u32 ftop = 0;                                       // T~(0, n-1) of each half when its read ended
+        // In the block-resolved path the running maximum and its column live PACKED (best2: the tracked
+        // score term, pos2: the column as two u16; 0xFFFF = none yet): a new maximum costs five packed ops
+        // per column for both halves instead of two conversions and two compare / select chains.  The int
+        // copies (bs, bj) are brought up to date where the per-stream path or the output needs them.
+        u32 pos2 = ((u32)bj_lo & 0xFFFFu) | ((u32)bj_hi << 16);
+        bool packed_ahead = false;                          // wave-uniform: (best2, pos2) are newer than (bs, bj)
+        auto unpack_best = [&]() {
+            bs_lo = ((best2 & 0xFFFFu) == (PC_NEGBITS & 0xFFFFu)) ? -32768 : lo16(best2) - R * PC_EPS;
+            bs_hi = ((best2 >> 16) == (PC_NEGBITS >> 16)) ? -32768 : hi16(best2) - R * PC_EPS;
+            bj_lo = ((pos2 & 0xFFFFu) == 0xFFFFu) ? -1 : (int)(pos2 & 0xFFFFu);
+            bj_hi = ((pos2 >> 16) == 0xFFFFu) ? -1 : (int)(pos2 >> 16);
+            bi_lo = a.m_lo; bi_hi = a.m_hi;                 // every cell tracked inside the column loop is a last-row cell
+            packed_ahead = false;
+        };
+        const u32 ONE2 = a.one2;
         // wave-uniform extents: columns in (tfmax, nmin) are tracked by every stream of the tile
         int nmax = n_lo > n_hi ? n_lo : n_hi;
         int nmin = have_lo ? n_lo : 0x7FFFFFFF;
@@ -502,15 +530,29 @@ extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P
                 column2(SC, SD, c2, c3);
                 const u32 nb = pk_max(pk_max(best2, pk_max(c0, c1)), pk_max(c2, c3));
                 if (__any(nb != best2)) {
-                    // a new maximum somewhere in the block: resolve the column, in visiting order
+                    // a new maximum somewhere in the block: resolve the column, in visiting order (strict '>',
+                    // the earlier column wins)
                     const u32 cs[4] = {c0, c1, c2, c3};
+                    if (nmax <= 65000) {
+                        u32 b = best2, ps = pos2;
 #pragma clang loop unroll(full)
-                    for (int k = 0; k < 4; ++k) {
-                        const int cl = lo16(cs[k]) - R * PC_EPS, ch = hi16(cs[k]) - R * PC_EPS;
-                        if (cl > bs_lo) { bs_lo = cl; bi_lo = a.m_lo; bj_lo = j0 + k; }
-                        if (ch > bs_hi) { bs_hi = ch; bi_hi = a.m_hi; bj_hi = j0 + k; }
+                        for (int k = 0; k < 4; ++k) {
+                            const u32 m = pk_maxq(b, cs[k]);
+                            const u32 f = pk_minu(m ^ b, ONE2);              // 1 in the halves where column k is a new maximum
+                            const u32 jk = (u32)(j0 + k) * 0x00010001u;
+                            ps = pk_madu(f, pk_subu(jk, ps), ps);            // their column becomes j0 + k
+                            b = m;
+                        }
+                        best2 = b; pos2 = ps; packed_ahead = true;
+                    } else {                                                  // columns beyond u16: the plain way
+#pragma clang loop unroll(full)
+                        for (int k = 0; k < 4; ++k) {
+                            const int cl = lo16(cs[k]) - R * PC_EPS, ch = hi16(cs[k]) - R * PC_EPS;
+                            if (cl > bs_lo) { bs_lo = cl; bi_lo = a.m_lo; bj_lo = j0 + k; }
+                            if (ch > bs_hi) { bs_hi = ch; bi_hi = a.m_hi; bj_hi = j0 + k; }
+                        }
+                        best2 = nb;
                     }
-                    best2 = nb;
                 }
             } else {
 #if PC_CHECK_RANGE
@@ -518,6 +560,7 @@ extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P
 #else
 #define PC_NOTE
 #endif
+                if (packed_ahead) unpack_best();
                 fetch_S(SB, (cur_lo >> 8) & 0xFF, (cur_hi >> 8) & 0xFF);
                 column(SlowT{}, j0, SA); PC_NOTE
                 fetch_S(SA, (cur_lo >> 16) & 0xFF, (cur_hi >> 16) & 0xFF);
@@ -527,12 +570,14 @@ extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P
                 fetch_S(SA, nxt_lo & 0xFF, nxt_hi & 0xFF);
                 column(SlowT{}, j0 + 3, SB); PC_NOTE
                 best2 = packbest(bs_lo, bs_hi);
+                pos2 = ((u32)bj_lo & 0xFFFFu) | ((u32)bj_hi << 16);
             }
             jj += 4;
             cur_lo = nxt_lo; cur_hi = nxt_hi;
             nxt_lo = load_dw(w_lo, n_lo, j0 + 7);
             if (!one_stream) nxt_hi = load_dw(w_hi, n_hi, j0 + 7);
         }
+        if (packed_ahead) unpack_best();
         // ---- the reads' last columns, all lanes at once: rolled re-run of the column from the parked
         // state, cells visited top to bottom with strict '>' (dp_scout.h:165-179).  The last column is the
         // last one the reference visits, so doing it after the loop keeps the visiting order.

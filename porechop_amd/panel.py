@@ -1,7 +1,8 @@
 """The adapter panel and the set-level rules that depend only on names and sequences.
 
-The 119 sets (names + sequences) are data recorded from porechop/adapters.py:78-463 by
-tests/golden/make_golden.py into porechop_amd/panel.json.  The rules mirrored here:
+The 119 sets (names + sequences) are read from the unchanged reference module at run time when Porechop is
+importable (load_panel); porechop_amd/panel.json is the copy recorded from porechop/adapters.py:78-463 by
+tests/golden/make_golden.py for environments without it.  The rules mirrored here:
 
   adapters.py:29-52    best_start_or_end_score, is_barcode, barcode_direction, get_barcode_name
   adapters.py:466-499  the three "full sequence" barcode adapters (flanking sequences are ONT's)
@@ -18,7 +19,29 @@ from .pipeline import AdapterSet
 _HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def load_panel() -> List[AdapterSet]:
+def panel_from_reference_module():
+    """The panel as the UNCHANGED reference module defines it, when Porechop is importable in this
+    environment (`porechop.adapters.ADAPTERS`, porechop/adapters.py:77-463) -- read at run time, so a
+    Porechop with a newer adapter list is followed without touching this package.  None if it is not."""
+    try:
+        from porechop.adapters import ADAPTERS          # noqa: the reference's own table
+    except Exception:
+        return None
+    out = []
+    for a in ADAPTERS:
+        st = tuple(a.start_sequence) if getattr(a, "start_sequence", None) else None
+        en = tuple(a.end_sequence) if getattr(a, "end_sequence", None) else None
+        out.append(AdapterSet(a.name, st, en))
+    return out or None
+
+
+def load_panel(prefer_reference: bool = True) -> List[AdapterSet]:
+    """The adapter panel: from the reference's own module when it is importable (see above), otherwise the
+    copy recorded from it into panel.json (tests/golden/make_golden.py; tests compare the two)."""
+    if prefer_reference:
+        p = panel_from_reference_module()
+        if p is not None:
+            return p
     with open(os.path.join(_HERE, "panel.json")) as f:
         raw = json.load(f)
     return [AdapterSet(a["name"], tuple(a["start"]) if a["start"] else None, tuple(a["end"]) if a["end"] else None)

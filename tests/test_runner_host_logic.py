@@ -74,3 +74,26 @@ def test_read_blocks_do_not_change_the_outputs(oracle, tmp_path, monkeypatch):
         if done >= 6:
             break
     assert done >= 3
+
+
+def test_panel_follows_the_reference_module_when_importable():
+    """load_panel() reads porechop.adapters.ADAPTERS at run time when the reference is importable, and the
+    recorded copy (panel.json) otherwise; the two must be the same table (where /root/reference exists)."""
+    import os
+    import sys
+    import pytest
+    from porechop_amd import panel
+    recorded = panel.load_panel(prefer_reference=False)
+    assert len(recorded) == 119
+    if not os.path.isdir("/root/reference/porechop"):
+        pytest.skip("reference checkout not present")
+    sys.path.insert(0, "/root/reference")
+    try:
+        for m in [k for k in sys.modules if k == "porechop" or k.startswith("porechop.")]:
+            del sys.modules[m]
+        live = panel.load_panel()
+    finally:
+        sys.path.remove("/root/reference")
+        for m in [k for k in sys.modules if k == "porechop" or k.startswith("porechop.")]:
+            del sys.modules[m]
+    assert [(s.name, s.start, s.end) for s in live] == [(s.name, s.start, s.end) for s in recorded]

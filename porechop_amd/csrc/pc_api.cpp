@@ -947,6 +947,14 @@ int pc_align_batch_host(pc_ctx *c, const char *read_arena, int64_t arena_bytes, 
     if (rc) return rc;
     const int nad = (int)c->adapters.size();
 
+    // The read bytes start crossing PCIe FIRST (one asynchronous copy on the context's stream -- a direct DMA
+    // when the caller's arena is pinned): validating, grouping and sorting the pairs below runs on the host
+    // meanwhile, and nothing waits for the copy but the kernels, by stream order.
+    if ((rc = c->d_arena.ensure((size_t)arena_bytes + 64))) return rc;
+    HIP_TRY(hipMemcpyAsync(c->d_arena.p, read_arena, (size_t)arena_bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemsetAsync((char *)c->d_arena.p + arena_bytes, 'N', 64, c->stream));
+    auto drained = [&](int code) { (void)hipStreamSynchronize(c->stream); return code; };   // nothing in flight on a return
+
     // empties are answered here exactly as the reference reports them (alignment.cpp:9-21):
     // only field 0 (-1) and the score (INT_MIN, dp_algorithm_impl.h:1540-1541) are defined
     struct Key { int ad; int cls; int len; int64_t idx; };
@@ -954,7 +962,7 @@ int pc_align_batch_host(pc_ctx *c, const char *read_arena, int64_t arena_bytes, 
     keys.reserve((size_t)npairs);
     for (int64_t p = 0; p < npairs; ++p) {
         const int ad = adapter_idx[p];
-        if (ad < 0 || ad >= nad || win_len[p] < 0 || win_off[p] < 0 || win_off[p] + win_len[p] > arena_bytes) return PC_ERR_BAD_ARG;
+        if (ad < 0 || ad >= nad || win_len[p] < 0 || win_off[p] < 0 || win_off[p] + win_len[p] > arena_bytes) return drained(PC_ERR_BAD_ARG);
         int32_t *o = out + p * PC_RESULT_INTS;
         if (win_len[p] == 0 || c->ad_len[ad] == 0) {
             o[0] = -1; o[1] = 0; o[2] = -1; o[3] = 0; o[4] = INT_MIN; o[5] = 0; o[6] = 0; o[7] = 0;
@@ -964,7 +972,7 @@ int pc_align_batch_host(pc_ctx *c, const char *read_arena, int64_t arena_bytes, 
         const bool two = (mode == PC_MODE_TWO_PASS) || (mode == PC_MODE_AUTO && win_len[p] > 2 * window + 64);
         keys.push_back({ad, two ? 1 : 0, win_len[p], p});
     }
-    if (keys.empty()) return PC_OK;
+    if (keys.empty()) return drained(PC_OK);
     // group by (class, adapter); inside a job longest windows first so tiles are length-balanced
     std::sort(keys.begin(), keys.end(), [](const Key &a, const Key &b) {
         if (a.cls != b.cls) return a.cls < b.cls;
@@ -977,14 +985,12 @@ int pc_align_batch_host(pc_ctx *c, const char *read_arena, int64_t arena_bytes, 
     std::vector<int32_t> s_len(n);
     for (size_t i = 0; i < n; ++i) { s_off[i] = win_off[keys[i].idx]; s_len[i] = keys[i].len; }
 
-    if ((rc = c->d_arena.ensure((size_t)arena_bytes + 64)) || (rc = c->d_woff.ensure(n * 8)) ||
-        (rc = c->d_wlen.ensure(n * 4)) || (rc = c->d_out.ensure(n * PC_RESULT_INTS * 4)))
-        return rc;
-    HIP_TRY(hipMemcpyAsync(c->d_arena.p, read_arena, (size_t)arena_bytes, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemsetAsync((char *)c->d_arena.p + arena_bytes, 'N', 64, c->stream));
-    HIP_TRY(hipMemcpyAsync(c->d_woff.p, s_off.data(), n * 8, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemcpyAsync(c->d_wlen.p, s_len.data(), n * 4, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    if ((rc = c->d_woff.ensure(n * 8)) || (rc = c->d_wlen.ensure(n * 4)) || (rc = c->d_out.ensure(n * PC_RESULT_INTS * 4)))
+        return drained(rc);
+    // (s_off / s_len are locals: every return below goes through a stream synchronisation)
+    if (hipMemcpyAsync(c->d_woff.p, s_off.data(), n * 8, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+        hipMemcpyAsync(c->d_wlen.p, s_len.data(), n * 4, hipMemcpyHostToDevice, c->stream) != hipSuccess)
+        return drained(PC_ERR_NO_DEVICE);
 
     // one pc_scan_device call per class (their max_len differ by orders of magnitude)
     size_t i0 = 0;
@@ -1003,9 +1009,9 @@ int pc_align_batch_host(pc_ctx *c, const char *read_arena, int64_t arena_bytes, 
                             (int64_t)(i1 - i0), job_ad.data(), nullptr, job_start.data(), (int)job_ad.size(), max_len,
                             keys[i0].cls ? PC_MODE_TWO_PASS : PC_MODE_TRACE,
                             c->d_out.as<int32_t>() + i0 * PC_RESULT_INTS, c->stream);
-        if (rc) return rc;
+        if (rc) return drained(rc);
         // the tile cache is keyed by the job table; descriptors differ per class, so drain here
-        if ((rc = pc_sync(c, c->stream))) return rc;
+        if ((rc = pc_sync(c, c->stream))) return drained(rc);
         i0 = i1;
     }
     std::vector<int32_t> tmp(n * PC_RESULT_INTS);

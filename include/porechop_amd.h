@@ -225,6 +225,14 @@ int pc_readset_is_rna(const pc_readset *rs, int64_t i);
  * directory input of porechop/porechop.py:232-259; pc_readset_file_index()[i] = which path read i
  * came from. */
 int pc_readset_load_many(const char *const *paths, int npaths, pc_readset **out);
+/* Streaming ingest of a plain, regular 4-line FASTQ file: the records that start in [byte_begin, cut), where
+ * cut is the first record start at or after byte_begin + target_bytes (or the end of the file); *next_begin = cut.
+ * Successive calls (byte_begin = the previous *next_begin, starting at 0) yield the reads of pc_readset_load in
+ * the same order, a block at a time -- so that a run's memory is bounded by its blocks and ingest, scan and
+ * writing of successive blocks overlap.  Returns PC_ERR_UNSUPPORTED_SCORES ("not streamable") for gzip, FASTA or
+ * an irregular record: load the whole file with pc_readset_load then. */
+int pc_readset_load_segment(const char *path, int64_t byte_begin, int64_t target_bytes, int64_t *next_begin,
+                            pc_readset **out);
 const int32_t *pc_readset_file_index(const pc_readset *rs);
 
 /* Output writer: the byte-level half of nanopore_read.py:97-147 (get_fasta /
@@ -240,6 +248,12 @@ const int32_t *pc_readset_file_index(const pc_readset *rs);
 int pc_readset_write(const pc_readset *rs, int64_t npieces, const int64_t *piece_read, const int32_t *piece_start,
                      const int32_t *piece_len, const int32_t *piece_number, const int32_t *piece_file, int nfiles,
                      const char *const *file_paths, int fastq, int64_t *bytes_written);
+
+/* pc_readset_write for a streamed run: file_pos[f] is where file f continues (0 = create / truncate it now) and is
+ * updated to where it ends.  A "-" (stdout) path is simply appended to. */
+int pc_readset_write_at(const pc_readset *rs, int64_t npieces, const int64_t *piece_read, const int32_t *piece_start,
+                        const int32_t *piece_len, const int32_t *piece_number, const int32_t *piece_file, int nfiles,
+                        const char *const *file_paths, int fastq, int64_t *file_pos);
 
 #ifdef __cplusplus
 }

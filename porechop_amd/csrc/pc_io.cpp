@@ -267,14 +267,15 @@ template <class Fn> bool for_each_record(const Span &sp, Fn fn)
     return true;
 }
 
-bool parse_fastq_parallel(pc_readset *rs, const FileData &data, int nthreads)
+bool parse_fastq_range(pc_readset *rs, const char *begin, const char *end, int nthreads)
 {
-    const char *begin = data.data(), *end = begin + data.size();
     std::vector<Span> spans;
     const char *prev = begin;
+    const size_t size = (size_t)(end - begin);
     for (int t = 1; t <= nthreads; ++t) {
-        const char *cut = t == nthreads ? end : find_record_start(begin + data.size() / (size_t)nthreads * (size_t)t, begin, end);
-        if (!cut) return false;
+        const char *cut = t == nthreads ? end : find_record_start(begin + size / (size_t)nthreads * (size_t)t, begin, end);
+        if (!cut) cut = end;             // no record start found from there on (a long last record, or an irregular file:
+                                         // the record walk below rejects those): the rest is one span
         if (cut > prev) { Span sp; sp.b = prev; sp.e = cut; spans.push_back(sp); prev = cut; }
     }
     auto run = [&](auto fn) {
@@ -326,6 +327,11 @@ bool parse_fastq_parallel(pc_readset *rs, const FileData &data, int nthreads)
         });
     });
     return true;
+}
+
+bool parse_fastq_parallel(pc_readset *rs, const FileData &data, int nthreads)
+{
+    return parse_fastq_range(rs, data.data(), data.data() + data.size(), nthreads);
 }
 
 }  // namespace
@@ -402,6 +408,58 @@ int pc_readset_load(const char *path, pc_readset **out)
     return pc_readset_load_many(&path, 1, out);
 }
 
+// One segment of a plain, regular 4-line FASTQ file: the records that START in [byte_begin, cut), cut = the first
+// record start at or after byte_begin + target_bytes (or the end of the file).  *next_begin = cut (== the file
+// size after the last segment).  PC_ERR_UNSUPPORTED_SCORES is (re)used as "not streamable" (gzip, FASTA, an
+// irregular record): the caller then loads the whole file with pc_readset_load, which reproduces the reference's
+// behaviour and messages for those inputs.
+int pc_readset_load_segment(const char *path, int64_t byte_begin, int64_t target_bytes, int64_t *next_begin, pc_readset **out)
+{
+    if (!path || !out || !next_begin || byte_begin < 0 || target_bytes <= 0) return PC_ERR_BAD_ARG;
+    pc_readset *rs = new pc_readset();
+    *out = rs;
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) { rs->error = std::string("could not find ") + path; return PC_ERR_BAD_ARG; }
+    struct stat st;
+    if (fstat(fd, &st) != 0 || st.st_size <= 0 || byte_begin > (int64_t)st.st_size) { close(fd); rs->error = "not streamable"; return PC_ERR_UNSUPPORTED_SCORES; }
+    const size_t size = (size_t)st.st_size;
+    void *m = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
+    close(fd);
+    if (m == MAP_FAILED) { rs->error = "not streamable"; return PC_ERR_UNSUPPORTED_SCORES; }
+    const char *base = (const char *)m, *fend = base + size;
+    int rc = PC_OK;
+    if (base[0] != '@') rc = PC_ERR_UNSUPPORTED_SCORES;             // FASTA, gzip, ...: not a plain FASTQ
+    const char *b = base + byte_begin, *e = fend;
+    if (rc == PC_OK && b < fend) {
+        if ((size_t)(fend - b) > (size_t)target_bytes) {
+            e = find_record_start(b + target_bytes, b, fend);
+            if (!e) {
+                // no record starts after the target: the file's last record (fewer than eight lines remain), or irregular
+                const char *q = next_line(b + target_bytes - 1, fend);
+                for (int tries = 0; tries < 8 && q < fend; ++tries) q = next_line(q, fend);
+                if (q >= fend) e = fend; else rc = PC_ERR_UNSUPPORTED_SCORES;
+            }
+        }
+        if (rc == PC_OK) {
+            {
+                const size_t first = (size_t)(b - base) & ~(size_t)4095;
+                madvise((void *)(base + first), (size_t)(e - base) - first, MADV_WILLNEED);
+            }
+            rs->fastq = true;
+            if (e > b && !parse_fastq_range(rs, b, e, usable_threads())) rc = PC_ERR_UNSUPPORTED_SCORES;
+        }
+    }
+    if (rc == PC_OK) {
+        rs->file_index.resize(rs->off.size(), 0);
+        rs->arena.fill(64, 'N');
+        *next_begin = (int64_t)(e - base);
+    } else {
+        rs->error = "not streamable";
+    }
+    munmap(m, size);
+    return rc;
+}
+
 void pc_readset_free(pc_readset *rs) { delete rs; }
 const char *pc_readset_error(const pc_readset *rs) { return rs ? rs->error.c_str() : "null readset"; }
 int64_t pc_readset_count(const pc_readset *rs) { return rs ? (int64_t)rs->off.size() : 0; }
@@ -428,9 +486,32 @@ int pc_readset_is_rna(const pc_readset *rs, int64_t i)
 }
 const int32_t *pc_readset_file_index(const pc_readset *rs) { return rs ? rs->file_index.data() : nullptr; }
 
+static int write_pieces(const pc_readset *rs, int64_t npieces, const int64_t *piece_read, const int32_t *piece_start,
+                        const int32_t *piece_len, const int32_t *piece_number, const int32_t *piece_file, int nfiles,
+                        const char *const *file_paths, int fastq, int64_t *bytes_written, int64_t *file_pos);
+
 int pc_readset_write(const pc_readset *rs, int64_t npieces, const int64_t *piece_read, const int32_t *piece_start,
                      const int32_t *piece_len, const int32_t *piece_number, const int32_t *piece_file, int nfiles,
                      const char *const *file_paths, int fastq, int64_t *bytes_written)
+{
+    return write_pieces(rs, npieces, piece_read, piece_start, piece_len, piece_number, piece_file, nfiles, file_paths, fastq,
+                        bytes_written, nullptr);
+}
+
+// The same, block after block of a streamed input: file_pos[f] is where file f continues (0: create / truncate it now),
+// updated to where it ends after this call.
+int pc_readset_write_at(const pc_readset *rs, int64_t npieces, const int64_t *piece_read, const int32_t *piece_start,
+                        const int32_t *piece_len, const int32_t *piece_number, const int32_t *piece_file, int nfiles,
+                        const char *const *file_paths, int fastq, int64_t *file_pos)
+{
+    if (!file_pos) return PC_ERR_BAD_ARG;
+    return write_pieces(rs, npieces, piece_read, piece_start, piece_len, piece_number, piece_file, nfiles, file_paths, fastq,
+                        nullptr, file_pos);
+}
+
+static int write_pieces(const pc_readset *rs, int64_t npieces, const int64_t *piece_read, const int32_t *piece_start,
+                        const int32_t *piece_len, const int32_t *piece_number, const int32_t *piece_file, int nfiles,
+                        const char *const *file_paths, int fastq, int64_t *bytes_written, int64_t *file_pos)
 {
     if (!rs || npieces < 0 || nfiles < 0 || (npieces > 0 && (!piece_read || !piece_start || !piece_len || !piece_file || !file_paths)))
         return PC_ERR_BAD_ARG;
@@ -516,7 +597,8 @@ int pc_readset_write(const pc_readset *rs, int64_t npieces, const int64_t *piece
             }
             fflush(stdout);
         } else {
-            const int fd = open(path, O_WRONLY | O_CREAT | O_TRUNC, 0666);
+            const size_t base_pos = file_pos ? (size_t)file_pos[f] : 0;
+            const int fd = open(path, base_pos ? O_WRONLY : (O_WRONLY | O_CREAT | O_TRUNC), 0666);
             if (fd < 0) { rc = PC_ERR_BAD_ARG; break; }
             // spans of pieces with about equal bytes, formatted by one thread each and written in place
             const int T = (int)std::max<size_t>(1, std::min<size_t>((size_t)nthreads, bytes / ((size_t)1 << 22) + 1));
@@ -539,7 +621,7 @@ int pc_readset_write(const pc_readset *rs, int64_t npieces, const int64_t *piece
                     if ((size_t)(o - buf.data()) != buf.size()) { ok[(size_t)t] = 0; return; }
                     size_t done = 0;
                     while (done < buf.size()) {
-                        const ssize_t w = pwrite(fd, buf.data() + done, buf.size() - done, (off_t)(at[i] + done));
+                        const ssize_t w = pwrite(fd, buf.data() + done, buf.size() - done, (off_t)(base_pos + at[i] + done));
                         if (w <= 0) { ok[(size_t)t] = 0; return; }
                         done += (size_t)w;
                     }
@@ -552,6 +634,7 @@ int pc_readset_write(const pc_readset *rs, int64_t npieces, const int64_t *piece
             for (auto &x : th) x.join();
             for (int t = 0; t < T; ++t) if (!ok[(size_t)t]) rc = PC_ERR_BAD_ARG;
             if (close(fd) != 0) rc = PC_ERR_BAD_ARG;
+            if (file_pos) file_pos[f] = (int64_t)(base_pos + bytes);
         }
         total += (int64_t)bytes;
     }

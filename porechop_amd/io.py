@@ -12,17 +12,37 @@ class ReadSet:
     """Reads of one file -- or of several files, in order (Albacore directory input) -- normalised
     like NanoporeRead.__init__, as numpy views over one arena."""
 
-    def __init__(self, path):
+    def __init__(self, path, _handle=None):
         self.lib = load_library()
         self._h = ctypes.c_void_p()
         paths = [path] if isinstance(path, (str, bytes)) or hasattr(path, "__fspath__") else list(path)
         self.paths = [str(p) for p in paths]
-        arr = (ctypes.c_char_p * len(self.paths))(*[p.encode() for p in self.paths])
-        rc = self.lib.pc_readset_load_many(arr, len(self.paths), ctypes.byref(self._h))
+        if _handle is not None:
+            self._h = _handle
+        else:
+            arr = (ctypes.c_char_p * len(self.paths))(*[p.encode() for p in self.paths])
+            rc = self.lib.pc_readset_load_many(arr, len(self.paths), ctypes.byref(self._h))
+            if rc != 0:
+                msg = self.lib.pc_readset_error(self._h).decode() if self._h else "load failed"
+                self.close()
+                raise ValueError("Error: " + msg)
+        self._bind()
+
+    @classmethod
+    def segment(cls, path, byte_begin, target_bytes):
+        """One block of a plain 4-line FASTQ file (pc_readset_load_segment): the records starting in
+        [byte_begin, about byte_begin + target_bytes) -> (ReadSet or None if the file is not streamable, next_begin)."""
+        lib = load_library()
+        h = ctypes.c_void_p()
+        nxt = ctypes.c_int64()
+        rc = lib.pc_readset_load_segment(str(path).encode(), int(byte_begin), int(target_bytes), ctypes.byref(nxt), ctypes.byref(h))
         if rc != 0:
-            msg = self.lib.pc_readset_error(self._h).decode() if self._h else "load failed"
-            self.close()
-            raise ValueError("Error: " + msg)
+            if h:
+                lib.pc_readset_free(h)
+            return None, int(byte_begin)
+        return cls(path, _handle=h), int(nxt.value)
+
+    def _bind(self):
         n = self.lib.pc_readset_count(self._h)
         self.count = int(n)
         self.is_fastq = bool(self.lib.pc_readset_is_fastq(self._h))
@@ -79,6 +99,23 @@ class ReadSet:
         if rc != 0:
             raise OSError("Error: could not write the output reads")
         return written.value
+
+    def write_at(self, piece_read, piece_start, piece_len, piece_number, piece_file, file_paths, fastq, file_pos):
+        """write() for a streamed run: file_pos (numpy int64 [len(file_paths)]) says where each file continues
+        (0 = create it) and is updated in place (pc_readset_write_at)."""
+        pr = np.ascontiguousarray(piece_read, dtype=np.int64)
+        ps = np.ascontiguousarray(piece_start, dtype=np.int32)
+        pl = np.ascontiguousarray(piece_len, dtype=np.int32)
+        pn = np.ascontiguousarray(piece_number, dtype=np.int32)
+        pf = np.ascontiguousarray(piece_file, dtype=np.int32)
+        assert pr.shape == ps.shape == pl.shape == pn.shape == pf.shape
+        assert file_pos.dtype == np.int64 and file_pos.flags["C_CONTIGUOUS"] and file_pos.shape[0] == len(file_paths)
+        paths = (ctypes.c_char_p * max(1, len(file_paths)))(*[str(p).encode() for p in file_paths])
+        rc = self.lib.pc_readset_write_at(self._h, pr.shape[0], pr.ctypes.data, ps.ctypes.data, pl.ctypes.data,
+                                          pn.ctypes.data, pf.ctypes.data, len(file_paths), paths, 1 if fastq else 0,
+                                          file_pos.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)))
+        if rc != 0:
+            raise OSError("Error: could not write the output reads")
 
     def close(self):
         if getattr(self, "_h", None):

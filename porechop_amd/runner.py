@@ -198,6 +198,141 @@ def _gzip_file(src, dst):
     os.remove(src)
 
 
+def _find_sets(pl, panel, reads, check_idx, opts, barcode_dir, sharded=False):
+    """Phase A over the check reads + the set-level rules (porechop.py:286-436) -> (matching sets incl. the full
+    barcode sets, their indices in pl.sets, barcode orientation or None)."""
+    dev = pl.device
+    if reads is not None and check_idx.size:
+        # the pruned search gives the same matching sets and best identities, but the table
+        # entries of the side of a set that stays below the threshold are only lower bounds; the
+        # barcode-kit choice (porechop.py:343-366) sums BOTH sides of every matching barcode set
+        # in its tie-break, so a binning run needs the exact table
+        bs, be = pl.phase_a(reads, torch.from_numpy(np.ascontiguousarray(check_idx)).to(dev), prune=barcode_dir is None)
+    else:
+        bs = torch.zeros(len(panel), dtype=torch.float64, device=dev)
+        be = torch.zeros(len(panel), dtype=torch.float64, device=dev)
+    if sharded:
+        bs, be = reduce_presence(bs, be)                    # nanopore_read.py:159,164 across all ranks' check reads
+    bs, be = bs.cpu().numpy(), be.cpu().numpy()
+    index_of = {id(s): i for i, s in enumerate(pl.sets)}
+    score = lambda s: max(bs[index_of[id(s)]], be[index_of[id(s)]])
+    matching = [s for s in panel if "(full sequence)" not in s.name and score(s) >= opts.adapter_threshold]
+    matching = panel_rules.fix_up_1d2(matching, score)
+    orientation = None
+    if barcode_dir is not None:
+        try:
+            orientation = panel_rules.choose_barcoding_kit(matching, lambda s: bs[index_of[id(s)]],
+                                                           lambda s: be[index_of[id(s)]])
+        except panel_rules.NoBarcodes as e:
+            raise UsageError(str(e))
+    with_full = panel_rules.add_full_barcode_sets(panel, matching)
+    pl.add_sets(with_full[len(matching):])
+    index_of = {id(s): i for i, s in enumerate(pl.sets)}
+    matching = with_full
+    return matching, [index_of[id(s)] for s in matching], orientation
+
+
+def _scan_reads(pl, reads, R, match_idx, opts, barcode_dir, orientation, lap=lambda *a, **k: None):
+    """Phases B (+ barcode calls) and C for R resident reads -> (start_trim, end_trim [device int32], bin index per
+    read [numpy int64, -1 = none], MiddleHits or None, bin names)."""
+    dev = pl.device
+    start_trim = torch.zeros(R, dtype=torch.int32, device=dev)
+    end_trim = torch.zeros(R, dtype=torch.int32, device=dev)
+    hits = None
+    ci = np.full(R, -1, dtype=np.int64)
+    names = []
+    if match_idx and R:
+        # ---- phase B (+ barcode calls) ------------------------------------------------
+        check_barcodes = barcode_dir is not None
+        bc_sets = [i for i in match_idx if check_barcodes and panel_rules.is_barcode(pl.sets[i])
+                   and panel_rules.barcode_direction(pl.sets[i]) == orientation]
+        # Phases B and C are per read: they run over blocks of reads so that the scratch of a run
+        # (8 ints per (read, adapter) pair, all middle adapters at once) is bounded by the block, not by
+        # the input -- the reference holds one read's alignments at a time (nanopore_read.py:149-243).
+        if check_barcodes:
+            names, bins = barcode_bins(pl, bc_sets)
+        n_mid = max(1, len(pl.middle_adapter_list(match_idx)))
+        n_end = max(1, 2 * len(match_idx))
+        block = max(MIN_READ_BLOCK, int(READ_BLOCK_PAIRS // max(n_mid, n_end)))
+        st_parts, et_parts, ci_parts, hit_parts = [], [], [], []
+        for b0 in range(0, R, block):
+            b1 = min(R, b0 + block)
+            sub = reads if (b0 == 0 and b1 == R) else DeviceReads(reads.arena, reads.off[b0:b1], reads.length[b0:b1])
+            if check_barcodes:
+                st_b, et_b, ci_b = pl.phase_b_demux(sub, match_idx, bins, opts.barcode_threshold, opts.barcode_diff,
+                                                    opts.require_two_barcodes)
+                ci_parts.append(ci_b)
+            else:
+                st_b, et_b = pl.phase_b(sub, match_idx)
+            lap("phase_b", sync=True)
+            if not opts.no_split:
+                hb = pl.phase_c(sub, st_b, et_b, match_idx, prove=True)   # identical hits, fewer tracebacks
+                if hb.read.numel():
+                    hb.read = hb.read + b0
+                    hit_parts.append(hb)
+                lap("phase_c", sync=True)
+            st_parts.append(st_b); et_parts.append(et_b)
+        start_trim, end_trim = torch.cat(st_parts), torch.cat(et_parts)
+        if check_barcodes:
+            ci = np.concatenate(ci_parts)
+        if not opts.no_split:
+            from .pipeline import MiddleHits
+            if hit_parts:
+                hits = MiddleHits(*(torch.cat([getattr(h_, f) for h_ in hit_parts]) for f in ("read", "adapter", "start", "end", "identity")),
+                                  max(h_.rounds for h_ in hit_parts), sum(h_.alignments for h_ in hit_parts))
+            else:
+                hits = MiddleHits(*(torch.empty(0, dtype=dt, device=dev) for dt in
+                                    (torch.int64, torch.int32, torch.int32, torch.int32, torch.float64)))
+    return start_trim, end_trim, ci, hits, names
+
+
+def _plan_pieces(opts, lengths, st, et, h, calls, barcode_dir, discard_middle, matching, pl, match_idx):
+    """Which pieces of which reads are written (porechop.py:607-734, nanopore_read.py:76-147): lengths / st / et per
+    read (numpy), h = middle hits [H, 4] (read, adapter, start, end in trimmed-read coordinates), calls = bin name
+    per read or None -> (piece_read, piece_start, piece_len, piece_number, trimmed lengths, reads with middle hits)."""
+    s_pos, e_pos = trimmed_interval(torch.from_numpy(np.ascontiguousarray(lengths).copy()), torch.from_numpy(st), torch.from_numpy(et))
+    s_pos, e_pos = s_pos.numpy(), e_pos.numpy()
+    tlen = np.maximum(e_pos - s_pos, 0)
+    split_of = {}
+    if h.shape[0]:
+        start_names = {s.start[0] for s in matching if s.start is not None}
+        end_names = {s.end[0] for s in matching if s.end is not None}
+        good, bad = opts.extra_middle_trim_good_side, opts.extra_middle_trim_bad_side
+        ad_names = [a[0] for a in pl.middle_adapter_list(match_idx)]
+        lo = np.array([bad if n in start_names else good for n in ad_names], dtype=np.int64)
+        hi = np.array([bad if n in end_names else good for n in ad_names], dtype=np.int64)
+        for r, a, s, e in h:
+            split_of.setdefault(int(r), []).append((int(s - lo[a]), int(e + hi[a])))
+    whole = opts.untrimmed
+    p_start = np.where(whole, 0, s_pos).astype(np.int64)
+    p_len = np.where(whole, lengths, tlen).astype(np.int64)
+    emit = p_len > 0                                            # "Don't return empty sequences"
+    if split_of:
+        emit[np.fromiter(split_of.keys(), dtype=np.int64)] = False
+    if barcode_dir is not None and opts.discard_unassigned:
+        emit &= np.array([c != "none" for c in calls], dtype=bool)
+    # reads with middle hits: dropped when discarding, otherwise split and numbered
+    extra = []                                                  # (read, start, len, number)
+    if split_of and not discard_middle:
+        for r, ivs in split_of.items():
+            if barcode_dir is not None and opts.discard_unassigned and calls[r] == "none":
+                continue
+            for k, (ps, pn) in enumerate(_split_parts(int(tlen[r]), ivs, opts.min_split_read_size)):
+                extra.append((r, int(s_pos[r]) + ps, pn, k + 1))
+    base_reads = np.nonzero(emit)[0].astype(np.int64)
+    if extra:
+        ex = np.array(extra, dtype=np.int64)
+        pr = np.concatenate([base_reads, ex[:, 0]])
+        ps_ = np.concatenate([p_start[base_reads], ex[:, 1]])
+        pn_ = np.concatenate([p_len[base_reads], ex[:, 2]])
+        num = np.concatenate([np.zeros(base_reads.size, dtype=np.int64), ex[:, 3]])
+        order = np.lexsort((num, pr))                           # read order, pieces of a read in order
+        pr, ps_, pn_, num = pr[order], ps_[order], pn_[order], num[order]
+    else:
+        pr, ps_, pn_, num = base_reads, p_start[base_reads], p_len[base_reads], np.zeros(base_reads.size, dtype=np.int64)
+    return pr, ps_, pn_, num, tlen, len(split_of)
+
+
 def run(input_path, output=None, barcode_dir=None, options: Options = None, device=None, aligner=None,
         adapter_panel: List[AdapterSet] = None) -> RunResult:
     """Porechop's main() on arrays.  output=None and barcode_dir=None writes to stdout.
@@ -259,86 +394,14 @@ def run(input_path, output=None, barcode_dir=None, options: Options = None, devi
         lap("upload", sync=True)
 
         # ---- phase A and the set-level rules ---------------------------------------------
-        if R and check_idx.size:
-            # the pruned search gives the same matching sets and best identities, but the table
-            # entries of the side of a set that stays below the threshold are only lower bounds; the
-            # barcode-kit choice (porechop.py:343-366) sums BOTH sides of every matching barcode set
-            # in its tie-break, so a binning run needs the exact table
-            bs, be = pl.phase_a(reads, torch.from_numpy(check_idx).to(dev), prune=barcode_dir is None)
-        else:
-            bs = torch.zeros(len(panel), dtype=torch.float64, device=dev)
-            be = torch.zeros(len(panel), dtype=torch.float64, device=dev)
-        if sharded:
-            bs, be = reduce_presence(bs, be)                    # nanopore_read.py:159,164 across all ranks' check reads
-        bs, be = bs.cpu().numpy(), be.cpu().numpy()
-        index_of = {id(s): i for i, s in enumerate(pl.sets)}
-        score = lambda s: max(bs[index_of[id(s)]], be[index_of[id(s)]])
-        matching = [s for s in panel if "(full sequence)" not in s.name and score(s) >= opts.adapter_threshold]
-        matching = panel_rules.fix_up_1d2(matching, score)
-        orientation = None
-        if barcode_dir is not None:
-            try:
-                orientation = panel_rules.choose_barcoding_kit(matching, lambda s: bs[index_of[id(s)]],
-                                                               lambda s: be[index_of[id(s)]])
-            except panel_rules.NoBarcodes as e:
-                raise UsageError(str(e))
-        with_full = panel_rules.add_full_barcode_sets(panel, matching)
-        pl.add_sets(with_full[len(matching):])
-        index_of = {id(s): i for i, s in enumerate(pl.sets)}
-        matching = with_full
-        match_idx = [index_of[id(s)] for s in matching]
+        matching, match_idx, orientation = _find_sets(pl, panel, reads, check_idx if R else np.zeros(0, dtype=np.int64), opts,
+                                                      barcode_dir, sharded)
         res.matching_sets = [s.name for s in matching]
         res.barcode_orientation = orientation
         lap("phase_a", sync=True)
 
-        start_trim = torch.zeros(R, dtype=torch.int32, device=dev)
-        end_trim = torch.zeros(R, dtype=torch.int32, device=dev)
         calls = None
-        hits = None
-        ci = np.full(R, -1, dtype=np.int64)
-        names = []
-        if matching and R:
-            # ---- phase B (+ barcode calls) ------------------------------------------------
-            check_barcodes = barcode_dir is not None
-            bc_sets = [i for i in match_idx if check_barcodes and panel_rules.is_barcode(pl.sets[i])
-                       and panel_rules.barcode_direction(pl.sets[i]) == orientation]
-            # Phases B and C are per read: they run over blocks of reads so that the scratch of a run
-            # (8 ints per (read, adapter) pair, all middle adapters at once) is bounded by the block, not by
-            # the input -- the reference holds one read's alignments at a time (nanopore_read.py:149-243).
-            if check_barcodes:
-                names, bins = barcode_bins(pl, bc_sets)
-            n_mid = max(1, len(pl.middle_adapter_list(match_idx)))
-            n_end = max(1, 2 * len(match_idx))
-            block = max(MIN_READ_BLOCK, int(READ_BLOCK_PAIRS // max(n_mid, n_end)))
-            st_parts, et_parts, ci_parts, hit_parts = [], [], [], []
-            for b0 in range(0, R, block):
-                b1 = min(R, b0 + block)
-                sub = reads if (b0 == 0 and b1 == R) else DeviceReads(reads.arena, reads.off[b0:b1], reads.length[b0:b1])
-                if check_barcodes:
-                    st_b, et_b, ci_b = pl.phase_b_demux(sub, match_idx, bins, opts.barcode_threshold, opts.barcode_diff,
-                                                        opts.require_two_barcodes)
-                    ci_parts.append(ci_b)
-                else:
-                    st_b, et_b = pl.phase_b(sub, match_idx)
-                lap("phase_b", sync=True)
-                if not opts.no_split:
-                    hb = pl.phase_c(sub, st_b, et_b, match_idx, prove=True)   # identical hits, fewer tracebacks
-                    if hb.read.numel():
-                        hb.read = hb.read + b0
-                        hit_parts.append(hb)
-                    lap("phase_c", sync=True)
-                st_parts.append(st_b); et_parts.append(et_b)
-            start_trim, end_trim = torch.cat(st_parts), torch.cat(et_parts)
-            if check_barcodes:
-                ci = np.concatenate(ci_parts)
-            if not opts.no_split:
-                from .pipeline import MiddleHits
-                if hit_parts:
-                    hits = MiddleHits(*(torch.cat([getattr(h_, f) for h_ in hit_parts]) for f in ("read", "adapter", "start", "end", "identity")),
-                                      max(h_.rounds for h_ in hit_parts), sum(h_.alignments for h_ in hit_parts))
-                else:
-                    hits = MiddleHits(*(torch.empty(0, dtype=dt, device=dev) for dt in
-                                        (torch.int64, torch.int32, torch.int32, torch.int32, torch.float64)))
+        start_trim, end_trim, ci, hits, names = _scan_reads(pl, reads, R, match_idx, opts, barcode_dir, orientation, lap)
         if hasattr(pl.aligner, "sync"):
             pl.aligner.sync()
 
@@ -367,50 +430,12 @@ def run(input_path, output=None, barcode_dir=None, options: Options = None, devi
         res.start_trim, res.end_trim, res.barcode_calls = st, et, calls
 
         # ---- which pieces of which reads -------------------------------------------------
-        s_pos, e_pos = trimmed_interval(torch.from_numpy(rs.lengths.copy()), torch.from_numpy(st), torch.from_numpy(et))
-        s_pos, e_pos = s_pos.numpy(), e_pos.numpy()
-        tlen = np.maximum(e_pos - s_pos, 0)
-        split_of = {}
-        if h.shape[0]:
-            start_names = {s.start[0] for s in matching if s.start is not None}
-            end_names = {s.end[0] for s in matching if s.end is not None}
-            good, bad = opts.extra_middle_trim_good_side, opts.extra_middle_trim_bad_side
-            ad_names = [a[0] for a in pl.middle_adapter_list(match_idx)]
-            lo = np.array([bad if n in start_names else good for n in ad_names], dtype=np.int64)
-            hi = np.array([bad if n in end_names else good for n in ad_names], dtype=np.int64)
-            for r, a, s, e in h:
-                split_of.setdefault(int(r), []).append((int(s - lo[a]), int(e + hi[a])))
-        res.middle_hit_reads = len(split_of)
-
         fmt, gz = _resolve_format(opts, output, barcode_dir, res.read_type, input_path)
         res.out_format = fmt
         whole = opts.untrimmed
-        p_start = np.where(whole, 0, s_pos).astype(np.int64)
-        p_len = np.where(whole, rs.lengths, tlen).astype(np.int64)
-        emit = p_len > 0                                            # "Don't return empty sequences"
-        if split_of:
-            emit[np.fromiter(split_of.keys(), dtype=np.int64)] = False
-        if barcode_dir is not None and opts.discard_unassigned:
-            emit &= np.array([c != "none" for c in calls], dtype=bool)
-        # reads with middle hits: dropped when discarding, otherwise split and numbered
-        extra = []                                                  # (read, start, len, number)
-        if split_of and not discard_middle:
-            for r, ivs in split_of.items():
-                if barcode_dir is not None and opts.discard_unassigned and calls[r] == "none":
-                    continue
-                for k, (ps, pn) in enumerate(_split_parts(int(tlen[r]), ivs, opts.min_split_read_size)):
-                    extra.append((r, int(s_pos[r]) + ps, pn, k + 1))
-        base_reads = np.nonzero(emit)[0].astype(np.int64)
-        if extra:
-            ex = np.array(extra, dtype=np.int64)
-            pr = np.concatenate([base_reads, ex[:, 0]])
-            ps_ = np.concatenate([p_start[base_reads], ex[:, 1]])
-            pn_ = np.concatenate([p_len[base_reads], ex[:, 2]])
-            num = np.concatenate([np.zeros(base_reads.size, dtype=np.int64), ex[:, 3]])
-            order = np.lexsort((num, pr))                           # read order, pieces of a read in order
-            pr, ps_, pn_, num = pr[order], ps_[order], pn_[order], num[order]
-        else:
-            pr, ps_, pn_, num = base_reads, p_start[base_reads], p_len[base_reads], np.zeros(base_reads.size, dtype=np.int64)
+        pr, ps_, pn_, num, tlen, n_split = _plan_pieces(opts, rs.lengths, st, et, h, calls, barcode_dir, discard_middle,
+                                                       matching, pl, match_idx)
+        res.middle_hit_reads = n_split
 
         lap("plan_output")
         # ---- write -------------------------------------------------------------------------

@@ -333,6 +333,217 @@ def _plan_pieces(opts, lengths, st, et, h, calls, barcode_dir, discard_middle, m
     return pr, ps_, pn_, num, tlen, len(split_of)
 
 
+# A plain FASTQ file larger than this is run as a stream of blocks (run_streamed); PC_STREAM_BLOCK_BYTES overrides
+STREAM_BLOCK_BYTES = 1 << 30
+
+
+def _stream_block_bytes():
+    v = os.environ.get("PC_STREAM_BLOCK_BYTES")
+    return int(v) if v else STREAM_BLOCK_BYTES
+
+
+def run_streamed(input_path, output, barcode_dir, opts: Options, device=None, aligner=None,
+                 adapter_panel: List[AdapterSet] = None, block_bytes: int = None) -> Optional[RunResult]:
+    """run() for a plain FASTQ file as a STREAM of blocks: a loader thread parses block k+1 (pc_readset_load_segment,
+    all host cores) while block k is uploaded and scanned on the GPU and a writer thread formats and writes block k-1
+    (pc_readset_write_at) -- host memory holds three blocks instead of the input, and ingest, scan and writing overlap.
+    Phase A and the set-level rules run once, on the first block, which must hold the check reads.  Everything after
+    that is per read in Porechop (phases B and C, barcode calls, splitting, naming), so the output files are the ones
+    run() writes.  -> None when the input is not streamable (gzip, FASTA, a directory, irregular records, or a first
+    block without the check reads): the caller loads the whole file."""
+    import queue
+    import threading
+    block_bytes = block_bytes or _stream_block_bytes()
+    size = os.path.getsize(input_path)
+    t_start = time.perf_counter()
+    # the first block is made large enough to hold the check reads (phase A looks at the first N reads of the file)
+    first_bytes = block_bytes
+    while True:
+        first, pos = ReadSet.segment(input_path, 0, first_bytes)
+        if first is None:
+            return None
+        if pos >= size or first.count >= max(0, opts.check_reads):
+            break
+        first.close()
+        first_bytes *= 4
+    discard_middle = opts.discard_middle or barcode_dir is not None
+    res = RunResult(n_reads=0, read_type="FASTQ")
+    busy = {"load": time.perf_counter() - t_start, "scan": 0.0, "write": 0.0}
+
+    panel = list(adapter_panel) if adapter_panel is not None else panel_rules.load_panel()
+    params = ScanParams(end_size=opts.end_size, min_trim_size=opts.min_trim_size, extra_end_trim=opts.extra_end_trim,
+                        end_threshold=opts.end_threshold, middle_threshold=opts.middle_threshold,
+                        adapter_threshold=opts.adapter_threshold, check_reads=opts.check_reads,
+                        scores=tuple(int(x) for x in opts.scoring_scheme))
+    pl = Pipeline(panel, params, device=device, aligner=aligner)
+    dev = pl.device
+    if aligner is None:
+        pl.aligner.lib.pc_jit_async(1)
+
+    fmt, gz = _resolve_format(opts, output, barcode_dir, res.read_type, input_path)
+    res.out_format = fmt
+    fastq = fmt != "fasta"
+    whole = opts.untrimmed
+    if barcode_dir is not None:
+        os.makedirs(barcode_dir, exist_ok=True)
+        target = None
+    elif output is None:
+        target = "-"
+    elif gz:
+        tmp = tempfile.NamedTemporaryFile(prefix="porechop_amd_", suffix="." + fmt, delete=False,
+                                          dir=os.path.dirname(os.path.abspath(output)))
+        tmp.close()
+        target = tmp.name
+    else:
+        target = output
+
+    # ---- loader: blocks 1.. (block 0 is in hand) ------------------------------------------------------
+    loaded = queue.Queue(maxsize=1)
+    failure = []
+    stop = threading.Event()
+
+    def loader():
+        p_ = pos
+        try:
+            while p_ < size and not stop.is_set():
+                t0 = time.perf_counter()
+                rs_, nxt = ReadSet.segment(input_path, p_, block_bytes)
+                busy["load"] += time.perf_counter() - t0
+                if rs_ is None or nxt <= p_:
+                    raise ValueError("Error: " + input_path + " could not be parsed - is it formatted correctly?")
+                p_ = nxt
+                loaded.put(rs_)
+        except BaseException as e:           # noqa: handed to the main thread
+            failure.append(e)
+        loaded.put(None)
+
+    # ---- writer ---------------------------------------------------------------------------------------
+    to_write = queue.Queue(maxsize=1)
+    paths, file_pos, stats = [], np.zeros(0, dtype=np.int64), {}
+
+    def writer():
+        nonlocal file_pos
+        try:
+            while True:
+                item = to_write.get()
+                if item is None:
+                    return
+                rs_, pr, ps_, pn_, num, bins_of_piece, tlen = item
+                t0 = time.perf_counter()
+                if barcode_dir is not None:
+                    pf = np.zeros(pr.size, dtype=np.int32)
+                    for b in sorted(set(bins_of_piece)):
+                        path = os.path.join(barcode_dir, b + "." + fmt)
+                        if path not in paths:
+                            paths.append(path)
+                            file_pos = np.concatenate([file_pos, np.zeros(1, dtype=np.int64)])
+                    index = {p_: k for k, p_ in enumerate(paths)}
+                    pf = np.fromiter((index[os.path.join(barcode_dir, b + "." + fmt)] for b in bins_of_piece), dtype=np.int32,
+                                     count=len(bins_of_piece))
+                else:
+                    if not paths:
+                        paths.append(target)
+                        file_pos = np.zeros(1, dtype=np.int64)
+                    pf = np.zeros(pr.size, dtype=np.int32)
+                if pr.size:
+                    rs_.write_at(pr, ps_, pn_, num, pf, paths, fastq, file_pos)
+                for k in np.unique(pf) if pr.size else []:
+                    sel = pf == k
+                    rr = np.unique(pr[sel])
+                    n0, b0 = stats.get(paths[k], (0, 0))
+                    if barcode_dir is not None:
+                        # the reference counts reads (not pieces) and their end-trimmed (or whole) lengths
+                        stats[paths[k]] = (n0 + int(rr.size), b0 + int((rs_.lengths[rr] if whole else tlen[rr]).sum()))
+                    else:
+                        stats[paths[k]] = (n0 + int(rr.size), b0 + int(pn_[sel].sum()))
+                rs_.close()
+                busy["write"] += time.perf_counter() - t0
+        except BaseException as e:           # noqa
+            failure.append(e)
+            while to_write.get() is not None:
+                pass
+
+    lt = threading.Thread(target=loader, daemon=True)
+    wt = threading.Thread(target=writer, daemon=True)
+    lt.start(); wt.start()
+    st_all, et_all, calls_all = [], [], []
+    matching = match_idx = orientation = None
+    try:
+        rs = first
+        while rs is not None:
+            if failure:
+                break
+            t0 = time.perf_counter()
+            R = rs.count
+            reads = None
+            if R:
+                reads = DeviceReads(torch.from_numpy(rs.arena).to(dev), torch.from_numpy(rs.offsets.copy()).to(dev),
+                                    torch.from_numpy(rs.lengths.copy()).to(dev))
+            if matching is None:
+                check_idx = np.arange(min(R, max(0, opts.check_reads)), dtype=np.int64)
+                matching, match_idx, orientation = _find_sets(pl, panel, reads, check_idx, opts, barcode_dir)
+                res.matching_sets = [s.name for s in matching]
+                res.barcode_orientation = orientation
+            start_trim, end_trim, ci, hits, _ = _scan_reads(pl, reads, R, match_idx, opts, barcode_dir, orientation)
+            if hasattr(pl.aligner, "sync"):
+                pl.aligner.sync()
+            if hits is not None and hits.read.numel():
+                h = torch.stack([hits.read, hits.adapter.to(torch.int64), hits.start.to(torch.int64),
+                                 hits.end.to(torch.int64)], dim=1).cpu().numpy()
+            else:
+                h = np.zeros((0, 4), dtype=np.int64)
+            st, et = start_trim.cpu().numpy(), end_trim.cpu().numpy()
+            calls = None
+            if barcode_dir is not None:
+                names_all = _barcode_bin_names(pl, match_idx, orientation)
+                calls = [names_all[k] if k >= 0 else "none" for k in ci]
+                calls_all.extend(calls)
+            pr, ps_, pn_, num, tlen, n_split = _plan_pieces(opts, rs.lengths, st, et, h, calls, barcode_dir, discard_middle,
+                                                           matching, pl, match_idx)
+            res.middle_hit_reads += n_split
+            res.n_reads += R
+            st_all.append(st); et_all.append(et)
+            bins_of_piece = [calls[r] for r in pr] if barcode_dir is not None else None
+            del reads
+            busy["scan"] += time.perf_counter() - t0
+            to_write.put((rs, pr, ps_, pn_, num, bins_of_piece, tlen))
+            rs = loaded.get()
+    finally:
+        stop.set()
+        to_write.put(None)
+        wt.join()
+        while lt.is_alive() or not loaded.empty():   # blocks the loader had in flight when we stopped early
+            try:
+                x = loaded.get(timeout=0.05)
+                if x is not None:
+                    x.close()
+            except queue.Empty:
+                pass
+        if aligner is None:
+            pl.close()
+    if failure:
+        raise failure[0]
+    res.start_trim = np.concatenate(st_all) if st_all else np.zeros(0, dtype=np.int32)
+    res.end_trim = np.concatenate(et_all) if et_all else np.zeros(0, dtype=np.int32)
+    res.barcode_calls = calls_all if barcode_dir is not None else None
+    # ---- what a whole-file run does after writing -------------------------------------------------------
+    if barcode_dir is not None:
+        for path in paths:
+            res.files[path + (".gz" if gz else "")] = stats.get(path, (0, 0))
+            if gz:
+                if os.path.isfile(path + ".gz"):
+                    os.remove(path + ".gz")
+                _gzip_file(path, path + ".gz")
+    elif output is not None:
+        if not paths or file_pos[0] == 0:
+            open(target, "wb").close()                              # the reference always creates the file
+        if gz:
+            _gzip_file(target, output)
+        res.files[output] = stats.get(target, (0, 0))
+    res.seconds = {"wall": time.perf_counter() - t_start, "load_busy": busy["load"], "scan_busy": busy["scan"], "write_busy": busy["write"]}
+    return res
+
+
 def run(input_path, output=None, barcode_dir=None, options: Options = None, device=None, aligner=None,
         adapter_panel: List[AdapterSet] = None) -> RunResult:
     """Porechop's main() on arrays.  output=None and barcode_dir=None writes to stdout.
@@ -352,6 +563,13 @@ def run(input_path, output=None, barcode_dir=None, options: Options = None, devi
         raise UsageError("Error: --untrimmed can only be used with --barcode_dir")
     discard_middle = opts.discard_middle or barcode_dir is not None          # porechop.py:203-204
     input_path = str(input_path)
+
+    import torch.distributed as dist
+    if (os.path.isfile(input_path) and os.path.getsize(input_path) > 2 * _stream_block_bytes()
+            and not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)):
+        streamed = run_streamed(input_path, output, barcode_dir, opts, device=device, aligner=aligner, adapter_panel=adapter_panel)
+        if streamed is not None:
+            return streamed
 
     t_last = [time.perf_counter()]
 

@@ -97,3 +97,58 @@ def test_panel_follows_the_reference_module_when_importable():
         for m in [k for k in sys.modules if k == "porechop" or k.startswith("porechop.")]:
             del sys.modules[m]
     assert [(s.name, s.start, s.end) for s in live] == [(s.name, s.start, s.end) for s in recorded]
+
+
+def test_streamed_runs_write_the_same_files(oracle, tmp_path, monkeypatch):
+    """A plain FASTQ input larger than two stream blocks is run as a stream of blocks (runner.run_streamed: parse
+    block k+1 | scan block k | write block k-1).  With blocks of a few kB: (1) the recorded runs of the reference CLI
+    are still reproduced byte for byte, and (2) with a small --check_reads -- so that the first block does not
+    swallow the file -- streamed and whole-file runs of the same options write identical files (bins, splits,
+    numbering, FASTA / gzip output, --untrimmed, --discard_unassigned)."""
+    import hashlib
+    import os
+    from porechop_amd import runner
+    from tests import readgen
+    cases = load_cases()
+    datasets = {}
+    seen_blocks = []
+    real_segment = runner.ReadSet.segment
+
+    def counting_segment(path, begin, target):
+        rs, nxt = real_segment(path, begin, target)
+        seen_blocks.append((begin, nxt))
+        return rs, nxt
+    monkeypatch.setattr(runner.ReadSet, "segment", staticmethod(counting_segment))
+    monkeypatch.setenv("PC_STREAM_BLOCK_BYTES", "6000")
+    # (1) goldens
+    done = 0
+    for name in ("native_check20", "native_check0", "native_default", "native_bins", "ligation_default", "edge_default"):
+        case = cases[name]
+        got = run_case(name, case, str(tmp_path), datasets, make_aligner=lambda sc: OracleAligner(oracle, sc))
+        assert got == case["outputs"], (name, got, case["outputs"])
+        done += 1
+    assert done == 6 and len(seen_blocks) > 20          # the small --check_reads cases really ran as many blocks
+
+    # (2) streamed == whole-file, options that depend on per-read results only
+    def md5s(path):
+        return readgen.output_md5s(path)
+    inp = datasets[cases["native_bins"]["dataset"]]
+    variants = [("o", "out.fastq", {}), ("o", "out.fasta", {}), ("o", "out.fastq.gz", {}), ("b", "bins", {}),
+                ("b", "bins_u", {"untrimmed": True}), ("b", "bins_d", {"discard_unassigned": True, "require_two_barcodes": True}),
+                ("o", "split.fastq", {"min_split_read_size": 100, "middle_threshold": 80.0})]
+    for k, (mode, fname, extra) in enumerate(variants):
+        outs = []
+        for streamed in (True, False):
+            monkeypatch.setenv("PC_STREAM_BLOCK_BYTES", "6000" if streamed else str(1 << 40))
+            opts = runner.Options(check_reads=15, **extra)
+            work = tmp_path / ("v%d_%d" % (k, streamed))
+            work.mkdir()
+            target = str(work / fname)
+            n0 = len(seen_blocks)
+            if mode == "b":
+                runner.run(inp, barcode_dir=target, options=opts, aligner=OracleAligner(oracle, opts.scoring_scheme))
+            else:
+                runner.run(inp, output=target, options=opts, aligner=OracleAligner(oracle, opts.scoring_scheme))
+            assert (len(seen_blocks) - n0 > 3) == streamed
+            outs.append(md5s(target))
+        assert outs[0] == outs[1] and outs[0], (fname, outs)

@@ -334,7 +334,7 @@ def _plan_pieces(opts, lengths, st, et, h, calls, barcode_dir, discard_middle, m
 
 
 # A plain FASTQ file larger than this is run as a stream of blocks (run_streamed); PC_STREAM_BLOCK_BYTES overrides
-STREAM_BLOCK_BYTES = 1 << 30
+STREAM_BLOCK_BYTES = 1 << 28
 
 
 def _stream_block_bytes():

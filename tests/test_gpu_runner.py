@@ -33,3 +33,19 @@ def test_command_line_entry(tmp_path):
         assert res.returncode == 0, res.stderr[-2000:]
         assert "adapter sets:" in res.stdout
         assert readgen.output_md5s(target) == case["outputs"], name
+
+
+def test_streamed_run_on_gpu(tmp_path, monkeypatch):
+    """The streamed path (blocks of a few kB here; 256 MB in production) with the HIP library behind it: the
+    reference CLI's recorded outputs again, from many blocks."""
+    from porechop_amd import runner
+    monkeypatch.setenv("PC_STREAM_BLOCK_BYTES", "6000")
+    blocks = []
+    real = runner.ReadSet.segment
+    monkeypatch.setattr(runner.ReadSet, "segment", staticmethod(lambda p, b, t: (blocks.append(b), real(p, b, t))[1]))
+    cases = load_cases()
+    datasets = {}
+    for name in ("native_check20", "native_check0"):
+        got = run_case(name, cases[name], str(tmp_path), datasets, device="cuda")
+        assert got == cases[name]["outputs"], (name, got)
+    assert len(blocks) > 10

@@ -120,9 +120,6 @@ def test_streamed_runs_write_the_same_files(oracle, tmp_path, monkeypatch):
         return rs, nxt
     monkeypatch.setattr(runner.ReadSet, "segment", staticmethod(counting_segment))
     monkeypatch.setenv("PC_STREAM_BLOCK_BYTES", "6000")
-    # (the writer's mapped path -- normally for outputs of 64 kB and more -- for every block: files continued at
-    # unaligned offsets; the library reads the variable once per process, so this only bites in a fresh one)
-    monkeypatch.setenv("PC_IO_MMAP_MIN", "1")
     # (1) goldens
     done = 0
     for name in ("native_check20", "native_check0", "native_default", "native_bins", "ligation_default", "edge_default"):

@@ -607,36 +607,6 @@ static int write_pieces(const pc_readset *rs, int64_t npieces, const int64_t *pi
             for (int t = 1; t < T; ++t)
                 cut[(size_t)t] = (size_t)(std::lower_bound(at.begin(), at.end(), bytes / (size_t)T * (size_t)t) - at.begin());
             std::vector<int> ok((size_t)T, 1);
-            // Preferred: the file is grown and MAPPED, and every thread formats its span straight into the mapping.
-            // Buffered pwrite()s to one file serialise on the inode lock (measured: 16 threads wrote 2 GB/s, one
-            // thread's memcpy rate); page faults on a shared mapping do not, and the bounce buffer goes away too.
-            // Anything that refuses (a pipe, a FIFO, an odd filesystem) takes the pwrite path below.
-            bool mapped_ok = false;
-            static const size_t map_min = [] { const char *e = getenv("PC_IO_MMAP_MIN"); return e && *e ? (size_t)atoll(e) : ((size_t)1 << 16); }();
-            if (bytes >= map_min) {
-                const size_t page = (size_t)sysconf(_SC_PAGESIZE);
-                const size_t map_from = base_pos / page * page, lead = base_pos - map_from;
-                struct stat st_;
-                if (fstat(fd, &st_) == 0 && S_ISREG(st_.st_mode) && ftruncate(fd, (off_t)(base_pos + bytes)) == 0) {
-                    void *m = mmap(nullptr, lead + bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, (off_t)map_from);
-                    if (m != MAP_FAILED) {
-                        char *dst0 = (char *)m + lead;
-                        auto fill = [&](int t) {
-                            const size_t stop = std::max(cut[(size_t)t], cut[(size_t)t + 1]);
-                            for (size_t q = cut[(size_t)t]; q < stop; ++q) {
-                                char *o = format(idx[q], dst0 + at[q]);
-                                if ((size_t)(o - dst0) != at[q + 1]) { ok[(size_t)t] = 0; return; }
-                            }
-                        };
-                        std::vector<std::thread> th;
-                        for (int t = 1; t < T; ++t) th.emplace_back(fill, t);
-                        fill(0);
-                        for (auto &x : th) x.join();
-                        munmap(m, lead + bytes);
-                        mapped_ok = true;
-                    }
-                }
-            }
             auto work = [&](int t) {
                 std::vector<char> buf;
                 size_t i = cut[(size_t)t];
@@ -658,12 +628,10 @@ static int write_pieces(const pc_readset *rs, int64_t npieces, const int64_t *pi
                     i = j;
                 }
             };
-            if (!mapped_ok) {
-                std::vector<std::thread> th;
-                for (int t = 1; t < T; ++t) th.emplace_back(work, t);
-                work(0);
-                for (auto &x : th) x.join();
-            }
+            std::vector<std::thread> th;
+            for (int t = 1; t < T; ++t) th.emplace_back(work, t);
+            work(0);
+            for (auto &x : th) x.join();
             for (int t = 0; t < T; ++t) if (!ok[(size_t)t]) rc = PC_ERR_BAD_ARG;
             if (close(fd) != 0) rc = PC_ERR_BAD_ARG;
             if (file_pos) file_pos[f] = (int64_t)(base_pos + bytes);

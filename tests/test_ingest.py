@@ -220,3 +220,56 @@ def test_writer_large_outputs(tmp_path):
                 assert open(out).read() == "".join(want), (from_fastq, fastq, threads)
         rs.close()
     os.environ.pop("PC_IO_THREADS", None)
+
+
+def test_segments_and_continued_writes_equal_whole_file(tmp_path):
+    """pc_readset_load_segment + pc_readset_write_at (the streamed runner's ingest and writer): the blocks of a
+    FASTQ file, each written where the previous one stopped, give byte for byte what one load + one write
+    give; FASTQ and FASTA output; qualities that start with '@' or '+'."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import hashlib, os, random, sys
+sys.path.insert(0, ".")
+import numpy as np
+from porechop_amd.io import ReadSet
+rng = random.Random(7)
+src = sys.argv[1]
+with open(src, "w") as f:
+    for i in range(1500):
+        n = rng.choice([1, 9, 80, 700, 3000])
+        f.write("@r%d extra words\n%s\n+\n%s\n" % (i, "".join(rng.choice("ACGTacgtNU") for _ in range(n)),
+                                               "".join(rng.choice("@+!5I") for _ in range(n))))
+size = os.path.getsize(src)
+whole = ReadSet(src)
+for fastq in (True, False):
+    def pieces(rs):
+        # decided per read from its own length only, so that blocks and the whole file describe the same pieces:
+        # one piece for every read, a second, numbered one for reads of even length; the file by length mod 3
+        n = rs.count
+        ln1 = rs.lengths.astype(np.int64)
+        twice = np.nonzero(ln1 % 2 == 0)[0]
+        pr = np.sort(np.concatenate([np.arange(n, dtype=np.int64), twice]), kind="stable")
+        second = np.concatenate([[False], pr[1:] == pr[:-1]])
+        ln = rs.lengths[pr]
+        st = np.minimum(ln // 5, 3).astype(np.int32)
+        return pr, st, (ln - st).astype(np.int32), np.where(second, 2, 0).astype(np.int32), (ln % 3 == 0).astype(np.int32)
+    ref = [src + ".whole%d.%d" % (fastq, k) for k in range(2)]
+    whole.write(*pieces(whole), ref, fastq)
+    out = [src + ".blocks%d.%d" % (fastq, k) for k in range(2)]
+    pos, fpos = 0, np.zeros(2, dtype=np.int64)
+    nblocks = 0
+    while pos < size:
+        rs, pos = ReadSet.segment(src, pos, 20000)
+        assert rs is not None
+        rs.write_at(*pieces(rs), out, fastq, fpos)
+        rs.close(); nblocks += 1
+    assert nblocks > 20
+    for a, b in zip(ref, out):
+        assert open(a, "rb").read() == open(b, "rb").read(), (fastq, a)
+print("OK")
+'''
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, "-c", code, str(tmp_path / "reads.fastq")], capture_output=True, text=True, cwd=repo, timeout=600)
+    assert res.returncode == 0 and "OK" in res.stdout, res.stdout[-1500:] + res.stderr[-3000:]

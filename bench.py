@@ -340,7 +340,7 @@ def leg_host_buffers(dev, args):
     from porechop_amd.synth import make_reads
     p = ScanParams()
     pl = Pipeline(load_panel_sets(), p, device=dev)
-    n, nb = args.reads, 8
+    n, nb = args.reads, int(os.environ.get("PC_BENCH_H2D_BATCHES", "8"))
     reads = make_reads(n, args.read_len, seed=3, start_frac=0.9, end_frac=0.5, chimera_frac=args.chimera, device=dev)
     total = int(reads.arena.shape[0])
     h_arena = torch.empty(total, dtype=torch.uint8, pin_memory=True)

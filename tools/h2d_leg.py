@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""The PCIe-inclusive leg of bench.py alone (GPU box): reads start in pinned host memory, every step uploads them again in
+batches while the previous batch is scanned.   python tools/h2d_leg.py   (PC_BENCH_H2D_BATCHES=n changes the batch count)"""
 import sys, json, argparse
 sys.path.insert(0, ".")
 import torch, bench

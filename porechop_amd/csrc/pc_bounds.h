@@ -83,6 +83,11 @@ inline F16Plan f16_plan(int match, int mismatch, int gap_open, int gap_extend, i
     if (-mismatch > 1000 || -gap_open > 1000 || match > 1000 || eps > 500) return p;
     // the substitution terms sub - open + eps of the kernel's table must be exact fp16 integers too
     if (match - gap_open + eps > kF16Limit || mismatch - gap_open + eps > kF16Limit || mismatch - gap_open + eps < -kF16Limit) return p;
+    // the tracked last-row term  T~(R,j) - top~(j) = M(R,j) + R*eps  is formed in fp16 as well (the scout's packed
+    // compare): it must be an exact integer too.  (Found by tools/fuzz_parity.py: match 29, a 64-base adapter copied
+    // exactly into a 150-column window -- 1856 + 448 = 2304 is not an fp16 integer, the score came out one off and
+    // the walk's score check flagged the pair.)
+    if (high + (long)R * eps > kF16Limit) return p;
     const long cols = (2L * kF16Limit - (high - low)) / eps - R - 2;
     if (cols < 32) return p;
     p.ok = true;

@@ -373,3 +373,36 @@ print("DIGEST", h.hexdigest(), porechop_amd.load_library().pc_trace_ops_x100(al.
         outs.append(lines[0].split())
     assert outs[0][1] == outs[1][1]
     assert (outs[0][2], outs[1][2]) == ("1325", "2100")          # the two runs really took different kernels
+
+
+def test_large_match_score_long_adapter_tracked_term_stays_exact(pa, oracle):
+    """Regression (found by tools/fuzz_parity.py 36 5, block 10): scheme (29, -19, -14, -7), a 64-base adapter
+    copied exactly -- or nearly -- into 149..151-column windows.  The traced fp16 kernel's tracked last-row term
+    M + R*eps reaches 1856 + 448 = 2304, which fp16 does not hold exactly; the host gate (pc_bounds.h f16_plan)
+    must send such a scheme / row class to the int16 kernel.  Every record against the oracle."""
+    import random
+    rng = random.Random(29)
+    scheme = (29, -19, -14, -7)
+    ad = "".join(rng.choice("ACGT") for _ in range(64))
+    others = ["".join(rng.choice("ACGT") for _ in range(n)) for n in (24, 38, 22, 5)]
+    pairs = []
+    for k in range(3000):
+        n = rng.choice([149, 150, 150, 151, 100])
+        w = [rng.choice("ACGT") for _ in range(n)]
+        copy = list(ad)
+        for _ in range(rng.choice([0, 0, 1, 3])):                    # exact copies and lightly mutated ones
+            copy[rng.randrange(64)] = rng.choice("ACGT")
+        p = rng.randrange(0, max(1, n - 64))
+        w[p:p + 64] = copy[: max(0, n - p)]
+        pairs.append(("".join(w[:n]), 0))
+        pairs.append(("".join(w[:n]), 1 + k % 4))
+    al = pa.Aligner([ad] + others, scores=scheme)
+    recs = al.align_pairs(pairs)
+    al.close()
+    ads = [ad] + others
+    n_full = 0
+    for (rd, ai), rec in zip(pairs, recs):
+        want = oracle.adapter_alignment(rd, ads[ai], scheme)
+        assert pa.format_result(rec) == want, (len(rd), ai, pa.format_result(rec), want)
+        n_full += int(rec[4] >= 29 * 60)
+    assert n_full > 500                                              # the near-perfect 64-base hits were there

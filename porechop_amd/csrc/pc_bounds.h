@@ -96,6 +96,32 @@ inline F16Plan f16_plan(int match, int mismatch, int gap_open, int gap_extend, i
     return p;
 }
 
+// Run-time specialised score kernel (pc_jit_source.h): the same drifting coordinates, renormalised (shifted back
+// down) every `kren` columns, values X held as X + (rho + jj [+1]) * eps - cen.  f16: the packed-fp16 variant
+// (5 ops per cell pair) is usable -- every value formed, the tracked term M + R*eps included, an exact fp16
+// integer -- otherwise packed int16 (6 ops); ok = false: the scheme leaves no useful period (generic kernels).
+struct SpecPlan { bool ok, f16; long kren, cen; };
+inline SpecPlan spec_plan(int match, int mismatch, int gap_open, int gap_extend, int R, bool force_int16)
+{
+    SpecPlan p = {false, false, 0, 0};
+    const long eps = -(long)gap_extend;
+    const long low = 2L * gap_open + (long)(R - 1) * gap_extend < (long)gap_open + (long)(R - 1) * gap_extend + mismatch
+                         ? 2L * gap_open + (long)(R - 1) * gap_extend
+                         : (long)gap_open + (long)(R - 1) * gap_extend + mismatch;
+    const long low2 = low < (long)gap_open ? low : (long)gap_open;
+    const long high = (long)match * R;
+    auto period = [&](long lim) -> long {
+        const long k = (2 * lim - (high - low2) - (long)(R + 6) * eps) / eps;
+        return k < 0 ? 0 : (k / 4 * 4 < (1L << 20) ? k / 4 * 4 : (1L << 20));
+    };
+    p.f16 = !force_int16 && period(kF16Limit) >= 64 && high + (long)R * eps <= kF16Limit && -mismatch <= 1000 && -gap_open <= 1000;
+    const long lim = p.f16 ? kF16Limit : 32000;
+    p.kren = period(lim);
+    p.ok = p.kren >= 64;
+    p.cen = low2 + lim;
+    return p;
+}
+
 inline bool compute_bounds(int match, int mismatch, int gap_open, int gap_extend, int m, Bounds &b)
 {
     if (!scores_supported(match, mismatch, gap_open, gap_extend, m > 0 ? m : 1)) return false;

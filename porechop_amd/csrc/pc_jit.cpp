@@ -288,23 +288,15 @@ Spec *get(int device, const std::string &ad_lo, const std::string &ad_hi, int ma
     // variant (5 ops per cell pair, v_pk_maximum3_f16) when that leaves a useful period, otherwise
     // packed-int16 (6 ops).  PC_JIT_INT16=1 forces the latter.
     const int eps = -gap_extend;
-    const long low = std::min<long>({2L * gap_open + (long)(R - 1) * gap_extend,
-                                     (long)gap_open + (long)(R - 1) * gap_extend + mismatch, (long)gap_open});
-    const long high = (long)match * R;
-    auto period = [&](long lim) -> long {
-        const long k = (2 * lim - (high - low) - (long)(R + 6) * eps) / eps;
-        return k < 0 ? 0 : std::min<long>(k / 4 * 4, 1L << 20);
-    };
     const char *force_int = getenv("PC_JIT_INT16");
-    const bool f16 = !(force_int && *force_int && *force_int != '0') && period(2040) >= 64 &&
-                     high + (long)R * eps <= 2040 && -mismatch <= 1000 && -gap_open <= 1000;
-    const long lim = f16 ? 2040 : 32000;
-    const long kren = period(lim);
-    if (kren < 64) {
+    const pcb::SpecPlan plan = pcb::spec_plan(match, mismatch, gap_open, gap_extend, R, force_int && *force_int && *force_int != '0');
+    const bool f16 = plan.f16;
+    const long kren = plan.kren;
+    if (!plan.ok) {
         if (verbose) fprintf(stderr, "porechop_amd: no specialised kernel: scores too large for drifting coordinates\n");
         return nullptr;
     }
-    const long cen = low + lim;
+    const long cen = plan.cen;
     char keybuf[64];
     snprintf(keybuf, sizeof keybuf, "|%d|%d,%d,%d,%d|%d", device, match, mismatch, gap_open, gap_extend, f16 ? 1 : 0);
     const std::string key = ad_lo + "|" + ad_hi + keybuf;

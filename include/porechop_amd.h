@@ -187,6 +187,19 @@ void pc_jit_async(int enabled);
  * the process image is torn down).  The Python binding registers it with atexit. */
 void pc_jit_shutdown(void);
 
+/* Specialised kernels are pure functions of (kernel source, adapter pair's row pattern, scoring scheme): their code
+ * objects are kept on disk and loaded instead of compiled -- from <directory of this library>/kernel_cache (filled
+ * when the library is built: every set of the static panel, porechop/adapters.py:77-463, under the default scheme)
+ * and from PC_JIT_CACHE_DIR / $XDG_CACHE_HOME/porechop_amd / ~/.cache/porechop_amd (what this machine compiled at
+ * run time; PC_JIT_CACHE_DIR=off disables it).  A kernel found on disk is used from the first launch on.
+ * pc_jit_precompile builds the kernel that scans adapter_a and adapter_b in one pass (adapter_b NULL or "": a alone)
+ * into cache_dir (NULL or "": the in-tree directory).  It needs hiprtc but NO device.  Returns 0 = compiled and
+ * written, 1 = already there, < 0 = this pair / scheme has no specialised kernel, or the compile or write failed. */
+int pc_jit_precompile(const char *adapter_a, const char *adapter_b, int match, int mismatch, int gap_open,
+                      int gap_extend, const char *cache_dir);
+/* Kernels this process compiled with hiprtc / took from a kernel cache on disk so far. */
+void pc_jit_stats(int64_t *compiled, int64_t *from_disk);
+
 /* Format one result record exactly as the reference prints it; buf must hold >= 160 bytes. */
 int pc_format_result(const int32_t *rec, char *buf, size_t buflen);
 

@@ -14,7 +14,7 @@ EXPORTS = [
     "adapterAlignment", "freeCString",
     "pc_version", "pc_strerror", "pc_scores_supported", "pc_create", "pc_destroy",
     "pc_set_scores", "pc_set_adapters", "pc_align_batch_host", "pc_scan_device", "pc_sync",
-    "pc_format_result", "pc_jit_async", "pc_jit_shutdown", "pc_prefetch", "pc_memo_clear", "pc_memo_stats", "pc_set_timing", "pc_get_timing", "pc_set_length_hint", "pc_copy_windows", "pc_trace_ops_x100", "pc_phase_b_reduce", "pc_debug_value_range",
+    "pc_format_result", "pc_jit_async", "pc_jit_shutdown", "pc_jit_precompile", "pc_jit_stats", "pc_prefetch", "pc_memo_clear", "pc_memo_stats", "pc_set_timing", "pc_get_timing", "pc_set_length_hint", "pc_copy_windows", "pc_trace_ops_x100", "pc_phase_b_reduce", "pc_debug_value_range",
     "pc_readset_load", "pc_readset_free", "pc_readset_error", "pc_readset_count", "pc_readset_is_fastq",
     "pc_readset_arena", "pc_readset_offsets", "pc_readset_lengths", "pc_readset_name", "pc_readset_quals",
     "pc_readset_is_rna", "pc_readset_load_many", "pc_readset_file_index", "pc_readset_write",
@@ -91,6 +91,10 @@ def load_library():
     L.pc_jit_async.restype = None
     L.pc_jit_shutdown.argtypes = []
     L.pc_jit_shutdown.restype = None
+    L.pc_jit_precompile.argtypes = [c_cp, c_cp, c_int, c_int, c_int, c_int, c_cp]
+    L.pc_jit_precompile.restype = c_int
+    L.pc_jit_stats.argtypes = [ctypes.POINTER(c_i64), ctypes.POINTER(c_i64)]
+    L.pc_jit_stats.restype = None
     import atexit
     atexit.register(L.pc_jit_shutdown)       # no worker thread inside hiprtc while the process is torn down
     L.pc_format_result.argtypes = [c_vp, c_cp, ctypes.c_size_t]

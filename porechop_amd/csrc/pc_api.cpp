@@ -896,6 +896,22 @@ int pc_copy_windows(pc_ctx *c, const void *d_arena, const int64_t *d_src_off, co
 void pc_jit_async(int enabled) { pcj::set_async(enabled); }
 void pc_jit_shutdown(void) { pcj::wait_idle(true); }
 
+int pc_jit_precompile(const char *adapter_a, const char *adapter_b, int match, int mismatch, int gap_open, int gap_extend,
+                      const char *cache_dir)
+{
+    if (!adapter_a || !*adapter_a) return PC_ERR_BAD_ARG;
+    const std::string a = adapter_a, b = (adapter_b && *adapter_b) ? adapter_b : adapter_a;
+    return pcj::precompile(a, b, match, mismatch, gap_open, gap_extend, cache_dir ? cache_dir : "");
+}
+
+void pc_jit_stats(int64_t *compiled, int64_t *from_disk)
+{
+    long c = 0, d = 0;
+    pcj::stats(&c, &d);
+    if (compiled) *compiled = c;
+    if (from_disk) *from_disk = d;
+}
+
 int pc_set_timing(pc_ctx *c, int enabled)
 {
     if (!c) return PC_ERR_BAD_ARG;

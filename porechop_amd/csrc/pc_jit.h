@@ -38,6 +38,12 @@ bool disabled();
 Spec *get(int device, const std::string &ad_lo, const std::string &ad_hi, int match, int mismatch, int gap_open,
           int gap_extend, double cells);
 int launch(const Spec *sp, const SpecArgs &a, int grid, void *stream);
+// Ahead-of-time build of one pair's kernel into a kernel cache directory ("" = the in-tree one next to the library).
+// Needs hiprtc, not a device.  0 = compiled and written, 1 = was already there, < 0 = no such kernel / failure.
+int precompile(const std::string &ad_lo, const std::string &ad_hi, int match, int mismatch, int gap_open, int gap_extend,
+               const std::string &dir);
+// kernels compiled by hiprtc / taken from a kernel cache on disk by this process so far
+void stats(long *compiled, long *from_disk);
 // Asynchronous specialisation: compiles run on a worker thread and launches keep using the generic
 // kernels until a kernel is ready (no stall for one-shot runs); default off (compile in place).
 void set_async(int on);

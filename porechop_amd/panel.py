@@ -1,8 +1,8 @@
 """The adapter panel and the set-level rules that depend only on names and sequences.
 
-The 119 sets (names + sequences) are read from the unchanged reference module at run time when Porechop is
-importable (load_panel); porechop_amd/panel.json is the copy recorded from porechop/adapters.py:78-463 by
-tests/golden/make_golden.py for environments without it.  The rules mirrored here:
+The 119 sets (names + sequences) come from porechop_amd/panel.json, the copy recorded from
+porechop/adapters.py:78-463 by tests/golden/make_golden.py; reading the installed reference module instead is an
+explicit opt-in (load_panel).  The rules mirrored here:
 
   adapters.py:29-52    best_start_or_end_score, is_barcode, barcode_direction, get_barcode_name
   adapters.py:466-499  the three "full sequence" barcode adapters (flanking sequences are ONT's)
@@ -35,15 +35,32 @@ def panel_from_reference_module():
     return out or None
 
 
-def load_panel(prefer_reference: bool = True) -> List[AdapterSet]:
-    """The adapter panel: from the reference's own module when it is importable (see above), otherwise the
-    copy recorded from it into panel.json (tests/golden/make_golden.py; tests compare the two)."""
+PANEL_SOURCE = None          # what the last load_panel() call used: "recorded" or "reference module"
+
+
+def load_panel(prefer_reference: Optional[bool] = None) -> List[AdapterSet]:
+    """The adapter panel.  Default: the copy recorded from the reference into panel.json
+    (tests/golden/make_golden.py) -- the panel every golden, test and benchmark of this package uses, so a run's
+    output never depends on what happens to be importable under the name `porechop`.
+
+    prefer_reference=True, or PORECHOP_AMD_PANEL=reference in the environment when the argument is None, is the
+    explicit opt-in to read `porechop.adapters.ADAPTERS` from an installed Porechop at run time instead (a newer
+    adapter list is then followed without touching this package; that module's code runs in this process).
+    The source used is kept in PANEL_SOURCE and said on stderr when it is not the recorded panel."""
+    global PANEL_SOURCE
+    if prefer_reference is None:
+        prefer_reference = os.environ.get("PORECHOP_AMD_PANEL", "").lower() == "reference"
     if prefer_reference:
         p = panel_from_reference_module()
         if p is not None:
+            PANEL_SOURCE = "reference module"
+            import sys
+            print("porechop_amd: adapter panel read from the installed porechop.adapters module (%d sets)" % len(p),
+                  file=sys.stderr)
             return p
     with open(os.path.join(_HERE, "panel.json")) as f:
         raw = json.load(f)
+    PANEL_SOURCE = "recorded"
     return [AdapterSet(a["name"], tuple(a["start"]) if a["start"] else None, tuple(a["end"]) if a["end"] else None)
             for a in raw]
 

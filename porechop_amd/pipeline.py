@@ -205,7 +205,7 @@ class Pipeline:
                 if key not in order_of:
                     order = torch.argsort(j[2], descending=True, stable=True)
                     order_of[key] = (order, j[1][order], j[2][order], j[1], j[2])   # keeps the originals alive (ids stay unique)
-                sorted_jobs.append((j[0], order_of[key][1], order_of[key][2]))
+                sorted_jobs.append((j[0], order_of[key][1], order_of[key][2]) + tuple(j[3:]))
             orders = [order_of[(id(j[1]), id(j[2]))][0] for j in jobs]
             jobs = sorted_jobs
         groups = {}
@@ -213,7 +213,23 @@ class Pipeline:
             groups.setdefault((id(j[1]), id(j[2])), []).append(k)
         fused = []                      # (job index a, job index b or None)
         for ks in groups.values():
-            ks = sorted(ks, key=lambda k: -len(self.seqs[jobs[k][0]]))
+            # jobs that carry the same pairing hint (the two sequences of one adapter set, phase C) go together,
+            # longer adapter first: a set's pair is the same in every run, so its specialised score kernel can
+            # be -- and for the static panel is -- built ahead of time (porechop_amd/aot.py)
+            by_hint, rest = {}, []
+            for k in ks:
+                h = jobs[k][3] if len(jobs[k]) > 3 else None
+                if h is None:
+                    rest.append(k)
+                else:
+                    by_hint.setdefault(h, []).append(k)
+            for h, hk in by_hint.items():
+                if len(hk) == 2 and self.seqs[jobs[hk[0]][0]] != self.seqs[jobs[hk[1]][0]]:
+                    a, b = hk
+                    fused.append((a, b) if len(self.seqs[jobs[a][0]]) >= len(self.seqs[jobs[b][0]]) else (b, a))
+                else:
+                    rest.extend(hk)
+            ks = sorted(rest, key=lambda k: -len(self.seqs[jobs[k][0]]))
             for i in range(0, len(ks) - 1, 2):
                 fused.append((ks[i], ks[i + 1]))
             if len(ks) % 2:
@@ -439,13 +455,17 @@ class Pipeline:
     def middle_adapter_list(self, matching: List[int]):
         """porechop.py:541-548: start sequence of every matching set, plus its end sequence when
         that differs from its own start sequence (duplicates across sets are kept, as there)."""
+        return [a for a, _ in self._middle_adapters_with_sets(matching)]
+
+    def _middle_adapters_with_sets(self, matching: List[int]):
+        """middle_adapter_list with the index of the set each sequence comes from (the pairing hint of _scan_jobs)."""
         ads = []
         for si in matching:
             s = self.sets[si]
             if s.start is not None:
-                ads.append(s.start)
+                ads.append((s.start, si))
             if s.end is not None and (s.start is None or s.end[1] != s.start[1]):
-                ads.append(s.end)
+                ads.append((s.end, si))
         return ads
 
     def phase_c(self, reads: DeviceReads, start_trim, end_trim, matching: List[int], prove: bool = False) -> MiddleHits:
@@ -468,7 +488,9 @@ class Pipeline:
         the proven non-hits are simply not produced (an option: the default computes them all)."""
         p = self.p
         dev = self.device
-        ads = self.middle_adapter_list(matching)
+        ads_sets = self._middle_adapters_with_sets(matching)
+        ads = [a for a, _ in ads_sets]
+        hint = [("set", si) for _, si in ads_sets]
         self.middle_adapters = ads
         A = len(ads)
         empty = MiddleHits(*(torch.empty(0, dtype=dt, device=dev) for dt in
@@ -493,7 +515,7 @@ class Pipeline:
             return torch.where(rec[..., 0] == -1, torch.zeros_like(full), full)
 
         # ---- round 0: all adapters x all reads, unmasked -------------------------------------
-        jobs0 = [(ai, loff, llen) for ai in aidx]
+        jobs0 = [(ai, loff, llen, h) for ai, h in zip(aidx, hint)]
         bounds = [self.identity_score_bound(len(self.seqs[ai]), p.middle_threshold) for ai in aidx] if prove else None
         if prove and all(b is not None for b in bounds):
             score = torch.stack(self._scan_jobs(reads.arena, jobs0, MODE_SCORE, max_len, sort_lengths=ragged, typ_len=typ_len))[:, :, 4]      # [A, L]
@@ -506,7 +528,7 @@ class Pipeline:
                 if counts[a]:
                     sel = cand[pos:pos + int(counts[a]), 1]
                     pos += int(counts[a])
-                    cjobs.append((aidx[a], loff[sel], llen[sel])); csel.append((a, sel))
+                    cjobs.append((aidx[a], loff[sel], llen[sel])); csel.append((a, sel))     # (different windows per adapter: never fused)
             if cjobs:
                 for (a, sel), o in zip(csel, self._scan_jobs(reads.arena, cjobs, MODE_TWO_PASS, max_len, sort_lengths=ragged, typ_len=typ_len)):
                     recs[a, sel] = o
@@ -579,7 +601,7 @@ class Pipeline:
                 rounds += 1
                 a0 = int(ah.min().item())
                 o_act, l_act = d_off[act], dlen[act]
-                outs_r = self._scan_jobs(dirty, [(aidx[a], o_act, l_act) for a in range(a0, A)], MODE_TWO_PASS, dmax,
+                outs_r = self._scan_jobs(dirty, [(aidx[a], o_act, l_act, hint[a]) for a in range(a0, A)], MODE_TWO_PASS, dmax,
                                          sort_lengths=ragged, typ_len=dtyp)
                 scheduled = (A - a0) * int(act.numel())
                 for a, o in zip(range(a0, A), outs_r):

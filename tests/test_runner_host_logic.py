@@ -76,22 +76,26 @@ def test_read_blocks_do_not_change_the_outputs(oracle, tmp_path, monkeypatch):
     assert done >= 3
 
 
-def test_panel_follows_the_reference_module_when_importable():
-    """load_panel() reads porechop.adapters.ADAPTERS at run time when the reference is importable, and the
-    recorded copy (panel.json) otherwise; the two must be the same table (where /root/reference exists)."""
+def test_panel_default_is_the_recorded_one_and_agrees_with_the_reference_module():
+    """load_panel() uses the recorded panel.json whatever is importable as `porechop` (the tested, benchmarked
+    panel); reading porechop.adapters.ADAPTERS is an explicit opt-in, and where /root/reference exists the two
+    must be the same table."""
     import os
     import sys
     import pytest
     from porechop_amd import panel
-    recorded = panel.load_panel(prefer_reference=False)
-    assert len(recorded) == 119
+    recorded = panel.load_panel()
+    assert len(recorded) == 119 and panel.PANEL_SOURCE == "recorded"
     if not os.path.isdir("/root/reference/porechop"):
         pytest.skip("reference checkout not present")
     sys.path.insert(0, "/root/reference")
     try:
         for m in [k for k in sys.modules if k == "porechop" or k.startswith("porechop.")]:
             del sys.modules[m]
-        live = panel.load_panel()
+        assert [(s.name, s.start, s.end) for s in panel.load_panel()] == [(s.name, s.start, s.end) for s in recorded]
+        assert panel.PANEL_SOURCE == "recorded"          # importable or not, the default does not change
+        live = panel.load_panel(prefer_reference=True)
+        assert panel.PANEL_SOURCE == "reference module"
     finally:
         sys.path.remove("/root/reference")
         for m in [k for k in sys.modules if k == "porechop" or k.startswith("porechop.")]:

@@ -20,6 +20,12 @@ Prints ONE JSON line on rank 0 (see the contract in the task statement) with ext
                   configs1 = 100 k reads, end-trim only (--no_split): phases A + B
                   configs2 = 1 M barcoded reads, full panel, end-trim + demultiplexing:
                              phases A + kit choice + B + barcode calls
+  config.also_measured.configs4_per_gpu (every N) -- the per-GPU shape of BASELINE configs[4] (full panel with the
+                  96 barcodes AND the middle scan over every matching set's sequences, 1 % chimeras), run by every
+                  rank on its own shard: its own roofline, CPU sample, parity, and the exact-prefilter variant
+  config.exact_prefilter -- the headline step with the middle scan behind the exact bit-parallel prefilter
+                  (pc_prefilter_device); identical hits, reported BESIDE `value`, which computes every record
+  parity.device_crosscheck -- packed-int16 kernels against the packed-fp16 ones over ALL pairs of the headline batch
 """
 import argparse
 import json
@@ -69,10 +75,11 @@ def host_cores():
     return max(1, n)
 
 
-def one_step(pl, reads, n_check, world, proofs=False):
+def one_step(pl, reads, n_check, world, proofs=False, prefilter=False):
     """The hot path over one resident batch.  Returns (matching, start_trim, end_trim, hits).
     proofs=True is the optional variant with the two exact prunings of DESIGN.md section 7 (f-4 and
-    the proven middle scan); the headline measurement never uses it."""
+    the proven middle scan), prefilter=True the one with the exact bit-parallel prefilter in front of the middle
+    scan; the headline measurement uses neither."""
     from porechop_amd.distributed import reduce_presence
     check = None if n_check >= reads.n else torch.arange(n_check, device=reads.off.device)
     best_s, best_e = pl.phase_a(reads, check, prune=proofs)
@@ -81,7 +88,7 @@ def one_step(pl, reads, n_check, world, proofs=False):
     best_s, best_e = reduce_presence(best_s, best_e)
     matching = pl.matching_sets(best_s, best_e)
     st, et = pl.phase_b(reads, matching)
-    hits = pl.phase_c(reads, st, et, matching, prove=proofs)
+    hits = pl.phase_c(reads, st, et, matching, prove=proofs, prefilter=prefilter)
     return matching, st, et, hits
 
 
@@ -173,7 +180,73 @@ def cpu_baseline(reads, pl, matching, st, et, hits, seconds, workers):
     return base, parity
 
 
-def trace_roofline(timing, n_windows, pairs, cells, steps, ops_per_2_cells):
+def cpu_phase_a_check(reads, pl, workers, nreads=1024):
+    """Phase A re-derived on the host for the first `nreads` reads (the reference's align_adapter_set over the whole
+    119-set panel, nanopore_read.py:149-164, through the compiled reference) against the GPU's phase A over the same
+    reads: every entry of both presence tables must be equal, and so must the matching sets -- the CPU parity legs
+    then no longer depend on a `matching` list the GPU made."""
+    import multiprocessing as mp
+    from dataclasses import asdict
+    from tests.cpu_worker import run_chunk_phase_a
+    k = min(reads.n, nreads)
+    seqs, _ = host_seqs(reads, k)
+    sets = [(s.name, s.start, s.end) for s in pl.sets]
+    per = max(1, (k + workers - 1) // workers)
+    chunks = [seqs[i:i + per] for i in range(0, k, per)]
+    with mp.get_context("spawn").Pool(min(workers, len(chunks))) as pool:
+        res = pool.map(run_chunk_phase_a, [(c, sets, asdict(pl.p), True) for c in chunks])
+    bs = np.max(np.array([r[2][0] for r in res]), axis=0)
+    be = np.max(np.array([r[2][1] for r in res]), axis=0)
+    gs, ge = pl.phase_a(reads, torch.arange(k, device=reads.off.device))
+    m_gpu = pl.matching_sets(gs, ge)
+    best = np.maximum(bs, be)
+    m_cpu = [i for i, s in enumerate(pl.sets) if "(full sequence)" not in s.name and best[i] >= pl.p.adapter_threshold]
+    gs, ge = gs.cpu().numpy(), ge.cpu().numpy()
+    bad = int((gs != bs).sum() + (ge != be).sum())
+    return {"reads": k, "table_entries": int(2 * len(sets)), "entries_differing": bad, "same_matching_sets": m_gpu == m_cpu,
+            "matching_sets_cpu": [pl.sets[i].name for i in m_cpu]}
+
+
+def device_crosscheck(pl, reads, matching, st, et, dev):
+    """Full-coverage exactness evidence at benchmark size, outside every timed region: phase B's end-window records
+    and phase C's whole-read records of ALL reads of the batch, once with the kernels the benchmark ran (packed fp16
+    where the host gates of csrc/pc_bounds.h prove it exact) and once with the packed-int16 kernels
+    (pc_set_int16_only), compared record for record on the device."""
+    import hashlib
+    from porechop_amd.batch import MODE_TRACE, MODE_TWO_PASS
+    from porechop_amd.pipeline import trimmed_interval
+
+    def records():
+        jobs, _ = pl._phase_b_jobs(reads, matching)
+        _, out_b, _ = pl._scan_jobs(reads.arena, jobs, MODE_TRACE, pl.p.end_size, with_layout=True)
+        s_pos, e_pos = trimmed_interval(reads.length, st, et)
+        tlen = torch.clamp(e_pos - s_pos, min=0).to(torch.int32)
+        toff = reads.off + s_pos
+        ads = pl._middle_adapters_with_sets(matching)
+        jobs_c = [(pl.seq_index[a[1]], toff, tlen, ("set", si)) for a, si in ads]
+        _, out_c, _ = pl._scan_jobs(reads.arena, jobs_c, MODE_TWO_PASS, int(tlen.max().item()), with_layout=True)
+        pl.aligner.sync()
+        return out_b, out_c
+
+    b16, c16 = records()
+    ops16 = pl.aligner.trace_ops_per_2_cells()
+    pl.aligner.set_int16_only(True)
+    try:
+        bi, ci = records()
+        opsi = pl.aligner.trace_ops_per_2_cells()
+    finally:
+        pl.aligner.set_int16_only(False)
+    diff_b = int((b16 != bi).any(dim=1).sum().item())
+    diff_c = int((c16 != ci).any(dim=1).sum().item())
+    sha = hashlib.sha1(b16.cpu().numpy().tobytes())
+    sha.update(c16.cpu().numpy().tobytes())
+    return {"device_crosscheck_pairs": int(b16.shape[0] + c16.shape[0]), "end_window_pairs": int(b16.shape[0]),
+            "whole_read_pairs": int(c16.shape[0]), "records_differing": diff_b + diff_c,
+            "traced_kernel_ops_per_2_cells": [ops16, opsi], "records_sha1": sha.hexdigest(),
+            "what": "every 8-int record of phases B and C of the whole headline batch: packed-fp16 kernels vs packed-int16 kernels"}
+
+
+def trace_roofline(timing, n_windows, pairs, cells, steps, ops_per_2_cells, leg=None):
     """Roofline object of the traced end-window kernel from the library's per-launch HIP-event timing.
     Algorithmic bytes: every end window (150 B) in once, 28 B out per (window, adapter)."""
     ms, launches, tpairs = timing["trace"]
@@ -185,7 +258,8 @@ def trace_roofline(timing, n_windows, pairs, cells, steps, ops_per_2_cells):
     gcups = cells * steps / (ms / 1e3) / 1e9
     peak_gcups = VALU_WAVE_INSTR_PER_S * 64 * 2 / ops_per_2_cells / 1e9
     return {"bound": "valu", "kernel": "traced end-window scan (trace bits + on-device traceback/digest)",
-            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": profile_traffic(leg, "trace16_kernel") if leg else None,
             "launches": int(launches), "avg_launch_ms": per_launch_s * 1e3,
             "algorithmic_bytes_per_launch": alg_total / launches,
             "valu": {"achieved_gcups": gcups, "peak_gcups": peak_gcups, "frac": gcups / peak_gcups,
@@ -252,7 +326,7 @@ def leg_configs1(dev, args, workers):
     pairs = n * sum((s is not None) + (e is not None) for s, e in ads)
     cells = n * 150 * sum((len(s[1]) if s else 0) + (len(e[1]) if e else 0) for s, e in ads)
     out["phase_b"] = {"reads_per_s": n * args.steps / dtb, "ms_per_step": dtb / args.steps * 1e3, "pairs_per_read": pairs / n}
-    out["roofline"] = trace_roofline(tb, 2 * n, pairs, cells, args.steps, pl.aligner.trace_ops_per_2_cells())
+    out["roofline"] = trace_roofline(tb, 2 * n, pairs, cells, args.steps, pl.aligner.trace_ops_per_2_cells(), leg="configs1")
     if args.cpu_seconds > 0:
         seqs, ln = host_seqs(reads, min(n, 16384))
         sets = [(s.name, s.start, s.end) for s in pl.sets]
@@ -312,7 +386,7 @@ def leg_configs2(dev, args, workers):
            "reads_binned_to_their_planted_barcode": float((calls == want).mean()), "reads_unassigned": float((calls < 0).mean()),
            "kernel_ms_per_step": {k: v[0] / steps for k, v in timing.items()},
            "roofline": trace_roofline(timing, 2 * n + 2 * nchk, pairs + pairs_a, cells + cells_a, steps,
-                                      pl.aligner.trace_ops_per_2_cells())}
+                                      pl.aligner.trace_ops_per_2_cells(), leg="configs2")}
     if args.cpu_seconds > 0:
         seqs, ln = host_seqs(reads, min(n, 4096))
         sets = [(s.name, s.start, s.end) for s in pl.sets]
@@ -327,8 +401,249 @@ def leg_configs2(dev, args, workers):
         out["parity"] = {"checked": done, "mismatches": len(bad), "what": "start trim, end trim, barcode call per read",
                          "first_mismatching_reads": bad[:8]}
         out["speedup_vs_cpu_baseline"] = out["reads_per_s"] / out["cpu_baseline"]["value"]
+    try:
+        out.setdefault("parity", {})["device_crosscheck"] = crosscheck_end_windows(pl, reads, matching)
+    except Exception as e:
+        out.setdefault("parity", {})["device_crosscheck"] = {"failed": repr(e)}
     pl.close()
     return out
+
+
+def crosscheck_end_windows(pl, reads, matching):
+    """All end-window records of phase B for the whole batch, packed-fp16 traced kernel vs packed-int16 one."""
+    from porechop_amd.batch import MODE_TRACE
+
+    def records():
+        jobs, _ = pl._phase_b_jobs(reads, matching)
+        _, out_b, _ = pl._scan_jobs(reads.arena, jobs, MODE_TRACE, pl.p.end_size, with_layout=True)
+        pl.aligner.sync()
+        return out_b
+
+    a = records()
+    ops_a = pl.aligner.trace_ops_per_2_cells()
+    pl.aligner.set_int16_only(True)
+    try:
+        b = records()
+        ops_b = pl.aligner.trace_ops_per_2_cells()
+    finally:
+        pl.aligner.set_int16_only(False)
+    return {"device_crosscheck_pairs": int(a.shape[0]), "records_differing": int((a != b).any(dim=1).sum().item()),
+            "traced_kernel_ops_per_2_cells": [ops_a, ops_b],
+            "what": "every 8-int end-window record of phase B of the whole batch: packed-fp16 traced kernel vs packed-int16 one"}
+
+
+
+def step_configs4(pl, reads, n_check, opts, prefilter=False):
+    """BASELINE configs[4] per GPU (-b DIR, middle scan on): phase A (+ MAX all-reduce of the presence table), the
+    barcode-kit choice (porechop.py:330-371), the full-barcode rule (porechop.py:410-436), phase B with the barcode
+    identities + determine_barcode for every read, phase C over every matching set's start / end sequences
+    (porechop.py:541-548, nanopore_read.py:210-243)."""
+    from porechop_amd import panel as rules
+    from porechop_amd.distributed import reduce_presence
+    from porechop_amd.runner import barcode_bins
+    bs, be = pl.phase_a(reads, torch.arange(min(n_check, reads.n), device=reads.off.device))
+    bs, be = reduce_presence(bs, be)
+    matching = pl.matching_sets(bs, be)
+    bsh, beh = bs.cpu().numpy(), be.cpu().numpy()
+    index_of = {id(s): i for i, s in enumerate(pl.sets)}
+    msets = [pl.sets[i] for i in matching]
+    orientation = rules.choose_barcoding_kit(msets, lambda s: bsh[index_of[id(s)]], lambda s: beh[index_of[id(s)]])
+    full = rules.add_full_barcode_sets(pl.sets[:pl.n_panel], msets)[len(msets):]
+    if full:                                               # native / rapid kits only: none for the PCR barcodes planted here
+        known = {s.name: i for i, s in enumerate(pl.sets)}
+        new = [s for s in full if s.name not in known]
+        if new:
+            pl.add_sets(new)
+            known = {s.name: i for i, s in enumerate(pl.sets)}
+        matching = matching + [known[s.name] for s in full]
+    bc_sets = [i for i in matching if rules.is_barcode(pl.sets[i]) and rules.barcode_direction(pl.sets[i]) == orientation]
+    names, bins = barcode_bins(pl, bc_sets)
+    st, et, calls = pl.phase_b_demux(reads, matching, bins, opts.barcode_threshold, opts.barcode_diff, opts.require_two_barcodes)
+    hits = pl.phase_c(reads, st, et, matching, prefilter=prefilter)
+    return matching, orientation, names, st, et, calls, hits
+
+
+def leg_configs4(dev, args, workers, world, rank, barrier):
+    """The per-GPU shape of BASELINE configs[4] ("10M reads, full panel + middle scan, read-sharded across 8 GPUs" =
+    1.25 M reads per GPU): every rank runs it on its own shard (seed 4 + 1000 * rank), no data-path collective but
+    the presence table's MAX all-reduce; the value is all ranks' reads over the slowest rank's time."""
+    from dataclasses import asdict
+    from porechop_amd.pipeline import Pipeline, ScanParams
+    from porechop_amd.runner import Options
+    from porechop_amd.synth import make_reads
+    from tests.cpu_worker import run_chunk_demux_middle
+    p = ScanParams()
+    opts = Options()
+    pl = Pipeline(load_panel_sets(), p, device=dev)
+    pl.n_panel = len(pl.sets)
+    n = args.reads4
+    fw = [a for a in load_panel_json() if a["name"].startswith("Barcode ") and "(forward)" in a["name"]]
+    reads = make_reads(n, args.read_len, seed=4 + 1000 * rank, start_frac=0.9, end_frac=0.5, chimera_frac=args.chimera, device=dev,
+                       barcodes_start=[a["start"][1] for a in fw], barcodes_end=[a["end"][1] for a in fw])
+    n_check = max(1, p.check_reads // world)
+
+    def run(steps, prefilter):
+        out = None
+        for _ in range(steps):
+            out = step_configs4(pl, reads, n_check, opts, prefilter=prefilter)
+        pl.aligner.sync()
+        return out
+
+    def timed_region(steps, prefilter):
+        barrier()
+        t0 = time.perf_counter()
+        out = run(steps, prefilter)
+        barrier()
+        dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+        return out, float(dt.item())
+
+    steps = max(1, min(args.steps, 2))
+    run(1, False)                                           # warm-up (kernels come from the library's kernel cache)
+    pl.aligner.set_timing(True)
+    pl.aligner.get_timing()
+    (matching, orientation, names, st, et, calls, hits), dt = timed_region(steps, False)
+    timing = pl.aligner.get_timing()
+    pl.aligner.set_timing(False)
+    psteps = max(1, min(args.steps, 3))
+    run(1, True)
+    pl.aligner.set_timing(True)
+    pl.aligner.get_timing()
+    (_, _, _, st_p, et_p, calls_p, hits_p), dt_p = timed_region(psteps, True)
+    timing_p = pl.aligner.get_timing()
+    pl.aligner.set_timing(False)
+    if rank != 0:
+        pl.close()
+        return None
+    same = bool(hits_p.read.numel() == hits.read.numel() and torch.equal(hits_p.read, hits.read) and
+                torch.equal(hits_p.adapter, hits.adapter) and torch.equal(hits_p.start, hits.start) and
+                torch.equal(hits_p.end, hits.end) and torch.equal(st_p, st) and torch.equal(et_p, et) and
+                np.array_equal(calls_p, calls))
+    ads = pl.middle_adapter_list(matching)
+    A = len(ads)
+    mean_trim_len = float((reads.length.to(torch.float64) - st.to(torch.float64) - et.to(torch.float64)).mean().item())
+    mean_m = float(np.mean([len(a[1]) for a in ads]))
+    truth = reads.truth_barcode.cpu().numpy()
+    want = np.array([names.index("BC%02d" % (b + 1)) if "BC%02d" % (b + 1) in names else -2 for b in range(len(fw))])[truth]
+    total = n * world
+    import ctypes
+    jc, jd = ctypes.c_int64(), ctypes.c_int64()
+    pl.aligner.lib.pc_jit_stats(ctypes.byref(jc), ctypes.byref(jd))
+    out = {"workload": "BASELINE configs[4] per GPU: %d synthetic %d-bp reads per GPU x %d GPU(s), barcode b ~ U{1..96} at both ends, "
+                       "%.0f%% chimeric junctions, full 119-set panel, -b style run: phases A + kit choice + full-barcode rule + B "
+                       "(%d pairs per read) + barcode calls + C over all %d sequences of the %d matching sets"
+                       % (n, args.read_len, world, args.chimera * 100, sum((pl.sets[i].start is not None) + (pl.sets[i].end is not None) for i in matching),
+                          A, len(matching)),
+           "n_gpus": world, "reads_per_gpu": n, "steps": steps,
+           "reads_per_s": total * steps / dt, "ms_per_step": dt / steps * 1e3, "read_bp_per_s": total * steps / dt * args.read_len,
+           "matching_sets": len(matching), "middle_adapters": A, "barcode_orientation": orientation,
+           "middle_hits_per_step": int(hits.read.numel()), "mask_rounds": hits.rounds,
+           "reads_binned_to_their_planted_barcode": float((calls == want).mean()),
+           "kernel_ms_per_step": {k: v[0] / steps for k, v in timing.items()},
+           "specialised_kernels": {"compiled_in_this_process": int(jc.value), "loaded_from_the_kernel_cache": int(jd.value)},
+           "exact_prefilter": {"reads_per_s": total * psteps / dt_p, "ms_per_step": dt_p / psteps * 1e3, "steps": psteps,
+                               "same_trims_calls_and_middle_hits": same,
+                               "kernel_ms_per_step": {k: v[0] / psteps for k, v in timing_p.items()},
+                               "speedup": (dt / steps) / (dt_p / psteps)}}
+    jit = timing["score_spec"][1] > 0
+    ms, launches, pairs = timing["score_spec"] if jit else timing["score"]
+    if launches > 0:
+        per_launch_s = ms / 1e3 / launches
+        ppl = pairs / launches
+        alg = ppl * (mean_trim_len / A + 28.0)
+        cells_s = ppl * mean_trim_len * mean_m / per_launch_s
+        ops = 5 if jit else 9
+        peak = VALU_WAVE_INSTR_PER_S * 64 * 2 / ops / 1e9
+        out["roofline"] = {"bound": "valu", "kernel": "pc_spec_score" if jit else "scan_kernel<R,PAD,false>",
+                           "achieved": alg / per_launch_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": alg / per_launch_s / 1e9 / HBM_PEAK_GBS, "traffic": profile_traffic("configs4", "pc_spec_score" if jit else ""),
+                           "launches": int(launches), "avg_launch_ms": per_launch_s * 1e3, "algorithmic_bytes_per_launch": alg,
+                           "valu": {"achieved_gcups": cells_s / 1e9, "peak_gcups": peak, "frac": cells_s / 1e9 / peak, "ops_per_2_cells": ops},
+                           "note": "score-only whole-read scan, %d adapter pairs per read; HBM fraction on ALGORITHMIC bytes "
+                                   "(|H|/A + 28 per pair); VALU-bound by construction" % ((A + 1) // 2)}
+    pms, pl_launches, ppairs = timing_p["prefilter"]
+    if pl_launches > 0:
+        out["exact_prefilter"]["roofline"] = prefilter_roofline(pms, pl_launches, ppairs, n * mean_trim_len, A)
+    if args.cpu_seconds > 0 and world == 1:
+        seqs, ln = host_seqs(reads, min(n, 2048))
+        sets = [(s.name, s.start, s.end) for s in pl.sets]
+        mk = lambda c: (c, sets, matching, asdict(p), True, orientation, opts.barcode_threshold, opts.barcode_diff,
+                        opts.require_two_barcodes)
+        done, dtc, res = cpu_sample(run_chunk_demux_middle, mk, seqs, max(args.cpu_seconds, 12.0), workers, probe=2)
+        got = {}
+        for r, a_, s_, e_ in zip(hits.read.cpu().tolist(), hits.adapter.cpu().tolist(), hits.start.cpu().tolist(), hits.end.cpu().tolist()):
+            if r < done:
+                got.setdefault(r, []).append((a_, s_, e_))
+        stl, etl = st[:done].cpu().tolist(), et[:done].cpu().tolist()
+        cl = [names[k] if k >= 0 else "none" for k in calls[:done]]
+        bad = [r for r in range(done) if (stl[r], etl[r], cl[r], got.get(r, [])) != (res[r][0], res[r][1], res[r][2], list(res[r][3]))]
+        out["cpu_baseline"] = {"value": done / dtc, "unit": "reads/s", "cores": workers, "kind": baseline_kind(),
+                               "sample": "%d reads, phase B + barcode call + phase C (%d adapters), %d worker processes over the %s, %.1f s wall"
+                                         % (done, A, workers, kind_text(baseline_kind()), dtc)}
+        out["parity"] = {"checked": done, "mismatches": len(bad),
+                         "what": "start trim, end trim, barcode call, middle hits (adapter, start, end) per read",
+                         "first_mismatching_reads": bad[:8]}
+        out["speedup_vs_cpu_baseline"] = out["reads_per_s"] / out["cpu_baseline"]["value"]
+    pl.close()
+    return out
+
+
+def prefilter_roofline(ms, launches, pairs, read_bytes, A):
+    """Roofline object of the exact bit-parallel prefilter: it streams every read byte once per launch
+    (algorithmic bytes = the reads' bytes + one mask word per read) and spends 12.5 VALU ops per
+    (column, <= 32-base adapter piece)."""
+    per_launch_s = ms / 1e3 / launches
+    alg = read_bytes + 4.0 * pairs / launches / max(A, 1)
+    steps_s = read_bytes * A / per_launch_s                 # (column, adapter) updates per second (adapters <= 32 bases: one piece each)
+    peak_steps = VALU_WAVE_INSTR_PER_S * 64 / 12.5
+    return {"bound": "valu", "kernel": "prefilter_kernel<P> (Myers bit-vector edit distance, one lane per read chunk, P adapter pieces per lane)",
+            "achieved": alg / per_launch_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / per_launch_s / 1e9 / HBM_PEAK_GBS,
+            "traffic": profile_traffic("prefilter", "prefilter_kernel"), "launches": int(launches), "avg_launch_ms": per_launch_s * 1e3,
+            "algorithmic_bytes_per_launch": alg,
+            "valu": {"achieved_column_updates_per_s": steps_s, "peak_column_updates_per_s": peak_steps, "frac": steps_s / peak_steps,
+                     "ops_per_column_and_adapter": 12.5}}
+
+
+def library_fingerprint():
+    """sha1 of the loaded libporechop_amd.so (what a profiles/*_summary.json must have been taken with)."""
+    import hashlib
+    import porechop_amd
+    h = hashlib.sha1()
+    with open(porechop_amd.LIB_PATH, "rb") as f:
+        for blk in iter(lambda: f.read(1 << 20), b""):
+            h.update(blk)
+    return h.hexdigest()
+
+
+_PROFILE = None
+
+
+def profile_traffic(leg, kernel):
+    """HBM-side traffic (FETCH_SIZE + WRITE_SIZE, bytes per launch) of `kernel` in `leg`, from the newest
+    profiles/*_summary.json -- ONLY if that summary was taken with the very library now loaded (its recorded sha1
+    equals the loaded .so's): a kernel change without a re-profile reports null, never stale counters."""
+    global _PROFILE
+    if _PROFILE is None:
+        _PROFILE = {}
+        try:
+            import glob
+            summ = sorted(glob.glob(os.path.join(REPO, "profiles", "*_summary.json")))
+            if summ:
+                with open(summ[-1]) as f:
+                    sj = json.load(f)
+                if sj.get("library_sha1") == library_fingerprint():
+                    _PROFILE = sj
+                    _PROFILE["_path"] = os.path.relpath(summ[-1], REPO)
+        except Exception:
+            _PROFILE = {}
+    try:
+        kk = _PROFILE.get("legs", {}).get(leg, {}).get(kernel)
+        if kk:
+            return (kk["FETCH_SIZE_KB_mean_launch"] + kk["WRITE_SIZE_KB_mean_launch"]) * 1024.0
+    except Exception:
+        pass
+    return None
 
 
 def leg_host_buffers(dev, args):
@@ -465,6 +780,8 @@ def main():
     ap.add_argument("--reads", type=int, default=1_000_000, help="reads per GPU (headline, configs[3])")
     ap.add_argument("--reads1", type=int, default=100_000, help="reads of the configs[1] leg")
     ap.add_argument("--reads2", type=int, default=1_000_000, help="reads of the configs[2] leg")
+    ap.add_argument("--reads4", type=int, default=1_250_000, help="reads per GPU of the configs[4]-shape leg (10 M over 8 GPUs)")
+    ap.add_argument("--repeats", type=int, default=3, help="timed regions of --steps steps (the first one is `value`)")
     ap.add_argument("--read-len", type=int, default=8000)
     ap.add_argument("--chimera", type=float, default=0.01)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="0 disables the CPU baseline / parity legs")
@@ -506,48 +823,64 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def region(steps, **kw):
+        """One timed region of the contract: barrier + synchronize, `steps` steps, barrier + synchronize; MAX over ranks."""
+        barrier()
+        t0 = time.perf_counter()
+        out = None
+        for _ in range(steps):
+            out = one_step(pl, reads, n_check, world, **kw)
+        pl.aligner.sync()
+        barrier()
+        tall = torch.zeros(world, dtype=torch.float64, device=dev)
+        tall[rank] = time.perf_counter() - t0
+        if world > 1:
+            dist.all_reduce(tall, op=dist.ReduceOp.SUM)
+        rank_s = [float(x) for x in tall.cpu()]
+        return out, max(rank_s), rank_s
+
     matching = None
     for _ in range(args.warmup):
         matching, st, et, hits = one_step(pl, reads, n_check, world)
         pl.aligner.sync()
     pl.aligner.set_timing(True)
+    pl.aligner.get_timing()
     pl.stats = {k: 0 for k in pl.stats}
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        matching, st, et, hits = one_step(pl, reads, n_check, world)
-    pl.aligner.sync()
-    barrier()
-    dt = time.perf_counter() - t0
+    # ---- THE measurement: exactly --steps steps ----------------------------------------------------------
+    (matching, st, et, hits), dt, rank_s = region(args.steps)
     timing = pl.aligner.get_timing()
     pl.aligner.set_timing(False)
 
-    tall = torch.zeros(world, dtype=torch.float64, device=dev)
-    tall[rank] = dt
-    if world > 1:
-        dist.all_reduce(tall, op=dist.ReduceOp.SUM)
-    rank_s = [float(x) for x in tall.cpu()]
-    dt = max(rank_s)                                    # MAX over ranks
+    # ---- AFTER it: the same region twice more (run-to-run spread; `value` stays the first region's) --------
+    region_ms = [dt / args.steps * 1e3]
+    for _ in range(max(0, args.repeats - 1)):
+        _, dtr, _ = region(args.steps)
+        region_ms.append(dtr / args.steps * 1e3)
 
-    # ---- AFTER the headline measurement: the same steps with the two optional exact prunings
-    # (score bound for the identity thresholds: fewer tracebacks, identical sets / trims / hits).
-    # Reported as an extra field; `value` above never includes it.
-    one_step(pl, reads, n_check, world, proofs=True)
-    pl.aligner.sync()
-    barrier()
-    t1 = time.perf_counter()
+    # ---- the same steps with the two optional exact prunings (score bound for the identity thresholds:
+    # fewer tracebacks, identical sets / trims / hits).  Reported as an extra field; never `value`.
     psteps = max(1, min(args.steps, 5))
-    for _ in range(psteps):
-        _, _, _, hits_p = one_step(pl, reads, n_check, world, proofs=True)
-    pl.aligner.sync()
-    barrier()
-    dtp = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(dtp, op=dist.ReduceOp.MAX)
-    dt_proofs = float(dtp.item())
+    one_step(pl, reads, n_check, world, proofs=True)
+    (_, _, _, hits_p), dt_proofs, _ = region(psteps, proofs=True)
     same_hits = bool(hits_p.read.numel() == hits.read.numel() and torch.equal(hits_p.read, hits.read) and
                      torch.equal(hits_p.start, hits.start) and torch.equal(hits_p.end, hits.end))
 
+    # ---- the same steps with the exact bit-parallel prefilter in front of the middle scan (SURVEY.md 8f-4, the
+    # alternative the reference's README.md:355-357 names): pairs farther than max_edits(m, threshold) from every
+    # substring are proven non-hits and never reach the DP.  Reported BESIDE the headline, never as `value`.
+    one_step(pl, reads, n_check, world, prefilter=True)
+    pl.aligner.set_timing(True)
+    pl.aligner.get_timing()
+    fsteps = max(1, min(args.steps, 10))
+    (_, st_f, et_f, hits_f), dt_pf, _ = region(fsteps, prefilter=True)
+    timing_pf = pl.aligner.get_timing()
+    pl.aligner.set_timing(False)
+    same_hits_f = bool(hits_f.read.numel() == hits.read.numel() and torch.equal(hits_f.read, hits.read) and
+                       torch.equal(hits_f.adapter, hits.adapter) and torch.equal(hits_f.start, hits.start) and
+                       torch.equal(hits_f.end, hits.end) and torch.equal(st_f, st) and torch.equal(et_f, et) and
+                       (hits_f.rounds, hits_f.alignments) == (hits.rounds, hits.alignments))
+
+    out = None
     if rank == 0:
         total_reads = args.reads * world
         reads_per_s = total_reads * args.steps / dt
@@ -555,7 +888,7 @@ def main():
         # algorithmic bytes: per read |H| input bytes ONCE for all A middle
         # adapters + 28 B of result per (read, adapter); a launch scanning one of A adapters is
         # credited 1/A of the read bytes.  cells = sum |H| x |V|.
-        # Dominant kernel = the run-time specialised scan (timing kind 'score_spec'); the generic
+        # Dominant kernel = the specialised scan (timing kind 'score_spec'); the generic
         # ahead-of-time one ('score') only if specialisation is off.  One timed region per launch,
         # so avg_launch_ms is directly rocprofv3's AverageNs for that kernel name.
         jit = timing["score_spec"][1] > 0
@@ -575,7 +908,7 @@ def main():
             ops_per_pair = (6 if os.environ.get("PC_JIT_INT16", "0") not in ("", "0") else 5) if jit else 9
             valu_peak_gcups = VALU_WAVE_INSTR_PER_S * 64 * 2 / ops_per_pair / 1e9
             roof = {"bound": "valu",
-                    "kernel": ("pc_spec_score (run-time specialised score-only whole-read scan)" if jit
+                    "kernel": ("pc_spec_score (specialised score-only whole-read scan)" if jit
                                else "scan_kernel<R,PAD,false> (generic score-only whole-read scan)"),
                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                     "traffic": None, "launches": int(launches), "avg_launch_ms": per_launch_s * 1e3,
@@ -591,43 +924,54 @@ def main():
                             "mask-and-realign launches of the same kernel (DESIGN.md section 4)"}
             # HBM-side traffic of that kernel comes from the separately collected rocprofv3 --pmc passes
             # of this same command (tools/profile_round.sh -> profiles/<round>_summary.json): FETCH_SIZE +
-            # WRITE_SIZE of one launch, KB as reported.  (The guide's x2 correction is for wide 16-B/lane
+            # WRITE_SIZE of one launch, KB as reported -- accepted only when that summary was taken with the
+            # library now loaded (profile_traffic).  (The guide's x2 correction is for wide 16-B/lane
             # streams; here lanes gather 4 B each and the kernel provably consumes 7.95 GB per launch
             # against a reported FETCH_SIZE of 6.4 GB, so no doubling is applied.)
-            try:
-                import glob
-                summ = sorted(glob.glob(os.path.join(REPO, "profiles", "*_summary.json")))
-                if summ:
-                    with open(summ[-1]) as f:
-                        sj = json.load(f)
-                    kk = sj["kernels"].get("pc_spec_score" if jit else "")
-                    if kk and sj.get("reads_per_gpu") == args.reads and world == 1:
-                        roof["traffic"] = (kk["FETCH_SIZE_KB_mean_launch"] + kk["WRITE_SIZE_KB_mean_launch"]) * 1024.0
-                        roof["traffic_source"] = os.path.relpath(summ[-1], REPO) + " (mean over this kernel's launches; FETCH_SIZE + WRITE_SIZE)"
-            except Exception:
-                pass
+            if world == 1:
+                roof["traffic"] = profile_traffic("headline", "pc_spec_score" if jit else "")
+                if roof["traffic"] is not None:
+                    roof["traffic_source"] = _PROFILE.get("_path", "") + " (mean over this kernel's launches; FETCH_SIZE + WRITE_SIZE; same library sha1)"
         kern_ms = {k: v[0] / args.steps for k, v in timing.items()}
+        srt = sorted(region_ms)
+        pf = {"reads_per_s": total_reads * fsteps / dt_pf, "ms_per_step": dt_pf / fsteps * 1e3, "steps": fsteps,
+              "same_trims_and_middle_hits": same_hits_f, "speedup_vs_headline": (dt / args.steps) / (dt_pf / fsteps),
+              "kernel_ms_per_step": {k: v[0] / fsteps for k, v in timing_pf.items()},
+              "pairs_reaching_the_dp_per_step": pl.stats.get("pairs_middle_scanned_after_prefilter", 0) // max(1, fsteps + 1),
+              "pairs_prefiltered_per_step": pl.stats.get("pairs_middle_prefiltered", 0) // max(1, fsteps + 1),
+              "note": "not the headline: phase C's round 0 runs Myers' bit-vector edit distance for every (read, adapter) pair "
+                      "(12.5 VALU ops per column instead of 2.5 per adapter row) and the DP only for pairs within "
+                      "max_edits(m, --middle_threshold) edits of a substring; everything else is proven not to be a hit "
+                      "(csrc/pc_prefilter.hip, tests/test_prefilter_bound.py)"}
+        if timing_pf["prefilter"][1] > 0:
+            pf["roofline"] = prefilter_roofline(timing_pf["prefilter"][0], timing_pf["prefilter"][1], timing_pf["prefilter"][2],
+                                                args.reads * mean_trim_len, A)
         out = {
             "metric": "reads/sec (and read-bp/sec) end+middle adapter scan, 8 kb reads",
             "value": reads_per_s, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f16-held integers (score scan) / i16 (traced scan), exact", "data": "synthetic",
             "read_bp_per_s": reads_per_s * args.read_len,
+            "repeats": {"ms_per_step": region_ms, "median": srt[len(srt) // 2], "min": srt[0], "max": srt[-1],
+                        "note": "%d timed regions of %d steps each, back to back; `value` is the FIRST (the contract's) region"
+                                % (len(region_ms), args.steps)},
             "config": {"workload": "BASELINE configs[3]: %d synthetic %d-bp reads per GPU, %.0f%% chimeras, "
                                    "phases A (119-set panel, %d check reads) + B + C (middle scan on)"
                                    % (args.reads, args.read_len, args.chimera * 100, params.check_reads),
                        "reads_per_gpu": args.reads, "read_len": args.read_len, "parallelism": "reads sharded x%d" % world,
                        "world_size": dist.get_world_size() if world > 1 else 1,
                        "backend": (dist.get_backend() if world > 1 else "none (single process)"),
-                       "ms_per_step_by_rank": [s / args.steps * 1e3 for s in rank_s],
+                       "ms_per_step_by_rank": [s_ / args.steps * 1e3 for s_ in rank_s],
                        "matching_sets": [pl.sets[i].name for i in matching],
                        "middle_hits_per_step": int(hits.read.numel()), "mask_rounds": hits.rounds,
                        "kernel_ms_per_step": kern_ms,
+                       "library_sha1": library_fingerprint(),
                        "optional_exact_pruning": {"reads_per_s": total_reads * psteps / dt_proofs,
                                                   "ms_per_step": dt_proofs / psteps * 1e3, "same_middle_hits": same_hits,
                                                   "note": "not the headline: phase A and the middle scan trace back only "
                                                           "pairs whose score can still reach the identity threshold "
-                                                          "(DESIGN.md section 7)"}},
+                                                          "(DESIGN.md section 7)"},
+                       "exact_prefilter": pf},
             "roofline": roof,
         }
         if args.cpu_seconds > 0 and world == 1:
@@ -637,12 +981,33 @@ def main():
             except Exception as e:   # the baseline leg must never break the bench line
                 out["cpu_baseline"] = {"value": None, "unit": "reads/s", "cores": 0, "kind": "port",
                                        "sample": "failed: %r" % (e,)}
+            try:
+                out.setdefault("parity", {})["phase_a_rederived_on_cpu"] = cpu_phase_a_check(reads, pl, host_cores())
+            except Exception as e:
+                out.setdefault("parity", {})["phase_a_rederived_on_cpu"] = {"failed": repr(e)}
+        if world == 1 and not args.no_extra:
+            try:
+                out.setdefault("parity", {})["device_crosscheck"] = device_crosscheck(pl, reads, matching, st, et, dev)
+            except Exception as e:
+                out.setdefault("parity", {})["device_crosscheck"] = {"failed": repr(e)}
     pl.close()
     del reads, pl
     torch.cuda.empty_cache()
+    also = {}
+    if not args.no_extra:
+        # the per-GPU shape of BASELINE configs[4], on EVERY rank (its own barriers / MAX over ranks inside)
+        note("leg configs4_per_gpu")
+        try:
+            r4 = leg_configs4(dev, args, host_cores(), world, rank, barrier)
+            if rank == 0:
+                also["configs4_per_gpu"] = r4
+        except Exception as e:
+            if world > 1:
+                raise                                    # a rank that fails alone would hang the others' collectives
+            also["configs4_per_gpu"] = {"failed": repr(e)}
+        torch.cuda.empty_cache()
     if rank == 0:
         if world == 1 and not args.no_extra:
-            also = {}
             legs = (("configs1", lambda: leg_configs1(dev, args, host_cores())),
                     ("configs2", lambda: leg_configs2(dev, args, host_cores())),
                     ("ragged_lengths", lambda: leg_ragged(dev, args, host_cores(), out["read_bp_per_s"])),
@@ -654,9 +1019,10 @@ def main():
                 except Exception as e:   # an extra leg must never break the bench line
                     also[name] = {"failed": repr(e)}
                 torch.cuda.empty_cache()
-            out["config"]["also_measured"] = also
             if "reads_per_s" in also.get("from_host_memory", {}):
                 out["value_incl_h2d"] = also["from_host_memory"]["reads_per_s"]
+        if also:
+            out["config"]["also_measured"] = also
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

@@ -122,6 +122,13 @@ int pc_scan_device(pc_ctx *ctx, const void *d_arena, const int64_t *d_win_off,
  * Affects scheduling only, never results (the chunked pass is exact, pc_bounds.h). */
 int pc_set_length_hint(pc_ctx *ctx, int typical_len);
 
+/* Kernel-variant switch for cross-checks: enabled != 0 makes every later launch of this context use the packed-int16
+ * kernels (21 / 6 ops per cell pair) even where the packed-fp16 ones (13.25 / 5) are proven exact by the host gates
+ * of csrc/pc_bounds.h.  Results are bit-identical either way -- that is what a cross-check of the two asserts
+ * (bench.py's device_crosscheck leg, tests/test_gpu_parity.py).  Default 0; PC_DISABLE_F16=1 / PC_JIT_INT16=1 in the
+ * environment force the same process-wide. */
+int pc_set_int16_only(pc_ctx *ctx, int enabled);
+
 /* Waits for `stream` and returns PC_ERR_INTERNAL if any kernel since the last pc_sync reported
  * an inconsistency. */
 int pc_sync(pc_ctx *ctx, void *stream);
@@ -129,10 +136,10 @@ int pc_sync(pc_ctx *ctx, void *stream);
 /* Kernel timing hooks (bench.py roofline leg): when enabled, every kernel launch made by
  * pc_scan_device is bracketed by HIP events on the launch stream.  pc_get_timing waits for the
  * stream, then returns per kernel kind (0 = generic score-only scan, 1 = window planner, 2 = traced
- * scan, 3 = run-time specialised score-only scan) the summed duration in milliseconds, the number
+ * scan, 3 = run-time specialised score-only scan, 4 = bit-parallel prefilter) the summed duration in milliseconds, the number
  * of launches and the number of pairs they covered, and resets the accumulators.  Each array
  * holds PC_KERNEL_KINDS entries. */
-#define PC_KERNEL_KINDS 4
+#define PC_KERNEL_KINDS 5
 int pc_set_timing(pc_ctx *ctx, int enabled);
 int pc_get_timing(pc_ctx *ctx, void *stream, double *ms, int64_t *launches, int64_t *pairs);
 
@@ -163,6 +170,25 @@ int pc_phase_b_reduce(pc_ctx *ctx, const int32_t *d_records, int64_t n, int njob
  * back to back whatever their lengths.  Asynchronous on `stream`. */
 int pc_copy_windows(pc_ctx *ctx, const void *d_arena, const int64_t *d_src_off, const int32_t *d_len,
                     int64_t n, void *d_dst, const int64_t *d_dst_off, int pad, void *stream);
+
+/* Exact bit-parallel prefilter of the whole-read ("middle") scan.  Porechop keeps a whole-read alignment only when
+ * its full-adapter identity reaches --middle_threshold (porechop/nanopore_read.py:224-241); such an alignment has at
+ * most pc_prefilter_max_edits(adapter length, threshold) non-matching columns inside the adapter's span, so the
+ * adapter lies within that many unit-cost edits (substitutions, insertions, deletions; adapter global, overhanging
+ * adapter bases are deletions; read local; equality of Dna5 codes, N == N, as in the reference) of a substring of
+ * the read.  pc_prefilter_device decides that for every (window, adapter) pair with Myers' bit-vector algorithm,
+ * one lane per (window chunk, adapter piece) (csrc/pc_prefilter.hip; the alternative the reference's README.md:355-357
+ * points to).  Row w of d_mask ([nwindows][ceil(nadapters / 32)] words, written by the call) gets bit j set iff window
+ * w MAY hold adapters[j] within max_edits[j] edits: always set when it does (so a pair whose bit is clear is PROVEN not
+ * to be a hit, and only the survivors need the DP), never set when it does not for adapters of at most 32 bases;
+ * longer adapters are cut into ceil(m / 32) pieces and survive when one piece lies within floor(max_edits / pieces)
+ * edits (pigeonhole: a superset).  max_edits[j] < 0 = do not filter adapter j (bit set for every non-empty window).
+ * adapters[] indexes the table of pc_set_adapters; max_len bounds every win_len; the arena must be readable 16 bytes
+ * past its last window.  Asynchronous on `stream`; honours pc_set_length_hint. */
+int pc_prefilter_max_edits(int adapter_len, double threshold_percent);
+int pc_prefilter_device(pc_ctx *ctx, const void *d_arena, const int64_t *d_win_off, const int32_t *d_win_len,
+                        int64_t nwindows, int max_len, const int32_t *adapters, const int32_t *max_edits,
+                        int nadapters, uint32_t *d_mask, void *stream);
 
 /* Debug builds of the 16-bit kernels (PC_CHECK_RANGE=1: packed-fp16 traced kernel, row classes 24/28/30/40;
  * PC_JIT_CHECK_RANGE=1: the run-time specialised score kernel) record the extremes of every DP value they

@@ -59,6 +59,10 @@ class Oracle:
         L.pc_oracle_align_many.argtypes = [ctypes.c_void_p] * 6 + [ctypes.c_int64] + [ctypes.c_int] * 4 + \
             [ctypes.c_void_p]
         L.pc_oracle_align_many.restype = ctypes.c_int
+        L.pc_oracle_min_edits.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_char_p, ctypes.c_int]
+        L.pc_oracle_min_edits.restype = ctypes.c_int
+        L.pc_oracle_min_edits_many.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_char_p, ctypes.c_int, ctypes.c_int64, ctypes.c_void_p]
+        L.pc_oracle_min_edits_many.restype = ctypes.c_int
 
     def adapter_alignment(self, read, adapter, scores=DEFAULT_SCORES):
         if isinstance(read, str):
@@ -82,6 +86,28 @@ class Oracle:
         if rc:
             raise RuntimeError("oracle rc=%d" % rc)
         return r
+
+    def min_edits(self, read, adapter):
+        """Smallest unit-cost edit distance between the whole adapter and any substring of the read (the quantity
+        the exact prefilter bounds; pc_oracle.c)."""
+        if isinstance(read, str):
+            read = read.encode()
+        if isinstance(adapter, str):
+            adapter = adapter.encode()
+        return int(self.lib.pc_oracle_min_edits(read, len(read), adapter, len(adapter)))
+
+    def min_edits_many(self, read_arena, read_off, read_len, adapter):
+        read_arena = np.ascontiguousarray(read_arena, dtype=np.uint8)
+        read_off = np.ascontiguousarray(read_off, dtype=np.int64)
+        read_len = np.ascontiguousarray(read_len, dtype=np.int32)
+        if isinstance(adapter, str):
+            adapter = adapter.encode()
+        out = np.zeros(read_off.shape[0], dtype=np.int32)
+        rc = self.lib.pc_oracle_min_edits_many(read_arena.ctypes.data, read_off.ctypes.data, read_len.ctypes.data,
+                                               adapter, len(adapter), read_off.shape[0], out.ctypes.data)
+        if rc:
+            raise RuntimeError("oracle rc=%d" % rc)
+        return out
 
     def align_many(self, read_arena, read_off, read_len, ad_arena, ad_off, ad_len, scores=DEFAULT_SCORES):
         """Bulk API over numpy arrays; returns int32 [npairs, 9]

@@ -27,6 +27,11 @@ int pc_oracle_align_many(const char *read_arena, const int64_t *read_off, const 
                          const char *adapter_arena, const int64_t *ad_off, const int32_t *ad_len,
                          int64_t npairs, int match, int mismatch, int gap_open, int gap_extend,
                          int32_t *out9);
+/* smallest unit-cost edit distance between the whole adapter and any substring of the read (checker of the
+   exact prefilter, see pc_oracle.c) */
+int pc_oracle_min_edits(const char *read, int n, const char *adapter, int m);
+int pc_oracle_min_edits_many(const char *read_arena, const int64_t *read_off, const int32_t *read_len,
+                             const char *adapter, int m, int64_t n, int32_t *out);
 #ifdef __cplusplus
 }
 #endif

@@ -14,7 +14,7 @@ EXPORTS = [
     "adapterAlignment", "freeCString",
     "pc_version", "pc_strerror", "pc_scores_supported", "pc_create", "pc_destroy",
     "pc_set_scores", "pc_set_adapters", "pc_align_batch_host", "pc_scan_device", "pc_sync",
-    "pc_format_result", "pc_jit_async", "pc_jit_shutdown", "pc_jit_precompile", "pc_jit_stats", "pc_prefetch", "pc_memo_clear", "pc_memo_stats", "pc_set_timing", "pc_get_timing", "pc_set_length_hint", "pc_copy_windows", "pc_trace_ops_x100", "pc_phase_b_reduce", "pc_debug_value_range",
+    "pc_format_result", "pc_jit_async", "pc_jit_shutdown", "pc_jit_precompile", "pc_jit_stats", "pc_prefilter_max_edits", "pc_prefilter_device", "pc_prefetch", "pc_memo_clear", "pc_memo_stats", "pc_set_timing", "pc_get_timing", "pc_set_length_hint", "pc_set_int16_only", "pc_copy_windows", "pc_trace_ops_x100", "pc_phase_b_reduce", "pc_debug_value_range",
     "pc_readset_load", "pc_readset_free", "pc_readset_error", "pc_readset_count", "pc_readset_is_fastq",
     "pc_readset_arena", "pc_readset_offsets", "pc_readset_lengths", "pc_readset_name", "pc_readset_quals",
     "pc_readset_is_rna", "pc_readset_load_many", "pc_readset_file_index", "pc_readset_write",
@@ -76,6 +76,8 @@ def load_library():
     L.pc_copy_windows.restype = c_int
     L.pc_set_length_hint.argtypes = [c_vp, c_int]
     L.pc_set_length_hint.restype = c_int
+    L.pc_set_int16_only.argtypes = [c_vp, c_int]
+    L.pc_set_int16_only.restype = c_int
     L.pc_set_timing.argtypes = [c_vp, c_int]
     L.pc_set_timing.restype = c_int
     L.pc_get_timing.argtypes = [c_vp, c_vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_i64), ctypes.POINTER(c_i64)]
@@ -95,6 +97,10 @@ def load_library():
     L.pc_jit_precompile.restype = c_int
     L.pc_jit_stats.argtypes = [ctypes.POINTER(c_i64), ctypes.POINTER(c_i64)]
     L.pc_jit_stats.restype = None
+    L.pc_prefilter_max_edits.argtypes = [c_int, ctypes.c_double]
+    L.pc_prefilter_max_edits.restype = c_int
+    L.pc_prefilter_device.argtypes = [c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_vp, c_vp, c_int, c_vp, c_vp]
+    L.pc_prefilter_device.restype = c_int
     import atexit
     atexit.register(L.pc_jit_shutdown)       # no worker thread inside hiprtc while the process is torn down
     L.pc_format_result.argtypes = [c_vp, c_cp, ctypes.c_size_t]

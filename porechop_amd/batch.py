@@ -126,19 +126,24 @@ class Aligner:
         score pass only, never results (pc_set_length_hint)."""
         check(self.lib.pc_set_length_hint(self._ctx, int(max(0, typical_len))), "pc_set_length_hint")
 
+    def set_int16_only(self, enabled=True):
+        """Use the packed-int16 kernel variants even where the packed-fp16 ones are proven exact (cross-checks)."""
+        check(self.lib.pc_set_int16_only(self._ctx, 1 if enabled else 0), "pc_set_int16_only")
+
     def set_timing(self, enabled=True):
         check(self.lib.pc_set_timing(self._ctx, 1 if enabled else 0), "pc_set_timing")
 
     def get_timing(self, stream=None):
         """-> dict kind -> (ms, launches, pairs) since the last call, for the kinds 'score' (generic
-        score-only scan), 'plan', 'trace' and 'score_spec' (run-time specialised score-only scan)."""
+        score-only scan), 'plan', 'trace', 'score_spec' (run-time specialised score-only scan) and 'prefilter'
+        (bit-parallel prefilter; its "pairs" are (window, adapter) pairs)."""
         import torch
         s = stream if stream is not None else torch.cuda.current_stream().cuda_stream
-        ms = (ctypes.c_double * 4)()
-        ln = (ctypes.c_int64 * 4)()
-        pr = (ctypes.c_int64 * 4)()
+        ms = (ctypes.c_double * 5)()
+        ln = (ctypes.c_int64 * 5)()
+        pr = (ctypes.c_int64 * 5)()
         check(self.lib.pc_get_timing(self._ctx, ctypes.c_void_p(s), ms, ln, pr), "pc_get_timing")
-        return {k: (ms[i], ln[i], pr[i]) for i, k in enumerate(("score", "plan", "trace", "score_spec"))}
+        return {k: (ms[i], ln[i], pr[i]) for i, k in enumerate(("score", "plan", "trace", "score_spec", "prefilter"))}
 
     def phase_b_reduce(self, records, n, job_record_offset, job_side, end_size, min_trim_size, extra_end_trim,
                        end_threshold, start_trim, end_trim, bins=None, barcode_threshold=0.0, barcode_diff=0.0,
@@ -174,6 +179,31 @@ class Aligner:
         s = stream if stream is not None else torch.cuda.current_stream().cuda_stream
         check(self.lib.pc_copy_windows(self._ctx, arena.data_ptr(), src_off.data_ptr(), length.data_ptr(), n, dst.data_ptr(),
                                        dst_off.data_ptr(), int(pad), ctypes.c_void_p(s)), "pc_copy_windows")
+
+    def max_edits(self, adapter_len, threshold_percent):
+        """Most non-matching columns an alignment of an adapter_len-base adapter can have inside the adapter's span if
+        its full-adapter identity reaches threshold_percent (pc_prefilter_max_edits)."""
+        return int(self.lib.pc_prefilter_max_edits(int(adapter_len), float(threshold_percent)))
+
+    def prefilter(self, arena, win_off, win_len, max_len, adapters, max_edits, stream=None):
+        """Exact bit-parallel prefilter (pc_prefilter_device): -> bool CUDA tensor [len(adapters), n]; False = window w
+        is PROVEN not to hold adapters[j] within max_edits[j] edits (so that alignment cannot reach the identity
+        threshold the bound was derived from)."""
+        import torch
+        assert arena.is_cuda and win_off.is_cuda and win_len.is_cuda
+        assert win_off.dtype == torch.int64 and win_len.dtype == torch.int32 and win_off.is_contiguous() and win_len.is_contiguous()
+        n, na = int(win_off.shape[0]), len(adapters)
+        words = (na + 31) // 32
+        mask = torch.empty((n, max(words, 1)), dtype=torch.int32, device=arena.device)
+        ad = np.ascontiguousarray(adapters, dtype=np.int32)
+        ed = np.ascontiguousarray(max_edits, dtype=np.int32)
+        s = stream if stream is not None else torch.cuda.current_stream().cuda_stream
+        check(self.lib.pc_prefilter_device(self._ctx, arena.data_ptr(), win_off.data_ptr(), win_len.data_ptr(), n, int(max_len),
+                                           ad.ctypes.data, ed.ctypes.data, na, mask.data_ptr(), ctypes.c_void_p(s)),
+              "pc_prefilter_device")
+        bits = torch.arange(32, device=arena.device, dtype=torch.int32)
+        out = ((mask[:, :, None] >> bits[None, None, :]) & 1).reshape(n, -1)[:, :na]
+        return out.t().to(torch.bool)
 
     def debug_value_range(self):
         """(lo, hi) of the DP values the range-checking kernel builds have held since the last call."""

@@ -18,6 +18,8 @@
 #include <unordered_map>
 #include <vector>
 
+#include <cmath>
+
 #include "../../include/porechop_amd.h"
 #include "pc_bounds.h"
 #include "pc_jit.h"
@@ -101,13 +103,22 @@ struct pc_ctx {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // host-API staging
     DevBuf d_arena, d_woff, d_wlen, d_out;
-    // pc_phase_b_reduce: job / bin tables (host copies stay alive until the next call's upload)
-    DevBuf d_red;
+    // pc_phase_b_reduce: job / bin tables in two slots (pinned host staging + device copy each); a slot is reused
+    // once the reduce kernel that read it two calls ago has finished (red_done), so a call never waits for the
+    // scan it was enqueued behind
+    DevBuf d_red_slot[2];
+    void *h_red[2] = {nullptr, nullptr};
+    size_t h_red_cap[2] = {0, 0};
+    hipEvent_t red_done[2] = {nullptr, nullptr};
+    int red_slot = 0;
     // score pass: one work counter per launch (units beyond the grid are drawn from it)
     DevBuf d_work;
     int len_hint = 0;            // pc_set_length_hint
-    std::vector<int64_t> red_off;
-    std::vector<int32_t> red_tab;
+    bool int16_only = false;     // pc_set_int16_only: never use the packed-fp16 kernel variants
+    // pc_prefilter_device: Eq tables + piece metadata of the last (adapter list, edit bounds), kept on the device
+    DevBuf d_pf_tables, d_pf_meta;
+    std::vector<int32_t> pf_key;             // adapters..., max_edits... of the cached tables
+    int pf_P = 0, pf_groups = 0, pf_warm = 0;
     // cached job table (bench loops repeat the same one: skip the re-upload).  The tile table itself only
     // exists on the device: it is expanded there from the groups' runs (one per job and shape).
     std::vector<Group> groups;
@@ -184,6 +195,7 @@ int upload_panel(pc_ctx *c)
     HIP_TRY(hipMemcpy(c->d_ad_window.p, c->ad_window.data(), c->ad_window.size() * 4, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(c->d_ad_span.p, c->ad_span.data(), c->ad_span.size() * 4, hipMemcpyHostToDevice));
     c->panel_dirty = false;
+    c->pf_key.clear();
     c->tiles_uploaded = false;
     c->last_max_len = -1;
     return PC_OK;
@@ -266,6 +278,10 @@ int build_tiles(pc_ctx *c, const int32_t *job_adapter, const int32_t *job_adapte
             out_pos += n;
         }
     }
+    // from here on the cached table is being replaced: an error below must not leave the "same job list" fast
+    // path pointing at half-built groups or an unbuilt slot
+    c->tiles_uploaded = false;
+    c->last_max_len = -1;
     c->groups.clear();
     std::vector<pck::TileRun> all_runs;
     size_t ntiles = 0;
@@ -412,7 +428,7 @@ bool f16_disabled()
 
 bool trace16_plan(const pc_ctx *c, int rows, int cols, pcb::F16Plan *out)
 {
-    if (f16_disabled() || rows <= 0 || !pck::trace16_has(rows)) return false;
+    if (f16_disabled() || c->int16_only || rows <= 0 || !pck::trace16_has(rows)) return false;
     const pcb::F16Plan p = pcb::f16_plan(c->match, c->mismatch, c->gap_open, c->gap_extend, rows);
     if (!p.ok || cols > p.max_cols) return false;
     *out = p;
@@ -464,7 +480,7 @@ std::vector<ScoreLaunch> plan_score_launches(pc_ctx *c, const Group &g, int max_
         const double est_len = ragged_lengths(c, max_len) ? (double)c->len_hint : (double)max_len;
         const double est_cells = (double)group_pairs(g, i, e) * est_len * (double)(g.rows ? g.rows : g.gen_max_rows);
         pcj::Spec *sp = !linear ? pcj::get(c->device, c->adapters[r0.adapter_lo], c->adapters[r0.adapter_hi], c->match,
-                                           c->mismatch, c->gap_open, c->gap_extend, est_cells)
+                                           c->mismatch, c->gap_open, c->gap_extend, est_cells, c->int16_only)
                                 : nullptr;
         const size_t n = e - i;
         if (!sp) {
@@ -545,6 +561,8 @@ int pc_create(pc_ctx **out, int device)
     for (int i = 0; i < 2; ++i)
         if (hipEventCreateWithFlags(&c->slot_free[i], hipEventDisableTiming) != hipSuccess) { delete c; return PC_ERR_NO_DEVICE; }
     if (hipEventCreateWithFlags(&c->table_ready, hipEventDisableTiming) != hipSuccess) { delete c; return PC_ERR_NO_DEVICE; }
+    for (int i = 0; i < 2; ++i)
+        if (hipEventCreateWithFlags(&c->red_done[i], hipEventDisableTiming) != hipSuccess) { delete c; return PC_ERR_NO_DEVICE; }
     if (hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) { delete c; return PC_ERR_NO_DEVICE; }
     *out = c;
@@ -559,12 +577,16 @@ void pc_destroy(pc_ctx *c)
     (void)hipDeviceSynchronize();
     for (int i = 0; i < 2; ++i) if (c->slot_free[i]) (void)hipEventDestroy(c->slot_free[i]);
     if (c->table_ready) (void)hipEventDestroy(c->table_ready);
+    for (int i = 0; i < 2; ++i) {
+        if (c->red_done[i]) (void)hipEventDestroy(c->red_done[i]);
+        if (c->h_red[i]) (void)hipHostFree(c->h_red[i]);
+    }
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     DevBuf *bufs[] = {&c->d_ad_codes, &c->d_ad_len, &c->d_ad_window, &c->d_ad_span, &c->d_tiles_slot[0], &c->d_tiles_slot[1],
                       &c->d_runs_slot[0], &c->d_runs_slot[1], &c->d_slab, &c->d_fin, &c->d_k1, &c->d_woff2,
                       &c->d_wlen2, &c->d_col0, &c->d_ntot, &c->d_frow, &c->d_fscore, &c->d_err, &c->d_arena,
-                      &c->d_woff, &c->d_wlen, &c->d_out, &c->d_red, &c->d_work};
+                      &c->d_woff, &c->d_wlen, &c->d_out, &c->d_red_slot[0], &c->d_red_slot[1], &c->d_work, &c->d_pf_tables, &c->d_pf_meta};
     for (DevBuf *b : bufs) b->release();
     (void)hipStreamDestroy(c->stream);
     delete c;
@@ -578,6 +600,13 @@ int pc_set_scores(pc_ctx *c, int match, int mismatch, int gap_open, int gap_exte
         c->match = match; c->mismatch = mismatch; c->gap_open = gap_open; c->gap_extend = gap_extend;
         c->panel_dirty = true;
     }
+    return PC_OK;
+}
+
+int pc_set_int16_only(pc_ctx *c, int enabled)
+{
+    if (!c) return PC_ERR_BAD_ARG;
+    c->int16_only = enabled != 0;
     return PC_OK;
 }
 
@@ -857,29 +886,43 @@ int pc_phase_b_reduce(pc_ctx *c, const int32_t *d_records, int64_t n, int njobs,
         if (bin_start_job[k] >= njobs || bin_end_job[k] >= njobs) return PC_ERR_BAD_ARG;
     (void)hipSetDevice(c->device);
     hipStream_t stream = (stream_v == PC_STREAM_CONTEXT) ? c->stream : (hipStream_t)stream_v;
-    // the previous call's tables may still be read by its kernel
-    HIP_TRY(hipStreamSynchronize(stream));
-    c->red_off.assign(job_record_offset, job_record_offset + njobs);
-    c->red_tab.assign(job_side, job_side + njobs);
-    c->red_tab.insert(c->red_tab.end(), bin_start_job, bin_start_job + nbins);
-    c->red_tab.insert(c->red_tab.end(), bin_end_job, bin_end_job + nbins);
+    // tables: [njobs] int64 record offsets, then job_side[njobs], bin_start[nbins], bin_end[nbins] as int32 -- staged
+    // in pinned host memory and copied asynchronously; the slot's previous user (two calls ago) has long finished
+    c->red_slot ^= 1;
+    const int sl = c->red_slot;
+    HIP_TRY(hipEventSynchronize(c->red_done[sl]));
     const size_t off_bytes = ((size_t)std::max(njobs, 1) * 8 + 15) / 16 * 16;
-    int rc = c->d_red.ensure(off_bytes + (c->red_tab.size() + 4) * 4);
+    const size_t tab_ints = (size_t)njobs + 2 * (size_t)nbins;
+    const size_t total = off_bytes + (tab_ints + 4) * 4;
+    if (c->h_red_cap[sl] < total) {
+        if (c->h_red[sl]) { (void)hipHostFree(c->h_red[sl]); c->h_red[sl] = nullptr; c->h_red_cap[sl] = 0; }
+        HIP_TRY(hipHostMalloc(&c->h_red[sl], total * 2, hipHostMallocDefault));
+        c->h_red_cap[sl] = total * 2;
+    }
+    int rc = c->d_red_slot[sl].ensure(total);
     if (rc) return rc;
-    if (njobs > 0) HIP_TRY(hipMemcpyAsync(c->d_red.p, c->red_off.data(), (size_t)njobs * 8, hipMemcpyHostToDevice, stream));
-    if (!c->red_tab.empty())
-        HIP_TRY(hipMemcpyAsync((char *)c->d_red.p + off_bytes, c->red_tab.data(), c->red_tab.size() * 4, hipMemcpyHostToDevice, stream));
+    char *h = (char *)c->h_red[sl];
+    if (njobs > 0) memcpy(h, job_record_offset, (size_t)njobs * 8);
+    int32_t *tab = (int32_t *)(h + off_bytes);
+    if (njobs > 0) memcpy(tab, job_side, (size_t)njobs * 4);
+    if (nbins > 0) {
+        memcpy(tab + njobs, bin_start_job, (size_t)nbins * 4);
+        memcpy(tab + njobs + nbins, bin_end_job, (size_t)nbins * 4);
+    }
+    HIP_TRY(hipMemcpyAsync(c->d_red_slot[sl].p, h, total, hipMemcpyHostToDevice, stream));
     pck::ReduceArgs a;
     memset(&a, 0, sizeof(a));
     a.records = d_records; a.n = n; a.njobs = njobs;
-    a.job_off = c->d_red.as<int64_t>();
-    a.job_side = (const int32_t *)((char *)c->d_red.p + off_bytes);
+    a.job_off = c->d_red_slot[sl].as<int64_t>();
+    a.job_side = (const int32_t *)((char *)c->d_red_slot[sl].p + off_bytes);
     a.end_size = end_size; a.min_trim_size = min_trim_size; a.extra_end_trim = extra_end_trim; a.end_threshold = end_threshold;
     a.start_trim = d_start_trim; a.end_trim = d_end_trim;
     a.nbins = nbins; a.bin_start = a.job_side + njobs; a.bin_end = a.bin_start + nbins;
     a.barcode_threshold = barcode_threshold; a.barcode_diff = barcode_diff; a.require_two = require_two ? 1 : 0;
     a.call = d_call;
-    return pck::launch_reduce(a, stream) ? PC_ERR_NO_DEVICE : PC_OK;
+    if (pck::launch_reduce(a, stream)) return PC_ERR_NO_DEVICE;
+    HIP_TRY(hipEventRecord(c->red_done[sl], stream));
+    return PC_OK;
 }
 
 int pc_copy_windows(pc_ctx *c, const void *d_arena, const int64_t *d_src_off, const int32_t *d_len, int64_t n,
@@ -891,6 +934,109 @@ int pc_copy_windows(pc_ctx *c, const void *d_arena, const int64_t *d_src_off, co
     (void)hipSetDevice(c->device);
     hipStream_t stream = (stream_v == PC_STREAM_CONTEXT) ? c->stream : (hipStream_t)stream_v;
     return pck::launch_copy_windows((const uint8_t *)d_arena, d_src_off, d_len, n, (uint8_t *)d_dst, d_dst_off, pad, stream) ? PC_ERR_NO_DEVICE : PC_OK;
+}
+
+int pc_prefilter_max_edits(int adapter_len, double threshold_percent)
+{
+    // A hit has full-adapter identity 100 M / L >= threshold after the reference's %f rounding (six decimals;
+    // alignment.cpp:113-121 -> nanopore_read.py:476-491), L = alignment columns from the adapter's first to its
+    // last base, M <= adapter_len of them matches.  With tau = (threshold - 1e-6) / 100:  M >= tau L,  so the
+    // e = L - M non-matching columns -- each one unit-cost edit between the adapter and the read bases under its
+    // span -- number at most M (1 - tau) / tau <= adapter_len (1 - tau) / tau.
+    if (adapter_len <= 0) return -1;
+    const double tau = (threshold_percent - 1e-6) / 100.0;
+    if (!(tau > 0.0)) return adapter_len;                 // everything is a hit: nothing can be excluded
+    if (tau >= 1.0) return 0;
+    const double e = (double)adapter_len * (1.0 - tau) / tau;
+    const int k = (int)floor(e + 1e-9);                   // + 1e-9: never round a bound DOWN across an integer
+    return k > adapter_len ? adapter_len : k;
+}
+
+int pc_prefilter_device(pc_ctx *c, const void *d_arena, const int64_t *d_win_off, const int32_t *d_win_len,
+                        int64_t nwindows, int max_len, const int32_t *adapters, const int32_t *max_edits, int nadapters,
+                        uint32_t *d_mask, void *stream_v)
+{
+    if (!c || nwindows < 0 || nadapters < 0 || max_len < 0) return PC_ERR_BAD_ARG;
+    if (nwindows == 0 || nadapters == 0) return PC_OK;
+    if (!d_arena || !d_win_off || !d_win_len || !adapters || !max_edits || !d_mask) return PC_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    (void)hipSetDevice(c->device);
+    hipStream_t stream = (stream_v == PC_STREAM_CONTEXT) ? c->stream : (hipStream_t)stream_v;
+    const int words = (nadapters + 31) / 32;
+    std::vector<int32_t> key(adapters, adapters + nadapters);
+    key.insert(key.end(), max_edits, max_edits + nadapters);
+    if (key != c->pf_key) {
+        // pieces: an adapter of m bases is cut into p = ceil(m / 32) pieces of nearly equal length; if the adapter is
+        // within k edits of a substring, one piece is within floor(k / p) (pigeonhole)
+        struct Piece { int adapter, begin, len, k, word; uint32_t bit; };
+        std::vector<Piece> pieces;
+        int warm = 0;
+        for (int j = 0; j < nadapters; ++j) {
+            const int ai = adapters[j];
+            if (ai < 0 || ai >= (int)c->adapters.size()) return PC_ERR_BAD_ARG;
+            const int m = (int)c->adapters[ai].size();
+            if (m <= 0) continue;                                     // an empty adapter never hits (failure record)
+            const int k = max_edits[j] < 0 ? m : max_edits[j];        // < 0: do not filter this adapter
+            const int np = (m + 31) / 32;
+            int pos = 0;
+            for (int q = 0; q < np; ++q) {
+                const int len = m / np + (q < m % np ? 1 : 0);
+                pieces.push_back({ai, pos, len, k / np, j / 32, 1u << (j % 32)});
+                warm = std::max(warm, len + k / np);
+                pos += len;
+            }
+        }
+        const int P = pieces.size() > 4 ? 8 : pieces.size() > 2 ? 4 : pieces.size() > 1 ? 2 : 1;
+        const int groups = (int)((pieces.size() + P - 1) / P);
+        std::vector<uint32_t> tables((size_t)std::max(groups, 1) * 256 * P, 0xFFFFFFFFu);   // unused slots: all wildcards
+        std::vector<int32_t> meta((size_t)std::max(groups, 1) * P * 4, 0);
+        for (size_t i = 0; i < pieces.size(); ++i) {
+            const Piece &pc = pieces[i];
+            const size_t g = i / P, slot = i % P;
+            const std::string &ad = c->adapters[pc.adapter];
+            const uint32_t wild = pc.len >= 32 ? 0u : (0xFFFFFFFFu >> pc.len);       // the bits below the piece
+            uint32_t eq_of_code[5];
+            for (int code = 0; code < 5; ++code) {
+                uint32_t e = wild;
+                for (int r = 0; r < pc.len; ++r)
+                    if (dna5((unsigned char)ad[pc.begin + r]) == code) e |= 1u << (32 - pc.len + r);
+                eq_of_code[code] = e;
+            }
+            for (int b = 0; b < 256; ++b) tables[(g * 256 + b) * P + slot] = eq_of_code[dna5((unsigned char)b)];
+            int32_t *mt = &meta[(g * P + slot) * 4];
+            mt[0] = pc.len; mt[1] = pc.k; mt[2] = pc.word; mt[3] = (int32_t)pc.bit;
+        }
+        // the tables of the previous list may still be read by a launch in flight on the caller's stream
+        HIP_TRY(hipStreamSynchronize(stream));
+        int rc;
+        if ((rc = c->d_pf_tables.ensure(tables.size() * 4)) || (rc = c->d_pf_meta.ensure(meta.size() * 4))) return rc;
+        HIP_TRY(hipMemcpy(c->d_pf_tables.p, tables.data(), tables.size() * 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(c->d_pf_meta.p, meta.data(), meta.size() * 4, hipMemcpyHostToDevice));
+        c->pf_key = key; c->pf_P = P; c->pf_groups = pieces.empty() ? 0 : groups; c->pf_warm = warm;
+    }
+    HIP_TRY(hipMemsetAsync(d_mask, 0, (size_t)nwindows * words * 4, stream));
+    if (c->pf_groups == 0 || max_len == 0) return PC_OK;
+    // column chunks: enough (window, chunk) units to fill the chip several times over, chunks no shorter than 512
+    // columns (the warm-up before a chunk is the longest piece + its edit bound: ~35 columns)
+    const int64_t target = (int64_t)c->ncu * 2048 * 6;
+    int64_t chunks = (target + nwindows - 1) / nwindows;
+    chunks = std::max<int64_t>(1, std::min<int64_t>(chunks, (max_len + 511) / 512));
+    if (c->len_hint > 0 && (int64_t)c->len_hint * 2 < max_len)           // ragged lengths: chunks about as long as a typical read
+        chunks = std::max<int64_t>(chunks, (max_len + c->len_hint - 1) / c->len_hint);
+    int chunk_len = (int)(((int64_t)max_len + chunks - 1) / chunks);
+    chunk_len = (chunk_len + 15) / 16 * 16;
+    chunks = ((int64_t)max_len + chunk_len - 1) / chunk_len;
+    pck::PrefilterArgs a;
+    memset(&a, 0, sizeof a);
+    a.arena = (const uint8_t *)d_arena; a.win_off = d_win_off; a.win_len = d_win_len; a.nwindows = nwindows;
+    a.chunks = (int32_t)chunks; a.chunk_len = chunk_len; a.warm = c->pf_warm;
+    a.tables = c->d_pf_tables.as<uint32_t>(); a.piece_meta = c->d_pf_meta.as<int32_t>();
+    a.mask = d_mask; a.words = words;
+    {
+        ScopedTimer tm(c, stream, 4, nwindows * nadapters);
+        if (pck::launch_prefilter(a, c->pf_P, c->pf_groups, stream)) return PC_ERR_NO_DEVICE;
+    }
+    return PC_OK;
 }
 
 void pc_jit_async(int enabled) { pcj::set_async(enabled); }

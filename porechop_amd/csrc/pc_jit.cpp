@@ -448,7 +448,7 @@ struct JoinAtExit { ~JoinAtExit() { wait_idle(true); } } g_join_at_exit;
 }  // namespace
 
 Spec *get(int device, const std::string &ad_lo, const std::string &ad_hi, int match, int mismatch, int gap_open,
-          int gap_extend, double cells)
+          int gap_extend, double cells, bool int16_only)
 {
     if (disabled()) return nullptr;
     const int m_lo = (int)ad_lo.size(), m_hi = (int)ad_hi.size();
@@ -466,7 +466,7 @@ Spec *get(int device, const std::string &ad_lo, const std::string &ad_hi, int ma
     // packed-int16 (6 ops).  PC_JIT_INT16=1 forces the latter.
     const int eps = -gap_extend;
     const char *force_int = getenv("PC_JIT_INT16");
-    const pcb::SpecPlan plan = pcb::spec_plan(match, mismatch, gap_open, gap_extend, R, force_int && *force_int && *force_int != '0');
+    const pcb::SpecPlan plan = pcb::spec_plan(match, mismatch, gap_open, gap_extend, R, int16_only || (force_int && *force_int && *force_int != '0'));
     const bool f16 = plan.f16;
     const long kren = plan.kren;
     if (!plan.ok) {

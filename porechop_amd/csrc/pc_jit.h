@@ -35,8 +35,9 @@ bool disabled();
 // nullptr when specialisation is unavailable for this pair, or not yet worth its compile: `cells`
 // (the launch's work) is added to the pair's running total, and the kernel is compiled once that
 // total reaches PC_JIT_MIN_CELLS (caller uses the generic kernels until then).
+// int16_only: the packed-int16 variant (6 ops per cell pair) even where packed fp16 is exact (pc_set_int16_only).
 Spec *get(int device, const std::string &ad_lo, const std::string &ad_hi, int match, int mismatch, int gap_open,
-          int gap_extend, double cells);
+          int gap_extend, double cells, bool int16_only = false);
 int launch(const Spec *sp, const SpecArgs &a, int grid, void *stream);
 // Ahead-of-time build of one pair's kernel into a kernel cache directory ("" = the in-tree one next to the library).
 // Needs hiprtc, not a device.  0 = compiled and written, 1 = was already there, < 0 = no such kernel / failure.

@@ -99,6 +99,20 @@ int launch_reduce(const ReduceArgs &a, void *stream);
 int launch_copy_windows(const uint8_t *arena, const int64_t *src_off, const int32_t *len, int64_t n, uint8_t *dst,
                         const int64_t *dst_off, int pad, void *stream);
 
+// exact bit-parallel prefilter of the whole-read scan (pc_prefilter.hip)
+struct PrefilterArgs {
+    const uint8_t *arena;
+    const int64_t *win_off;          // [nwindows]
+    const int32_t *win_len;          // [nwindows]
+    int64_t nwindows;
+    int32_t chunks, chunk_len, warm; // every window is cut into `chunks` column chunks of chunk_len (+ warm columns before)
+    const uint32_t *tables;          // [ngroups][256 byte values][P] Eq words (piece in the top bits, wildcard bits below)
+    const int32_t *piece_meta;       // [ngroups][P][4]: piece length (0 = unused slot), max edits, mask word, mask bit
+    uint32_t *mask;                  // [nwindows][words], zeroed by the host; bit set = the pair survives
+    int32_t words;
+};
+int launch_prefilter(const PrefilterArgs &a, int pieces_per_lane, int ngroups, void *stream);
+
 constexpr int TRACE_OUT_INTS = 8;
 constexpr int SCORE_OUT_INTS = 4;
 

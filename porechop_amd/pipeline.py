@@ -468,7 +468,8 @@ class Pipeline:
                 ads.append((s.end, si))
         return ads
 
-    def phase_c(self, reads: DeviceReads, start_trim, end_trim, matching: List[int], prove: bool = False) -> MiddleHits:
+    def phase_c(self, reads: DeviceReads, start_trim, end_trim, matching: List[int], prove: bool = False,
+                prefilter: bool = False) -> MiddleHits:
         """nanopore_read.py:210-243 for every read: adapters in order, and for each adapter keep
         re-aligning against the progressively masked read while the hit reaches --middle_threshold.
 
@@ -485,7 +486,15 @@ class Pipeline:
         traceback only for pairs whose score can still mean an identity >= --middle_threshold
         (identity_score_bound) -- everything else is PROVEN not to be a hit, which is all the
         reference does with those alignments.  Hits, masks and splits are identical; the records of
-        the proven non-hits are simply not produced (an option: the default computes them all)."""
+        the proven non-hits are simply not produced (an option: the default computes them all).
+
+        prefilter=True: the same, with the proof coming from the exact bit-parallel prefilter instead of the
+        score pass (pc_prefilter_device: Myers' bit-vector edit distance, one lane per read chunk and adapter; the
+        alternative the reference's README.md:355-357 names).  A hit needs full-adapter identity >=
+        --middle_threshold, hence at most max_edits(m, threshold) unit-cost edits between the adapter and some
+        substring of the read; pairs farther apart are PROVEN not to be hits and never reach the DP.  The reads
+        that survive for one of a set's sequences run the two-pass scan for that set (both of its sequences in one
+        pass, on the set's ahead-of-time kernel).  Hits, masks, rounds and alignment counts are identical."""
         p = self.p
         dev = self.device
         ads_sets = self._middle_adapters_with_sets(matching)
@@ -517,7 +526,50 @@ class Pipeline:
         # ---- round 0: all adapters x all reads, unmasked -------------------------------------
         jobs0 = [(ai, loff, llen, h) for ai, h in zip(aidx, hint)]
         bounds = [self.identity_score_bound(len(self.seqs[ai]), p.middle_threshold) for ai in aidx] if prove else None
-        if prove and all(b is not None for b in bounds):
+        if prefilter:
+            L = int(live.numel())
+            ks = [self.aligner.max_edits(len(self.seqs[ai]), p.middle_threshold) for ai in aidx]
+            order = None
+            pf_off, pf_len = loff, llen
+            if ragged:                                   # a wave runs 64 consecutive windows: similar lengths together
+                order = torch.argsort(llen, descending=True, stable=True)
+                pf_off, pf_len = loff[order].contiguous(), llen[order].contiguous()
+            self.aligner.set_length_hint(typ_len if ragged else 0)
+            cand = self.aligner.prefilter(reads.arena, pf_off.contiguous(), pf_len.contiguous(), max_len, aidx, ks)     # [A, L] bool
+            if order is not None:
+                back = torch.empty_like(cand)
+                back[:, order] = cand
+                cand = back
+            # survivors by SET: the reads that pass for one of a set's sequences are scanned for all of them
+            groups, gidx = {}, []
+            for a, h in enumerate(hint):
+                gidx.append(groups.setdefault(h, len(groups)))
+            G = len(groups)
+            member = torch.zeros((G, A), dtype=torch.bool, device=dev)
+            member[torch.tensor(gidx, device=dev), torch.arange(A, device=dev)] = True
+            cand_g = (member[:, :, None] & cand[None, :, :]).any(dim=1) if G * A * L <= (1 << 28) else \
+                torch.stack([cand[torch.tensor([a for a in range(A) if gidx[a] == g], device=dev)].any(dim=0) for g in range(G)])
+            hitg = torch.nonzero(cand_g)                                  # [C, 2] (group, read), group-major
+            counts = torch.bincount(hitg[:, 0], minlength=G).cpu().numpy()     # the one synchronisation of this stage
+            recs = torch.zeros((A, L, RESULT_INTS), dtype=torch.int32, device=dev)
+            cjobs, csel, pos = [], [], 0
+            for g in range(G):
+                if counts[g]:
+                    sel = hitg[pos:pos + int(counts[g]), 1]
+                    pos += int(counts[g])
+                    so, sl = loff[sel], llen[sel]
+                    for a in range(A):
+                        if gidx[a] == g:
+                            cjobs.append((aidx[a], so, sl, hint[a])); csel.append((a, sel))
+            if cjobs:
+                for (a, sel), o in zip(csel, self._scan_jobs(reads.arena, cjobs, MODE_TWO_PASS, max_len, sort_lengths=ragged, typ_len=typ_len)):
+                    recs[a, sel] = o
+            outs = [recs[a] for a in range(A)]
+            fulls = torch.stack([torch.nan_to_num(identity_of(rec), nan=0.0) for rec in outs])
+            self.stats["pairs_middle_prefiltered"] = self.stats.get("pairs_middle_prefiltered", 0) + A * L
+            self.stats["pairs_middle_scanned_after_prefilter"] = self.stats.get("pairs_middle_scanned_after_prefilter", 0) + \
+                sum(int(j[1].shape[0]) for j in cjobs)
+        elif prove and all(b is not None for b in bounds):
             score = torch.stack(self._scan_jobs(reads.arena, jobs0, MODE_SCORE, max_len, sort_lengths=ragged, typ_len=typ_len))[:, :, 4]      # [A, L]
             cand = torch.nonzero(score >= torch.tensor(bounds, device=dev)[:, None])                     # adapter-major
             counts = torch.bincount(cand[:, 0], minlength=A).cpu().numpy()

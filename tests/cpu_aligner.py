@@ -68,6 +68,30 @@ class OracleAligner:
                 out[pos:pos + n] = torch.from_numpy(self._records(a, wo[s:e], wl[s:e], int(job_adapter_b[k]), mode))
                 pos += n
 
+    def max_edits(self, adapter_len, threshold_percent):
+        """Restatement of pc_prefilter_max_edits (include/porechop_amd.h) for machines without the library's GPU."""
+        import math
+        if adapter_len <= 0:
+            return -1
+        tau = (threshold_percent - 1e-6) / 100.0
+        if not tau > 0.0:
+            return adapter_len
+        if tau >= 1.0:
+            return 0
+        return min(adapter_len, int(math.floor(adapter_len * (1.0 - tau) / tau + 1e-9)))
+
+    def prefilter(self, arena, win_off, win_len, max_len, adapters, max_edits, stream=None):
+        """The exact prefilter's contract, decided by the oracle's plain DP: True where the window holds the adapter
+        within max_edits edits (max_edits < 0: every non-empty window)."""
+        a = arena.cpu().numpy()
+        wo, wl = win_off.cpu().numpy(), win_len.cpu().numpy()
+        rows = []
+        for ad, k in zip(adapters, max_edits):
+            d = self.oracle.min_edits_many(a, wo, wl, self.adapters[int(ad)])
+            ok = (d <= (k if k >= 0 else 1 << 30)) & (wl > 0) & (len(self.adapters[int(ad)]) > 0)
+            rows.append(torch.from_numpy(ok))
+        return torch.stack(rows) if rows else torch.zeros((0, wo.shape[0]), dtype=torch.bool)
+
     def sync(self, stream=None):
         pass
 

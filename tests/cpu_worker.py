@@ -65,3 +65,42 @@ def run_chunk_barcodes(args):
         st, et, ss, es = ref_pipeline.phase_b_barcodes(fn, seq, sets, matching, p, orientation)
         out.append((st, et, ref_pipeline.determine_barcode(ss, es, thr, diff, two)))
     return len(seqs), time.perf_counter() - t0, out
+
+
+def run_chunk_phase_a(args):
+    """Phase A (adapter-set presence, nanopore_read.py:149-164) of a chunk of reads on the CPU: the best start / end
+    full-adapter identity of every set over these reads -> (reads done, seconds, (best_start, best_end))."""
+    seqs, sets, params, want_ref = args
+    from tests import ref_pipeline
+    fn = _backend(want_ref).adapter_alignment
+    sets = [_Set(*s) for s in sets]
+    p = _Params(params)
+    t0 = time.perf_counter()
+    bs, be = ref_pipeline.phase_a(fn, seqs, sets, p)
+    return len(seqs), time.perf_counter() - t0, (bs, be)
+
+
+def run_chunk_demux_middle(args):
+    """A whole demultiplexing run with the middle scan on (BASELINE configs[4] shape) for a chunk of reads: phase B with
+    barcode scores, the barcode call, phase C over every matching set's sequences
+    -> (reads done, seconds, [(start_trim, end_trim, bin name, [(adapter, start, end), ...]), ...])."""
+    seqs, sets, matching, params, want_ref, orientation, thr, diff, two = args
+    from tests import ref_pipeline
+    fn = _backend(want_ref).adapter_alignment
+    sets = [_Set(*s) for s in sets]
+    p = _Params(params)
+    adapters = []
+    for i in matching:
+        s = sets[i]
+        if s.start is not None:
+            adapters.append(s.start)
+        if s.end is not None and (s.start is None or s.end[1] != s.start[1]):
+            adapters.append(s.end)
+    out = []
+    t0 = time.perf_counter()
+    for seq in seqs:
+        st, et, ss, es = ref_pipeline.phase_b_barcodes(fn, seq, sets, matching, p, orientation)
+        call = ref_pipeline.determine_barcode(ss, es, thr, diff, two)
+        hits = ref_pipeline.phase_c(fn, seq, st, et, adapters, p)
+        out.append((st, et, call, [(a, rs, re) for a, rs, re, _ in hits]))
+    return len(seqs), time.perf_counter() - t0, out

@@ -199,3 +199,63 @@ print("DIGEST", hashlib.sha1(out.cpu().numpy().tobytes()).hexdigest(), int((out[
         outs.append(lines[0])
     assert outs[0] == outs[1] == outs[2]
     assert int(outs[0].split()[-1]) > 1000
+
+
+def test_configs4_shape_barcodes_and_middle_scan():
+    """The per-GPU shape of BASELINE configs[4] (bench.py step_configs4): 50 000 reads carrying one of the 96 PCR
+    barcodes at both ends and 1 % chimeric junctions, full 119-set panel, demultiplexing run with the middle scan over
+    every matching set's sequences (~196 adapters).  320 reads go through the reference's sequential per-read logic
+    (phase B with barcode scores, determine_barcode, phase C) on the host cores through the compiled reference / the
+    oracle; the exact-prefilter variant must reproduce trims, calls and hits of the full scan bit for bit."""
+    import multiprocessing as mp
+    from dataclasses import asdict
+    import bench
+    from porechop_amd.pipeline import Pipeline, ScanParams
+    from porechop_amd.runner import Options
+    from porechop_amd.synth import make_reads
+    from tests.cpu_worker import run_chunk_demux_middle
+    p, opts = ScanParams(), Options()
+    pl = Pipeline(panel_sets(), p)
+    pl.n_panel = len(pl.sets)
+    fw = [a for a in load_panel() if a["name"].startswith("Barcode ") and "(forward)" in a["name"]]
+    n = 50_000
+    reads = make_reads(n, 8000, seed=4, start_frac=0.9, end_frac=0.5, chimera_frac=0.01,
+                       barcodes_start=[a["start"][1] for a in fw], barcodes_end=[a["end"][1] for a in fw])
+    matching, orientation, names, st, et, calls, hits = bench.step_configs4(pl, reads, p.check_reads, opts)
+    pl.aligner.sync()
+    m2, o2, n2, st2, et2, calls2, hits2 = bench.step_configs4(pl, reads, p.check_reads, opts, prefilter=True)
+    pl.aligner.sync()
+    assert orientation == "forward" and len(matching) >= 97 and len(pl.middle_adapter_list(matching)) >= 194
+    assert (m2, o2, n2) == (matching, orientation, names)
+    assert torch.equal(st, st2) and torch.equal(et, et2) and np.array_equal(calls, calls2)
+    for f in ("read", "adapter", "start", "end", "identity"):
+        assert torch.equal(getattr(hits, f), getattr(hits2, f)), f
+    assert (hits.rounds, hits.alignments) == (hits2.rounds, hits2.alignments)
+    hit_reads = torch.unique(hits.read).numel()
+    assert 0.5 * 0.01 * n < hit_reads < 2.0 * 0.01 * n
+    truth = reads.truth_barcode.cpu().numpy()
+    want = np.array([names.index("BC%02d" % (b + 1)) if "BC%02d" % (b + 1) in names else -2 for b in range(len(fw))])[truth]
+    assert float((calls == want).mean()) > 0.99
+
+    # host check of a sample that contains reads WITH middle hits: the first 256 reads + 64 reads that had a hit
+    with_hits = torch.unique(hits.read)[:64].cpu().tolist()
+    sample = sorted(set(range(256)) | set(with_hits))
+    seqs = [host_seq(reads, r) for r in sample]
+    sets = [(s.name, s.start, s.end) for s in pl.sets]
+    workers = bench.host_cores()
+    per = max(1, (len(seqs) + workers - 1) // workers)
+    chunks = [seqs[i:i + per] for i in range(0, len(seqs), per)]
+    mk = lambda c: (c, sets, matching, asdict(p), True, orientation, opts.barcode_threshold, opts.barcode_diff, opts.require_two_barcodes)
+    with mp.get_context("spawn").Pool(min(workers, len(chunks))) as pool:
+        res = [x for r in pool.map(run_chunk_demux_middle, [mk(c) for c in chunks]) for x in r[2]]
+    got = {}
+    for r, a, s, e in zip(hits.read.cpu().tolist(), hits.adapter.cpu().tolist(), hits.start.cpu().tolist(), hits.end.cpu().tolist()):
+        got.setdefault(r, []).append((a, s, e))
+    stl, etl = st.cpu().tolist(), et.cpu().tolist()
+    n_hits = 0
+    for r, want_r in zip(sample, res):
+        call = names[calls[r]] if calls[r] >= 0 else "none"
+        assert (stl[r], etl[r], call, got.get(r, [])) == (want_r[0], want_r[1], want_r[2], list(want_r[3])), r
+        n_hits += len(want_r[3])
+    assert n_hits >= 64
+    pl.close()

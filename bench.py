@@ -259,7 +259,7 @@ def trace_roofline(timing, n_windows, pairs, cells, steps, ops_per_2_cells, leg=
     peak_gcups = VALU_WAVE_INSTR_PER_S * 64 * 2 / ops_per_2_cells / 1e9
     return {"bound": "valu", "kernel": "traced end-window scan (trace bits + on-device traceback/digest)",
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": profile_traffic(leg, "trace16_kernel") if leg else None,
+            "traffic": profile_traffic(leg, "trace16_kernel", launches / max(1, steps)) if leg else None,
             "launches": int(launches), "avg_launch_ms": per_launch_s * 1e3,
             "algorithmic_bytes_per_launch": alg_total / launches,
             "valu": {"achieved_gcups": gcups, "peak_gcups": peak_gcups, "frac": gcups / peak_gcups,
@@ -476,6 +476,9 @@ def leg_configs4(dev, args, workers, world, rank, barrier):
     opts = Options()
     pl = Pipeline(load_panel_sets(), p, device=dev)
     pl.n_panel = len(pl.sets)
+    import ctypes
+    jc0, jd0 = ctypes.c_int64(), ctypes.c_int64()
+    pl.aligner.lib.pc_jit_stats(ctypes.byref(jc0), ctypes.byref(jd0))          # process-wide counters: this leg's share below
     n = args.reads4
     fw = [a for a in load_panel_json() if a["name"].startswith("Barcode ") and "(forward)" in a["name"]]
     reads = make_reads(n, args.read_len, seed=4 + 1000 * rank, start_frac=0.9, end_frac=0.5, chimera_frac=args.chimera, device=dev,
@@ -527,9 +530,10 @@ def leg_configs4(dev, args, workers, world, rank, barrier):
     truth = reads.truth_barcode.cpu().numpy()
     want = np.array([names.index("BC%02d" % (b + 1)) if "BC%02d" % (b + 1) in names else -2 for b in range(len(fw))])[truth]
     total = n * world
-    import ctypes
     jc, jd = ctypes.c_int64(), ctypes.c_int64()
     pl.aligner.lib.pc_jit_stats(ctypes.byref(jc), ctypes.byref(jd))
+    jc.value -= jc0.value
+    jd.value -= jd0.value
     out = {"workload": "BASELINE configs[4] per GPU: %d synthetic %d-bp reads per GPU x %d GPU(s), barcode b ~ U{1..96} at both ends, "
                        "%.0f%% chimeric junctions, full 119-set panel, -b style run: phases A + kit choice + full-barcode rule + B "
                        "(%d pairs per read) + barcode calls + C over all %d sequences of the %d matching sets"
@@ -557,14 +561,15 @@ def leg_configs4(dev, args, workers, world, rank, barrier):
         peak = VALU_WAVE_INSTR_PER_S * 64 * 2 / ops / 1e9
         out["roofline"] = {"bound": "valu", "kernel": "pc_spec_score" if jit else "scan_kernel<R,PAD,false>",
                            "achieved": alg / per_launch_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": alg / per_launch_s / 1e9 / HBM_PEAK_GBS, "traffic": profile_traffic("configs4", "pc_spec_score" if jit else ""),
+                           "frac": alg / per_launch_s / 1e9 / HBM_PEAK_GBS,
+                           "traffic": profile_traffic("configs4", "pc_spec_score" if jit else "scan_kernel<score>", launches / steps),
                            "launches": int(launches), "avg_launch_ms": per_launch_s * 1e3, "algorithmic_bytes_per_launch": alg,
                            "valu": {"achieved_gcups": cells_s / 1e9, "peak_gcups": peak, "frac": cells_s / 1e9 / peak, "ops_per_2_cells": ops},
                            "note": "score-only whole-read scan, %d adapter pairs per read; HBM fraction on ALGORITHMIC bytes "
                                    "(|H|/A + 28 per pair); VALU-bound by construction" % ((A + 1) // 2)}
     pms, pl_launches, ppairs = timing_p["prefilter"]
     if pl_launches > 0:
-        out["exact_prefilter"]["roofline"] = prefilter_roofline(pms, pl_launches, ppairs, n * mean_trim_len, A)
+        out["exact_prefilter"]["roofline"] = prefilter_roofline(pms, pl_launches, ppairs, n * mean_trim_len, A, leg="configs4_prefilter")
     if args.cpu_seconds > 0 and world == 1:
         seqs, ln = host_seqs(reads, min(n, 2048))
         sets = [(s.name, s.start, s.end) for s in pl.sets]
@@ -589,7 +594,7 @@ def leg_configs4(dev, args, workers, world, rank, barrier):
     return out
 
 
-def prefilter_roofline(ms, launches, pairs, read_bytes, A):
+def prefilter_roofline(ms, launches, pairs, read_bytes, A, leg="prefilter"):
     """Roofline object of the exact bit-parallel prefilter: it streams every read byte once per launch
     (algorithmic bytes = the reads' bytes + one mask word per read) and spends 12.5 VALU ops per
     (column, <= 32-base adapter piece)."""
@@ -599,7 +604,7 @@ def prefilter_roofline(ms, launches, pairs, read_bytes, A):
     peak_steps = VALU_WAVE_INSTR_PER_S * 64 / 12.5
     return {"bound": "valu", "kernel": "prefilter_kernel<P> (Myers bit-vector edit distance, one lane per read chunk, P adapter pieces per lane)",
             "achieved": alg / per_launch_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / per_launch_s / 1e9 / HBM_PEAK_GBS,
-            "traffic": profile_traffic("prefilter", "prefilter_kernel"), "launches": int(launches), "avg_launch_ms": per_launch_s * 1e3,
+            "traffic": profile_traffic(leg, "prefilter_kernel"), "launches": int(launches), "avg_launch_ms": per_launch_s * 1e3,
             "algorithmic_bytes_per_launch": alg,
             "valu": {"achieved_column_updates_per_s": steps_s, "peak_column_updates_per_s": peak_steps, "frac": steps_s / peak_steps,
                      "ops_per_column_and_adapter": 12.5}}
@@ -619,10 +624,12 @@ def library_fingerprint():
 _PROFILE = None
 
 
-def profile_traffic(leg, kernel):
-    """HBM-side traffic (FETCH_SIZE + WRITE_SIZE, bytes per launch) of `kernel` in `leg`, from the newest
-    profiles/*_summary.json -- ONLY if that summary was taken with the very library now loaded (its recorded sha1
-    equals the loaded .so's): a kernel change without a re-profile reports null, never stale counters."""
+def profile_traffic(leg, kernel, launches_per_step=None):
+    """HBM-side traffic (FETCH_SIZE + WRITE_SIZE, bytes per launch) of the kernel family `kernel` in `leg`, from the newest
+    profiles/*_summary.json (tools/profile_round3.sh + summarize_profile3.py: rocprofv3 --pmc, one counter per pass, a
+    process that runs only that leg) -- ONLY if that summary was taken with the very library now loaded (its recorded sha1
+    equals the loaded .so's): a kernel change without a re-profile reports null, never stale counters.  The summary holds
+    per-step sums; `launches_per_step` is this run's count of timed launches of the kernel per step (None: the profile's own)."""
     global _PROFILE
     if _PROFILE is None:
         _PROFILE = {}
@@ -638,9 +645,10 @@ def profile_traffic(leg, kernel):
         except Exception:
             _PROFILE = {}
     try:
-        kk = _PROFILE.get("legs", {}).get(leg, {}).get(kernel)
-        if kk:
-            return (kk["FETCH_SIZE_KB_mean_launch"] + kk["WRITE_SIZE_KB_mean_launch"]) * 1024.0
+        kk = _PROFILE.get("legs", {}).get(leg, {}).get("kernels", {}).get(kernel)
+        if kk and "FETCH_SIZE_bytes_per_step" in kk and "WRITE_SIZE_bytes_per_step" in kk:
+            per_step = kk["FETCH_SIZE_bytes_per_step"] + kk["WRITE_SIZE_bytes_per_step"]
+            return per_step / max(1e-9, launches_per_step if launches_per_step else kk["launches_per_step"])
     except Exception:
         pass
     return None
@@ -929,7 +937,7 @@ def main():
             # streams; here lanes gather 4 B each and the kernel provably consumes 7.95 GB per launch
             # against a reported FETCH_SIZE of 6.4 GB, so no doubling is applied.)
             if world == 1:
-                roof["traffic"] = profile_traffic("headline", "pc_spec_score" if jit else "")
+                roof["traffic"] = profile_traffic("headline", "pc_spec_score" if jit else "scan_kernel<score>", launches / args.steps)
                 if roof["traffic"] is not None:
                     roof["traffic_source"] = _PROFILE.get("_path", "") + " (mean over this kernel's launches; FETCH_SIZE + WRITE_SIZE; same library sha1)"
         kern_ms = {k: v[0] / args.steps for k, v in timing.items()}

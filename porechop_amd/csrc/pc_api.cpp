@@ -453,7 +453,9 @@ int launch_traced(const pc_ctx *c, pck::ScanArgs &a, const Group &g, int grid, h
 // One launch of the score pass: a run of tiles, each cut into `chunks` column chunks, writing its
 // [pair][chunk] maxima at k1_ints of the pass-1 buffer; spec = the run-time specialised kernel of
 // the run's adapter pair, or null for the generic kernel (which takes the adapter from each tile).
-struct ScoreLaunch { size_t begin, count; int chunks; size_t k1_ints; pcj::Spec *spec; int adapter_lo, adapter_hi; };
+// k1_ints may be "virtual": the kernels index a launch's region by GLOBAL pair index, a chunked tail's region only
+// holds its own job's pairs, so its base is moved back by the job's first pair (never dereferenced below the region).
+struct ScoreLaunch { size_t begin, count; int chunks; int64_t k1_ints; pcj::Spec *spec; int adapter_lo, adapter_hi; };
 
 // Launch plan of a two-pass group.  Tiles of one job (= one adapter pair) are contiguous.  A job
 // with a specialised kernel and more tiles than resident waves is launched as a balanced head (a
@@ -492,7 +494,17 @@ std::vector<ScoreLaunch> plan_score_launches(pc_ctx *c, const Group &g, int max_
             size_t head = n;
             int tail_chunks = 1;
             const size_t slots = (size_t)c->ncu * (size_t)sp->blocks_per_cu;
-            if (group_chunks == 1 && n > slots && n % slots) {
+            // the job's records are [out0, out0 + pairs): its chunked tail gets a region of that many [pair][chunk]
+            // entries (not one sized for the whole call: 98 barcode jobs x 245 M pairs would be terabytes), and only
+            // while the tails of the call stay within kTailBudget -- later jobs then run whole tiles to the end
+            int64_t job_out0 = r0.out0, job_pairs = 0;
+            for (size_t q = ri; q < re; ++q) {
+                job_out0 = std::min<int64_t>(job_out0, g.runs[q].out0);
+                job_pairs = std::max<int64_t>(job_pairs, g.runs[q].out0 + (g.runs[q].dual ? 2 : 1) * g.runs[q].n);
+            }
+            job_pairs -= job_out0;
+            constexpr size_t kTailBudget = (size_t)6 << 30;
+            if (group_chunks == 1 && n > slots && n % slots && (k1 + (size_t)job_pairs * 4 * 8) * 4 <= kTailBudget + (size_t)npairs * 16) {
                 const size_t tail = n % slots;
                 double best = 1.0;                           // in tile-times: one more round of whole tiles
                 const double span = 0.5 * g.max_window;
@@ -506,8 +518,8 @@ std::vector<ScoreLaunch> plan_score_launches(pc_ctx *c, const Group &g, int max_
             }
             out.push_back({i, head, group_chunks, 0, sp, r0.adapter_lo, r0.adapter_hi});
             if (head < n) {
-                out.push_back({i + head, n - head, tail_chunks, k1, sp, r0.adapter_lo, r0.adapter_hi});
-                k1 += (size_t)npairs * 4 * (size_t)tail_chunks;
+                out.push_back({i + head, n - head, tail_chunks, (int64_t)k1 - job_out0 * 4 * tail_chunks, sp, r0.adapter_lo, r0.adapter_hi});
+                k1 += (size_t)job_pairs * 4 * (size_t)tail_chunks;
             }
         }
         ri = re;

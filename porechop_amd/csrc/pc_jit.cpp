@@ -185,6 +185,10 @@ std::vector<uint32_t> substitution_table(const Recipe &rc, const Derived &d)
         for (int ch = 0; ch < 5; ++ch)
             for (size_t k = 0; k < d.combos.size(); ++k) {
                 const int l = term(d.combos[k] / 6, cl), h = term(d.combos[k] % 6, ch);
+                // the table terms are values the kernel adds in its lane type: they must be exact there too
+                // (spec_plan's gate bounds match, mismatch and open for the fp16 variant; asserted here, where they are formed)
+                const int lim = rc.f16 ? pcb::kF16Limit : 32000;
+                if (l > lim || l < -lim || h > lim || h < -lim) return std::vector<uint32_t>();
                 table[(size_t)(cl * 5 + ch) * d.K + k] = rc.f16 ? (half_bits(l) | (half_bits(h) << 16))
                                                                 : (((uint32_t)l & 0xFFFFu) | ((uint32_t)h << 16));
             }
@@ -347,7 +351,7 @@ bool hiprtc_compile(const std::vector<std::string> &opts, std::vector<char> &cod
 void fill_entry(Entry *e, const Recipe &rc, const Derived &d)
 {
     e->R = rc.R; e->K = d.K; e->m_lo = rc.m_lo; e->m_hi = rc.m_hi; e->f16 = rc.f16; e->waves = d.waves; e->kren = rc.kren;
-    e->table = substitution_table(rc, d);
+    e->table = substitution_table(rc, d);           // empty: a table term outside the lane type's exact range (never expected)
 }
 
 // The kernel from one of the caches on disk, if it is there.  No HIP runtime calls.
@@ -356,6 +360,7 @@ bool load_entry_from_disk(Entry *e, const Recipe &rc)
     const Derived d = derive(rc);
     if (!cache_read(intree_cache_dir(), d.opts, e->code) && !cache_read(user_cache_dir(), d.opts, e->code)) return false;
     fill_entry(e, rc, d);
+    if (e->table.empty()) { e->code.clear(); return false; }
     e->compiled_ok = true;
     e->from_disk = true;
     g_n_disk.fetch_add(1);
@@ -370,7 +375,8 @@ void compile_entry(Entry *e, const Recipe rc)
     if (g_cancel.load()) { e->log = "cancelled"; e->compile_done.store(true, std::memory_order_release); return; }
     const Derived d = derive(rc);
     fill_entry(e, rc, d);
-    e->compiled_ok = hiprtc_compile(d.opts, e->code, e->log);
+    e->compiled_ok = !e->table.empty() && hiprtc_compile(d.opts, e->code, e->log);
+    if (e->table.empty()) e->log = "a substitution-table term lies outside the lane type's exact range";
     if (e->compiled_ok) {
         g_n_compiled.fetch_add(1);
         (void)cache_write(user_cache_dir(), d.opts, e->code);
@@ -412,7 +418,7 @@ void finalize_entry(Entry *e, bool verbose)
         return;
     }
     sp->d_table = d;
-    if (verbose) fprintf(stderr, "porechop_amd: specialised kernel R=%d K=%d f16=%d kren=%ld waves/CU=%d (%s)\n", e->R, e->K, e->f16 ? 1 : 0, e->kren, sp->blocks_per_cu, e->from_disk ? "from the kernel cache on disk" : "compiled by hiprtc now");
+    if (verbose) fprintf(stderr, "porechop_amd: specialised kernel R=%d K=%d f16=%d kren=%ld waves/CU=%d (%s)\n", e->R, e->K, e->f16 ? 1 : 0, e->kren, sp->blocks_per_cu, e->from_disk ? "from the kernel cache on disk" : "compiled now");
     e->code.clear(); e->code.shrink_to_fit();
     e->spec = sp;
     e->state = Entry::READY;

@@ -234,6 +234,18 @@ extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P
             const int k = (col < n) ? col : (n > 0 ? ((n - 1) & ~3) : 0);      // finished streams re-read their last dword
             return *(const u32_unaligned *)(w + k);
         };
+#if PC_CHECK_RANGE
+        // debug build (PC_JIT_CHECK_RANGE=1): every column takes the one-column path and the extremes of EVERY value
+        // formed are recorded -- the column state T / U after each column, every row's diagonal term d and vertical
+        // state V (the cell maximum M is one of d, H, V; the new T is recorded with the state), the top-row term, the
+        // tracked last-row term the scout compares, the last-column re-run's values -- the host-side range gate
+        // (pc_bounds.h spec_plan) asserted on the device.  (The substitution-table terms are bounded on the host, where
+        // the table is built: pc_jit.cpp.)  The "-infinity" a column's H / V start from is absorbed by the first max.
+        u32 vmax = PC_NEGBITS, vmin = PC_POSBITS;
+#define PC_NOTE_V(x) { vmax = pk_max(vmax, (x)); vmin = pk_min(vmin, (x)); }
+#else
+#define PC_NOTE_V(x)
+#endif
         auto fetch_S = [&](u32 (&S)[K], u32 bl, u32 bh) {
 #if PC_DUAL
             const uint4 *row = s_tab + (u32)lut_one[bl];
@@ -330,6 +342,7 @@ extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P
                             : [vprev] "v"(Vprev), [tup] "v"(Tup), [oe] "s"(OE2), [d0] "v"(T[q - 1]),
                               [t0] "v"(T[q]), [t1] "v"(T[q + 1]), [s0] "v"(S[COMBO[q]]), [s1] "v"(S[COMBO[q + 1]]),
                               [dhr0] "v"(dh[r]), [dhr1] "v"(dh[r + 1]), [ur0] "v"(U[r]), [ur1] "v"(U[r + 1]));
+                        PC_NOTE_V(dh[r]) PC_NOTE_V(dh[r + 1]) PC_NOTE_V(vs0) PC_NOTE_V(vs1)
                         Tup = T[r + 1]; Vprev = vs1;
                     } else {
                         // tail rows (and an odd last row): one row at a time
@@ -349,6 +362,7 @@ extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P
                                              : [vprev] "v"(Vprev), [tup] "v"(Tup), [dhr0] "v"(dh[rr]),
                                                [ur0] "v"(U[rr]), [oe] "s"(OE2));
                             }
+                            PC_NOTE_V(dh[rr]) PC_NOTE_V(vs0)
                             Tup = T[rr]; Vprev = vs0;
                         }
                     }
@@ -357,6 +371,7 @@ extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P
 #undef PC_ROW_TAIL
             }
             const u32 cand = pk_sub(T[R - 1], topn);
+            PC_NOTE_V(cand) PC_NOTE_V(topn)
             if constexpr (!FAST) {
                 const int cl = lo16(cand) - R * PC_EPS, ch = hi16(cand) - R * PC_EPS;
                 const bool tr_lo = j > tf_lo && (tail_lo ? j < n_lo : j <= n_lo);
@@ -499,9 +514,6 @@ extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P
 #undef PC_PAIR_ATAIL
         };
 #if PC_CHECK_RANGE
-        // debug build (PC_JIT_CHECK_RANGE=1): every column takes the one-column path and the extremes of
-        // every T / U held after it are recorded -- the host-side range gate (pc_jit.cpp) asserted on the device
-        u32 vmax = PC_NEGBITS, vmin = PC_POSBITS;
         auto note_range = [&]() {
 #pragma clang loop unroll(full)
             for (int r = 0; r < R; ++r) { vmax = pk_max(vmax, pk_max(T[r], U[r])); vmin = pk_min(vmin, T[r]); }
@@ -606,6 +618,9 @@ extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P
                     const u32 Tn = pk_add(pk_max(pk_max(d, Hs), Vs), OE2);
                     diag = old.x; Tup = Tn; Vprev = Vs;
                     const u32 c = pk_sub(Tn, topn);                  // M(rho, n) + rho*eps, rho = r+1
+#if PC_CHECK_RANGE
+                    if (ev_lo || ev_hi) { PC_NOTE_V(d) PC_NOTE_V(Vs) PC_NOTE_V(Tn) PC_NOTE_V(c) PC_NOTE_V(pk_max(pk_max(d, Hs), Vs)) }
+#endif
                     const int il = r - pad_lo + 1, ih = r - pad_hi + 1;
                     const int cl = lo16(c) - (r + 1) * PC_EPS, ch = hi16(c) - (r + 1) * PC_EPS;
                     if (ev_lo && il >= 1 && cl > bs_lo) { bs_lo = cl; bi_lo = il; bj_lo = n_lo; }

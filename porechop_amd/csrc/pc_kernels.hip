@@ -669,9 +669,14 @@ constexpr u32 H_NEGINF2 = 0xFC00FC00u, H_POSINF2 = 0x7C007C00u;
     PC_ACC0                                                         \
     PC_HADD "%[b3], %[mn], %[dr] neg_lo:[0,1] neg_hi:[0,1] clamp"
 
-// CHECK: debug build (PC_CHECK_RANGE=1, a few row classes): records the extremes of every T / U held after a
-// column into err[4] (max) and err[5] (-min) -- the host-side range gate (pc_bounds.h f16_plan) asserted on
-// the device; read with pc_debug_value_range.
+// CHECK: debug build (PC_CHECK_RANGE=1, every row class): records the extremes of EVERY finite value the kernel
+// forms in fp16 -- the column state T / U after each column, and inside the column each row's diagonal term d,
+// vertical state V, cell maximum M and new T, the top-row term T~(0,j), the substitution-table terms, the tracked
+// last-row term M(R,j) + R*eps the scout compares (`cand`, before its mask) and the packed running maxima `best2`,
+// the warm-up columns' and the last-column re-run's values, the byte accumulators of the trace bits -- into err[4]
+// (max) and err[5] (-min): the host-side range gate (pc_bounds.h f16_plan) asserted on the device; read with
+// pc_debug_value_range.  (-inf only ever enters as the initial H / V of a column and as the scout's mask; it is
+// absorbed by the first max and is not a "value formed".)
 template <int R, bool CHECK = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(R <= 30 ? 4 : R <= 44 ? 3 : 2))) void trace16_kernel(ScanArgs a)
 {
@@ -708,6 +713,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(R <= 30 ? 4 
             if (lane == 0) atomicAdd(a.err, 1u);
             continue;
         }
+        int tab_max = 0, tab_min = 0;                             // CHECK: extremes of the table terms this lane wrote
         // ---- substitution table of this adapter pair: s_tab[(c_lo*5 + c_hi)][row] = packed
         // (sub_lo - open + eps | sub_hi - open + eps); a padding row scores 0, which keeps its
         // M = 0 and re-opens V exactly like the true row 0 (DESIGN.md "top padding")
@@ -722,6 +728,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(R <= 30 ? 4 
                 if (ih >= 0) sh = ((int)codes_hi[ih] == ch) ? a.match : a.mismatch;
             }
             s_tab[pair * STRIDE + r] = hpack2x(sl - a.gap_open + eps, sh - a.gap_open + eps);
+            if constexpr (CHECK) {
+                const int lo_ = sl < sh ? sl : sh, hi_ = sl > sh ? sl : sh;
+                tab_max = tab_max > hi_ - a.gap_open + eps ? tab_max : hi_ - a.gap_open + eps;
+                tab_min = tab_min < lo_ - a.gap_open + eps ? tab_min : lo_ - a.gap_open + eps;
+            }
         }
         __syncthreads();
 
@@ -830,6 +841,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(R <= 30 ? 4 
         u32 cur_lo = load_dw(w_lo, n_lo, 0), cur_hi = one_stream ? 0u : load_dw(w_hi, n_hi, 0);
         int trow = row_of(cur_lo & 0xFF, cur_hi & 0xFF);
         u32 vmax = H_NEGINF2, vmin = H_POSINF2;
+        auto note = [&](u32 x) { vmax = hk_max(vmax, x); vmin = hk_min(vmin, x); };      // CHECK builds only
         // ---- warm-up columns of pass-2 windows: the traced path provably cannot reach them (pc_bounds.h),
         // every pair's end cell is forced and no window ends here, so they run the bare recurrence -- five
         // ops per two cells, no trace bits, no slab stores, no scout -- left to the compiler's scheduler
@@ -854,10 +866,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(R <= 30 ? 4 
                         const u32 d = hk_add(dq, Sg[k]);
                         const u32 Vs = hk_maximum(Vp, Tup);
                         const u32 Tn = hk_add(hk_maximum(hk_maximum(d, Hs), Vs), OE2);
+                        if constexpr (CHECK) { note(d); note(Vs); note(Tn); note(hk_maximum(hk_maximum(d, Hs), Vs)); vmax = hk_max(vmax, Hs); }
                         dq = T[r]; U[r] = Hs; T[r] = Tn; Tup = Tn; Vp = Vs;
                     }
                 }
             }
+            if constexpr (CHECK) note(topn);
             top = topn;
             if (j_first <= shmax) reach_column0(j_first);
         }
@@ -945,6 +959,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(R <= 30 ? 4 
                     if ((pr & 3) == 3) { const u32 wd = __builtin_amdgcn_perm(accA, acc, 0x06020400u); SLAB_STORE(&trace_dst[(pr >> 2) * 64], wd); }
                 }
                 if (r == R - 1) { d_last = dh[r]; h_last = U[r]; v_last = vs; }
+                if constexpr (CHECK) {
+                    // (a finished stream re-reads its last bytes and its state is never used: not noted)
+                    if (j <= (n_lo > n_hi ? n_lo : n_hi)) { note(dh[r]); note(vs); note(mn); note(tn); vmax = hk_max(vmax, acc); }
+                }
                 T[r] = tn; Tup = tn; Vp = vs; pb1 = b1; pb2 = b2; pb3 = b3;
             }
             // the last row's bits (R is even, so this row completes a byte)
@@ -968,6 +986,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(R <= 30 ? 4 
             }
             // ---- tracked cells ---------------------------------------------------------------
             const u32 cand = hk_min(hk_sub(T[R - 1], topn), limit2);     // M(R,j) + R*eps where tracked, else -inf
+            if constexpr (CHECK) {
+                if (j <= (n_lo > n_hi ? n_lo : n_hi)) { note(hk_sub(T[R - 1], topn)); note(topn); note(best2); vmax = hk_max(vmax, acc); }
+            }
             const u32 nb = hk_max(best2, cand);
             if (__any(nb != best2)) {
                 Best b_lo, b_hi;
@@ -997,6 +1018,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(R <= 30 ? 4 
                     const u32 Vs = hk_max(Vp2, Tu2);
                     const u32 g = hk_max(Hs, Vs);
                     const u32 Tn = hk_add(hk_max(d, g), OE2);
+                    if constexpr (CHECK) {
+                        if (fin_lo || fin_hi) { note(d); note(Vs); note(Tn); note(hk_max(d, g)); vmax = hk_max(vmax, Hs); }
+                    }
                     dq = old.x; Tu2 = Tn; Vp2 = Vs;
                     scan_row(r, j, Tn, HV(d).x == HV(g).x, HV(d).y == HV(g).y, fin_lo, fin_hi, b_lo, b_hi, fr_lo, fr_hi);
                 }
@@ -1007,7 +1031,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(R <= 30 ? 4 
             if (j <= shmax) reach_column0(j);
         }
         if constexpr (CHECK) {
-            const int hi = hlo(vmax) > hhi(vmax) ? hlo(vmax) : hhi(vmax), lo = hlo(vmin) < hhi(vmin) ? hlo(vmin) : hhi(vmin);
+            int hi = hlo(vmax) > hhi(vmax) ? hlo(vmax) : hhi(vmax), lo = hlo(vmin) < hhi(vmin) ? hlo(vmin) : hhi(vmin);
+            hi = hi > tab_max ? hi : tab_max; lo = lo < tab_min ? lo : tab_min;
             if ((have_lo || have_hi) && nmax > 0) {
                 atomicMax((int *)a.err + 4, hi); atomicMax((int *)a.err + 5, -lo);
                 if (hi > pcb::kF16Limit || -lo > pcb::kF16Limit) atomicAdd(a.err, 1u);   // the on-device assertion
@@ -1118,7 +1143,11 @@ int launch_trace16(const ScanArgs &a, int rows, int grid, void *stream)
     hipStream_t s = (hipStream_t)stream;
     if (a.debug & 4) {      // range-checking build, where instantiated
 #define PC_T16C(RR) case RR: hipLaunchKernelGGL((trace16_kernel<RR, true>), dim3(grid), dim3(64), 0, s, a); return hipGetLastError() == hipSuccess ? 0 : -2;
-        switch (rows) { PC_T16C(24) PC_T16C(28) PC_T16C(30) PC_T16C(40) default: break; }
+        switch (rows) {
+            PC_T16C(16) PC_T16C(20) PC_T16C(22) PC_T16C(24) PC_T16C(26) PC_T16C(28) PC_T16C(30) PC_T16C(32) PC_T16C(34) PC_T16C(36)
+            PC_T16C(38) PC_T16C(40) PC_T16C(48) PC_T16C(56) PC_T16C(64) PC_T16C(68) PC_T16C(72)
+            default: break;
+        }
 #undef PC_T16C
     }
 #define PC_T16(RR) case RR: hipLaunchKernelGGL((trace16_kernel<RR>), dim3(grid), dim3(64), 0, s, a); break;

@@ -39,11 +39,23 @@ def check_read_share(check_reads, world, rank, n_total):
     return max(0, min(hi, check_reads) - lo)
 
 
+def _host_collectives(group=None):
+    """gloo moves bytes through host memory and implements only some collectives for device tensors: with it (the CPU
+    tests, and functional checks of the N > 1 path on a single-GPU box) device tensors take the host route explicitly.
+    RCCL ("nccl") works on the device tensors in place."""
+    return dist.get_backend(group) == "gloo"
+
+
 def reduce_presence(best_start, best_end, group=None):
     """MAX all-reduce of the [S] + [S] presence tables (in place on a stacked copy)."""
     table = torch.stack([best_start, best_end])
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(table, op=dist.ReduceOp.MAX, group=group)
+        if table.is_cuda and _host_collectives(group):
+            host = table.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.MAX, group=group)
+            table = host.to(table.device)
+        else:
+            dist.all_reduce(table, op=dist.ReduceOp.MAX, group=group)
     return table[0], table[1]
 
 
@@ -52,6 +64,8 @@ def gather_in_order(local, group=None):
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return local
     world = dist.get_world_size(group)
+    if local.is_cuda and _host_collectives(group):
+        return gather_in_order(local.cpu(), group).to(local.device)
     sizes = [torch.zeros(1, dtype=torch.int64, device=local.device) for _ in range(world)]
     dist.all_gather(sizes, torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device), group=group)
     mx = int(max(int(s.item()) for s in sizes))

@@ -67,18 +67,24 @@ class MiddleHits:
     alignments: int = 0
 
 
+def _round6(x):
+    """float("%f" % x) for non-negative doubles: the value Python parses back from the C side's six printed decimals.
+    The quotient is a TRUE division by a one-element device tensor: `tensor / 1e6` with a Python scalar is evaluated by
+    PyTorch as a multiplication by the rounded reciprocal, which lands one ulp off the correctly rounded value for about
+    one identity in seven (seen as 33 of 238 presence-table entries differing from the host's in the last bit)."""
+    million = torch.full((1,), 1e6, dtype=torch.float64, device=x.device)
+    return torch.round(x * 1e6) / million
+
+
 def _identities(rec):
     """float64 (full, partial) exactly as nanopore_read.py:476-491 parses them: the C side prints
-    (100.0*matches)/len with %f and Python float()s it back; comparing the unrounded doubles with
-    the thresholds is equivalent only if no value lies within 5e-7 of a threshold without being
-    equal to it -- identities are ratios of small integers (len <= a few hundred), whose distance
-    from a threshold such as 75.0 or 90.0 is either 0 or >= 100/len^2 >> 5e-7."""
-    m = rec[:, 5].to(torch.float64)
-    partial = 100.0 * m / rec[:, 6].to(torch.float64)
-    full = 100.0 * m / rec[:, 7].to(torch.float64)
-    # the %f round trip: round to 6 decimals (what float(str) sees)
-    partial = torch.round(partial * 1e6) / 1e6
-    full = torch.round(full * 1e6) / 1e6
+    (100.0*matches)/len with %f and Python float()s it back; rounding the unrounded double to six decimals
+    reproduces the printed digits as long as no value lies within 5e-7 of a rounding boundary without being on
+    it -- identities are ratios of small integers (len <= a few hundred), whose six-decimal digits are never
+    within 1e-8 of a tie."""
+    m = rec[..., 5].to(torch.float64)
+    partial = _round6(100.0 * m / rec[..., 6].to(torch.float64))
+    full = _round6(100.0 * m / rec[..., 7].to(torch.float64))
     return full, partial
 
 
@@ -318,7 +324,7 @@ class Pipeline:
         # one vectorised reduction for all jobs (they all cover the same n check reads)
         rec = torch.stack(outs)                                     # [J, n, 8]
         m = rec[:, :, 5].to(torch.float64)
-        full = torch.round(100.0 * m / rec[:, :, 7].to(torch.float64) * 1e6) / 1e6
+        full = _round6(100.0 * m / rec[:, :, 7].to(torch.float64))
         full = torch.where(rec[:, :, 0] == -1, torch.zeros_like(full), full).amax(dim=1)   # [J]
         si = torch.tensor([w[0] for w in where], device=self.device)
         side = torch.tensor([w[1] for w in where], device=self.device)
@@ -468,6 +474,54 @@ class Pipeline:
                 ads.append((s.end, si))
         return ads
 
+    def _prefiltered_scan(self, arena, off, length, max_len, a_list, aidx, hint, ks, ragged, typ_len):
+        """Whole-read records of the adapters a_list (positions in the middle-adapter list) against the n windows
+        (off, length), computed only where the exact prefilter cannot exclude a hit: [len(a_list), n, 8] int32, all-zero
+        records (not hits) for the proven pairs.  The windows that survive for one of a set's sequences are scanned for
+        all of that set's sequences in one pass (the set's ahead-of-time kernel)."""
+        dev = self.device
+        n, B = int(off.shape[0]), len(a_list)
+        recs = torch.zeros((B, n, RESULT_INTS), dtype=torch.int32, device=dev)
+        if n == 0 or B == 0:
+            return recs
+        order = None
+        pf_off, pf_len = off.contiguous(), length.contiguous()
+        if ragged:                                       # a wave runs 64 consecutive windows: similar lengths together
+            order = torch.argsort(length, descending=True, stable=True)
+            pf_off, pf_len = off[order].contiguous(), length[order].contiguous()
+        self.aligner.set_length_hint(typ_len if ragged else 0)
+        cand = self.aligner.prefilter(arena, pf_off, pf_len, max_len, [aidx[a] for a in a_list], [ks[a] for a in a_list])   # [B, n] bool
+        if order is not None:
+            back = torch.empty_like(cand)
+            back[:, order] = cand
+            cand = back
+        groups, gidx = {}, []
+        for a in a_list:
+            gidx.append(groups.setdefault(hint[a], len(groups)))
+        G = len(groups)
+        if G == B:
+            cand_g = cand
+        else:
+            cand_g = torch.zeros((G, n), dtype=torch.int32, device=dev).index_add_(0, torch.tensor(gidx, device=dev), cand.to(torch.int32)) > 0
+        hitg = torch.nonzero(cand_g)                                  # [C, 2] (group, window), group-major
+        counts = torch.bincount(hitg[:, 0], minlength=G).cpu().numpy()     # the one synchronisation of this stage
+        cjobs, csel, pos = [], [], 0
+        members = [[b for b in range(B) if gidx[b] == g] for g in range(G)]
+        for g in range(G):
+            if counts[g]:
+                sel = hitg[pos:pos + int(counts[g]), 1]
+                pos += int(counts[g])
+                so, sl = off[sel], length[sel]
+                for b in members[g]:
+                    cjobs.append((aidx[a_list[b]], so, sl, hint[a_list[b]])); csel.append((b, sel))
+        if cjobs:
+            for (b, sel), o in zip(csel, self._scan_jobs(arena, cjobs, MODE_TWO_PASS, max_len, sort_lengths=ragged, typ_len=typ_len)):
+                recs[b, sel] = o
+        self.stats["pairs_middle_prefiltered"] = self.stats.get("pairs_middle_prefiltered", 0) + B * n
+        self.stats["pairs_middle_scanned_after_prefilter"] = self.stats.get("pairs_middle_scanned_after_prefilter", 0) + \
+            sum(int(j[1].shape[0]) for j in cjobs)
+        return recs
+
     def phase_c(self, reads: DeviceReads, start_trim, end_trim, matching: List[int], prove: bool = False,
                 prefilter: bool = False) -> MiddleHits:
         """nanopore_read.py:210-243 for every read: adapters in order, and for each adapter keep
@@ -527,48 +581,10 @@ class Pipeline:
         jobs0 = [(ai, loff, llen, h) for ai, h in zip(aidx, hint)]
         bounds = [self.identity_score_bound(len(self.seqs[ai]), p.middle_threshold) for ai in aidx] if prove else None
         if prefilter:
-            L = int(live.numel())
             ks = [self.aligner.max_edits(len(self.seqs[ai]), p.middle_threshold) for ai in aidx]
-            order = None
-            pf_off, pf_len = loff, llen
-            if ragged:                                   # a wave runs 64 consecutive windows: similar lengths together
-                order = torch.argsort(llen, descending=True, stable=True)
-                pf_off, pf_len = loff[order].contiguous(), llen[order].contiguous()
-            self.aligner.set_length_hint(typ_len if ragged else 0)
-            cand = self.aligner.prefilter(reads.arena, pf_off.contiguous(), pf_len.contiguous(), max_len, aidx, ks)     # [A, L] bool
-            if order is not None:
-                back = torch.empty_like(cand)
-                back[:, order] = cand
-                cand = back
-            # survivors by SET: the reads that pass for one of a set's sequences are scanned for all of them
-            groups, gidx = {}, []
-            for a, h in enumerate(hint):
-                gidx.append(groups.setdefault(h, len(groups)))
-            G = len(groups)
-            member = torch.zeros((G, A), dtype=torch.bool, device=dev)
-            member[torch.tensor(gidx, device=dev), torch.arange(A, device=dev)] = True
-            cand_g = (member[:, :, None] & cand[None, :, :]).any(dim=1) if G * A * L <= (1 << 28) else \
-                torch.stack([cand[torch.tensor([a for a in range(A) if gidx[a] == g], device=dev)].any(dim=0) for g in range(G)])
-            hitg = torch.nonzero(cand_g)                                  # [C, 2] (group, read), group-major
-            counts = torch.bincount(hitg[:, 0], minlength=G).cpu().numpy()     # the one synchronisation of this stage
-            recs = torch.zeros((A, L, RESULT_INTS), dtype=torch.int32, device=dev)
-            cjobs, csel, pos = [], [], 0
-            for g in range(G):
-                if counts[g]:
-                    sel = hitg[pos:pos + int(counts[g]), 1]
-                    pos += int(counts[g])
-                    so, sl = loff[sel], llen[sel]
-                    for a in range(A):
-                        if gidx[a] == g:
-                            cjobs.append((aidx[a], so, sl, hint[a])); csel.append((a, sel))
-            if cjobs:
-                for (a, sel), o in zip(csel, self._scan_jobs(reads.arena, cjobs, MODE_TWO_PASS, max_len, sort_lengths=ragged, typ_len=typ_len)):
-                    recs[a, sel] = o
+            recs = self._prefiltered_scan(reads.arena, loff, llen, max_len, list(range(A)), aidx, hint, ks, ragged, typ_len)
             outs = [recs[a] for a in range(A)]
             fulls = torch.stack([torch.nan_to_num(identity_of(rec), nan=0.0) for rec in outs])
-            self.stats["pairs_middle_prefiltered"] = self.stats.get("pairs_middle_prefiltered", 0) + A * L
-            self.stats["pairs_middle_scanned_after_prefilter"] = self.stats.get("pairs_middle_scanned_after_prefilter", 0) + \
-                sum(int(j[1].shape[0]) for j in cjobs)
         elif prove and all(b is not None for b in bounds):
             score = torch.stack(self._scan_jobs(reads.arena, jobs0, MODE_SCORE, max_len, sort_lengths=ragged, typ_len=typ_len))[:, :, 4]      # [A, L]
             cand = torch.nonzero(score >= torch.tensor(bounds, device=dev)[:, None])                     # adapter-major
@@ -653,12 +669,15 @@ class Pipeline:
                 rounds += 1
                 a0 = int(ah.min().item())
                 o_act, l_act = d_off[act], dlen[act]
-                outs_r = self._scan_jobs(dirty, [(aidx[a], o_act, l_act, hint[a]) for a in range(a0, A)], MODE_TWO_PASS, dmax,
-                                         sort_lengths=ragged, typ_len=dtyp)
+                if prefilter:                                        # the masked reads go through the same proof first
+                    outs_r = self._prefiltered_scan(dirty, o_act, l_act, dmax, list(range(a0, A)), aidx, hint, ks, ragged, dtyp)
+                else:
+                    outs_r = self._scan_jobs(dirty, [(aidx[a], o_act, l_act, hint[a]) for a in range(a0, A)], MODE_TWO_PASS, dmax,
+                                             sort_lengths=ragged, typ_len=dtyp)
                 scheduled = (A - a0) * int(act.numel())
                 for a, o in zip(range(a0, A), outs_r):
                     rec_all[a, act] = o
-                    full_all[a, act] = identity_of(o)
+                    full_all[a, act] = torch.nan_to_num(identity_of(o), nan=0.0)
         self.stats["pairs_middle"] += n_align
         self.stats["pairs_middle_speculative"] = self.stats.get("pairs_middle_speculative", 0) + n_spec
         if not H_read:

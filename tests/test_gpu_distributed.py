@@ -1,0 +1,82 @@
+"""The N > 1 path on the one GPU of the test box (functional checks only -- no scaling claim): two ranks over gloo
+sharing cuda:0 run the END-TO-END runner with the real HIP library (reads sharded by bases, the presence table
+MAX-all-reduced, per-read results gathered in rank order, rank 0 writes): the output files must be the reference CLI's;
+and bench.py launched through torch.distributed.run with one rank prints what plain `python bench.py` prints."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CASES = ["native_default", "native_bins", "ligation_default", "edge_default"]
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, workdir, q):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    from tests.runner_cases import load_cases, run_case
+    cases = load_cases()
+    datasets, out = {}, {}
+    for name in CASES:
+        got = run_case(name, cases[name], os.path.join(workdir, "rank%d" % rank), datasets, device="cuda:0")
+        dist.barrier()
+        out[name] = got
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_on_one_gpu_write_the_reference_files(tmp_path):
+    from tests.runner_cases import load_cases
+    cases = load_cases()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, str(tmp_path), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=600) for _ in range(2))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for name in CASES:
+        assert got[0][name] == cases[name]["outputs"], (name, got[0][name])
+        assert got[1][name] == {}, name          # only rank 0 writes
+
+
+def test_one_rank_launcher_equals_plain_bench():
+    """`python -m torch.distributed.run --nproc-per-node 1 bench.py --gpus 1` (the driver's launch line) and plain
+    `python bench.py`: the same workload, the same results (matching sets, hits, parity), throughput within noise."""
+    args = ["--gpus", "1", "--steps", "3", "--warmup", "1", "--reads", "200000", "--cpu-seconds", "0", "--no-extra", "--repeats", "1"]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    plain = subprocess.run([sys.executable, "bench.py"] + args, cwd=REPO, env=env, capture_output=True, text=True, timeout=900)
+    assert plain.returncode == 0, plain.stderr[-2000:]
+    launched = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                               "--master-port", str(_free_port()), "bench.py"] + args, cwd=REPO, env=env, capture_output=True, text=True, timeout=900)
+    assert launched.returncode == 0, launched.stderr[-2000:]
+    a = json.loads(plain.stdout.strip().splitlines()[-1])
+    b = json.loads(launched.stdout.strip().splitlines()[-1])
+    for k in ("metric", "unit", "n_gpus", "steps", "scaling", "dtype"):
+        assert a[k] == b[k], k
+    for k in ("workload", "matching_sets", "middle_hits_per_step", "mask_rounds", "world_size"):
+        assert a["config"][k] == b["config"][k], k
+    assert a["config"]["exact_prefilter"]["same_trims_and_middle_hits"] and b["config"]["exact_prefilter"]["same_trims_and_middle_hits"]
+    assert 0.8 < a["value"] / b["value"] < 1.25, (a["value"], b["value"])

@@ -2,7 +2,11 @@
 """Large randomised parity run (GPU box): the HIP library against the C oracle, bit for bit, on
 millions of end-window pairs and tens of thousands of whole reads, over random valid scoring
 schemes and adapters of 1..120 bases.  Prints one line per block and a final tally.
-    python tools/fuzz_parity.py [blocks] [seed]"""
+    python tools/fuzz_parity.py [blocks] [seed]
+With PC_CHECK_RANGE=1 PC_JIT_CHECK_RANGE=1 PC_JIT_MIN_CELLS=1 in the environment the range-checking builds of the 16-bit
+kernels run (every row class of the packed-fp16 traced kernel, the specialised score kernel of every adapter pair met):
+each block then also prints the extremes of every value those kernels formed (pc_debug_value_range; the exactness argument
+needs |value| <= 2040 in the fp16 kernels, <= 32000 in the int16 ones -- a launch outside fails by itself)."""
 import os
 import random
 import sys
@@ -21,6 +25,8 @@ rng = random.Random(seed)
 nrng = np.random.default_rng(seed)
 o = Oracle()
 bad = total = 0
+checking = os.environ.get("PC_CHECK_RANGE", "0") not in ("", "0") or os.environ.get("PC_JIT_CHECK_RANGE", "0") not in ("", "0")
+worst = [0, 0]
 t0 = time.time()
 for blk in range(blocks):
     while True:
@@ -59,6 +65,11 @@ for blk in range(blocks):
         bad += n; total += n
         al.close()
         continue
+    rng_txt = ""
+    if checking:
+        lo, hi = al.debug_value_range()
+        worst = [min(worst[0], lo), max(worst[1], hi)]
+        rng_txt = "  values formed in [%d, %d]" % (lo, hi)
     ad_arena = np.frombuffer("".join(ads).encode(), dtype=np.uint8)
     ad_len = np.array([len(a) for a in ads], dtype=np.int32)
     ad_off = np.concatenate([[0], np.cumsum(ad_len[:-1].astype(np.int64))]).astype(np.int64)
@@ -67,9 +78,9 @@ for blk in range(blocks):
     ok = (got == want8).all(axis=1) | ((want[:, 0] == -1) & (got[:, 0] == -1))
     bad += int((~ok).sum())
     total += n
-    print("block %2d scheme %-20s %s n=%6d mismatches=%d  (%.0f s)" % (blk, sc, "whole reads" if whole else "end windows", n, int((~ok).sum()), time.time() - t0), flush=True)
+    print("block %2d scheme %-20s %s n=%6d mismatches=%d%s  (%.0f s)" % (blk, sc, "whole reads" if whole else "end windows", n, int((~ok).sum()), rng_txt, time.time() - t0), flush=True)
     if (~ok).any():
         i = int(np.nonzero(~ok)[0][0])
         print("   first:", arena[offs[i]:offs[i] + lens[i]].tobytes()[:200], ads[aidx[i]], got[i], want8[i])
     al.close()
-print("TOTAL pairs=%d mismatches=%d" % (total, bad))
+print("TOTAL pairs=%d mismatches=%d" % (total, bad) + ("  extremes of all values formed by the range-checking kernels: [%d, %d]" % tuple(worst) if checking else ""))

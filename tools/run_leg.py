@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""One leg of bench.py, alone, for the profiler: every launch in the process then belongs to that leg, so rocprofv3's
+per-kernel numbers can be attributed to it.  `steps` identical steps, nothing else (no CPU legs, no cross-checks).
+usage: run_leg.py headline|prefilter|configs1|configs2|configs4|configs4_prefilter [steps]"""
+import argparse
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+import bench  # noqa: E402
+from porechop_amd.pipeline import Pipeline, ScanParams  # noqa: E402
+from porechop_amd.runner import Options  # noqa: E402
+from porechop_amd.synth import make_reads  # noqa: E402
+
+leg = sys.argv[1]
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+dev = torch.device("cuda", 0)
+p, opts = ScanParams(), Options()
+pl = Pipeline(bench.load_panel_sets(), p, device=dev)
+pl.n_panel = len(pl.sets)
+fw = [a for a in bench.load_panel_json() if a["name"].startswith("Barcode ") and "(forward)" in a["name"]]
+bc = dict(barcodes_start=[a["start"][1] for a in fw], barcodes_end=[a["end"][1] for a in fw])
+if leg in ("headline", "prefilter"):
+    reads = make_reads(1_000_000, 8000, seed=3, start_frac=0.9, end_frac=0.5, chimera_frac=0.01, device=dev)
+    step = lambda: bench.one_step(pl, reads, p.check_reads, 1, prefilter=(leg == "prefilter"))
+elif leg == "configs1":
+    reads = make_reads(100_000, 8000, seed=1, start_frac=0.9, end_frac=0.5, chimera_frac=0.0, device=dev)
+    step = lambda: bench.step_end_trim(pl, reads, p.check_reads)
+elif leg == "configs2":
+    reads = make_reads(1_000_000, 8000, seed=2, start_frac=0.9, end_frac=0.5, chimera_frac=0.0, device=dev, **bc)
+    step = lambda: bench.step_demux(pl, reads, p.check_reads, opts)
+elif leg in ("configs4", "configs4_prefilter"):
+    reads = make_reads(int(os.environ.get("PC_LEG_READS4", "1250000")), 8000, seed=4, start_frac=0.9, end_frac=0.5, chimera_frac=0.01, device=dev, **bc)
+    step = lambda: bench.step_configs4(pl, reads, p.check_reads, opts, prefilter=(leg == "configs4_prefilter"))
+else:
+    raise SystemExit("unknown leg " + leg)
+for _ in range(steps):
+    step()
+    pl.aligner.sync()
+torch.cuda.synchronize()
+print("LEG", leg, "steps", steps, "library_sha1", bench.library_fingerprint())
+pl.close()

@@ -181,8 +181,9 @@ int pc_copy_windows(pc_ctx *ctx, const void *d_arena, const int64_t *d_src_off, 
  * points to).  Row w of d_mask ([nwindows][ceil(nadapters / 32)] words, written by the call) gets bit j set iff window
  * w MAY hold adapters[j] within max_edits[j] edits: always set when it does (so a pair whose bit is clear is PROVEN not
  * to be a hit, and only the survivors need the DP), never set when it does not for adapters of at most 32 bases;
- * longer adapters are cut into ceil(m / 32) pieces and survive when one piece lies within floor(max_edits / pieces)
- * edits (pigeonhole: a superset).  max_edits[j] < 0 = do not filter adapter j (bit set for every non-empty window).
+ * a longer adapter is represented by its first 32 bases with the same bound when max_edits <= 8, and otherwise cut into
+ * ceil(m / 32) pieces, surviving when one piece lies within floor(max_edits / pieces) edits (pigeonhole) -- a superset
+ * either way.  max_edits[j] < 0 = do not filter adapter j (bit set for every non-empty window).
  * adapters[] indexes the table of pc_set_adapters; max_len bounds every win_len; the arena must be readable 16 bytes
  * past its last window.  Asynchronous on `stream`; honours pc_set_length_hint. */
 int pc_prefilter_max_edits(int adapter_len, double threshold_percent);

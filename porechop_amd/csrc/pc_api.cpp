@@ -118,7 +118,16 @@ struct pc_ctx {
     // pc_prefilter_device: Eq tables + piece metadata of the last (adapter list, edit bounds), kept on the device
     DevBuf d_pf_tables, d_pf_meta;
     std::vector<int32_t> pf_key;             // adapters..., max_edits... of the cached tables
-    int pf_P = 0, pf_groups = 0, pf_warm = 0;
+    struct PfLaunch { int P, groups; size_t table_off, meta_off; };     // one kernel launch: `groups` groups of P pieces
+    std::vector<PfLaunch> pf_launches;       // the exhaustive kernel's launches over ALL pieces (fallback, PC_PF_NO_SEEDS=1)
+    std::vector<PfLaunch> pf_rest_launches;  // ... over the pieces the seed stage cannot take
+    int pf_warm = 0;
+    // seed stage (pc_prefilter.hip seed_scan_kernel / seed_verify_kernel): bitmaps, q-gram -> entry ranges, entries,
+    // the seeded pieces' metadata and Eq words; candidate list and its counter
+    DevBuf d_sd_bitmaps, d_sd_first, d_sd_entries, d_sd_meta, d_sd_eq, d_sd_cand, d_sd_count;
+    int sd_nq = 0, sd_q[3] = {6, 6, 6}, sd_first_off[3] = {0, 0, 0}, sd_npieces = 0;
+    double sd_rate = 0.0;                    // expected candidates per read column
+    unsigned long long *h_sd_count = nullptr;   // pinned host copy of the candidate count
     // cached job table (bench loops repeat the same one: skip the re-upload).  The tile table itself only
     // exists on the device: it is expanded there from the groups' runs (one per job and shape).
     std::vector<Group> groups;
@@ -598,7 +607,9 @@ void pc_destroy(pc_ctx *c)
     DevBuf *bufs[] = {&c->d_ad_codes, &c->d_ad_len, &c->d_ad_window, &c->d_ad_span, &c->d_tiles_slot[0], &c->d_tiles_slot[1],
                       &c->d_runs_slot[0], &c->d_runs_slot[1], &c->d_slab, &c->d_fin, &c->d_k1, &c->d_woff2,
                       &c->d_wlen2, &c->d_col0, &c->d_ntot, &c->d_frow, &c->d_fscore, &c->d_err, &c->d_arena,
-                      &c->d_woff, &c->d_wlen, &c->d_out, &c->d_red_slot[0], &c->d_red_slot[1], &c->d_work, &c->d_pf_tables, &c->d_pf_meta};
+                      &c->d_woff, &c->d_wlen, &c->d_out, &c->d_red_slot[0], &c->d_red_slot[1], &c->d_work, &c->d_pf_tables, &c->d_pf_meta, &c->d_sd_bitmaps, &c->d_sd_first,
+                      &c->d_sd_entries, &c->d_sd_meta, &c->d_sd_eq, &c->d_sd_cand, &c->d_sd_count};
+    if (c->h_sd_count) (void)hipHostFree(c->h_sd_count);
     for (DevBuf *b : bufs) b->release();
     (void)hipStreamDestroy(c->stream);
     delete c;
@@ -978,8 +989,10 @@ int pc_prefilter_device(pc_ctx *c, const void *d_arena, const int64_t *d_win_off
     std::vector<int32_t> key(adapters, adapters + nadapters);
     key.insert(key.end(), max_edits, max_edits + nadapters);
     if (key != c->pf_key) {
-        // pieces: an adapter of m bases is cut into p = ceil(m / 32) pieces of nearly equal length; if the adapter is
-        // within k edits of a substring, one piece is within floor(k / p) (pigeonhole)
+        // Pieces.  An adapter of at most 32 bases is one piece with its own bound.  A longer one that allows at most 8
+        // edits is represented by its FIRST 32 BASES with the same bound (within k edits of a substring, so is every
+        // substring of it: still a proof, and a 32-mer within <= 8 edits of random text is rare).  Beyond that it is cut
+        // into p = ceil(m / 32) pieces of nearly equal length, one of which lies within floor(k / p) (pigeonhole).
         struct Piece { int adapter, begin, len, k, word; uint32_t bit; };
         std::vector<Piece> pieces;
         int warm = 0;
@@ -989,6 +1002,11 @@ int pc_prefilter_device(pc_ctx *c, const void *d_arena, const int64_t *d_win_off
             const int m = (int)c->adapters[ai].size();
             if (m <= 0) continue;                                     // an empty adapter never hits (failure record)
             const int k = max_edits[j] < 0 ? m : max_edits[j];        // < 0: do not filter this adapter
+            if (m > 32 && k <= 8) {
+                pieces.push_back({ai, 0, 32, k, j / 32, 1u << (j % 32)});
+                warm = std::max(warm, 32 + k);
+                continue;
+            }
             const int np = (m + 31) / 32;
             int pos = 0;
             for (int q = 0; q < np; ++q) {
@@ -998,36 +1016,179 @@ int pc_prefilter_device(pc_ctx *c, const void *d_arena, const int64_t *d_win_off
                 pos += len;
             }
         }
-        const int P = pieces.size() > 4 ? 8 : pieces.size() > 2 ? 4 : pieces.size() > 1 ? 2 : 1;
-        const int groups = (int)((pieces.size() + P - 1) / P);
-        std::vector<uint32_t> tables((size_t)std::max(groups, 1) * 256 * P, 0xFFFFFFFFu);   // unused slots: all wildcards
-        std::vector<int32_t> meta((size_t)std::max(groups, 1) * P * 4, 0);
+        // Launches: groups of 8 pieces per lane, the remainder r as one smaller group where an unused slot would cost
+        // more than a second pass over the reads (r = 5 -> 4 + 1, r = 6 -> 4 + 2; r = 3 -> 4, r = 7 -> 8 with a slot idle).
+        std::vector<pc_ctx::PfLaunch> launches;
+        std::vector<uint32_t> tables;
+        std::vector<int32_t> meta;
+        auto add_groups = [&](size_t first, size_t count, int P) {
+            const int groups = (int)((count + P - 1) / P);
+            pc_ctx::PfLaunch L{P, groups, tables.size(), meta.size()};
+            tables.resize(tables.size() + (size_t)groups * 256 * P, 0xFFFFFFFFu);           // unused slots: all wildcards
+            meta.resize(meta.size() + (size_t)groups * P * 4, 0);
+            for (size_t i = 0; i < count; ++i) {
+                const Piece &pc = pieces[first + i];
+                const size_t g = i / P, slot = i % P;
+                const std::string &ad = c->adapters[pc.adapter];
+                const uint32_t wild = pc.len >= 32 ? 0u : (0xFFFFFFFFu >> pc.len);     // the bits below the piece
+                uint32_t eq_of_code[5];
+                for (int code = 0; code < 5; ++code) {
+                    uint32_t e = wild;
+                    for (int r = 0; r < pc.len; ++r)
+                        if (dna5((unsigned char)ad[pc.begin + r]) == code) e |= 1u << (32 - pc.len + r);
+                    eq_of_code[code] = e;
+                }
+                for (int b = 0; b < 256; ++b) tables[L.table_off + (g * 256 + b) * P + slot] = eq_of_code[dna5((unsigned char)b)];
+                int32_t *mt = &meta[L.meta_off + (g * P + slot) * 4];
+                mt[0] = pc.len; mt[1] = pc.k; mt[2] = pc.word; mt[3] = (int32_t)pc.bit;
+            }
+            launches.push_back(L);
+        };
+        {
+            const size_t n = pieces.size(), n8 = n / 8 * 8, r = n - n8;
+            if (n8) add_groups(0, n8, 8);
+            switch (r) {
+                case 0: break;
+                case 1: add_groups(n8, 1, 1); break;
+                case 2: add_groups(n8, 2, 2); break;
+                case 3: case 4: add_groups(n8, r, 4); break;
+                case 5: add_groups(n8, 4, 4); add_groups(n8 + 4, 1, 1); break;
+                case 6: add_groups(n8, 4, 4); add_groups(n8 + 4, 2, 2); break;
+                default: add_groups(n8, r, 8); break;
+            }
+        }
+        const std::vector<pc_ctx::PfLaunch> all_launches = launches;
+        // ---- seed stage: which pieces it can take, and its tables ---------------------------------------------
+        // A piece of len bases with bound k is cut into k + 1 parts of floor/ceil(len / (k + 1)) bases; it is seeded
+        // when those parts are at least 6 bases long, k + 1 <= 8, and every seed is made of A/C/G/T.  Its seed length is
+        // min(8, floor(len / (k + 1))); up to three different lengths (6, 7, 8) each get their own bitmap.
+        struct Seed { int cls; uint32_t gram; int piece, off; };
+        std::vector<Seed> seeds;
+        std::vector<int> seeded_piece;            // indices into `pieces`
+        std::vector<size_t> rest_piece;
+        bool have_q[9] = {false, false, false, false, false, false, false, false, false};
+        static const bool no_seeds = [] { const char *e = getenv("PC_PF_NO_SEEDS"); return e && *e && *e != '0'; }();
         for (size_t i = 0; i < pieces.size(); ++i) {
             const Piece &pc = pieces[i];
-            const size_t g = i / P, slot = i % P;
-            const std::string &ad = c->adapters[pc.adapter];
-            const uint32_t wild = pc.len >= 32 ? 0u : (0xFFFFFFFFu >> pc.len);       // the bits below the piece
-            uint32_t eq_of_code[5];
-            for (int code = 0; code < 5; ++code) {
-                uint32_t e = wild;
-                for (int r = 0; r < pc.len; ++r)
-                    if (dna5((unsigned char)ad[pc.begin + r]) == code) e |= 1u << (32 - pc.len + r);
-                eq_of_code[code] = e;
+            const int parts = pc.k + 1;
+            const int q = std::min(8, pc.len / std::max(1, parts));
+            bool ok = !no_seeds && pc.k >= 0 && pc.k < pc.len && parts <= 8 && q >= 6;
+            std::vector<Seed> mine;
+            if (ok) {
+                const std::string &ad = c->adapters[pc.adapter];
+                int pos = 0;
+                for (int t = 0; t < parts && ok; ++t) {
+                    const int plen = pc.len / parts + (t < pc.len % parts ? 1 : 0);
+                    uint32_t gram = 0;
+                    for (int r = 0; r < q; ++r) {
+                        const int code = dna5((unsigned char)ad[pc.begin + pos + r]);
+                        if (code > 3) { ok = false; break; }
+                        gram = (gram << 2) | (uint32_t)code;
+                    }
+                    mine.push_back({q, gram, (int)seeded_piece.size(), pos});
+                    pos += plen;
+                }
             }
-            for (int b = 0; b < 256; ++b) tables[(g * 256 + b) * P + slot] = eq_of_code[dna5((unsigned char)b)];
-            int32_t *mt = &meta[(g * P + slot) * 4];
-            mt[0] = pc.len; mt[1] = pc.k; mt[2] = pc.word; mt[3] = (int32_t)pc.bit;
+            if (ok) {
+                have_q[q] = true;
+                seeded_piece.push_back((int)i);
+                seeds.insert(seeds.end(), mine.begin(), mine.end());
+            } else {
+                rest_piece.push_back(i);
+            }
         }
+        c->sd_nq = 0;
+        int cls_of_q[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        for (int q = 8; q >= 6; --q) if (have_q[q]) { cls_of_q[q] = c->sd_nq; c->sd_q[c->sd_nq++] = q; }
+        for (int t = c->sd_nq; t < 3; ++t) c->sd_q[t] = 6;
+        c->sd_npieces = (int)seeded_piece.size();
+        c->sd_rate = 0.0;
+        std::vector<pc_ctx::PfLaunch> rest_launches;
+        if (c->sd_nq > 0) {
+            std::vector<uint32_t> bitmaps(pck::kSeedBitmapWords, 0u);
+            const int bm_off[3] = {0, (1 << 16) / 32, (1 << 16) / 32 + (1 << 14) / 32};
+            for (Seed &sd : seeds) sd.cls = cls_of_q[sd.cls];
+            std::stable_sort(seeds.begin(), seeds.end(), [](const Seed &x, const Seed &y) { return x.cls != y.cls ? x.cls < y.cls : x.gram < y.gram; });
+            std::vector<uint32_t> first;
+            std::vector<int32_t> entries(seeds.size() * 4 + 4, 0);
+            size_t e = 0;
+            for (int cl = 0; cl < c->sd_nq; ++cl) {
+                const uint32_t ngram = 1u << (2 * c->sd_q[cl]);
+                c->sd_first_off[cl] = (int)first.size();
+                first.resize(first.size() + ngram + 1, 0u);
+                uint32_t *f = first.data() + c->sd_first_off[cl];
+                for (uint32_t g = 0; g < ngram; ++g) {
+                    f[g] = (uint32_t)e;
+                    while (e < seeds.size() && seeds[e].cls == cl && seeds[e].gram == g) {
+                        entries[e * 4] = seeds[e].piece; entries[e * 4 + 1] = seeds[e].off;
+                        bitmaps[bm_off[cl] + (g >> 5)] |= 1u << (g & 31);
+                        ++e;
+                    }
+                }
+                f[ngram] = (uint32_t)e;
+                c->sd_rate += (double)(f[ngram] - f[0]) / (double)ngram;
+            }
+            std::vector<int32_t> smeta((size_t)c->sd_npieces * 4 + 4, 0);
+            std::vector<uint32_t> seq((size_t)c->sd_npieces * 8 + 8, 0u);
+            for (int i = 0; i < c->sd_npieces; ++i) {
+                const Piece &pc = pieces[seeded_piece[i]];
+                smeta[i * 4] = pc.len; smeta[i * 4 + 1] = pc.k; smeta[i * 4 + 2] = pc.word; smeta[i * 4 + 3] = (int32_t)pc.bit;
+                const std::string &ad = c->adapters[pc.adapter];
+                const uint32_t wild = pc.len >= 32 ? 0u : (0xFFFFFFFFu >> pc.len);
+                for (int code = 0; code < 5; ++code) {
+                    uint32_t eq = wild;
+                    for (int r = 0; r < pc.len; ++r)
+                        if (dna5((unsigned char)ad[pc.begin + r]) == code) eq |= 1u << (32 - pc.len + r);
+                    seq[i * 8 + code] = eq;
+                }
+            }
+            // the rest (long pieces with large bounds, tiny adapters, seeds with an N) keeps the exhaustive kernel:
+            // its groups are appended to the same tables
+            launches.clear();
+            const std::vector<Piece> all = pieces;
+            pieces.clear();
+            for (size_t i : rest_piece) pieces.push_back(all[i]);
+            {
+                const size_t n = pieces.size(), n8 = n / 8 * 8, r = n - n8;
+                if (n8) add_groups(0, n8, 8);
+                switch (r) {
+                    case 0: break;
+                    case 1: add_groups(n8, 1, 1); break;
+                    case 2: add_groups(n8, 2, 2); break;
+                    case 3: case 4: add_groups(n8, r, 4); break;
+                    case 5: add_groups(n8, 4, 4); add_groups(n8 + 4, 1, 1); break;
+                    case 6: add_groups(n8, 4, 4); add_groups(n8 + 4, 2, 2); break;
+                    default: add_groups(n8, r, 8); break;
+                }
+            }
+            rest_launches = launches;
+            pieces = all;
+            HIP_TRY(hipStreamSynchronize(stream));
+            int rc2;
+            if ((rc2 = c->d_sd_bitmaps.ensure(bitmaps.size() * 4)) || (rc2 = c->d_sd_first.ensure(first.size() * 4)) ||
+                (rc2 = c->d_sd_entries.ensure(entries.size() * 4)) || (rc2 = c->d_sd_meta.ensure(smeta.size() * 4)) ||
+                (rc2 = c->d_sd_eq.ensure(seq.size() * 4)) || (rc2 = c->d_sd_count.ensure(64)))
+                return rc2;
+            HIP_TRY(hipMemcpy(c->d_sd_bitmaps.p, bitmaps.data(), bitmaps.size() * 4, hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(c->d_sd_first.p, first.data(), first.size() * 4, hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(c->d_sd_entries.p, entries.data(), entries.size() * 4, hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(c->d_sd_meta.p, smeta.data(), smeta.size() * 4, hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(c->d_sd_eq.p, seq.data(), seq.size() * 4, hipMemcpyHostToDevice));
+            if (!c->h_sd_count) HIP_TRY(hipHostMalloc((void **)&c->h_sd_count, 64, hipHostMallocDefault));
+        }
+        launches = all_launches;
+        if (tables.empty()) { tables.assign(4, 0); meta.assign(4, 0); }
+
         // the tables of the previous list may still be read by a launch in flight on the caller's stream
         HIP_TRY(hipStreamSynchronize(stream));
         int rc;
         if ((rc = c->d_pf_tables.ensure(tables.size() * 4)) || (rc = c->d_pf_meta.ensure(meta.size() * 4))) return rc;
         HIP_TRY(hipMemcpy(c->d_pf_tables.p, tables.data(), tables.size() * 4, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(c->d_pf_meta.p, meta.data(), meta.size() * 4, hipMemcpyHostToDevice));
-        c->pf_key = key; c->pf_P = P; c->pf_groups = pieces.empty() ? 0 : groups; c->pf_warm = warm;
+        c->pf_key = key; c->pf_launches = launches; c->pf_rest_launches = rest_launches; c->pf_warm = warm;
     }
     HIP_TRY(hipMemsetAsync(d_mask, 0, (size_t)nwindows * words * 4, stream));
-    if (c->pf_groups == 0 || max_len == 0) return PC_OK;
+    if (c->pf_launches.empty() || max_len == 0) return PC_OK;
     // column chunks: enough (window, chunk) units to fill the chip several times over, chunks no shorter than 512
     // columns (the warm-up before a chunk is the longest piece + its edit bound: ~35 columns)
     const int64_t target = (int64_t)c->ncu * 2048 * 6;
@@ -1042,13 +1203,63 @@ int pc_prefilter_device(pc_ctx *c, const void *d_arena, const int64_t *d_win_off
     memset(&a, 0, sizeof a);
     a.arena = (const uint8_t *)d_arena; a.win_off = d_win_off; a.win_len = d_win_len; a.nwindows = nwindows;
     a.chunks = (int32_t)chunks; a.chunk_len = chunk_len; a.warm = c->pf_warm;
-    a.tables = c->d_pf_tables.as<uint32_t>(); a.piece_meta = c->d_pf_meta.as<int32_t>();
     a.mask = d_mask; a.words = words;
+    auto exhaustive = [&](const std::vector<pc_ctx::PfLaunch> &ls) -> int {
+        for (const pc_ctx::PfLaunch &L : ls) {
+            a.tables = c->d_pf_tables.as<uint32_t>() + L.table_off; a.piece_meta = c->d_pf_meta.as<int32_t>() + L.meta_off;
+            if (pck::launch_prefilter(a, L.P, L.groups, stream)) return PC_ERR_NO_DEVICE;
+        }
+        return PC_OK;
+    };
+    ScopedTimer tm(c, stream, 4, nwindows * nadapters);              // the launches of one call are timed as ONE region
+    if (c->sd_nq == 0) return exhaustive(c->pf_launches);
+    // ---- seed stage: one pass over the reads finds the exact seeds, the finds are verified; the pieces without
+    // seeds run the exhaustive kernel.  The candidate list is sized from the seeds' expected rate on random sequence
+    // (x2 + slack, at most a sixteenth of the columns); a batch that overflows it -- low-complexity reads against a
+    // low-complexity seed -- is redone by the exhaustive kernel: never much slower than that, never inexact.
+    double columns = 0.0;
     {
-        ScopedTimer tm(c, stream, 4, nwindows * nadapters);
-        if (pck::launch_prefilter(a, c->pf_P, c->pf_groups, stream)) return PC_ERR_NO_DEVICE;
+        const double typ = (c->len_hint > 0 && c->len_hint < max_len) ? (double)c->len_hint : (double)max_len;
+        columns = (double)nwindows * typ;
     }
+    static const int64_t cap_env = [] { const char *e = getenv("PC_PF_SEED_CAP"); return e ? (int64_t)atoll(e) : (int64_t)0; }();
+    int64_t cap = (int64_t)std::min(columns * c->sd_rate * 2.0 + 1e6, std::max(4e6, columns / 16.0));
+    if (cap_env > 0) cap = cap_env;
+    int rc = c->d_sd_cand.ensure((size_t)cap * 8 + 64);
+    if (rc) return rc;
+    HIP_TRY(hipMemsetAsync(c->d_sd_count.p, 0, 8, stream));
+    pck::SeedScanArgs sa;
+    memset(&sa, 0, sizeof sa);
+    sa.arena = a.arena; sa.win_off = d_win_off; sa.win_len = d_win_len; sa.nwindows = nwindows;
+    sa.chunks = a.chunks; sa.chunk_len = a.chunk_len; sa.warm = c->sd_q[0] - 1;
+    sa.nq = c->sd_nq;
+    for (int t = 0; t < 3; ++t) sa.q[t] = c->sd_q[t];
+    sa.bitmaps = c->d_sd_bitmaps.as<uint32_t>();
+    sa.cand = c->d_sd_cand.as<uint32_t>(); sa.count = c->d_sd_count.as<unsigned long long>(); sa.cap = cap;
+    if (pck::launch_seed_scan(sa, stream)) return PC_ERR_NO_DEVICE;
+    if ((rc = exhaustive(c->pf_rest_launches))) return rc;          // independent of the candidate count
+    HIP_TRY(hipMemcpyAsync(c->h_sd_count, c->d_sd_count.p, 8, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));                          // the one host round trip of the stage
+    const unsigned long long found = *c->h_sd_count;
+    if (found > (unsigned long long)cap) {
+        static bool told = false;
+        if (!told) fprintf(stderr, "porechop_amd: %llu seed candidates for a list of %lld: this batch is filtered by the exhaustive kernel\n",
+                           found, (long long)cap);
+        told = true;
+        HIP_TRY(hipMemsetAsync(d_mask, 0, (size_t)nwindows * words * 4, stream));
+        return exhaustive(c->pf_launches);
+    }
+    pck::SeedVerifyArgs va;
+    memset(&va, 0, sizeof va);
+    va.arena = a.arena; va.win_off = d_win_off; va.win_len = d_win_len;
+    va.cand = c->d_sd_cand.as<uint32_t>(); va.count = c->d_sd_count.as<unsigned long long>(); va.cap = cap;
+    for (int t = 0; t < 3; ++t) { va.q[t] = c->sd_q[t]; va.first_off[t] = c->sd_first_off[t]; }
+    va.first = c->d_sd_first.as<uint32_t>(); va.entries = c->d_sd_entries.as<int32_t>();
+    va.piece_meta = c->d_sd_meta.as<int32_t>(); va.piece_eq = c->d_sd_eq.as<uint32_t>(); va.npieces = c->sd_npieces;
+    va.mask = d_mask; va.words = words;
+    if (pck::launch_seed_verify(va, (int64_t)found, stream)) return PC_ERR_NO_DEVICE;
     return PC_OK;
+
 }
 
 void pc_jit_async(int enabled) { pcj::set_async(enabled); }

@@ -113,6 +113,42 @@ struct PrefilterArgs {
 };
 int launch_prefilter(const PrefilterArgs &a, int pieces_per_lane, int ngroups, void *stream);
 
+// seed stage of the prefilter (pc_prefilter.hip): exact q-grams of the adapter pieces, found by one pass over the reads,
+// then verified by the same edit-distance test on the few columns around each find
+struct SeedScanArgs {
+    const uint8_t *arena;
+    const int64_t *win_off;
+    const int32_t *win_len;
+    int64_t nwindows;
+    int32_t chunks, chunk_len, warm;     // warm = longest seed - 1
+    int32_t nq;                          // seed lengths present (1..3)
+    int32_t q[3];                        // the lengths, longest first (8 >= q[0] >= q[1] >= q[2] >= 6; unused: 6)
+    const uint32_t *bitmaps;             // kSeedBitmapWords words: 4^8 bits for q[0], then 4^7 for q[1], then 4^6 for q[2]
+    uint32_t *cand;                      // candidates, 2 words each: window, column of the seed's last base | class << 28
+    unsigned long long *count;           // appended so far (may exceed cap: then the host falls back to the exhaustive kernel)
+    int64_t cap;
+};
+struct SeedVerifyArgs {
+    const uint8_t *arena;
+    const int64_t *win_off;
+    const int32_t *win_len;
+    const uint32_t *cand;
+    const unsigned long long *count;
+    int64_t cap;
+    int32_t q[3];
+    int32_t first_off[3];                // per class: offset of its [4^q + 1] entry-range table in `first`
+    const uint32_t *first;
+    const int32_t *entries;              // 4 ints each: piece, offset of the seed in the piece, 0, 0; sorted by (class, q-gram)
+    const int32_t *piece_meta;           // 4 ints each: len, k, mask word, mask bit
+    const uint32_t *piece_eq;            // [npieces][8] Eq words of codes 0..4
+    int32_t npieces;
+    uint32_t *mask;
+    int32_t words;
+};
+constexpr int kSeedBitmapWords = (1 << 16) / 32 + (1 << 14) / 32 + (1 << 12) / 32;
+int launch_seed_scan(const SeedScanArgs &a, void *stream);
+int launch_seed_verify(const SeedVerifyArgs &a, int64_t ncand, void *stream);
+
 constexpr int TRACE_OUT_INTS = 8;
 constexpr int SCORE_OUT_INTS = 4;
 

@@ -24,8 +24,10 @@
 // specialised score kernel.
 // Equality is the reference's: Dna5 codes, everything that is not ACGTU is N, N == N (the per-byte Eq table
 // is built by the host from the same code table).
-// Adapters above 32 bases are cut into p = ceil(m/32) pieces; by pigeonhole one of them has <= floor(k/p)
-// edits, so the pair survives iff some piece does (a superset for those; exact for m <= 32).
+// Adapters above 32 bases: with k <= 8 the first 32 bases stand for the adapter with the same bound (every substring
+// of a string within k edits is within k edits); beyond that the adapter is cut into p = ceil(m/32) pieces, of which
+// one has <= floor(k/p) edits by pigeonhole.  Either way the pair survives iff some piece does (a superset for those
+// adapters; exact for m <= 32).
 // Reads are cut into column chunks (warm-up = piece length + k columns before the chunk: an occurrence
 // with <= k edits ending in the chunk starts inside the warm-up), so a launch fills the chip whatever the
 // read lengths.
@@ -200,7 +202,191 @@ __global__ __launch_bounds__(256) void prefilter_kernel(PrefilterArgs a)
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Seed stage: the same decision, most of it without any edit-distance arithmetic.
+//
+// Pigeonhole (the partition lemma of approximate matching): cut a piece of len bases that may take k edits into
+// k + 1 disjoint parts; an occurrence with <= k edits leaves at least one part untouched, so that part's first q
+// bases occur EXACTLY in the read, where the alignment puts them.  seed_scan_kernel streams every read once, keeps
+// the last 16 bases as 2-bit codes in a register and tests the last q against a bitmap of all seeds of that length
+// (one bitmap per seed length present, at most three, all in LDS): 2 + 4 VALU operations per read base and seed
+// length, whatever the number of adapters -- the kernel is bound by HBM, not by the VALU.  Positions that hit (a few per thousand)
+// are appended to a candidate list; seed_verify_kernel then runs Myers' recurrence for the candidate's piece over
+// the len + 2k read columns the occurrence would have to lie in.  A pair is marked iff some candidate verifies:
+// exactly the pairs within k edits (the verification is the same exact test on a window that contains every
+// occurrence through that seed), so the mask is identical to the exhaustive kernel's.
+// Seeds hold only A/C/G/T (a piece with another letter in a seed is left to the exhaustive kernel); read bytes that
+// are not bases are scanned as 'A', which can only add candidates -- the verifier reads the real bytes.
+// ---------------------------------------------------------------------------------------------------------
+// Bitmap slots in LDS (words): the seed lengths are handed over longest first, so slot c always fits 4^q[c] bits
+constexpr int kBmOff0 = 0, kBmOff1 = (1 << 16) / 32, kBmOff2 = kBmOff1 + (1 << 14) / 32, kBmWords = kBmOff2 + (1 << 12) / 32;
+
+template <int NQ>
+__global__ __launch_bounds__(256) void seed_scan_kernel(SeedScanArgs a)
+{
+    __shared__ uint32_t lut[256];                    // byte -> 2-bit code (anything that is not a base: 0, see below)
+    __shared__ uint32_t bm[kBmWords];
+    for (int i = threadIdx.x; i < 256; i += 256) {
+        uint32_t v = 0;
+        switch (i) {
+            case 'C': case 'c': v = 1; break;
+            case 'G': case 'g': v = 2; break;
+            case 'T': case 't': case 'U': case 'u': v = 3; break;
+            default: break;
+        }
+        lut[i] = v;
+    }
+    for (int i = threadIdx.x; i < kBmWords; i += 256) bm[i] = a.bitmaps[i];
+    __syncthreads();
+    const int64_t wblocks = (a.nwindows + 255) / 256;
+    const int chunk = (int)(blockIdx.x / wblocks);
+    const int64_t w = (int64_t)(blockIdx.x % wblocks) * 256 + threadIdx.x;
+    int n = 0, start = 0, c0 = 0;
+    const uint8_t *p = a.arena;
+    if (w < a.nwindows) {
+        const int len = a.win_len[w];
+        c0 = chunk * a.chunk_len;
+        if (c0 < len) {
+            start = c0 > a.warm ? c0 - a.warm : 0;
+            const int end = (c0 + a.chunk_len < len) ? c0 + a.chunk_len : len;
+            n = end - start;
+            p = a.arena + a.win_off[w] + start;
+        }
+    }
+    if (n <= 0) return;
+    // A byte that is not a base is scanned as 'A': that can only ADD candidates (the verifier looks at the real bytes
+    // and drops them); a true seed occurrence consists of bases and is always found.  Likewise the register starts as
+    // "AAAAAAAA" and the warm-up columns before a chunk may re-find the previous chunk's last seeds.
+    const int qb[3] = {2 * a.q[0], 2 * a.q[1], 2 * a.q[2]};
+    constexpr int boff[3] = {kBmOff0, kBmOff1, kBmOff2};
+    uint32_t x = 0;
+    const int nblocks = (n + 15) >> 4;
+    u32x4 cur = *(const u32x4_unaligned *)p, nxt = cur;
+    if (nblocks > 1) nxt = *(const u32x4_unaligned *)(p + 16);
+    for (int b = 0; b < nblocks; ++b) {
+        u32x4 nn = nxt;
+        if (b + 2 < nblocks) nn = *(const u32x4_unaligned *)(p + 16 * (b + 2));     // two blocks ahead
+        const uint32_t wd[4] = {cur.x, cur.y, cur.z, cur.w};
+        uint32_t hb[NQ];                             // per seed length: bit 15 - t = a seed ends at column t of this block
+#pragma unroll
+        for (int c = 0; c < NQ; ++c) hb[c] = 0;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            x = (x << 2) | lut[(wd[t >> 2] >> (8 * (t & 3))) & 0xFFu];
+#pragma unroll
+            for (int c = 0; c < NQ; ++c) {
+                const uint32_t word = bm[boff[c] + __builtin_amdgcn_ubfe(x, 5, qb[c] - 5)];
+                hb[c] = (hb[c] << 1) | __builtin_amdgcn_ubfe(word, x & 31u, 1);
+            }
+        }
+        uint32_t any = hb[0];
+#pragma unroll
+        for (int c = 1; c < NQ; ++c) any |= hb[c];
+        if (any) {                                   // a few blocks per thousand per lane
+            const int left = n - 16 * b;             // columns of this block that belong to the chunk
+#pragma unroll
+            for (int c = 0; c < NQ; ++c) {
+                uint32_t h = hb[c];
+                while (h) {
+                    const int t = 15 - (31 - __builtin_clz(h));
+                    h &= ~(1u << (15 - t));
+                    const int j = start + 16 * b + t;            // window coordinate of the seed's last base
+                    if (t < left && j >= c0 && j >= a.q[c] - 1) {  // (warm-up columns belong to the previous chunk)
+                        const unsigned long long slot = atomicAdd(a.count, 1ull);
+                        if (slot < (unsigned long long)a.cap)
+                            ((uint2 *)a.cand)[slot] = make_uint2((uint32_t)w, (uint32_t)j | ((uint32_t)c << 28));
+                    }
+                }
+            }
+        }
+        cur = nxt; nxt = nn;
+    }
+}
+
+// One lane per candidate: every piece that has the seed (class c, q-gram value) at some offset is verified over the read
+// columns an occurrence through that seed can span.
+__global__ __launch_bounds__(256) void seed_verify_kernel(SeedVerifyArgs a)
+{
+    extern __shared__ uint32_t eq_tab[];             // [npieces][8]: Eq word of codes 0..4 (5..7 unused)
+    for (int i = threadIdx.x; i < a.npieces * 8; i += 256) eq_tab[i] = a.piece_eq[i];
+    __shared__ uint8_t code_of[256];
+    for (int i = threadIdx.x; i < 256; i += 256) {
+        uint8_t v = 4;
+        switch (i) {
+            case 'A': case 'a': v = 0; break;
+            case 'C': case 'c': v = 1; break;
+            case 'G': case 'g': v = 2; break;
+            case 'T': case 't': case 'U': case 'u': v = 3; break;
+            default: break;
+        }
+        code_of[i] = v;
+    }
+    __syncthreads();
+    const unsigned long long total = *a.count < (unsigned long long)a.cap ? *a.count : (unsigned long long)a.cap;
+    const unsigned long long ci = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+    if (ci >= total) return;
+    const uint2 cd = ((const uint2 *)a.cand)[ci];
+    const int64_t w = (int64_t)cd.x;
+    const int j = (int)(cd.y & 0x0FFFFFFFu);          // window column of the seed's last base
+    const int cls = (int)(cd.y >> 28);
+    const int q = a.q[cls];
+    const int n = a.win_len[w];
+    const uint8_t *rd = a.arena + a.win_off[w];
+    uint32_t *mrow = a.mask + w * a.words;
+    // the q-gram from the read's real bytes; a byte that is not a base means the scan's find was not a seed
+    uint32_t idx = 0;
+    for (int col = j - q + 1; col <= j; ++col) {
+        const uint32_t cde = code_of[rd[col]];
+        if (cde > 3u) return;
+        idx = (idx << 2) | cde;
+    }
+    const uint32_t e0 = a.first[a.first_off[cls] + idx], e1 = a.first[a.first_off[cls] + idx + 1];
+    for (uint32_t e = e0; e < e1; ++e) {
+        const int4 en = ((const int4 *)a.entries)[e];                 // piece, offset of the seed in the piece, -, -
+        const int pi = en.x, off = en.y;
+        const int4 pm = ((const int4 *)a.piece_meta)[pi];             // len, k, mask word, mask bit
+        const int len = pm.x, k = pm.y;
+        if (mrow[pm.z] & (uint32_t)pm.w) continue;    // this pair is already marked
+        // the seed's first base is at column j - q + 1 and at piece offset off: the occurrence starts within k columns
+        // of  j - q + 1 - off  and ends within k columns of that + len
+        int lo = j - q + 1 - off - k, hi = j - q + 1 - off + len + k;
+        lo = lo < 0 ? 0 : lo; hi = hi > n ? n : hi;
+        uint32_t pv = len >= 32 ? 0xFFFFFFFFu : ~(0xFFFFFFFFu >> len), mv = 0, sc = (uint32_t)len, mn = (uint32_t)len;
+        const uint32_t *eqp = eq_tab + pi * 8;
+        for (int col = lo; col < hi; ++col) {
+            sc = myers_step(eqp[code_of[rd[col]]], pv, mv, sc);
+            mn = sc < mn ? sc : mn;
+        }
+        if ((int)mn <= k) atomicOr(mrow + pm.z, (uint32_t)pm.w);
+    }
+}
+
 }  // namespace
+
+int launch_seed_scan(const SeedScanArgs &a, void *stream)
+{
+    if (a.nwindows <= 0) return 0;
+    const int64_t wblocks = (a.nwindows + 255) / 256;
+    const int64_t gx = wblocks * a.chunks;
+    if (gx > 0x7FFFFFFFll) return -1;
+    hipStream_t s = (hipStream_t)stream;
+    switch (a.nq) {
+        case 1: hipLaunchKernelGGL(seed_scan_kernel<1>, dim3((unsigned)gx), dim3(256), 0, s, a); break;
+        case 2: hipLaunchKernelGGL(seed_scan_kernel<2>, dim3((unsigned)gx), dim3(256), 0, s, a); break;
+        case 3: hipLaunchKernelGGL(seed_scan_kernel<3>, dim3((unsigned)gx), dim3(256), 0, s, a); break;
+        default: return -1;
+    }
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+int launch_seed_verify(const SeedVerifyArgs &a, int64_t ncand, void *stream)
+{
+    if (ncand <= 0) return 0;
+    const int64_t gx = (ncand + 255) / 256;
+    if (gx > 0x7FFFFFFFll) return -1;
+    hipLaunchKernelGGL(seed_verify_kernel, dim3((unsigned)gx), dim3(256), (size_t)a.npieces * 32, (hipStream_t)stream, a);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
 
 int launch_prefilter(const PrefilterArgs &a, int pieces_per_lane, int ngroups, void *stream)
 {

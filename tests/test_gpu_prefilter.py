@@ -179,3 +179,33 @@ def test_prefiltered_middle_scan_with_a_barcode_panel_vs_reference_logic(oracle)
         n_hits += len(want)
     assert n_hits > 20
     pl.close()
+
+
+_CHILD = r"""
+import random, sys
+sys.path.insert(0, %r)
+from oracle.oracle import Oracle
+from tests.test_gpu_prefilter import make_cases, run_and_check
+rng = random.Random(5)
+adapters = ["AATGTACTTCGTTCAGTTACGTATTGCT", "GCAATACGTAACTGAACGAAGT", "ACGTACGTAC", "".join(rng.choice("ACGT") for _ in range(24)),
+            "".join(rng.choice("ACGT") for _ in range(32)), "ACGTNNACGTTTGACCAGTNAC", "AAAAAAAAAAAAAAAAAAAAAAAA"]
+reads = make_cases(31, 1500, [0, 5, 17, 150, 151, 600, 2500], adapters) + ["A" * 3000, "ACGT" * 500]
+edits = [3, 2, 1, 2, 3, 2, 2]
+exact, sound = run_and_check(Oracle(), reads, adapters, edits)
+print("CHILD_OK", exact, sound)
+"""
+
+
+@pytest.mark.parametrize("env", [{}, {"PC_PF_NO_SEEDS": "1"}, {"PC_PF_SEED_CAP": "64"}])
+def test_seed_stage_exhaustive_kernel_and_overflow_fallback_agree_with_the_plain_dp(env):
+    """The same batch -- seeds of two lengths, an adapter without seeds (N inside), a low-complexity adapter against
+    poly-A reads -- through the seed stage, through the exhaustive kernel alone (PC_PF_NO_SEEDS=1) and through the
+    overflow fallback (a 64-entry candidate list): each equals the oracle's plain DP."""
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _CHILD % repo], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600, cwd=repo)
+    assert r.returncode == 0 and "CHILD_OK" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+    if "PC_PF_SEED_CAP" in env:
+        assert "filtered by the exhaustive kernel" in r.stderr

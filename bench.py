@@ -567,9 +567,7 @@ def leg_configs4(dev, args, workers, world, rank, barrier):
                            "valu": {"achieved_gcups": cells_s / 1e9, "peak_gcups": peak, "frac": cells_s / 1e9 / peak, "ops_per_2_cells": ops},
                            "note": "score-only whole-read scan, %d adapter pairs per read; HBM fraction on ALGORITHMIC bytes "
                                    "(|H|/A + 28 per pair); VALU-bound by construction" % ((A + 1) // 2)}
-    pms, pl_launches, ppairs = timing_p["prefilter"]
-    if pl_launches > 0:
-        out["exact_prefilter"]["roofline"] = prefilter_roofline(pms, pl_launches, ppairs, n * mean_trim_len, A, leg="configs4_prefilter")
+    out["exact_prefilter"]["roofline"] = prefilter_roofline(timing_p, mean_trim_len, A, leg="configs4_prefilter")
     if args.cpu_seconds > 0 and world == 1:
         seqs, ln = host_seqs(reads, min(n, 2048))
         sets = [(s.name, s.start, s.end) for s in pl.sets]
@@ -594,17 +592,33 @@ def leg_configs4(dev, args, workers, world, rank, barrier):
     return out
 
 
-def prefilter_roofline(ms, launches, pairs, read_bytes, A, leg="prefilter"):
-    """Roofline object of the exact bit-parallel prefilter: it streams every read byte once per launch
-    (algorithmic bytes = the reads' bytes + one mask word per read) and spends 12.5 VALU ops per
-    (column, <= 32-base adapter piece)."""
-    per_launch_s = ms / 1e3 / launches
-    alg = read_bytes + 4.0 * pairs / launches / max(A, 1)
-    steps_s = read_bytes * A / per_launch_s                 # (column, adapter) updates per second (adapters <= 32 bases: one piece each)
-    peak_steps = VALU_WAVE_INSTR_PER_S * 64 / 12.5
+def prefilter_roofline(timing, mean_len, A, leg="prefilter"):
+    """Roofline object of the exact prefilter.  Its dominant kernel is the seed scan (seed_scan_kernel): every read byte
+    streamed ONCE, whatever the number of adapters, 2 + 4 VALU operations per byte and seed length -- bound by HBM.
+    Algorithmic bytes per launch = the windows' bytes; the duration is that kernel's own timed launches (kind
+    'seed_scan'), small mask-round launches included in the average.  When no adapter can be seeded the exhaustive
+    Myers kernel runs instead (VALU-bound, 12.5 operations per column and adapter piece): then the whole stage is the unit."""
+    sms, slaunches, swindows = timing["seed_scan"]
+    pms, planches, ppairs = timing["prefilter"]
+    if slaunches > 0:
+        per_launch_s = sms / 1e3 / slaunches
+        alg = swindows / slaunches * mean_len
+        return {"bound": "hbm", "kernel": "seed_scan_kernel<NQ> (exact q-gram seeds of all adapters, one pass over the reads)",
+                "achieved": alg / per_launch_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / per_launch_s / 1e9 / HBM_PEAK_GBS,
+                "traffic": profile_traffic(leg, "seed_scan_kernel"), "launches": int(slaunches), "avg_launch_ms": per_launch_s * 1e3,
+                "algorithmic_bytes_per_launch": alg,
+                "whole_stage_ms_per_call": pms / max(1, planches),
+                "note": "the stage also runs seed_verify_kernel over the finds (and the exhaustive Myers kernel for adapters without "
+                        "seeds); whole_stage_ms_per_call includes them and the stage's one host round trip"}
+    if planches <= 0:
+        return None
+    per_launch_s = pms / 1e3 / planches
+    alg = ppairs / planches / max(A, 1) * mean_len
+    steps_s = alg * A / per_launch_s
+    peak_steps = 1024 * 2.4e9 / 2.0 * 64 / 12.5            # plain 32-bit VALU ops: one wave64 instruction per 2 cycles per SIMD
     return {"bound": "valu", "kernel": "prefilter_kernel<P> (Myers bit-vector edit distance, one lane per read chunk, P adapter pieces per lane)",
             "achieved": alg / per_launch_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / per_launch_s / 1e9 / HBM_PEAK_GBS,
-            "traffic": profile_traffic(leg, "prefilter_kernel"), "launches": int(launches), "avg_launch_ms": per_launch_s * 1e3,
+            "traffic": profile_traffic(leg, "prefilter_kernel"), "launches": int(planches), "avg_launch_ms": per_launch_s * 1e3,
             "algorithmic_bytes_per_launch": alg,
             "valu": {"achieved_column_updates_per_s": steps_s, "peak_column_updates_per_s": peak_steps, "frac": steps_s / peak_steps,
                      "ops_per_column_and_adapter": 12.5}}
@@ -737,6 +751,81 @@ def leg_host_buffers(dev, args):
     return out
 
 
+
+def leg_end_to_end(dev, args):
+    """FASTQ file in -> trimmed / split FASTQ file out, through porechop_amd.runner (SURVEY.md 8f-1..3 around the hot
+    path): the configs[3] read set written as a plain FASTQ file, runner.run() on it (the streamed path: a loader thread
+    parses block k+1 with all host cores while block k is scanned and block k-1 is formatted and written), wall clock
+    of the whole call.  Files live on tmpfs when /dev/shm has the room (stated in the result), else under /tmp (page
+    cache).  The streamed run's output must equal the whole-file path's byte for byte."""
+    import filecmp
+    import shutil
+    from porechop_amd import runner
+    from porechop_amd.synth import make_reads
+    n, L = args.reads_e2e, args.read_len
+    need = n * (2 * L + 16) * 2.2
+    base = os.environ.get("PC_BENCH_E2E_DIR")
+    if not base:
+        try:
+            base = "/dev/shm" if shutil.disk_usage("/dev/shm").free > need else "/tmp"
+        except Exception:
+            base = "/tmp"
+    work = os.path.join(base, "porechop_amd_e2e_%d" % os.getpid())
+    os.makedirs(work, exist_ok=True)
+    try:
+        reads = make_reads(n, L, seed=9, start_frac=0.9, end_frac=0.5, chimera_frac=args.chimera, device=dev)
+        seq = reads.arena[: n * L].view(n, L).cpu().numpy()
+        del reads
+        torch.cuda.empty_cache()
+        name_w = 9
+        rec = np.empty((n, 1 + name_w + 1 + L + 3 + L + 1), dtype=np.uint8)
+        rec[:, 0] = ord("@"); rec[:, 1] = ord("r")
+        rec[:, 2:1 + name_w] = np.arange(n)[:, None] // (10 ** np.arange(name_w - 2, -1, -1))[None, :] % 10 + ord("0")
+        c = 1 + name_w
+        rec[:, c] = 10
+        rec[:, c + 1:c + 1 + L] = seq
+        rec[:, c + 1 + L:c + 4 + L] = np.frombuffer(b"\n+\n", dtype=np.uint8)
+        rec[:, c + 4 + L:c + 4 + 2 * L] = ord("5")
+        rec[:, -1] = 10
+        inp = os.path.join(work, "in.fastq")
+        rec.tofile(inp)
+        in_bytes = int(rec.size)
+        del rec, seq
+        runs = []
+        out_s = os.path.join(work, "out_streamed.fastq")
+        for _ in range(2):
+            t0 = time.perf_counter()
+            res = runner.run(inp, output=out_s, device=dev)
+            dt = time.perf_counter() - t0
+            runs.append({"wall_s": dt, "reads_per_s": res.n_reads / dt, "stage_seconds": {k: round(v, 3) for k, v in res.seconds.items()}})
+        out_w = os.path.join(work, "out_whole.fastq")
+        old = os.environ.get("PC_STREAM_BLOCK_BYTES")
+        os.environ["PC_STREAM_BLOCK_BYTES"] = str(1 << 50)          # whole-file path
+        try:
+            t0 = time.perf_counter()
+            res_w = runner.run(inp, output=out_w, device=dev)
+            dt_w = time.perf_counter() - t0
+        finally:
+            if old is None:
+                del os.environ["PC_STREAM_BLOCK_BYTES"]
+            else:
+                os.environ["PC_STREAM_BLOCK_BYTES"] = old
+        same = filecmp.cmp(out_s, out_w, shallow=False)
+        best = max(runs, key=lambda r: r["reads_per_s"])
+        return {"workload": "end to end: %d synthetic %d-bp reads (configs[3] shape) as a %.1f GB plain FASTQ file -> trimmed / split FASTQ "
+                            "(%.1f GB) through porechop_amd.runner.run (streamed: ingest, scan and writing of successive 256 MB blocks overlap)"
+                            % (n, L, in_bytes / 1e9, os.path.getsize(out_s) / 1e9),
+                "files_on": "tmpfs (/dev/shm)" if base == "/dev/shm" else base + " (page cache)",
+                "reads_per_s": best["reads_per_s"], "wall_s": best["wall_s"], "runs": runs,
+                "whole_file_path": {"wall_s": dt_w, "reads_per_s": res_w.n_reads / dt_w,
+                                    "stage_seconds": {k: round(v, 3) for k, v in res_w.seconds.items()}},
+                "streamed_output_identical_to_whole_file_output": bool(same),
+                "matching_sets": res.matching_sets, "reads_with_middle_hits": int(res.middle_hit_reads),
+                "input_gb_per_s": in_bytes / 1e9 / best["wall_s"]}
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+
+
 def leg_ragged(dev, args, workers, uniform_bp_per_s):
     """The headline workload (configs[3] shape: phases A + B + C, 1 % chimeras) on a realistic length
     distribution instead of exactly 8 000 bases per read: log-normal, mean 8 kb, sigma 0.6."""
@@ -789,6 +878,7 @@ def main():
     ap.add_argument("--reads1", type=int, default=100_000, help="reads of the configs[1] leg")
     ap.add_argument("--reads2", type=int, default=1_000_000, help="reads of the configs[2] leg")
     ap.add_argument("--reads4", type=int, default=1_250_000, help="reads per GPU of the configs[4]-shape leg (10 M over 8 GPUs)")
+    ap.add_argument("--reads-e2e", type=int, default=400_000, help="reads of the end-to-end (file -> file) leg")
     ap.add_argument("--repeats", type=int, default=3, help="timed regions of --steps steps (the first one is `value`)")
     ap.add_argument("--read-len", type=int, default=8000)
     ap.add_argument("--chimera", type=float, default=0.01)
@@ -947,13 +1037,12 @@ def main():
               "kernel_ms_per_step": {k: v[0] / fsteps for k, v in timing_pf.items()},
               "pairs_reaching_the_dp_per_step": pl.stats.get("pairs_middle_scanned_after_prefilter", 0) // max(1, fsteps + 1),
               "pairs_prefiltered_per_step": pl.stats.get("pairs_middle_prefiltered", 0) // max(1, fsteps + 1),
-              "note": "not the headline: phase C's round 0 runs Myers' bit-vector edit distance for every (read, adapter) pair "
-                      "(12.5 VALU ops per column instead of 2.5 per adapter row) and the DP only for pairs within "
-                      "max_edits(m, --middle_threshold) edits of a substring; everything else is proven not to be a hit "
-                      "(csrc/pc_prefilter.hip, tests/test_prefilter_bound.py)"}
-        if timing_pf["prefilter"][1] > 0:
-            pf["roofline"] = prefilter_roofline(timing_pf["prefilter"][0], timing_pf["prefilter"][1], timing_pf["prefilter"][2],
-                                                args.reads * mean_trim_len, A)
+              "note": "not the headline: every (read, adapter) pair of the middle scan first goes through the exact prefilter -- a hit "
+                      "needs the adapter within max_edits(m, --middle_threshold) unit-cost edits of a substring of the read; that is "
+                      "decided exactly by one HBM-bound pass that finds the exact q-gram seeds such an occurrence must contain, Myers' "
+                      "bit-vector edit distance on the finds -- and only the surviving pairs run the DP; everything else is proven "
+                      "not to be a hit (csrc/pc_prefilter.hip, tests/test_prefilter_bound.py, tests/test_gpu_prefilter.py)"}
+        pf["roofline"] = prefilter_roofline(timing_pf, mean_trim_len, A)
         out = {
             "metric": "reads/sec (and read-bp/sec) end+middle adapter scan, 8 kb reads",
             "value": reads_per_s, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -1019,7 +1108,8 @@ def main():
             legs = (("configs1", lambda: leg_configs1(dev, args, host_cores())),
                     ("configs2", lambda: leg_configs2(dev, args, host_cores())),
                     ("ragged_lengths", lambda: leg_ragged(dev, args, host_cores(), out["read_bp_per_s"])),
-                    ("from_host_memory", lambda: leg_host_buffers(dev, args)))
+                    ("from_host_memory", lambda: leg_host_buffers(dev, args)),
+                    ("end_to_end", lambda: leg_end_to_end(dev, args)))
             for name, leg in legs:
                 note("leg " + name)
                 try:

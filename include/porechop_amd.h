@@ -136,10 +136,11 @@ int pc_sync(pc_ctx *ctx, void *stream);
 /* Kernel timing hooks (bench.py roofline leg): when enabled, every kernel launch made by
  * pc_scan_device is bracketed by HIP events on the launch stream.  pc_get_timing waits for the
  * stream, then returns per kernel kind (0 = generic score-only scan, 1 = window planner, 2 = traced
- * scan, 3 = run-time specialised score-only scan, 4 = bit-parallel prefilter) the summed duration in milliseconds, the number
+ * scan, 3 = run-time specialised score-only scan, 4 = exact prefilter: all its launches and its one host round trip,
+ * 5 = the prefilter's seed scan alone, a sub-interval of 4 whose "pairs" are windows) the summed duration in milliseconds, the number
  * of launches and the number of pairs they covered, and resets the accumulators.  Each array
  * holds PC_KERNEL_KINDS entries. */
-#define PC_KERNEL_KINDS 5
+#define PC_KERNEL_KINDS 6
 int pc_set_timing(pc_ctx *ctx, int enabled);
 int pc_get_timing(pc_ctx *ctx, void *stream, double *ms, int64_t *launches, int64_t *pairs);
 

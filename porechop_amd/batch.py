@@ -44,6 +44,7 @@ def records_to_fields(recs):
 
 class Aligner:
     """One GPU context: a scoring scheme + an adapter panel + scratch buffers."""
+    fast_prefilter = True      # prefilter_rows is the device's exact prefilter (callers may put it in front of the middle scan)
 
     def __init__(self, adapters, scores=DEFAULT_SCORES, device=-1):
         self.lib = load_library()
@@ -136,14 +137,15 @@ class Aligner:
     def get_timing(self, stream=None):
         """-> dict kind -> (ms, launches, pairs) since the last call, for the kinds 'score' (generic
         score-only scan), 'plan', 'trace', 'score_spec' (run-time specialised score-only scan) and 'prefilter'
-        (bit-parallel prefilter; its "pairs" are (window, adapter) pairs)."""
+        (exact prefilter, all launches of a call as one region; its "pairs" are (window, adapter) pairs) and 'seed_scan' (the
+        prefilter's seed scan alone: a sub-interval of 'prefilter'; its "pairs" are windows)."""
         import torch
         s = stream if stream is not None else torch.cuda.current_stream().cuda_stream
-        ms = (ctypes.c_double * 5)()
-        ln = (ctypes.c_int64 * 5)()
-        pr = (ctypes.c_int64 * 5)()
+        ms = (ctypes.c_double * 6)()
+        ln = (ctypes.c_int64 * 6)()
+        pr = (ctypes.c_int64 * 6)()
         check(self.lib.pc_get_timing(self._ctx, ctypes.c_void_p(s), ms, ln, pr), "pc_get_timing")
-        return {k: (ms[i], ln[i], pr[i]) for i, k in enumerate(("score", "plan", "trace", "score_spec", "prefilter"))}
+        return {k: (ms[i], ln[i], pr[i]) for i, k in enumerate(("score", "plan", "trace", "score_spec", "prefilter", "seed_scan"))}
 
     def phase_b_reduce(self, records, n, job_record_offset, job_side, end_size, min_trim_size, extra_end_trim,
                        end_threshold, start_trim, end_trim, bins=None, barcode_threshold=0.0, barcode_diff=0.0,
@@ -185,25 +187,44 @@ class Aligner:
         its full-adapter identity reaches threshold_percent (pc_prefilter_max_edits)."""
         return int(self.lib.pc_prefilter_max_edits(int(adapter_len), float(threshold_percent)))
 
-    def prefilter(self, arena, win_off, win_len, max_len, adapters, max_edits, stream=None):
-        """Exact bit-parallel prefilter (pc_prefilter_device): -> bool CUDA tensor [len(adapters), n]; False = window w
-        is PROVEN not to hold adapters[j] within max_edits[j] edits (so that alignment cannot reach the identity
-        threshold the bound was derived from)."""
+    def prefilter_mask(self, arena, win_off, win_len, max_len, adapters, max_edits, stream=None):
+        """Exact prefilter (pc_prefilter_device) -> int32 CUDA tensor [n, ceil(len(adapters) / 32)]: bit j % 32 of word
+        j // 32 of row w is clear when window w is PROVEN not to hold adapters[j] within max_edits[j] edits."""
         import torch
         assert arena.is_cuda and win_off.is_cuda and win_len.is_cuda
         assert win_off.dtype == torch.int64 and win_len.dtype == torch.int32 and win_off.is_contiguous() and win_len.is_contiguous()
         n, na = int(win_off.shape[0]), len(adapters)
         words = (na + 31) // 32
         mask = torch.empty((n, max(words, 1)), dtype=torch.int32, device=arena.device)
+        if na == 0:
+            return mask.zero_()
         ad = np.ascontiguousarray(adapters, dtype=np.int32)
         ed = np.ascontiguousarray(max_edits, dtype=np.int32)
         s = stream if stream is not None else torch.cuda.current_stream().cuda_stream
         check(self.lib.pc_prefilter_device(self._ctx, arena.data_ptr(), win_off.data_ptr(), win_len.data_ptr(), n, int(max_len),
                                            ad.ctypes.data, ed.ctypes.data, na, mask.data_ptr(), ctypes.c_void_p(s)),
               "pc_prefilter_device")
-        bits = torch.arange(32, device=arena.device, dtype=torch.int32)
-        out = ((mask[:, :, None] >> bits[None, None, :]) & 1).reshape(n, -1)[:, :na]
-        return out.t().to(torch.bool)
+        return mask
+
+    def prefilter_rows(self, arena, win_off, win_len, max_len, adapters, max_edits, stream=None):
+        """The prefilter's survivors, sparsely: -> (rows int64 [R]: the windows with at least one surviving adapter, in
+        increasing order; bits bool [R, len(adapters)]: which).  Everything not listed is PROVEN not to be a hit."""
+        import torch
+        mask = self.prefilter_mask(arena, win_off, win_len, max_len, adapters, max_edits, stream)
+        na = len(adapters)
+        rows = torch.nonzero((mask != 0).any(dim=1)).flatten()
+        sub = mask[rows]
+        shifts = torch.arange(32, device=mask.device, dtype=torch.int32)
+        bits = ((sub[:, :, None] >> shifts[None, None, :]) & 1).reshape(int(rows.shape[0]), 32 * int(mask.shape[1]))[:, :na].to(torch.bool)
+        return rows, bits
+
+    def prefilter(self, arena, win_off, win_len, max_len, adapters, max_edits, stream=None):
+        """Dense form of prefilter_rows: bool CUDA tensor [len(adapters), n] (small batches, tests)."""
+        import torch
+        rows, bits = self.prefilter_rows(arena, win_off, win_len, max_len, adapters, max_edits, stream)
+        out = torch.zeros((len(adapters), int(win_off.shape[0])), dtype=torch.bool, device=arena.device)
+        out[:, rows] = bits.t()
+        return out
 
     def debug_value_range(self):
         """(lo, hi) of the DP values the range-checking kernel builds have held since the last call."""

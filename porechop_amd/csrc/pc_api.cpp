@@ -1236,7 +1236,10 @@ int pc_prefilter_device(pc_ctx *c, const void *d_arena, const int64_t *d_win_off
     for (int t = 0; t < 3; ++t) sa.q[t] = c->sd_q[t];
     sa.bitmaps = c->d_sd_bitmaps.as<uint32_t>();
     sa.cand = c->d_sd_cand.as<uint32_t>(); sa.count = c->d_sd_count.as<unsigned long long>(); sa.cap = cap;
-    if (pck::launch_seed_scan(sa, stream)) return PC_ERR_NO_DEVICE;
+    {
+        ScopedTimer ts(c, stream, 5, nwindows);     // the scan alone (pairs = windows)
+        if (pck::launch_seed_scan(sa, stream)) return PC_ERR_NO_DEVICE;
+    }
     if ((rc = exhaustive(c->pf_rest_launches))) return rc;          // independent of the candidate count
     HIP_TRY(hipMemcpyAsync(c->h_sd_count, c->d_sd_count.p, 8, hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));                          // the one host round trip of the stage

@@ -40,9 +40,9 @@ namespace pck {
 
 namespace {
 
-// read bytes are consumed as delivered: a window starts at any byte (the hardware handles unaligned vector loads)
+// read bytes are consumed as delivered: a window starts at any byte; the kernels fetch the aligned 16-byte blocks around it
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-typedef u32x4 u32x4_unaligned __attribute__((aligned(1)));
+typedef uint32_t u32_unaligned __attribute__((aligned(1)));
 
 __device__ __forceinline__ int wave_min(int v)
 {
@@ -119,7 +119,10 @@ __global__ __launch_bounds__(256) void prefilter_kernel(PrefilterArgs a)
     const int64_t wblocks = (a.nwindows + 255) / 256;
     const int chunk = (int)(blockIdx.x / wblocks);
     const int64_t w = (int64_t)(blockIdx.x % wblocks) * 256 + threadIdx.x;
-    int n = 0;
+    // Columns are fetched as ALIGNED 16-byte blocks (an unaligned vector load is split by the memory pipeline): a lane
+    // starts `skip` bytes before its chunk, at the 16-byte boundary below it, and sits those columns out.  Below,
+    // columns are counted from that boundary: the chunk is [skip, n).
+    int n = 0, skip = 0;
     const uint8_t *p = a.arena;
     if (w < a.nwindows) {
         const int len = a.win_len[w];
@@ -127,14 +130,17 @@ __global__ __launch_bounds__(256) void prefilter_kernel(PrefilterArgs a)
         if (c0 < len) {
             const int start = c0 > a.warm ? c0 - a.warm : 0;
             const int end = (c0 + a.chunk_len < len) ? c0 + a.chunk_len : len;
-            n = end - start;
             p = a.arena + a.win_off[w] + start;
+            skip = (int)((uintptr_t)p & 15u);
+            p -= skip;
+            n = end - start + skip;
         }
     }
     const int nmax = __builtin_amdgcn_readfirstlane(wave_max(n));
     if (nmax == 0) return;
     // shortest chunk among the lanes that have one (lanes past the end of their read sit the whole launch out)
     const int nmin = __builtin_amdgcn_readfirstlane(wave_min(n > 0 ? n : 0x7FFFFFFF));
+    const int any_skip = __builtin_amdgcn_readfirstlane(wave_max(skip));
     if (n <= 0) return;
 
     uint32_t pv[P], mv[P], sc[P], mn[P];
@@ -148,13 +154,34 @@ __global__ __launch_bounds__(256) void prefilter_kernel(PrefilterArgs a)
         mn[i] = m == 0 ? 0x7FFFFFFFu : (uint32_t)m;
     }
 
+    // ---- first block, when some lane has columns to sit out in it: column by column ------------------------------
+    auto masked_block = [&](int j0) {
+        if (j0 < n) {
+            const u32x4 blk = *(const u32x4 *)(p + j0);
+            const uint32_t wd[4] = {blk.x, blk.y, blk.z, blk.w};
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                if (j0 + c >= skip && j0 + c < n) {
+                    uint32_t e[P];
+                    load_row<P>(tab, (wd[c >> 2] >> (8 * (c & 3))) & 0xFFu, e);
+#pragma unroll
+                    for (int i = 0; i < P; ++i) {
+                        sc[i] = myers_step(e[i], pv[i], mv[i], sc[i]);
+                        mn[i] = sc[i] < mn[i] ? sc[i] : mn[i];
+                    }
+                }
+            }
+        }
+    };
+    const int first = any_skip ? 16 : 0;
+    if (any_skip) masked_block(0);
     // ---- 16-column blocks every active lane of the wave has: no masking, next block's bytes in flight ----------
     const int full = nmin & ~15;
     u32x4 cur = {0, 0, 0, 0};
-    if (full > 0) cur = *(const u32x4_unaligned *)p;
-    for (int j0 = 0; j0 < full; j0 += 16) {
+    if (full > first) cur = *(const u32x4 *)(p + first);
+    for (int j0 = first; j0 < full; j0 += 16) {
         u32x4 nxt = cur;
-        if (j0 + 16 < full) nxt = *(const u32x4_unaligned *)(p + j0 + 16);
+        if (j0 + 16 < full) nxt = *(const u32x4 *)(p + j0 + 16);
         const uint32_t wd[4] = {cur.x, cur.y, cur.z, cur.w};
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -177,24 +204,7 @@ __global__ __launch_bounds__(256) void prefilter_kernel(PrefilterArgs a)
     }
     // ---- the rest (chunks of unequal length in one wave, the last < 16 columns): lanes sit out column by column.
     // A lane's last block may read up to 15 bytes past its window: the arena is readable 16 bytes past its end.
-    for (int j0 = full; j0 < nmax; j0 += 16) {
-        if (j0 < n) {
-            const u32x4 blk = *(const u32x4_unaligned *)(p + j0);
-            const uint32_t wd[4] = {blk.x, blk.y, blk.z, blk.w};
-#pragma unroll
-            for (int c = 0; c < 16; ++c) {
-                if (j0 + c < n) {
-                    uint32_t e[P];
-                    load_row<P>(tab, (wd[c >> 2] >> (8 * (c & 3))) & 0xFFu, e);
-#pragma unroll
-                    for (int i = 0; i < P; ++i) {
-                        sc[i] = myers_step(e[i], pv[i], mv[i], sc[i]);
-                        mn[i] = sc[i] < mn[i] ? sc[i] : mn[i];
-                    }
-                }
-            }
-        }
-    }
+    for (int j0 = full > first ? full : first; j0 < nmax; j0 += 16) masked_block(j0);
 #pragma unroll
     for (int i = 0; i < P; ++i) {
         const int m = meta[i * 4 + 0], k = meta[i * 4 + 1];
@@ -221,11 +231,34 @@ __global__ __launch_bounds__(256) void prefilter_kernel(PrefilterArgs a)
 // Bitmap slots in LDS (words): the seed lengths are handed over longest first, so slot c always fits 4^q[c] bits
 constexpr int kBmOff0 = 0, kBmOff1 = (1 << 16) / 32, kBmOff2 = kBmOff1 + (1 << 14) / 32, kBmWords = kBmOff2 + (1 << 12) / 32;
 
+constexpr int kWaveBuf = 512;                        // finds a wave can keep in LDS; it flushes them from half that on
+
+__device__ __forceinline__ void flush_wave(const SeedScanArgs &a, int *wcnt, uint2 (*wbuf)[kWaveBuf], int wv, int lane)
+{
+    int n = wcnt[wv];
+    n = n < kWaveBuf ? n : kWaveBuf;
+    n = __builtin_amdgcn_readfirstlane(n);
+    if (n <= 0) return;
+    unsigned long long base = 0;
+    if (lane == __builtin_amdgcn_readfirstlane(lane)) base = atomicAdd(a.count, (unsigned long long)n);
+    const uint32_t blo = __builtin_amdgcn_readfirstlane((uint32_t)base), bhi = __builtin_amdgcn_readfirstlane((uint32_t)(base >> 32));
+    base = ((unsigned long long)bhi << 32) | blo;
+    for (int i = lane; i < n; i += 64)
+        if (base + i < (unsigned long long)a.cap) ((uint2 *)a.cand)[base + i] = wbuf[wv][i];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if (lane == __builtin_amdgcn_readfirstlane(lane)) wcnt[wv] = 0;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+}
+
 template <int NQ>
 __global__ __launch_bounds__(256) void seed_scan_kernel(SeedScanArgs a)
 {
     __shared__ uint32_t lut[256];                    // byte -> 2-bit code (anything that is not a base: 0, see below)
     __shared__ uint32_t bm[kBmWords];
+    __shared__ int wcnt[4];
+    __shared__ uint2 wbuf[4][kWaveBuf];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (threadIdx.x < 4) wcnt[threadIdx.x] = 0;
     for (int i = threadIdx.x; i < 256; i += 256) {
         uint32_t v = 0;
         switch (i) {
@@ -249,58 +282,89 @@ __global__ __launch_bounds__(256) void seed_scan_kernel(SeedScanArgs a)
         if (c0 < len) {
             start = c0 > a.warm ? c0 - a.warm : 0;
             const int end = (c0 + a.chunk_len < len) ? c0 + a.chunk_len : len;
-            n = end - start;
             p = a.arena + a.win_off[w] + start;
+            // Whole aligned 128-byte LINES: start at the line boundary below the chunk.  The extra bytes are scanned like
+            // any others (they can only add finds, and a find is kept only where its q-gram lies inside window and chunk).
+            const int skip = (int)((uintptr_t)p & 127u);
+            p -= skip; start -= skip;
+            n = end - start;
         }
     }
-    if (n <= 0) return;
+    // (lanes without a chunk stay: the wave's last flush below is wave-wide)
     // A byte that is not a base is scanned as 'A': that can only ADD candidates (the verifier looks at the real bytes
     // and drops them); a true seed occurrence consists of bases and is always found.  Likewise the register starts as
     // "AAAAAAAA" and the warm-up columns before a chunk may re-find the previous chunk's last seeds.
     const int qb[3] = {2 * a.q[0], 2 * a.q[1], 2 * a.q[2]};
     constexpr int boff[3] = {kBmOff0, kBmOff1, kBmOff2};
     uint32_t x = 0;
-    const int nblocks = (n + 15) >> 4;
-    u32x4 cur = *(const u32x4_unaligned *)p, nxt = cur;
-    if (nblocks > 1) nxt = *(const u32x4_unaligned *)(p + 16);
-    for (int b = 0; b < nblocks; ++b) {
-        u32x4 nn = nxt;
-        if (b + 2 < nblocks) nn = *(const u32x4_unaligned *)(p + 16 * (b + 2));     // two blocks ahead
-        const uint32_t wd[4] = {cur.x, cur.y, cur.z, cur.w};
-        uint32_t hb[NQ];                             // per seed length: bit 15 - t = a seed ends at column t of this block
+    // A lane takes its stream a whole cache line (128 columns) at a time, the next line in flight meanwhile.  Sixteen
+    // bytes per visit -- eight visits per line, microseconds apart, by two thousand lanes per CU -- made every visit
+    // after the first an L2 miss served by the Infinity Cache: 8x the traffic behind the L2 and 0.85 TB/s of useful
+    // bytes; with one visit per line the L2 sees each line once.
+    const int nlines = (n + 127) >> 7;               // 0 for a lane without a chunk
+    const int nl_wave = __builtin_amdgcn_readfirstlane(wave_max(nlines));
+    u32x4 r[8], nx[8];
 #pragma unroll
-        for (int c = 0; c < NQ; ++c) hb[c] = 0;
+    for (int i = 0; i < 8; ++i) { r[i] = u32x4{0, 0, 0, 0}; if (nlines > 0) r[i] = *(const u32x4 *)(p + 16 * i); }
+    for (int L = 0; L < nl_wave; ++L) {
 #pragma unroll
-        for (int t = 0; t < 16; ++t) {
-            x = (x << 2) | lut[(wd[t >> 2] >> (8 * (t & 3))) & 0xFFu];
+        for (int i = 0; i < 8; ++i) { nx[i] = r[i]; if (L + 1 < nlines) nx[i] = *(const u32x4 *)(p + 128 * (L + 1) + 16 * i); }
+        uint32_t hb[NQ][8];                          // per seed length and 16-column block: bit 15 - t = a seed ends at column t
+        uint32_t any = 0;
 #pragma unroll
-            for (int c = 0; c < NQ; ++c) {
-                const uint32_t word = bm[boff[c] + __builtin_amdgcn_ubfe(x, 5, qb[c] - 5)];
-                hb[c] = (hb[c] << 1) | __builtin_amdgcn_ubfe(word, x & 31u, 1);
+        for (int blk = 0; blk < 8; ++blk) {
+            const uint32_t wd[4] = {r[blk].x, r[blk].y, r[blk].z, r[blk].w};
+#pragma unroll
+            for (int c = 0; c < NQ; ++c) hb[c][blk] = 0;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                x = (x << 2) | lut[(wd[t >> 2] >> (8 * (t & 3))) & 0xFFu];
+#pragma unroll
+                for (int c = 0; c < NQ; ++c) {
+                    const uint32_t word = bm[boff[c] + __builtin_amdgcn_ubfe(x, 5, qb[c] - 5)];
+                    hb[c][blk] = (hb[c][blk] << 1) | __builtin_amdgcn_ubfe(word, x & 31u, 1);
+                }
             }
+#pragma unroll
+            for (int c = 0; c < NQ; ++c) any |= hb[c][blk];
         }
-        uint32_t any = hb[0];
+        if (any && L < nlines) {                     // a few lines per hundred per lane
+            const int left = n - 128 * L;            // columns of this line that belong to the chunk
+#pragma unroll 1
+            for (int cb = 0; cb < NQ * 8; ++cb) {
+                const int c = cb >> 3, blk = cb & 7;
+                uint32_t h = 0;
 #pragma unroll
-        for (int c = 1; c < NQ; ++c) any |= hb[c];
-        if (any) {                                   // a few blocks per thousand per lane
-            const int left = n - 16 * b;             // columns of this block that belong to the chunk
+                for (int cc = 0; cc < NQ; ++cc)
 #pragma unroll
-            for (int c = 0; c < NQ; ++c) {
-                uint32_t h = hb[c];
+                    for (int bb = 0; bb < 8; ++bb) h = (cc == c && bb == blk) ? hb[cc][bb] : h;
                 while (h) {
                     const int t = 15 - (31 - __builtin_clz(h));
                     h &= ~(1u << (15 - t));
-                    const int j = start + 16 * b + t;            // window coordinate of the seed's last base
-                    if (t < left && j >= c0 && j >= a.q[c] - 1) {  // (warm-up columns belong to the previous chunk)
-                        const unsigned long long slot = atomicAdd(a.count, 1ull);
-                        if (slot < (unsigned long long)a.cap)
-                            ((uint2 *)a.cand)[slot] = make_uint2((uint32_t)w, (uint32_t)j | ((uint32_t)c << 28));
+                    const int col = 16 * blk + t;
+                    const int j = start + 128 * L + col;           // window coordinate of the seed's last base
+                    if (col < left && j >= c0 && j >= a.q[c] - 1) {  // (warm-up columns belong to the previous chunk)
+                        const uint2 cd = make_uint2((uint32_t)w, (uint32_t)j | ((uint32_t)c << 28));
+                        const int slot = atomicAdd(&wcnt[wv], 1);  // the wave's own buffer in LDS
+                        if (slot < kWaveBuf) {
+                            wbuf[wv][slot] = cd;
+                        } else {                                   // (more than the buffer holds: straight to the list)
+                            const unsigned long long g = atomicAdd(a.count, 1ull);
+                            if (g < (unsigned long long)a.cap) ((uint2 *)a.cand)[g] = cd;
+                        }
                     }
                 }
             }
         }
-        cur = nxt; nxt = nn;
+        // The finds of a wave are handed to the global list 64 and more at a time: ONE atomic on the list's counter per
+        // flush.  (One atomic per find -- seven million of them on one address -- took 50 ms; the scan itself takes 2.)
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        if (wcnt[wv] >= kWaveBuf / 2) flush_wave(a, wcnt, wbuf, wv, lane);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) r[i] = nx[i];
     }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    flush_wave(a, wcnt, wbuf, wv, lane);
 }
 
 // One lane per candidate: every piece that has the seed (class c, q-gram value) at some offset is verified over the read
@@ -353,9 +417,19 @@ __global__ __launch_bounds__(256) void seed_verify_kernel(SeedVerifyArgs a)
         lo = lo < 0 ? 0 : lo; hi = hi > n ? n : hi;
         uint32_t pv = len >= 32 ? 0xFFFFFFFFu : ~(0xFFFFFFFFu >> len), mv = 0, sc = (uint32_t)len, mn = (uint32_t)len;
         const uint32_t *eqp = eq_tab + pi * 8;
-        for (int col = lo; col < hi; ++col) {
-            sc = myers_step(eqp[code_of[rd[col]]], pv, mv, sc);
-            mn = sc < mn ? sc : mn;
+        // sixteen columns per fetch (four dwords at any alignment; up to 15 bytes past the window are readable): one
+        // memory round trip per sixteen columns instead of one per column
+        for (int base = lo; base < hi; base += 16) {
+            uint32_t wd[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) wd[i] = *(const u32_unaligned *)(rd + base + 4 * i);
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                if (base + t < hi) {
+                    sc = myers_step(eqp[code_of[(wd[t >> 2] >> (8 * (t & 3))) & 0xFFu]], pv, mv, sc);
+                    mn = sc < mn ? sc : mn;
+                }
+            }
         }
         if ((int)mn <= k) atomicOr(mrow + pm.z, (uint32_t)pm.w);
     }

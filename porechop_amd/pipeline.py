@@ -476,51 +476,53 @@ class Pipeline:
 
     def _prefiltered_scan(self, arena, off, length, max_len, a_list, aidx, hint, ks, ragged, typ_len):
         """Whole-read records of the adapters a_list (positions in the middle-adapter list) against the n windows
-        (off, length), computed only where the exact prefilter cannot exclude a hit: [len(a_list), n, 8] int32, all-zero
-        records (not hits) for the proven pairs.  The windows that survive for one of a set's sequences are scanned for
+        (off, length), computed only where the exact prefilter cannot exclude a hit.  SPARSE result
+        -> (b [C] int64: position in a_list, w [C] int64: window, rec [C, 8] int32); every (adapter, window) pair that
+        is not listed is proven not to be a hit.  The windows that survive for one of a set's sequences are scanned for
         all of that set's sequences in one pass (the set's ahead-of-time kernel)."""
         dev = self.device
         n, B = int(off.shape[0]), len(a_list)
-        recs = torch.zeros((B, n, RESULT_INTS), dtype=torch.int32, device=dev)
+        e64 = torch.empty(0, dtype=torch.int64, device=dev)
+        empty = (e64, e64, torch.empty((0, RESULT_INTS), dtype=torch.int32, device=dev))
         if n == 0 or B == 0:
-            return recs
+            return empty
         order = None
         pf_off, pf_len = off.contiguous(), length.contiguous()
         if ragged:                                       # a wave runs 64 consecutive windows: similar lengths together
             order = torch.argsort(length, descending=True, stable=True)
             pf_off, pf_len = off[order].contiguous(), length[order].contiguous()
         self.aligner.set_length_hint(typ_len if ragged else 0)
-        cand = self.aligner.prefilter(arena, pf_off, pf_len, max_len, [aidx[a] for a in a_list], [ks[a] for a in a_list])   # [B, n] bool
+        rows, bits = self.aligner.prefilter_rows(arena, pf_off, pf_len, max_len, [aidx[a] for a in a_list], [ks[a] for a in a_list])
         if order is not None:
-            back = torch.empty_like(cand)
-            back[:, order] = cand
-            cand = back
+            rows = order[rows]
+        self.stats["pairs_middle_prefiltered"] = self.stats.get("pairs_middle_prefiltered", 0) + B * n
         groups, gidx = {}, []
         for a in a_list:
             gidx.append(groups.setdefault(hint[a], len(groups)))
         G = len(groups)
         if G == B:
-            cand_g = cand
-        else:
-            cand_g = torch.zeros((G, n), dtype=torch.int32, device=dev).index_add_(0, torch.tensor(gidx, device=dev), cand.to(torch.int32)) > 0
-        hitg = torch.nonzero(cand_g)                                  # [C, 2] (group, window), group-major
+            cand_g = bits
+        else:                                            # union over the sequences of a set
+            cand_g = torch.zeros((int(rows.shape[0]), G), dtype=torch.int32, device=dev).index_add_(
+                1, torch.tensor(gidx, device=dev), bits.to(torch.int32)) > 0
+        hitg = torch.nonzero(cand_g.t())                              # [C, 2] (group, row), group-major
         counts = torch.bincount(hitg[:, 0], minlength=G).cpu().numpy()     # the one synchronisation of this stage
-        cjobs, csel, pos = [], [], 0
+        cjobs, cmeta, pos = [], [], 0
         members = [[b for b in range(B) if gidx[b] == g] for g in range(G)]
         for g in range(G):
             if counts[g]:
-                sel = hitg[pos:pos + int(counts[g]), 1]
+                sel = rows[hitg[pos:pos + int(counts[g]), 1]]
                 pos += int(counts[g])
                 so, sl = off[sel], length[sel]
                 for b in members[g]:
-                    cjobs.append((aidx[a_list[b]], so, sl, hint[a_list[b]])); csel.append((b, sel))
-        if cjobs:
-            for (b, sel), o in zip(csel, self._scan_jobs(arena, cjobs, MODE_TWO_PASS, max_len, sort_lengths=ragged, typ_len=typ_len)):
-                recs[b, sel] = o
-        self.stats["pairs_middle_prefiltered"] = self.stats.get("pairs_middle_prefiltered", 0) + B * n
+                    cjobs.append((aidx[a_list[b]], so, sl, hint[a_list[b]])); cmeta.append((b, sel))
+        if not cjobs:
+            return empty
+        outs = self._scan_jobs(arena, cjobs, MODE_TWO_PASS, max_len, sort_lengths=ragged, typ_len=typ_len)
         self.stats["pairs_middle_scanned_after_prefilter"] = self.stats.get("pairs_middle_scanned_after_prefilter", 0) + \
             sum(int(j[1].shape[0]) for j in cjobs)
-        return recs
+        sb = torch.cat([torch.full((int(sel.shape[0]),), b, dtype=torch.int64, device=dev) for b, sel in cmeta])
+        return sb, torch.cat([sel for _, sel in cmeta]), torch.cat(outs)
 
     def phase_c(self, reads: DeviceReads, start_trim, end_trim, matching: List[int], prove: bool = False,
                 prefilter: bool = False) -> MiddleHits:
@@ -580,11 +582,10 @@ class Pipeline:
         # ---- round 0: all adapters x all reads, unmasked -------------------------------------
         jobs0 = [(ai, loff, llen, h) for ai, h in zip(aidx, hint)]
         bounds = [self.identity_score_bound(len(self.seqs[ai]), p.middle_threshold) for ai in aidx] if prove else None
+        sparse0 = None
         if prefilter:
             ks = [self.aligner.max_edits(len(self.seqs[ai]), p.middle_threshold) for ai in aidx]
-            recs = self._prefiltered_scan(reads.arena, loff, llen, max_len, list(range(A)), aidx, hint, ks, ragged, typ_len)
-            outs = [recs[a] for a in range(A)]
-            fulls = torch.stack([torch.nan_to_num(identity_of(rec), nan=0.0) for rec in outs])
+            sparse0 = self._prefiltered_scan(reads.arena, loff, llen, max_len, list(range(A)), aidx, hint, ks, ragged, typ_len)
         elif prove and all(b is not None for b in bounds):
             score = torch.stack(self._scan_jobs(reads.arena, jobs0, MODE_SCORE, max_len, sort_lengths=ragged, typ_len=typ_len))[:, :, 4]      # [A, L]
             cand = torch.nonzero(score >= torch.tensor(bounds, device=dev)[:, None])                     # adapter-major
@@ -607,16 +608,31 @@ class Pipeline:
         else:
             outs = self._scan_jobs(reads.arena, jobs0, MODE_TWO_PASS, max_len, sort_lengths=ragged, typ_len=typ_len)
             fulls = torch.stack([identity_of(rec) for rec in outs])  # [A, L]
-        hit0 = (fulls >= p.middle_threshold) & torch.stack([rec[:, 0] != -1 for rec in outs])
-        d_sel = torch.nonzero(hit0.any(dim=0)).flatten()             # dirty reads (indices into live)
+        if sparse0 is not None:
+            sa, sw, sr = sparse0                                     # every pair not listed is proven not to be a hit
+            full_s = torch.nan_to_num(identity_of(sr), nan=0.0)
+            hit_s = (full_s >= p.middle_threshold) & (sr[:, 0] != -1)
+            d_sel = torch.unique(sw[hit_s])                          # dirty reads (indices into live), increasing
+        else:
+            hit0 = (fulls >= p.middle_threshold) & torch.stack([rec[:, 0] != -1 for rec in outs])
+            d_sel = torch.nonzero(hit0.any(dim=0)).flatten()         # dirty reads (indices into live)
         Dn = int(d_sel.numel())
         n_align = A * int(live.numel())                              # alignments the reference performs
         n_spec = 0                                                   # speculative ones, discarded
         rounds = 0
         H_read, H_ad, H_s, H_e, H_id = [], [], [], [], []
         if Dn > 0:
-            rec_all = torch.stack([o[d_sel] for o in outs])          # [A, Dn, 8] for the current masked state
-            full_all = fulls[:, d_sel]
+            if sparse0 is not None:                                  # [A, Dn, 8] from the sparse records of the dirty reads
+                where = torch.full((int(live.numel()),), -1, dtype=torch.int64, device=dev)
+                where[d_sel] = torch.arange(Dn, device=dev)
+                keep = where[sw] >= 0
+                rec_all = torch.zeros((A, Dn, RESULT_INTS), dtype=torch.int32, device=dev)
+                full_all = torch.zeros((A, Dn), dtype=torch.float64, device=dev)
+                rec_all[sa[keep], where[sw[keep]]] = sr[keep]
+                full_all[sa[keep], where[sw[keep]]] = full_s[keep]
+            else:
+                rec_all = torch.stack([o[d_sel] for o in outs])      # [A, Dn, 8] for the current masked state
+                full_all = fulls[:, d_sel]
             # private, maskable copies of the dirty reads, back to back whatever their lengths (each padded
             # with N to a multiple of 16 bytes plus slack: the kernels read whole dwords)
             dlen = llen[d_sel].contiguous()
@@ -670,7 +686,9 @@ class Pipeline:
                 a0 = int(ah.min().item())
                 o_act, l_act = d_off[act], dlen[act]
                 if prefilter:                                        # the masked reads go through the same proof first
-                    outs_r = self._prefiltered_scan(dirty, o_act, l_act, dmax, list(range(a0, A)), aidx, hint, ks, ragged, dtyp)
+                    rb, rw, rr = self._prefiltered_scan(dirty, o_act, l_act, dmax, list(range(a0, A)), aidx, hint, ks, ragged, dtyp)
+                    outs_r = torch.zeros((A - a0, int(act.numel()), RESULT_INTS), dtype=torch.int32, device=dev)
+                    outs_r[rb, rw] = rr
                 else:
                     outs_r = self._scan_jobs(dirty, [(aidx[a], o_act, l_act, hint[a]) for a in range(a0, A)], MODE_TWO_PASS, dmax,
                                              sort_lengths=ragged, typ_len=dtyp)

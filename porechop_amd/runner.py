@@ -266,7 +266,10 @@ def _scan_reads(pl, reads, R, match_idx, opts, barcode_dir, orientation, lap=lam
                 st_b, et_b = pl.phase_b(sub, match_idx)
             lap("phase_b", sync=True)
             if not opts.no_split:
-                hb = pl.phase_c(sub, st_b, et_b, match_idx, prove=True)   # identical hits, fewer tracebacks
+                # identical hits either way: behind the exact prefilter on the GPU library (most pairs never reach the
+                # DP), behind the score bound with an injected test aligner
+                fast = getattr(pl.aligner, "fast_prefilter", False)
+                hb = pl.phase_c(sub, st_b, et_b, match_idx, prove=not fast, prefilter=fast)
                 if hb.read.numel():
                     hb.read = hb.read + b0
                     hit_parts.append(hb)

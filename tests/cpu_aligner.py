@@ -92,6 +92,11 @@ class OracleAligner:
             rows.append(torch.from_numpy(ok))
         return torch.stack(rows) if rows else torch.zeros((0, wo.shape[0]), dtype=torch.bool)
 
+    def prefilter_rows(self, arena, win_off, win_len, max_len, adapters, max_edits, stream=None):
+        dense = self.prefilter(arena, win_off, win_len, max_len, adapters, max_edits)
+        rows = torch.nonzero(dense.any(dim=0)).flatten()
+        return rows, dense[:, rows].t().contiguous()
+
     def sync(self, stream=None):
         pass
 

@@ -19,7 +19,7 @@ src = os.path.join("gpurun_out", "prof_" + tag)
 
 
 def family(name):
-    m = re.search(r"(pc_spec_score|trace16_kernel|scan_kernel<[^,>]*,[^,>]*, *(?:true|false)>|scan_kernel|prefilter_kernel|plan_kernel|reduce_kernel|"
+    m = re.search(r"(pc_spec_score|trace16_kernel|seed_scan_kernel|seed_verify_kernel|(?<![a-z_])scan_kernel<[^,>]*,[^,>]*, *(?:true|false)>|(?<![a-z_])scan_kernel|prefilter_kernel|plan_kernel|reduce_kernel|"
                   r"expand_tiles_kernel|copy_windows_kernel)", name)
     if not m:
         return None

@@ -23,6 +23,7 @@
 #include <sched.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
+#include <sys/statvfs.h>
 #include <unistd.h>
 
 #include <algorithm>
@@ -598,8 +599,27 @@ static int write_pieces(const pc_readset *rs, int64_t npieces, const int64_t *pi
             fflush(stdout);
         } else {
             const size_t base_pos = file_pos ? (size_t)file_pos[f] : 0;
-            const int fd = open(path, base_pos ? O_WRONLY : (O_WRONLY | O_CREAT | O_TRUNC), 0666);
+            const int fd = open(path, base_pos ? O_RDWR : (O_RDWR | O_CREAT | O_TRUNC), 0666);
             if (fd < 0) { rc = PC_ERR_BAD_ARG; break; }
+            // Large outputs are formatted straight into a shared mapping of the file: concurrent pwrite()s to ONE file
+            // take turns on the inode's write lock (measured on tmpfs: 2.5 GB/s whatever the thread count), page faults
+            // on a mapping do not.  The file is extended first; the mapping is only used when the filesystem has the
+            // room (a fault on a full filesystem is a SIGBUS, a failed pwrite is an error code), PC_IO_NO_MMAP=1 keeps
+            // the pwrite path.
+            char *map = nullptr;
+            size_t map_len = 0, map_lead = 0;
+            static const bool no_mmap = [] { const char *e = getenv("PC_IO_NO_MMAP"); return e && *e && *e != '0'; }();
+            if (!no_mmap && bytes >= ((size_t)1 << 22)) {
+                struct statvfs sv;
+                if (fstatvfs(fd, &sv) == 0 && (unsigned long long)sv.f_bavail * (unsigned long long)sv.f_frsize > (unsigned long long)bytes + ((unsigned long long)256 << 20) &&
+                    ftruncate(fd, (off_t)(base_pos + bytes)) == 0) {
+                    const size_t pg = (size_t)sysconf(_SC_PAGESIZE);
+                    const size_t map_off = base_pos & ~(pg - 1);
+                    map_lead = base_pos - map_off;
+                    void *m = mmap(nullptr, map_lead + bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, (off_t)map_off);
+                    if (m != MAP_FAILED) { map = (char *)m; map_len = map_lead + bytes; }
+                }
+            }
             // spans of pieces with about equal bytes, formatted by one thread each and written in place
             const int T = (int)std::max<size_t>(1, std::min<size_t>((size_t)nthreads, bytes / ((size_t)1 << 22) + 1));
             std::vector<size_t> cut((size_t)T + 1, idx.size());
@@ -611,6 +631,12 @@ static int write_pieces(const pc_readset *rs, int64_t npieces, const int64_t *pi
                 std::vector<char> buf;
                 size_t i = cut[(size_t)t];
                 const size_t stop = std::max(cut[(size_t)t], cut[(size_t)t + 1]);
+                if (map) {
+                    char *o = map + map_lead + at[i];
+                    for (size_t q = i; q < stop; ++q) o = format(idx[q], o);
+                    if ((size_t)(o - (map + map_lead)) != at[stop]) ok[(size_t)t] = 0;
+                    return;
+                }
                 while (i < stop) {
                     size_t j = i;
                     while (j < stop && at[j + 1] - at[i] <= ((size_t)1 << 23)) ++j;
@@ -633,6 +659,7 @@ static int write_pieces(const pc_readset *rs, int64_t npieces, const int64_t *pi
             work(0);
             for (auto &x : th) x.join();
             for (int t = 0; t < T; ++t) if (!ok[(size_t)t]) rc = PC_ERR_BAD_ARG;
+            if (map && munmap(map, map_len) != 0) rc = PC_ERR_BAD_ARG;
             if (close(fd) != 0) rc = PC_ERR_BAD_ARG;
             if (file_pos) file_pos[f] = (int64_t)(base_pos + bytes);
         }

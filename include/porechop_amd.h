@@ -276,6 +276,12 @@ int pc_readset_load_segment(const char *path, int64_t byte_begin, int64_t target
                             pc_readset **out);
 const int32_t *pc_readset_file_index(const pc_readset *rs);
 
+/* Worker threads the ingest / writer calls made BY THE CALLING THREAD may use from now on (0 = the default: every core
+ * the process may run on -- its affinity mask, capped by the container's CPU quota and at 64).  A pipelined caller that
+ * loads one block on one thread while it writes another on a second gives each its share, so that the two together do
+ * not oversubscribe the cores. */
+void pc_io_set_thread_limit(int nthreads);
+
 /* Output writer: the byte-level half of nanopore_read.py:97-147 (get_fasta /
  * get_fastq) and porechop.py:607-734 (output_reads).  The caller has decided which pieces of which
  * reads go where; piece k is bases [piece_start[k], piece_start[k] + piece_len[k]) of read

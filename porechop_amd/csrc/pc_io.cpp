@@ -31,6 +31,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -208,12 +209,26 @@ void add_read(pc_readset *rs, const char *name_b, const char *name_e, const char
     }
 }
 
+thread_local int t_thread_limit = 0;      // pc_io_set_thread_limit: this caller thread's share of the host cores
+
 int usable_threads()
 {
+    if (t_thread_limit > 0) return t_thread_limit;
     cpu_set_t set;
     int n = 0;
     if (sched_getaffinity(0, sizeof(set), &set) == 0) n = CPU_COUNT(&set);
     if (n <= 0) n = (int)std::thread::hardware_concurrency();
+    // a container's CPU quota (cgroup v2 cpu.max "quota period"): more runnable threads than that only buy throttling --
+    // the GPU box shows 256 CPUs in its affinity mask and a quota of 16
+    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char q[32] = {0};
+        long period = 0;
+        if (fscanf(f, "%31s %ld", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) {
+            const long quota = atol(q);
+            if (quota > 0) n = std::min<long>(n, std::max<long>(1, (quota + period - 1) / period));
+        }
+        fclose(f);
+    }
     if (const char *e = getenv("PC_IO_THREADS")) { const int v = atoi(e); if (v > 0) n = v; }
     return std::max(1, std::min(n, 64));
 }
@@ -491,6 +506,8 @@ static int write_pieces(const pc_readset *rs, int64_t npieces, const int64_t *pi
                         const int32_t *piece_len, const int32_t *piece_number, const int32_t *piece_file, int nfiles,
                         const char *const *file_paths, int fastq, int64_t *bytes_written, int64_t *file_pos);
 
+void pc_io_set_thread_limit(int nthreads) { t_thread_limit = nthreads > 0 ? (nthreads > 64 ? 64 : nthreads) : 0; }
+
 int pc_readset_write(const pc_readset *rs, int64_t npieces, const int64_t *piece_read, const int32_t *piece_start,
                      const int32_t *piece_len, const int32_t *piece_number, const int32_t *piece_file, int nfiles,
                      const char *const *file_paths, int fastq, int64_t *bytes_written)
@@ -601,15 +618,18 @@ static int write_pieces(const pc_readset *rs, int64_t npieces, const int64_t *pi
             const size_t base_pos = file_pos ? (size_t)file_pos[f] : 0;
             const int fd = open(path, base_pos ? O_RDWR : (O_RDWR | O_CREAT | O_TRUNC), 0666);
             if (fd < 0) { rc = PC_ERR_BAD_ARG; break; }
-            // Large outputs are formatted straight into a shared mapping of the file: concurrent pwrite()s to ONE file
-            // take turns on the inode's write lock (measured on tmpfs: 2.5 GB/s whatever the thread count), page faults
-            // on a mapping do not.  The file is extended first; the mapping is only used when the filesystem has the
-            // room (a fault on a full filesystem is a SIGBUS, a failed pwrite is an error code), PC_IO_NO_MMAP=1 keeps
-            // the pwrite path.
+            // Threads format their spans in parallel; their pwrite()s take turns on a mutex of ours.  Writes to ONE file
+            // are serialised by the inode's lock anyway, and on the GPU box 16 threads fighting over that lock move
+            // 3.4 GB/s (tmpfs) / 12.5 GB/s (page cache) where a single writer moves 8.9 / 15 GB/s
+            // (tools/ubench_write.cpp).  Formatting straight into a shared mapping of the file (PC_IO_MMAP=1) is faster
+            // on some kernels (4x in the build container) and slower on that box (page faults on one file: 2-4 GB/s),
+            // so it is opt-in; it is only used when the filesystem has the room (a fault on a full filesystem is a
+            // SIGBUS, a failed pwrite an error code).
             char *map = nullptr;
             size_t map_len = 0, map_lead = 0;
-            static const bool no_mmap = [] { const char *e = getenv("PC_IO_NO_MMAP"); return e && *e && *e != '0'; }();
-            if (!no_mmap && bytes >= ((size_t)1 << 22)) {
+            static const bool use_mmap = [] { const char *e = getenv("PC_IO_MMAP"); return e && *e && *e != '0'; }();
+            std::mutex write_turn;
+            if (use_mmap && bytes >= ((size_t)1 << 22)) {
                 struct statvfs sv;
                 if (fstatvfs(fd, &sv) == 0 && (unsigned long long)sv.f_bavail * (unsigned long long)sv.f_frsize > (unsigned long long)bytes + ((unsigned long long)256 << 20) &&
                     ftruncate(fd, (off_t)(base_pos + bytes)) == 0) {
@@ -646,6 +666,7 @@ static int write_pieces(const pc_readset *rs, int64_t npieces, const int64_t *pi
                     for (size_t q = i; q < j; ++q) o = format(idx[q], o);
                     if ((size_t)(o - buf.data()) != buf.size()) { ok[(size_t)t] = 0; return; }
                     size_t done = 0;
+                    std::lock_guard<std::mutex> turn(write_turn);
                     while (done < buf.size()) {
                         const ssize_t w = pwrite(fd, buf.data() + done, buf.size() - done, (off_t)(base_pos + at[i] + done));
                         if (w <= 0) { ok[(size_t)t] = 0; return; }

@@ -405,8 +405,22 @@ def run_streamed(input_path, output, barcode_dir, opts: Options, device=None, al
     failure = []
     stop = threading.Event()
 
+    # the loader and the writer work at the same time: each gets about half of the cores this process may use
+    from ._lib import load_library
+    io_lib = load_library()
+    try:
+        ncores = len(os.sched_getaffinity(0))
+        with open("/sys/fs/cgroup/cpu.max") as f_:
+            quota, period = f_.read().split()
+        if quota != "max":
+            ncores = min(ncores, max(1, int(int(quota) / int(period))))
+    except Exception:
+        ncores = os.cpu_count() or 2
+    share = max(2, min(32, ncores // 2))
+
     def loader():
         p_ = pos
+        io_lib.pc_io_set_thread_limit(share)
         try:
             while p_ < size and not stop.is_set():
                 t0 = time.perf_counter()
@@ -426,6 +440,7 @@ def run_streamed(input_path, output, barcode_dir, opts: Options, device=None, al
 
     def writer():
         nonlocal file_pos
+        io_lib.pc_io_set_thread_limit(share)
         try:
             while True:
                 item = to_write.get()

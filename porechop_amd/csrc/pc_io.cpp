@@ -38,6 +38,40 @@
 
 #include "../../include/porechop_amd.h"
 
+// Big buffers are recycled: a streamed run loads and frees a read set per 256 MB block, and giving 128 MB back to
+// the kernel and faulting 128 MB of fresh zeroed pages in again cost as much as writing the block (measured: 0.8 s of
+// munmap per 6.4 GB run, as much again in page faults).  Freed buffers of 32 MB and more wait here (at most 3 GB) for
+// the next request they fit.
+namespace bigbuf {
+struct Slot { char *p; size_t cap; };
+inline std::mutex &mu() { static std::mutex m; return m; }
+inline std::vector<Slot> &pool() { static std::vector<Slot> v; return v; }
+inline size_t &held() { static size_t b = 0; return b; }
+constexpr size_t kMin = (size_t)32 << 20, kMaxHeld = (size_t)3 << 30;
+inline char *take(size_t want, size_t *cap)
+{
+    std::lock_guard<std::mutex> lk(mu());
+    int best = -1;
+    for (size_t i = 0; i < pool().size(); ++i)
+        if (pool()[i].cap >= want && pool()[i].cap <= want * 3 && (best < 0 || pool()[i].cap < pool()[(size_t)best].cap)) best = (int)i;
+    if (best < 0) return nullptr;
+    const Slot s = pool()[(size_t)best];
+    pool().erase(pool().begin() + best);
+    held() -= s.cap;
+    *cap = s.cap;
+    return s.p;
+}
+inline bool give(char *p, size_t cap)
+{
+    if (!p || cap < kMin) return false;
+    std::lock_guard<std::mutex> lk(mu());
+    if (held() + cap > kMaxHeld) return false;
+    pool().push_back({p, cap});
+    held() += cap;
+    return true;
+}
+}  // namespace bigbuf
+
 // Growable byte buffer WITHOUT value-initialisation: the big arenas are sized once and filled by
 // several threads; std::vector::resize would first zero gigabytes on one core.
 struct RawBuf {
@@ -46,13 +80,17 @@ struct RawBuf {
     RawBuf() = default;
     RawBuf(const RawBuf &) = delete;
     RawBuf &operator=(const RawBuf &) = delete;
-    ~RawBuf() { free(p); }
+    ~RawBuf() { if (!bigbuf::give(p, cap)) free(p); }
     char *data() { return p; }
     const char *data() const { return p; }
     size_t size() const { return n; }
     void reserve(size_t c)
     {
         if (c <= cap) return;
+        if (!p && c >= bigbuf::kMin) {                       // a first, large request: a recycled buffer if one fits
+            size_t got = 0;
+            if (char *q = bigbuf::take(c, &got)) { p = q; cap = got; return; }
+        }
         size_t nc = cap ? cap : 4096;
         while (nc < c) nc += nc / 2 + 4096;
         char *q = (char *)realloc(p, nc);

@@ -464,7 +464,9 @@ def run_streamed(input_path, output, barcode_dir, opts: Options, device=None, al
                         file_pos = np.zeros(1, dtype=np.int64)
                     pf = np.zeros(pr.size, dtype=np.int32)
                 if pr.size:
+                    t1 = time.perf_counter()
                     rs_.write_at(pr, ps_, pn_, num, pf, paths, fastq, file_pos)
+                    busy["write_call"] = busy.get("write_call", 0.0) + time.perf_counter() - t1
                 for k in np.unique(pf) if pr.size else []:
                     sel = pf == k
                     rr = np.unique(pr[sel])
@@ -474,7 +476,9 @@ def run_streamed(input_path, output, barcode_dir, opts: Options, device=None, al
                         stats[paths[k]] = (n0 + int(rr.size), b0 + int((rs_.lengths[rr] if whole else tlen[rr]).sum()))
                     else:
                         stats[paths[k]] = (n0 + int(rr.size), b0 + int(pn_[sel].sum()))
+                t1 = time.perf_counter()
                 rs_.close()
+                busy["free"] = busy.get("free", 0.0) + time.perf_counter() - t1
                 busy["write"] += time.perf_counter() - t0
         except BaseException as e:           # noqa
             failure.append(e)
@@ -558,7 +562,8 @@ def run_streamed(input_path, output, barcode_dir, opts: Options, device=None, al
         if gz:
             _gzip_file(target, output)
         res.files[output] = stats.get(target, (0, 0))
-    res.seconds = {"wall": time.perf_counter() - t_start, "load_busy": busy["load"], "scan_busy": busy["scan"], "write_busy": busy["write"]}
+    res.seconds = {"wall": time.perf_counter() - t_start, "load_busy": busy["load"], "scan_busy": busy["scan"], "write_busy": busy["write"],
+                   "write_call_busy": busy.get("write_call", 0.0), "free_busy": busy.get("free", 0.0)}
     return res
 
 

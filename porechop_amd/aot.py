@@ -27,7 +27,7 @@ def canonical_pair(a: str, b: Optional[str]) -> Tuple[str, Optional[str]]:
 
 def panel_kernel_pairs(panel, full_native=range(1, 13), full_rapid=range(1, 13)) -> List[Tuple[str, Optional[str]]]:
     """The (ordered) adapter pairs whose kernels ship with the library: every set of the panel -- its start and end
-    sequence together, or its one sequence alone -- plus the full native barcode adapters 1-12 (the panel has 12 reverse barcodes) and the full rapid
+    sequence together, or its one sequence alone -- every sequence of the panel alone as well, plus the full native barcode adapters 1-12 (the panel has 12 reverse barcodes) and the full rapid
     barcode adapters 1-12 (porechop.py:410-436; higher numbers are compiled at first use)."""
     from . import panel as rules
     pairs, seen = [], set()
@@ -43,6 +43,12 @@ def panel_kernel_pairs(panel, full_native=range(1, 13), full_rapid=range(1, 13))
 
     for s in panel:
         add(s)
+    # every sequence of the panel alone: the score pass of the pruned phase B scans end windows one adapter per kernel
+    for s in panel:
+        for x in (s.start, s.end):
+            if x is not None and (x[1], None) not in seen:
+                seen.add((x[1], None))
+                pairs.append((x[1], None))
     for i in full_native:
         add(rules.full_native_barcode(panel, i))
     for i in full_rapid:

@@ -45,6 +45,7 @@ def records_to_fields(recs):
 class Aligner:
     """One GPU context: a scoring scheme + an adapter panel + scratch buffers."""
     fast_prefilter = True      # prefilter_rows is the device's exact prefilter (callers may put it in front of the middle scan)
+    score_end_cell = True      # MODE_SCORE records carry the reference's end cell (row, column) besides the score
 
     def __init__(self, adapters, scores=DEFAULT_SCORES, device=-1):
         self.lib = load_library()

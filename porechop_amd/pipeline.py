@@ -191,7 +191,7 @@ class Pipeline:
             return off, wl
         return off + (ln - wl).to(torch.int64), wl
 
-    def _scan_jobs(self, arena, jobs, mode, max_len, with_layout=False, sort_lengths=False, typ_len=0):
+    def _scan_jobs(self, arena, jobs, mode, max_len, with_layout=False, sort_lengths=False, typ_len=0, fuse=True):
         """jobs: list of (adapter_index, win_off int64[n], win_len int32[n]) -> list of [n,8] views.
 
         Jobs that scan the very same windows (same tensors) are fused two adapters at a time
@@ -216,7 +216,8 @@ class Pipeline:
             jobs = sorted_jobs
         groups = {}
         for k, j in enumerate(jobs):
-            groups.setdefault((id(j[1]), id(j[2])), []).append(k)
+            # fuse=False: every job alone (one adapter per kernel: the single-sequence kernels ship with the library)
+            groups.setdefault((id(j[1]), id(j[2])) if fuse else k, []).append(k)
         fused = []                      # (job index a, job index b or None)
         for ks in groups.values():
             # jobs that carry the same pairing hint (the two sequences of one adapter set, phase C) go together,
@@ -389,7 +390,109 @@ class Pipeline:
         an injected test aligner without it takes the equivalent torch formulation below."""
         return hasattr(self.aligner, "phase_b_reduce")
 
-    def phase_b_demux(self, reads: DeviceReads, matching: List[int], bins, barcode_threshold, barcode_diff, require_two):
+    # ------------------------------------------------------------------------------------------
+    # Exact pruning of phase B.  Of the ~200 end-window alignments a barcoded read gets, three matter: phase B keeps the
+    # MAXIMUM trim over the alignments that qualify (nanopore_read.py:166-208) and the barcode call looks at full
+    # identities within --barcode_diff of the best (nanopore_read.py:399-466).  A score-only pass (5 instead of 13.25
+    # packed ops per two cells, no trace slab) gives every alignment's end cell (I adapter bases and Jc window columns
+    # consumed) and score S -- the reference's own end cell, the one the two-pass scan retraces -- and from those,
+    # UPPER BOUNDS on what the alignment can contribute:
+    #   full identity <= 100 min(I, Jc, m) / m              (matches <= diagonal columns <= bases consumed; span >= m)
+    #   start window:  read_end <= Jc + 1, so trim <= Jc + 1 + extra; none if Jc + 1 < min_trim_size; none if the path ends
+    #                  in the window's last column of a full window (then read_end == end_size, which disqualifies)
+    #   end window:    a qualifying alignment starts on the first row at a column j0 >= 1 (read_start = j0; a path from the
+    #                  first column has read_start 0, which disqualifies), consumes all I adapter bases and b = Jc - j0 window
+    #                  columns with  S <= (match + g) b - g I  and  b <= I + (match I - S) / g,  g = min(|open|, |extend|);
+    #                  so none if Jc - 1 < ceil((S + g I) / (match + g)), else trim <= end_size - max(1, Jc - bmax) + extra.
+    # Round 1 traces the pairs whose bound reaches a fixed level (and every barcode pair whose full identity could come
+    # within --barcode_diff of --barcode_threshold); the exact reduction of those gives each read's trims so far; round 2
+    # traces the pairs whose bound still exceeds them.  Every pair left untraced is proven unable to change the maximum
+    # or the call and enters the reduction as "no alignment".  tests/test_gpu_phase_b_pruning.py checks the bounds against
+    # the full records of EVERY pair of its batches and the results against the unpruned phase B.
+    def _phase_b_bounds(self, score_rec, jobs, where, sl, el):
+        """score_rec [J, R, 8] (MODE_SCORE records) -> (ub_trim int64 [J, R], ub_full float64 [J, R])."""
+        p = self.p
+        dev = self.device
+        match, _, go, ge = p.scores
+        g = min(-go, -ge)
+        m = torch.tensor([len(self.seqs[j[0]]) for j in jobs], dtype=torch.int64, device=dev)[:, None]
+        is_end = torch.tensor([w[0] for w in where], dtype=torch.bool, device=dev)[:, None]
+        n = torch.where(is_end, el[None, :].to(torch.int64), sl[None, :].to(torch.int64))
+        flag = score_rec[:, :, 0].to(torch.int64)
+        Jc = score_rec[:, :, 1].to(torch.int64)
+        I = score_rec[:, :, 2].to(torch.int64)
+        S = score_rec[:, :, 4].to(torch.int64)
+        ub_full = 100.0 * torch.minimum(torch.minimum(I, Jc), m).to(torch.float64) / m.to(torch.float64)
+        # start windows
+        ok_s = (Jc + 1 >= p.min_trim_size) & ~((Jc == n) & (n == p.end_size))
+        ub_s = torch.where(ok_s, Jc + 1 + p.extra_end_trim, torch.zeros_like(Jc))
+        # end windows
+        bmin = torch.div(S + g * I + (match + g - 1), match + g, rounding_mode="floor")
+        bmax = I + torch.div(torch.clamp(match * I - S, min=0), g, rounding_mode="floor")
+        ok_e = (Jc - 1 >= bmin) & (bmax + 1 >= p.min_trim_size)
+        ub_e = torch.where(ok_e, p.end_size - torch.clamp(Jc - bmax, min=1) + p.extra_end_trim, torch.zeros_like(Jc))
+        ub = torch.where(is_end, ub_e, ub_s)
+        odd = flag != -2                                   # anything that is not a plain score record: trace it
+        ub = torch.where(odd, torch.full_like(ub, 1 << 20), ub)
+        ub_full = torch.where(odd, torch.full_like(ub_full, 100.0), ub_full)
+        return ub, ub_full
+
+    def _phase_b_pruned_records(self, reads, jobs, where, call_sets, call_level, reduce_trims):
+        """Dense [J * R, 8] records of phase B with only the pairs that can matter traced (see above); the others are the
+        "no alignment" record.  call_sets: set indices whose full identities feed a barcode call (traced whenever their bound
+        reaches call_level).  reduce_trims(records, rec_off) -> (start_trim, end_trim) runs the exact reduction.
+        -> (records, rec_off)"""
+        p = self.p
+        dev = self.device
+        R, J = reads.n, len(jobs)
+        so, sl = self._end_windows(reads, None, "start")
+        eo, el = self._end_windows(reads, None, "end")
+        score_rec = torch.stack(self._scan_jobs(reads.arena, jobs, MODE_SCORE, p.end_size, fuse=False))        # [J, R, 8]
+        ub, ub_full = self._phase_b_bounds(score_rec, jobs, where, sl, el)
+        del score_rec
+        is_end = torch.tensor([w[0] for w in where], dtype=torch.bool, device=dev)
+        calls = torch.tensor([w[1] in call_sets for w in where], dtype=torch.bool, device=dev)[:, None]
+        fail = torch.tensor([-1, 0, -1, 0, -2147483648, 0, 0, 0], dtype=torch.int32, device=dev)
+        dense = fail.repeat(J * R, 1).view(J, R, RESULT_INTS)
+        rec_off = [k * R for k in range(J)]
+
+        def trace(need):
+            hit = torch.nonzero(need)                                   # [C, 2] (job, read), job-major
+            counts = torch.bincount(hit[:, 0], minlength=J).cpu().numpy()
+            if hit.shape[0] == 0:
+                return 0
+            jj, rr = hit[:, 0], hit[:, 1]
+            e = is_end[jj]
+            off = torch.where(e, eo[rr], so[rr])
+            ln = torch.where(e, el[rr], sl[rr])
+            cjobs, pos = [], 0
+            for k in range(J):
+                c = int(counts[k])
+                if c:
+                    cjobs.append((jobs[k][0], off[pos:pos + c], ln[pos:pos + c]))
+                    pos += c
+            outs = self._scan_jobs(reads.arena, cjobs, MODE_TRACE, p.end_size)
+            dense[jj, rr] = torch.cat(outs)
+            return int(hit.shape[0])
+
+        level = 16 + p.extra_end_trim
+        need1 = (ub >= level) | (calls & (ub_full >= call_level - 1e-6))
+        n1 = trace(need1)
+        st1, et1 = reduce_trims(dense.view(J * R, RESULT_INTS), rec_off)
+        so_far = torch.where(is_end[:, None], et1[None, :].to(torch.int64), st1[None, :].to(torch.int64))
+        need2 = ~need1 & (ub > so_far)
+        n2 = trace(need2)
+        self.stats["pairs_end"] += J * R
+        self.stats["pairs_end_traced_after_pruning"] = self.stats.get("pairs_end_traced_after_pruning", 0) + n1 + n2
+        return dense.view(J * R, RESULT_INTS), rec_off
+
+    @property
+    def can_prune_phase_b(self):
+        """Needs the reduction kernel and score records that carry the end cell (the GPU library's do)."""
+        return self.native_reduce and getattr(self.aligner, "score_end_cell", False)
+
+    def phase_b_demux(self, reads: DeviceReads, matching: List[int], bins, barcode_threshold, barcode_diff, require_two,
+                      prune: bool = False):
         """Phase B of a demultiplexing run: trims + the barcode call of every read.
         bins: one (start set index or None, end set index or None) per barcode bin, in the order the
         reference inserts the names into its score dicts (nanopore_read.py:185-187,206-208)
@@ -411,18 +514,29 @@ class Pipeline:
         call = torch.full((R,), -1, dtype=torch.int32, device=self.device)
         jobs, where = self._phase_b_jobs(reads, matching)
         if jobs and R:
-            _, out, rec_off = self._scan_jobs(reads.arena, jobs, MODE_TRACE, p.end_size, with_layout=True)
+            sides = [w[0] for w in where]
+            if prune and self.can_prune_phase_b:
+                def trims(records, offs):
+                    a = torch.zeros(R, dtype=torch.int32, device=self.device)
+                    b = torch.zeros(R, dtype=torch.int32, device=self.device)
+                    self.aligner.phase_b_reduce(records, R, offs, sides, p.end_size, p.min_trim_size, p.extra_end_trim,
+                                                p.end_threshold, a, b)
+                    return a, b
+                call_sets = {i for b in bins for i in b if i is not None}
+                out, rec_off = self._phase_b_pruned_records(reads, jobs, where, call_sets, barcode_threshold - barcode_diff, trims)
+            else:
+                _, out, rec_off = self._scan_jobs(reads.arena, jobs, MODE_TRACE, p.end_size, with_layout=True)
+                self.stats["pairs_end"] += sum(int(j[1].shape[0]) for j in jobs)
             job_of = {(si, side): k for k, (side, si) in enumerate(where)}
             jb = [(job_of.get((b[0], 0), -1) if b[0] is not None else -1,
                    job_of.get((b[1], 1), -1) if b[1] is not None else -1) for b in bins]
-            self.aligner.phase_b_reduce(out, R, rec_off, [w[0] for w in where], p.end_size, p.min_trim_size, p.extra_end_trim,
+            self.aligner.phase_b_reduce(out, R, rec_off, sides, p.end_size, p.min_trim_size, p.extra_end_trim,
                                         p.end_threshold, start_trim, end_trim, bins=jb if bins else None,
                                         barcode_threshold=barcode_threshold, barcode_diff=barcode_diff,
                                         require_two=require_two, call=call)
-            self.stats["pairs_end"] += sum(int(j[1].shape[0]) for j in jobs)
         return start_trim, end_trim, call.to(torch.int64).cpu().numpy()
 
-    def phase_b(self, reads: DeviceReads, matching: List[int], full_for=()):
+    def phase_b(self, reads: DeviceReads, matching: List[int], full_for=(), prune: bool = False):
         """-> (start_trim[R], end_trim[R]) int32: nanopore_read.py:166-208 for every read.
         full_for: set indices whose full-adapter identities are wanted too (barcode calling,
         nanopore_read.py:185-187,206-208) -> third result {(set, side): float64[R]}, side 0 = start."""
@@ -435,10 +549,20 @@ class Pipeline:
         if not jobs:
             return (start_trim, end_trim, fulls) if full_for else (start_trim, end_trim)
         if self.native_reduce and not full_for and R:
-            _, out, rec_off = self._scan_jobs(reads.arena, jobs, MODE_TRACE, p.end_size, with_layout=True)
-            self.aligner.phase_b_reduce(out, R, rec_off, [w[0] for w in where], p.end_size, p.min_trim_size, p.extra_end_trim,
+            sides = [w[0] for w in where]
+            if prune and self.can_prune_phase_b:
+                def trims(records, offs):
+                    a = torch.zeros(R, dtype=torch.int32, device=self.device)
+                    b = torch.zeros(R, dtype=torch.int32, device=self.device)
+                    self.aligner.phase_b_reduce(records, R, offs, sides, p.end_size, p.min_trim_size, p.extra_end_trim,
+                                                p.end_threshold, a, b)
+                    return a, b
+                out, rec_off = self._phase_b_pruned_records(reads, jobs, where, set(), 1e9, trims)
+            else:
+                _, out, rec_off = self._scan_jobs(reads.arena, jobs, MODE_TRACE, p.end_size, with_layout=True)
+                self.stats["pairs_end"] += sum(int(j[1].shape[0]) for j in jobs)
+            self.aligner.phase_b_reduce(out, R, rec_off, sides, p.end_size, p.min_trim_size, p.extra_end_trim,
                                         p.end_threshold, start_trim, end_trim)
-            self.stats["pairs_end"] += sum(int(j[1].shape[0]) for j in jobs)
             return start_trim, end_trim
         outs = self._scan_jobs(reads.arena, jobs, MODE_TRACE, p.end_size)
         for (side, si), rec in zip(where, outs):

@@ -404,9 +404,13 @@ class Pipeline:
     #                  first column has read_start 0, which disqualifies), consumes all I adapter bases and b = Jc - j0 window
     #                  columns with  S <= (match + g) b - g I  and  b <= I + (match I - S) / g,  g = min(|open|, |extend|);
     #                  so none if Jc - 1 < ceil((S + g I) / (match + g)), else trim <= end_size - max(1, Jc - bmax) + extra.
-    # Round 1 traces the pairs whose bound reaches a fixed level (and every barcode pair whose full identity could come
-    # within --barcode_diff of --barcode_threshold); the exact reduction of those gives each read's trims so far; round 2
-    # traces the pairs whose bound still exceeds them.  Every pair left untraced is proven unable to change the maximum
+    #   either side:   a qualifying alignment has aligned identity > --end_threshold over Lp >= min(I, Jc) columns, hence
+    #                  S > (tau match - (1 - tau) P) min(I, Jc)   (P = the dearest non-matching column)
+    # Round 1 traces, per read and side, the two best-scoring pairs that can trim at all and the two best-scoring barcode
+    # pairs; the exact reduction of those gives each read's trims so far and the best barcode identity per side; round 2 traces
+    # the pairs whose trim bound still exceeds the trims, and the barcode pairs that could reach
+    # max(best, --barcode_threshold) - --barcode_diff (a full identity of t also needs S >= m (t match - (1 - t) P)).
+    # Every pair left untraced is proven unable to change the maximum
     # or the call and enters the reduction as "no alignment".  tests/test_gpu_phase_b_pruning.py checks the bounds against
     # the full records of EVERY pair of its batches and the results against the unpruned phase B.
     def _phase_b_bounds(self, score_rec, jobs, where, sl, el):
@@ -432,15 +436,27 @@ class Pipeline:
         ok_e = (Jc - 1 >= bmin) & (bmax + 1 >= p.min_trim_size)
         ub_e = torch.where(ok_e, p.end_size - torch.clamp(Jc - bmax, min=1) + p.extra_end_trim, torch.zeros_like(Jc))
         ub = torch.where(is_end, ub_e, ub_s)
+        # either side: a trim needs aligned identity > --end_threshold over the path's Lp columns, Lp >= min(I, Jc) (a path
+        # from the first row consumes all I adapter bases, one from the first column all Jc window columns); with
+        # M > tau Lp matches and fewer than (1 - tau) Lp other columns at a cost of at most P each,
+        # S > (tau match - (1 - tau) P) Lp.  (Random 24-28-mers align into a full window at ~64 % identity with S = 7..17:
+        # this is what prunes them.)
+        tau = (p.end_threshold - 1e-6) / 100.0
+        P = max(-p.scores[1], -go, -ge, 0)
+        c = tau * match - (1.0 - tau) * P
+        if c > 0:
+            need_s = torch.floor(c * torch.clamp(torch.minimum(I, Jc), min=1).to(torch.float64)).to(torch.int64)
+            ub = torch.where(S > need_s, ub, torch.zeros_like(ub))
+        # and a full identity of t needs S >= m (t match - (1 - t) P)  (identity_score_bound, as in phase A's pruning)
         odd = flag != -2                                   # anything that is not a plain score record: trace it
         ub = torch.where(odd, torch.full_like(ub, 1 << 20), ub)
         ub_full = torch.where(odd, torch.full_like(ub_full, 100.0), ub_full)
         return ub, ub_full
 
-    def _phase_b_pruned_records(self, reads, jobs, where, call_sets, call_level, reduce_trims):
+    def _phase_b_pruned_records(self, reads, jobs, where, call_sets, call_level, reduce_trims, call_level_diff=0.0):
         """Dense [J * R, 8] records of phase B with only the pairs that can matter traced (see above); the others are the
-        "no alignment" record.  call_sets: set indices whose full identities feed a barcode call (traced whenever their bound
-        reaches call_level).  reduce_trims(records, rec_off) -> (start_trim, end_trim) runs the exact reduction.
+        "no alignment" record.  call_sets: set indices whose full identities feed a barcode call (traced whenever they can
+        reach call_level = threshold - diff, or come within call_level_diff of the best traced on their side).  reduce_trims(records, rec_off) -> (start_trim, end_trim) runs the exact reduction.
         -> (records, rec_off)"""
         p = self.p
         dev = self.device
@@ -449,12 +465,16 @@ class Pipeline:
         eo, el = self._end_windows(reads, None, "end")
         score_rec = torch.stack(self._scan_jobs(reads.arena, jobs, MODE_SCORE, p.end_size, fuse=False))        # [J, R, 8]
         ub, ub_full = self._phase_b_bounds(score_rec, jobs, where, sl, el)
+        score_S = score_rec[:, :, 4].to(torch.int64)
         del score_rec
         is_end = torch.tensor([w[0] for w in where], dtype=torch.bool, device=dev)
         calls = torch.tensor([w[1] in call_sets for w in where], dtype=torch.bool, device=dev)[:, None]
         fail = torch.tensor([-1, 0, -1, 0, -2147483648, 0, 0, 0], dtype=torch.int32, device=dev)
         dense = fail.repeat(J * R, 1).view(J, R, RESULT_INTS)
         rec_off = [k * R for k in range(J)]
+
+        best_full = torch.zeros((2, R), dtype=torch.float64, device=dev)   # best traced full identity of a call pair, per side
+        calls_j = calls.flatten()
 
         def trace(need):
             hit = torch.nonzero(need)                                   # [C, 2] (job, read), job-major
@@ -471,16 +491,49 @@ class Pipeline:
                 if c:
                     cjobs.append((jobs[k][0], off[pos:pos + c], ln[pos:pos + c]))
                     pos += c
-            outs = self._scan_jobs(reads.arena, cjobs, MODE_TRACE, p.end_size)
-            dense[jj, rr] = torch.cat(outs)
+            recs = torch.cat(self._scan_jobs(reads.arena, cjobs, MODE_TRACE, p.end_size))
+            dense[jj, rr] = recs
+            cm = calls_j[jj]
+            if bool(cm.any()):
+                rc = recs[cm]
+                full, _ = _identities(rc)
+                full = torch.where(rc[:, 0] == -1, torch.zeros_like(full), torch.nan_to_num(full, nan=0.0))
+                best_full.view(-1).scatter_reduce_(0, e[cm].to(torch.int64) * R + rr[cm], full, reduce="amax")
             return int(hit.shape[0])
 
-        level = 16 + p.extra_end_trim
-        need1 = (ub >= level) | (calls & (ub_full >= call_level - 1e-6))
+        def top2_by_score(rows_mask, eligible):
+            """per read: the two best-scoring pairs among the jobs of rows_mask that are `eligible`"""
+            pick_all = torch.zeros_like(eligible)
+            rows = torch.nonzero(rows_mask).flatten()
+            if rows.numel():
+                sub = torch.where(eligible[rows], score_S[rows], torch.full_like(score_S[rows], -1))    # [Js, R]
+                top = torch.topk(sub, min(2, int(rows.numel())), dim=0)
+                pick = torch.zeros_like(sub, dtype=torch.bool)
+                pick.scatter_(0, top.indices, top.values >= 0)
+                pick_all[rows] = pick
+            return pick_all
+
+        # round 1: per read and side the two best-SCORING pairs that can trim at all (the real adapter and the real barcode,
+        # where the read has them) and the two best-scoring barcode pairs (they fix the level a rival would have to reach)
+        need1 = torch.zeros_like(ub, dtype=torch.bool)
+        for side in (False, True):
+            need1 |= top2_by_score(is_end == side, ub > 0)
+            if call_level < 1e8:
+                need1 |= top2_by_score((is_end == side) & calls_j, torch.ones_like(need1))
         n1 = trace(need1)
         st1, et1 = reduce_trims(dense.view(J * R, RESULT_INTS), rec_off)
         so_far = torch.where(is_end[:, None], et1[None, :].to(torch.int64), st1[None, :].to(torch.int64))
         need2 = ~need1 & (ub > so_far)
+        if call_level < 1e8:
+            # A barcode pair left untraced counts as identity 0.  That changes no call as long as its identity is below
+            # max(best traced on its side, --barcode_threshold) - --barcode_diff: it can then neither become the best nor come
+            # within the difference of it.  An identity of t needs the geometric bound >= t AND S >= m (t match - (1 - t) P).
+            level = torch.clamp(best_full, min=call_level + call_level_diff) - call_level_diff      # [2, R]
+            lvl = torch.where(is_end[:, None], level[1][None, :], level[0][None, :]) - 1e-6
+            mj = torch.tensor([len(self.seqs[j[0]]) for j in jobs], dtype=torch.float64, device=dev)[:, None]
+            Pc = float(max(-p.scores[1], -p.scores[2], -p.scores[3], 0))
+            smin = torch.floor(mj * ((lvl / 100.0) * (p.scores[0] + Pc) - Pc) - 1e-9)
+            need2 |= ~need1 & calls & (ub_full >= lvl) & (score_S.to(torch.float64) >= smin)
         n2 = trace(need2)
         self.stats["pairs_end"] += J * R
         self.stats["pairs_end_traced_after_pruning"] = self.stats.get("pairs_end_traced_after_pruning", 0) + n1 + n2
@@ -523,7 +576,8 @@ class Pipeline:
                                                 p.end_threshold, a, b)
                     return a, b
                 call_sets = {i for b in bins for i in b if i is not None}
-                out, rec_off = self._phase_b_pruned_records(reads, jobs, where, call_sets, barcode_threshold - barcode_diff, trims)
+                out, rec_off = self._phase_b_pruned_records(reads, jobs, where, call_sets, barcode_threshold - barcode_diff, trims,
+                                                            call_level_diff=barcode_diff)
             else:
                 _, out, rec_off = self._scan_jobs(reads.arena, jobs, MODE_TRACE, p.end_size, with_layout=True)
                 self.stats["pairs_end"] += sum(int(j[1].shape[0]) for j in jobs)

@@ -43,9 +43,10 @@ def check_bounds_and_results(pl, reads, matching, bins, opts):
     assert bad.shape[0] == 0, ("a trim above its bound", bad[:5].tolist(), val[bad[:5, 0], bad[:5, 1]].tolist(), ub[bad[:5, 0], bad[:5, 1]].tolist(),
                                score[bad[:5, 0], bad[:5, 1]].tolist(), full_rec[bad[:5, 0], bad[:5, 1]].tolist())
     fullv = torch.where(ok, torch.nan_to_num(full, nan=0.0), torch.zeros_like(full))
-    badf = torch.nonzero(fullv > ub_full + 1e-9)
-    assert badf.shape[0] == 0, ("a full identity above its bound", badf[:5].tolist(), fullv[badf[:5, 0], badf[:5, 1]].tolist(),
-                                ub_full[badf[:5, 0], badf[:5, 1]].tolist(), score[badf[:5, 0], badf[:5, 1]].tolist())
+    badf = torch.nonzero(fullv > ub_full + 1e-6)          # (the identity is rounded to six decimals, possibly upwards)
+    assert badf.shape[0] == 0, ("a full identity above its bound", int(badf.shape[0]),
+                                [(bj, br, float(fullv[bj, br]), float(ub_full[bj, br]), score[bj, br].tolist(), full_rec[bj, br].tolist())
+                                 for bj, br in badf[:4].tolist()])
     # results
     pl.stats["pairs_end"] = 0
     pl.stats["pairs_end_traced_after_pruning"] = 0
@@ -58,6 +59,9 @@ def check_bounds_and_results(pl, reads, matching, bins, opts):
         b = pl.phase_b(reads, matching, prune=True)
     pl.aligner.sync()
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    print("phase B pruning: %d pairs, %d traced (%.1f %%), %d with a trim of their own" % (
+        int(ub.numel()), pl.stats["pairs_end_traced_after_pruning"], 100.0 * pl.stats["pairs_end_traced_after_pruning"] / max(1, int(ub.numel())),
+        int((val > 0).sum())))
     return int(ub.numel()), pl.stats["pairs_end_traced_after_pruning"], int((val > 0).sum())
 
 

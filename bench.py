@@ -387,27 +387,6 @@ def leg_configs2(dev, args, workers):
            "kernel_ms_per_step": {k: v[0] / steps for k, v in timing.items()},
            "roofline": trace_roofline(timing, 2 * n + 2 * nchk, pairs + pairs_a, cells + cells_a, steps,
                                       pl.aligner.trace_ops_per_2_cells(), leg="configs2")}
-    # ---- beside it: the same step with phase B's exact pruning (score pass for every pair, tracebacks only where an upper
-    # bound from the end cell says the pair can change the read's trims or barcode call; Pipeline._phase_b_pruned_records)
-    try:
-        step_demux(pl, reads, p.check_reads, opts, prune=True)
-        sync()
-        pl.stats["pairs_end"] = pl.stats["pairs_end_traced_after_pruning"] = 0
-        pl.aligner.set_timing(True)
-        pl.aligner.get_timing()
-        (m_p, o_p, n_p, st_p, et_p, calls_p), dt_p = timed(lambda: step_demux(pl, reads, p.check_reads, opts, prune=True), steps, 0, sync)
-        tp = pl.aligner.get_timing()
-        pl.aligner.set_timing(False)
-        out["exact_phase_b_pruning"] = {
-            "reads_per_s": n * steps / dt_p, "ms_per_step": dt_p / steps * 1e3, "speedup": dt / dt_p,
-            "same_trims_and_calls": bool(torch.equal(st_p, st) and torch.equal(et_p, et) and np.array_equal(calls_p, calls) and m_p == matching),
-            "pairs_traced_fraction": pl.stats["pairs_end_traced_after_pruning"] / max(1, pl.stats["pairs_end"]),
-            "kernel_ms_per_step": {k: v[0] / steps for k, v in tp.items()},
-            "note": "not the leg's number: the score-only pass gives every end-window alignment's end cell and score, from which upper "
-                    "bounds on its possible trim and full identity follow; two rounds of tracebacks cover every pair that can change a "
-                    "read's maximum trim or its barcode call (tests/test_gpu_phase_b_pruning.py checks the bounds on every pair)"}
-    except Exception as e:
-        out["exact_phase_b_pruning"] = {"failed": repr(e)}
     if args.cpu_seconds > 0:
         seqs, ln = host_seqs(reads, min(n, 4096))
         sets = [(s.name, s.start, s.end) for s in pl.sets]
@@ -538,25 +517,9 @@ def leg_configs4(dev, args, workers, world, rank, barrier):
     (_, _, _, st_p, et_p, calls_p, hits_p), dt_p = timed_region(psteps, True)
     timing_p = pl.aligner.get_timing()
     pl.aligner.set_timing(False)
-    # ... and with phase B's exact pruning on top of the prefilter
-    run(1, True, True)
-    pl.stats["pairs_end"] = pl.stats["pairs_end_traced_after_pruning"] = 0
-    pl.aligner.set_timing(True)
-    pl.aligner.get_timing()
-    (_, _, _, st_q, et_q, calls_q, hits_q), dt_q = timed_region(psteps, True, True)
-    timing_q = pl.aligner.get_timing()
-    pl.aligner.set_timing(False)
     if rank != 0:
         pl.close()
         return None
-    same_q = bool(hits_q.read.numel() == hits.read.numel() and torch.equal(hits_q.read, hits.read) and
-                  torch.equal(hits_q.adapter, hits.adapter) and torch.equal(hits_q.start, hits.start) and
-                  torch.equal(hits_q.end, hits.end) and torch.equal(st_q, st) and torch.equal(et_q, et) and
-                  np.array_equal(calls_q, calls))
-    same = bool(hits_p.read.numel() == hits.read.numel() and torch.equal(hits_p.read, hits.read) and
-                torch.equal(hits_p.adapter, hits.adapter) and torch.equal(hits_p.start, hits.start) and
-                torch.equal(hits_p.end, hits.end) and torch.equal(st_p, st) and torch.equal(et_p, et) and
-                np.array_equal(calls_p, calls))
     ads = pl.middle_adapter_list(matching)
     A = len(ads)
     mean_trim_len = float((reads.length.to(torch.float64) - st.to(torch.float64) - et.to(torch.float64)).mean().item())
@@ -583,12 +546,7 @@ def leg_configs4(dev, args, workers, world, rank, barrier):
            "exact_prefilter": {"reads_per_s": total * psteps / dt_p, "ms_per_step": dt_p / psteps * 1e3, "steps": psteps,
                                "same_trims_calls_and_middle_hits": same,
                                "kernel_ms_per_step": {k: v[0] / psteps for k, v in timing_p.items()},
-                               "speedup": (dt / steps) / (dt_p / psteps)},
-           "exact_prefilter_and_phase_b_pruning": {
-               "reads_per_s": total * psteps / dt_q, "ms_per_step": dt_q / psteps * 1e3, "steps": psteps,
-               "same_trims_calls_and_middle_hits": same_q, "speedup": (dt / steps) / (dt_q / psteps),
-               "end_window_pairs_traced_fraction": pl.stats["pairs_end_traced_after_pruning"] / max(1, pl.stats["pairs_end"]),
-               "kernel_ms_per_step": {k: v[0] / psteps for k, v in timing_q.items()}}}
+                               "speedup": (dt / steps) / (dt_p / psteps)}}
     jit = timing["score_spec"][1] > 0
     ms, launches, pairs = timing["score_spec"] if jit else timing["score"]
     if launches > 0:

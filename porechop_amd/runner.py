@@ -260,10 +260,10 @@ def _scan_reads(pl, reads, R, match_idx, opts, barcode_dir, orientation, lap=lam
             sub = reads if (b0 == 0 and b1 == R) else DeviceReads(reads.arena, reads.off[b0:b1], reads.length[b0:b1])
             if check_barcodes:
                 st_b, et_b, ci_b = pl.phase_b_demux(sub, match_idx, bins, opts.barcode_threshold, opts.barcode_diff,
-                                                    opts.require_two_barcodes, prune=len(match_idx) > 4)
+                                                    opts.require_two_barcodes)
                 ci_parts.append(ci_b)
             else:
-                st_b, et_b = pl.phase_b(sub, match_idx, prune=len(match_idx) > 4)     # (few sets: the traced scan is as cheap)
+                st_b, et_b = pl.phase_b(sub, match_idx)
             lap("phase_b", sync=True)
             if not opts.no_split:
                 # identical hits either way: behind the exact prefilter on the GPU library (most pairs never reach the

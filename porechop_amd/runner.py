@@ -544,6 +544,14 @@ def run_streamed(input_path, output, barcode_dir, opts: Options, device=None, al
         if aligner is None:
             pl.close()
     if failure:
+        # a streamed run that fails part-way (a later block that cannot be parsed, a full disk) has already written the
+        # earlier blocks: a whole-file run would have written nothing, so nothing is left behind here either
+        for path in list(paths) + ([target] if (output is not None and gz and target) else []):
+            try:
+                if path and path != "-" and os.path.isfile(path):
+                    os.remove(path)
+            except OSError:
+                pass
         raise failure[0]
     res.start_trim = np.concatenate(st_all) if st_all else np.zeros(0, dtype=np.int32)
     res.end_trim = np.concatenate(et_all) if et_all else np.zeros(0, dtype=np.int32)

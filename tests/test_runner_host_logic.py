@@ -156,3 +156,26 @@ def test_streamed_runs_write_the_same_files(oracle, tmp_path, monkeypatch):
             assert (len(seen_blocks) - n0 > 3) == streamed
             outs.append(md5s(target))
         assert outs[0] == outs[1] and outs[0], (fname, outs)
+
+
+def test_streamed_run_that_fails_midway_leaves_no_partial_output(tmp_path, oracle):
+    """A later block that cannot be parsed ends a streamed run with the loader's error -- and without the files the
+    earlier blocks had already written (a whole-file run would not have written anything)."""
+    import pytest
+    from porechop_amd import runner
+    from tests.cpu_aligner import OracleAligner
+    import random
+    rng = random.Random(3)
+    recs = []
+    for i in range(40):
+        s = "".join(rng.choice("ACGT") for _ in range(300))
+        recs.append("@r%d\n%s\n+\n%s\n" % (i, s, "5" * 300))
+    text = "".join(recs[:30]) + "@broken\nACGT\n" + "".join(recs[30:])        # a record without its '+' and quality lines
+    inp = tmp_path / "in.fastq"
+    inp.write_text(text)
+    out = tmp_path / "out.fastq"
+    opts = runner.Options()
+    opts.check_reads = 5              # the first block only has to hold these: the broken record lies in a later block
+    with pytest.raises(ValueError):
+        runner.run_streamed(str(inp), str(out), None, opts, aligner=OracleAligner(oracle, tuple(opts.scoring_scheme)), block_bytes=2500)
+    assert not out.exists()

@@ -161,7 +161,7 @@ def cpu_baseline(reads, pl, matching, st, et, hits, seconds, workers):
     from dataclasses import asdict
     from tests.cpu_worker import run_chunk
     kind = baseline_kind()
-    seqs, ln = host_seqs(reads, min(reads.n, 16384))
+    seqs, ln = host_seqs(reads, min(reads.n, 49152))       # (the probe sizes the sample to about --cpu-seconds of wall clock)
     sets = [(s.name, s.start, s.end) for s in pl.sets]
     params = asdict(pl.p)
     done, dt, res = cpu_sample(run_chunk, lambda c: (c, sets, matching, params, True), seqs, seconds, workers)

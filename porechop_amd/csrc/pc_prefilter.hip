@@ -304,11 +304,12 @@ __global__ __launch_bounds__(256) void seed_scan_kernel(SeedScanArgs a)
     const int nlines = (n + 127) >> 7;               // 0 for a lane without a chunk
     const int nl_wave = __builtin_amdgcn_readfirstlane(wave_max(nlines));
     u32x4 r[8], nx[8];
+    // (only the 16-byte blocks that hold columns of the chunk are fetched: never more than 15 bytes past a window's end)
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { r[i] = u32x4{0, 0, 0, 0}; if (nlines > 0) r[i] = *(const u32x4 *)(p + 16 * i); }
+    for (int i = 0; i < 8; ++i) { r[i] = u32x4{0, 0, 0, 0}; if (16 * i < n) r[i] = *(const u32x4 *)(p + 16 * i); }
     for (int L = 0; L < nl_wave; ++L) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { nx[i] = r[i]; if (L + 1 < nlines) nx[i] = *(const u32x4 *)(p + 128 * (L + 1) + 16 * i); }
+        for (int i = 0; i < 8; ++i) { nx[i] = r[i]; if (128 * (L + 1) + 16 * i < n) nx[i] = *(const u32x4 *)(p + 128 * (L + 1) + 16 * i); }
         uint32_t hb[NQ][8];                          // per seed length and 16-column block: bit 15 - t = a seed ends at column t
         uint32_t any = 0;
 #pragma unroll

@@ -1081,9 +1081,10 @@ int pc_prefilter_device(pc_ctx *c, const void *d_arena, const int64_t *d_win_off
                     const int plen = pc.len / parts + (t < pc.len % parts ? 1 : 0);
                     uint32_t gram = 0;
                     for (int r = 0; r < q; ++r) {
-                        const int code = dna5((unsigned char)ad[pc.begin + pos + r]);
-                        if (code > 3) { ok = false; break; }
-                        gram = (gram << 2) | (uint32_t)code;
+                        const unsigned char ch = (unsigned char)ad[pc.begin + pos + r];
+                        if (dna5(ch) > 3) { ok = false; break; }
+                        // the seed scan's code of a base: bits 1-2 of its ASCII byte (A 0, C 1, T/U 2, G 3; either case)
+                        gram = (gram << 2) | (((uint32_t)ch >> 1) & 3u);
                     }
                     mine.push_back({q, gram, (int)seeded_piece.size(), pos});
                     pos += plen;

@@ -253,22 +253,11 @@ __device__ __forceinline__ void flush_wave(const SeedScanArgs &a, int *wcnt, uin
 template <int NQ>
 __global__ __launch_bounds__(256) void seed_scan_kernel(SeedScanArgs a)
 {
-    __shared__ uint32_t lut[256];                    // byte -> 2-bit code (anything that is not a base: 0, see below)
     __shared__ uint32_t bm[kBmWords];
     __shared__ int wcnt[4];
     __shared__ uint2 wbuf[4][kWaveBuf];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (threadIdx.x < 4) wcnt[threadIdx.x] = 0;
-    for (int i = threadIdx.x; i < 256; i += 256) {
-        uint32_t v = 0;
-        switch (i) {
-            case 'C': case 'c': v = 1; break;
-            case 'G': case 'g': v = 2; break;
-            case 'T': case 't': case 'U': case 'u': v = 3; break;
-            default: break;
-        }
-        lut[i] = v;
-    }
     for (int i = threadIdx.x; i < kBmWords; i += 256) bm[i] = a.bitmaps[i];
     __syncthreads();
     const int64_t wblocks = (a.nwindows + 255) / 256;
@@ -291,9 +280,11 @@ __global__ __launch_bounds__(256) void seed_scan_kernel(SeedScanArgs a)
         }
     }
     // (lanes without a chunk stay: the wave's last flush below is wave-wide)
-    // A byte that is not a base is scanned as 'A': that can only ADD candidates (the verifier looks at the real bytes
-    // and drops them); a true seed occurrence consists of bases and is always found.  Likewise the register starts as
-    // "AAAAAAAA" and the warm-up columns before a chunk may re-find the previous chunk's last seeds.
+    // A base's 2-bit code is bits 1-2 of its ASCII byte (A/a 0, C/c 1, T/t/U/u 2, G/g 3: seed_code below): one v_bfe_u32
+    // straight from the fetched dword, no table.  Any other byte gets whatever code its bits spell: that can only ADD
+    // candidates (the verifier looks at the real bytes and drops them); a true seed occurrence consists of bases and is
+    // always found.  Likewise the register starts as "AAAAAAAA" and the warm-up columns before a chunk may re-find the
+    // previous chunk's last seeds.
     const int qb[3] = {2 * a.q[0], 2 * a.q[1], 2 * a.q[2]};
     constexpr int boff[3] = {kBmOff0, kBmOff1, kBmOff2};
     uint32_t x = 0;
@@ -319,7 +310,7 @@ __global__ __launch_bounds__(256) void seed_scan_kernel(SeedScanArgs a)
             for (int c = 0; c < NQ; ++c) hb[c][blk] = 0;
 #pragma unroll
             for (int t = 0; t < 16; ++t) {
-                x = (x << 2) | lut[(wd[t >> 2] >> (8 * (t & 3))) & 0xFFu];
+                x = (x << 2) | __builtin_amdgcn_ubfe(wd[t >> 2], 8 * (t & 3) + 1, 2);
 #pragma unroll
                 for (int c = 0; c < NQ; ++c) {
                     const uint32_t word = bm[boff[c] + __builtin_amdgcn_ubfe(x, 5, qb[c] - 5)];
@@ -401,9 +392,9 @@ __global__ __launch_bounds__(256) void seed_verify_kernel(SeedVerifyArgs a)
     // the q-gram from the read's real bytes; a byte that is not a base means the scan's find was not a seed
     uint32_t idx = 0;
     for (int col = j - q + 1; col <= j; ++col) {
-        const uint32_t cde = code_of[rd[col]];
-        if (cde > 3u) return;
-        idx = (idx << 2) | cde;
+        const uint32_t byte = rd[col];
+        if (code_of[byte] > 3u) return;
+        idx = (idx << 2) | ((byte >> 1) & 3u);       // the scan's code (seed_code)
     }
     const uint32_t e0 = a.first[a.first_off[cls] + idx], e1 = a.first[a.first_off[cls] + idx + 1];
     for (uint32_t e = e0; e < e1; ++e) {

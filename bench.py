@@ -520,6 +520,10 @@ def leg_configs4(dev, args, workers, world, rank, barrier):
     if rank != 0:
         pl.close()
         return None
+    same = bool(hits_p.read.numel() == hits.read.numel() and torch.equal(hits_p.read, hits.read) and
+                torch.equal(hits_p.adapter, hits.adapter) and torch.equal(hits_p.start, hits.start) and
+                torch.equal(hits_p.end, hits.end) and torch.equal(st_p, st) and torch.equal(et_p, et) and
+                np.array_equal(calls_p, calls))
     ads = pl.middle_adapter_list(matching)
     A = len(ads)
     mean_trim_len = float((reads.length.to(torch.float64) - st.to(torch.float64) - et.to(torch.float64)).mean().item())

@@ -101,6 +101,7 @@ def step_end_trim(pl, reads, n_check):
 
 
 def step_demux(pl, reads, n_check, opts, prune=False):
+    # prune=False: every end-window pair traced (the number earlier rounds reported); True: exact pruning (pc_select.hip)
     """BASELINE configs[2] (-b DIR): phase A, the barcode-kit choice (porechop.py:330-371), phase B
     with the barcode identities, determine_barcode (nanopore_read.py:399-466) for every read."""
     from porechop_amd import panel as rules
@@ -366,6 +367,23 @@ def leg_configs2(dev, args, workers):
     steps = max(1, min(args.steps, 10))
     (matching, orientation, names, st, et, calls), dt = timed(lambda: step_demux(pl, reads, p.check_reads, opts), steps, 0, sync)
     timing = pl.aligner.get_timing()
+    # the same step with phase B pruned exactly: a score-only pass over every pair, then only the pairs that can
+    # matter are traced (two selection rounds on the device)
+    pruned = None
+    if pl.can_prune_phase_b:
+        timed(lambda: step_demux(pl, reads, p.check_reads, opts, prune=True), 0, 1, sync)
+        pl.aligner.get_timing()
+        pl.stats["pairs_end"] = pl.stats["pairs_end_traced_after_pruning"] = 0
+        (_, _, _, st_p, et_p, calls_p), dt_p = timed(lambda: step_demux(pl, reads, p.check_reads, opts, prune=True), steps, 0, sync)
+        timing_p = pl.aligner.get_timing()
+        pruned = {"reads_per_s": n * steps / dt_p, "ms_per_step": dt_p / steps * 1e3, "steps": steps,
+                  "speedup": dt / dt_p,
+                  "same_trims_and_calls_as_tracing_every_pair": bool(torch.equal(st_p, st) and torch.equal(et_p, et) and np.array_equal(calls_p, calls)),
+                  "pairs_traced_fraction": pl.stats["pairs_end_traced_after_pruning"] / max(1, pl.stats["pairs_end"]),
+                  "kernel_ms_per_step": {k: v[0] / steps for k, v in timing_p.items() if v[1]},
+                  "what": "phase B as score-only pass over every (read end, sequence) pair + exact selection of the pairs that can "
+                          "change a trim or a call (bounds from the end cell and score; pc_select.hip) + traced scan of those; "
+                          "tests/test_gpu_phase_b_pruning.py checks the bounds for EVERY pair of its batches"}
     pl.aligner.set_timing(False)
     ads = [(pl.sets[i].start, pl.sets[i].end) for i in matching]
     pairs = n * sum((s is not None) + (e is not None) for s, e in ads)
@@ -387,6 +405,8 @@ def leg_configs2(dev, args, workers):
            "kernel_ms_per_step": {k: v[0] / steps for k, v in timing.items()},
            "roofline": trace_roofline(timing, 2 * n + 2 * nchk, pairs + pairs_a, cells + cells_a, steps,
                                       pl.aligner.trace_ops_per_2_cells(), leg="configs2")}
+    if pruned:
+        out["exact_pruning"] = pruned
     if args.cpu_seconds > 0:
         seqs, ln = host_seqs(reads, min(n, 4096))
         sets = [(s.name, s.start, s.end) for s in pl.sets]
@@ -511,10 +531,10 @@ def leg_configs4(dev, args, workers, world, rank, barrier):
     timing = pl.aligner.get_timing()
     pl.aligner.set_timing(False)
     psteps = max(1, min(args.steps, 3))
-    run(1, True)
+    run(1, True, True)
     pl.aligner.set_timing(True)
     pl.aligner.get_timing()
-    (_, _, _, st_p, et_p, calls_p, hits_p), dt_p = timed_region(psteps, True)
+    (_, _, _, st_p, et_p, calls_p, hits_p), dt_p = timed_region(psteps, True, True)
     timing_p = pl.aligner.get_timing()
     pl.aligner.set_timing(False)
     if rank != 0:
@@ -548,7 +568,7 @@ def leg_configs4(dev, args, workers, world, rank, barrier):
            "kernel_ms_per_step": {k: v[0] / steps for k, v in timing.items()},
            "specialised_kernels": {"compiled_in_this_process": int(jc.value), "loaded_from_the_kernel_cache": int(jd.value)},
            "exact_prefilter": {"reads_per_s": total * psteps / dt_p, "ms_per_step": dt_p / psteps * 1e3, "steps": psteps,
-                               "same_trims_calls_and_middle_hits": same,
+                               "same_trims_calls_and_middle_hits": same, "phase_b_pruned": bool(pl.can_prune_phase_b),
                                "kernel_ms_per_step": {k: v[0] / psteps for k, v in timing_p.items()},
                                "speedup": (dt / steps) / (dt_p / psteps)}}
     jit = timing["score_spec"][1] > 0

@@ -103,7 +103,7 @@ int pc_align_batch_host(pc_ctx *ctx, const char *read_arena, int64_t arena_bytes
  * window is then read from HBM once for both).  Results, PC_RESULT_INTS each, are written in job
  * order: for job k first its n_k records for job_adapter[k], then (if any) its n_k records for
  * job_adapter_b[k].  max_len is an upper bound on every win_len (checked on the device).  The
- * arena must be readable 8 bytes past its last window.  Asynchronous on `stream`; call pc_sync()
+ * arena must be readable 16 bytes past its last window (the kernels fetch 16 columns per load).  Asynchronous on `stream`; call pc_sync()
  * (or otherwise order your reads after it on the same stream) before reading d_out.
  * A context is used from ONE host thread and ONE stream at a time: its scratch (trace slab, pass-1
  * buffer, work counters) is shared by successive calls and ordered only by that stream.  Other streams
@@ -137,10 +137,11 @@ int pc_sync(pc_ctx *ctx, void *stream);
  * pc_scan_device is bracketed by HIP events on the launch stream.  pc_get_timing waits for the
  * stream, then returns per kernel kind (0 = generic score-only scan, 1 = window planner, 2 = traced
  * scan, 3 = run-time specialised score-only scan, 4 = exact prefilter: all its launches and its one host round trip,
- * 5 = the prefilter's seed scan alone, a sub-interval of 4 whose "pairs" are windows) the summed duration in milliseconds, the number
+ * 5 = the prefilter's seed scan alone, a sub-interval of 4 whose "pairs" are windows, 6 = the selection kernels of
+ * phase B's exact pruning: pc_phase_b_select / _gather / _scatter) the summed duration in milliseconds, the number
  * of launches and the number of pairs they covered, and resets the accumulators.  Each array
  * holds PC_KERNEL_KINDS entries. */
-#define PC_KERNEL_KINDS 6
+#define PC_KERNEL_KINDS 7
 int pc_set_timing(pc_ctx *ctx, int enabled);
 int pc_get_timing(pc_ctx *ctx, void *stream, double *ms, int64_t *launches, int64_t *pairs);
 
@@ -163,6 +164,48 @@ int pc_phase_b_reduce(pc_ctx *ctx, const int32_t *d_records, int64_t n, int njob
                       const int32_t *bin_start_job, const int32_t *bin_end_job,
                       double barcode_threshold, double barcode_diff, int require_two_barcodes,
                       int32_t *d_call, void *stream);
+
+/* Exact pruning of phase B: of the ~200 end-window alignments a barcoded read gets, two or three decide its trims and
+ * its barcode call; a score-only pass (PC_MODE_SCORE, 5 instead of 13.25 packed operations per two cells, no trace)
+ * gives every alignment's end cell and score, and those bound what the alignment can contribute (the bounds and
+ * their derivation: porechop_amd/csrc/pc_select.hip, porechop_amd/pipeline.py).  The caller runs
+ *   score scan -> select(round 1) -> gather -> traced scan of the gathered windows -> scatter -> pc_phase_b_reduce
+ *              -> select(round 2) -> gather -> traced scan -> scatter -> pc_phase_b_reduce (final),
+ * which yields exactly the trims and calls of tracing everything (pc_phase_b_reduce reads a score record left in
+ * place as "no alignment").  All pointers are DEVICE pointers; everything is asynchronous on `stream`.
+ *
+ * pc_phase_b_select: d_records as for pc_phase_b_reduce, but holding PC_MODE_SCORE records (round 1) or those with
+ * round 1's traced records scattered over them (round 2); d_job_adapter_len[j] the job's adapter length,
+ * d_job_calls[j] != 0 if its full identity feeds a barcode call; d_start_len / d_end_len the reads' end-window
+ * lengths.  call_level = barcode_threshold - barcode_diff and call_level_diff = barcode_diff (call_level >= 1e8: no
+ * barcode call).  Round 2 takes round 1's mask, the trims so far and d_best_full[2][n] (best traced barcode identity
+ * per side, maintained by pc_phase_b_scatter; zero it before round 1).  Writes d_mask_out[njobs][(n + 63) / 64] -- bit
+ * r % 64 of word r / 64 of row j: trace pair (j, r) -- and d_counts[njobs], the pairs selected per job.
+ * d_ub_trim_out / d_ub_full_out (optional, round 1): the bounds themselves, [njobs][n], for tests. */
+int pc_phase_b_select(pc_ctx *ctx, const int32_t *d_records, int64_t n, int njobs,
+                      const int64_t *d_job_record_offset, const int32_t *d_job_side,
+                      const int32_t *d_job_adapter_len, const int32_t *d_job_calls,
+                      const int32_t *d_start_len, const int32_t *d_end_len, int end_size,
+                      int min_trim_size, int extra_end_trim, double end_threshold, int round,
+                      double call_level, double call_level_diff, const uint64_t *d_mask_prev,
+                      const int32_t *d_start_trim, const int32_t *d_end_trim, const double *d_best_full,
+                      uint64_t *d_mask_out, uint64_t *d_counts, int32_t *d_ub_trim_out,
+                      double *d_ub_full_out, void *stream);
+/* The selected pairs of a mask as the window lists of a traced scan: job j's pairs become windows
+ * [d_job_first[j], d_job_first[j] + count[j]) (d_job_first = exclusive prefix sum of the counts), in no particular
+ * order within the job; d_dest / d_pair_job / d_pair_read give each window's record index, job and read.  d_cursor:
+ * njobs words of scratch. */
+int pc_phase_b_gather(pc_ctx *ctx, const uint64_t *d_mask, int64_t n, int njobs, const int64_t *d_job_first,
+                      uint64_t *d_cursor, const int64_t *d_job_record_offset, const int32_t *d_job_side,
+                      const int64_t *d_start_off, const int32_t *d_start_len, const int64_t *d_end_off,
+                      const int32_t *d_end_len, int64_t *d_win_off, int32_t *d_win_len, int64_t *d_dest,
+                      int32_t *d_pair_job, int64_t *d_pair_read, void *stream);
+/* The traced records of the gathered windows over the score records they replace; d_best_full (may be NULL) is
+ * raised to the full identity of every traced barcode pair. */
+int pc_phase_b_scatter(pc_ctx *ctx, const int32_t *d_traced, int64_t count, const int64_t *d_dest,
+                       const int32_t *d_pair_job, const int64_t *d_pair_read, int32_t *d_records,
+                       const int32_t *d_job_side, const int32_t *d_job_calls, double *d_best_full, int64_t n,
+                       void *stream);
 
 /* Packed private copies of n windows on the device: window i of d_arena (d_src_off[i], d_len[i]) is copied
  * to d_dst + d_dst_off[i], and the bytes from its end up to d_dst_off[i+1] are set to `pad` (d_dst_off has

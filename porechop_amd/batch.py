@@ -139,14 +139,15 @@ class Aligner:
         """-> dict kind -> (ms, launches, pairs) since the last call, for the kinds 'score' (generic
         score-only scan), 'plan', 'trace', 'score_spec' (run-time specialised score-only scan) and 'prefilter'
         (exact prefilter, all launches of a call as one region; its "pairs" are (window, adapter) pairs) and 'seed_scan' (the
-        prefilter's seed scan alone: a sub-interval of 'prefilter'; its "pairs" are windows)."""
+        prefilter's seed scan alone: a sub-interval of 'prefilter'; its "pairs" are windows) and 'select' (the selection
+        kernels of phase B's exact pruning)."""
         import torch
         s = stream if stream is not None else torch.cuda.current_stream().cuda_stream
-        ms = (ctypes.c_double * 6)()
-        ln = (ctypes.c_int64 * 6)()
-        pr = (ctypes.c_int64 * 6)()
+        ms = (ctypes.c_double * 7)()
+        ln = (ctypes.c_int64 * 7)()
+        pr = (ctypes.c_int64 * 7)()
         check(self.lib.pc_get_timing(self._ctx, ctypes.c_void_p(s), ms, ln, pr), "pc_get_timing")
-        return {k: (ms[i], ln[i], pr[i]) for i, k in enumerate(("score", "plan", "trace", "score_spec", "prefilter", "seed_scan"))}
+        return {k: (ms[i], ln[i], pr[i]) for i, k in enumerate(("score", "plan", "trace", "score_spec", "prefilter", "seed_scan", "select"))}
 
     def phase_b_reduce(self, records, n, job_record_offset, job_side, end_size, min_trim_size, extra_end_trim,
                        end_threshold, start_trim, end_trim, bins=None, barcode_threshold=0.0, barcode_diff=0.0,
@@ -170,6 +171,52 @@ class Aligner:
                                          start_trim.data_ptr(), end_trim.data_ptr(), nb, bs.ctypes.data, be.ctypes.data,
                                          float(barcode_threshold), float(barcode_diff), 1 if require_two else 0,
                                          call.data_ptr() if nb else None, ctypes.c_void_p(s)), "pc_phase_b_reduce")
+
+    def phase_b_select(self, records, n, job_off, job_side, job_len, job_calls, start_len, end_len, end_size, min_trim_size,
+                       extra_end_trim, end_threshold, rnd, call_level, call_level_diff, mask_out, counts, mask_prev=None,
+                       start_trim=None, end_trim=None, best_full=None, ub_trim_out=None, ub_full_out=None, stream=None):
+        """Exact pruning of phase B, selection (pc_phase_b_select): all arguments CUDA tensors -- job_off int64[J],
+        job_side / job_len / job_calls int32[J], start_len / end_len int32[n], mask_out / mask_prev int64[J, (n+63)//64],
+        counts int64[J], best_full float64[2, n]."""
+        import torch
+        J = int(job_side.shape[0])
+        assert records.dtype == torch.int32 and job_off.dtype == torch.int64 and mask_out.dtype == torch.int64 and counts.dtype == torch.int64
+        assert job_side.dtype == job_len.dtype == job_calls.dtype == start_len.dtype == end_len.dtype == torch.int32
+        assert tuple(mask_out.shape) == (J, (int(n) + 63) // 64) and mask_out.is_contiguous() and int(counts.shape[0]) == J
+        ptr = lambda t: None if t is None else t.data_ptr()
+        s = stream if stream is not None else torch.cuda.current_stream().cuda_stream
+        check(self.lib.pc_phase_b_select(self._ctx, records.data_ptr(), int(n), J, job_off.data_ptr(), job_side.data_ptr(),
+                                         job_len.data_ptr(), job_calls.data_ptr(), start_len.data_ptr(), end_len.data_ptr(),
+                                         int(end_size), int(min_trim_size), int(extra_end_trim), float(end_threshold), int(rnd),
+                                         float(call_level), float(call_level_diff), ptr(mask_prev), ptr(start_trim), ptr(end_trim),
+                                         ptr(best_full), mask_out.data_ptr(), counts.data_ptr(), ptr(ub_trim_out), ptr(ub_full_out),
+                                         ctypes.c_void_p(s)), "pc_phase_b_select")
+
+    def phase_b_gather(self, mask, n, job_first, cursor, job_off, job_side, start_off, start_len, end_off, end_len,
+                       win_off, win_len, dest, pair_job, pair_read, stream=None):
+        """The selected pairs as the window lists of a traced scan (pc_phase_b_gather)."""
+        import torch
+        J = int(job_side.shape[0])
+        assert mask.dtype == torch.int64 and job_first.dtype == torch.int64 and cursor.dtype == torch.int64
+        assert start_off.dtype == end_off.dtype == win_off.dtype == dest.dtype == pair_read.dtype == torch.int64
+        assert start_len.dtype == end_len.dtype == win_len.dtype == pair_job.dtype == torch.int32
+        assert start_off.is_contiguous() and end_off.is_contiguous() and start_len.is_contiguous() and end_len.is_contiguous()
+        s = stream if stream is not None else torch.cuda.current_stream().cuda_stream
+        check(self.lib.pc_phase_b_gather(self._ctx, mask.data_ptr(), int(n), J, job_first.data_ptr(), cursor.data_ptr(),
+                                         job_off.data_ptr(), job_side.data_ptr(), start_off.data_ptr(), start_len.data_ptr(),
+                                         end_off.data_ptr(), end_len.data_ptr(), win_off.data_ptr(), win_len.data_ptr(),
+                                         dest.data_ptr(), pair_job.data_ptr(), pair_read.data_ptr(), ctypes.c_void_p(s)),
+              "pc_phase_b_gather")
+
+    def phase_b_scatter(self, traced, dest, pair_job, pair_read, records, job_side, job_calls, best_full, n, stream=None):
+        """Traced records over the score records they replace (pc_phase_b_scatter)."""
+        import torch
+        assert traced.dtype == torch.int32 and traced.is_contiguous() and records.dtype == torch.int32
+        s = stream if stream is not None else torch.cuda.current_stream().cuda_stream
+        check(self.lib.pc_phase_b_scatter(self._ctx, traced.data_ptr(), int(dest.shape[0]), dest.data_ptr(), pair_job.data_ptr(),
+                                          pair_read.data_ptr(), records.data_ptr(), job_side.data_ptr(), job_calls.data_ptr(),
+                                          None if best_full is None else best_full.data_ptr(), int(n), ctypes.c_void_p(s)),
+              "pc_phase_b_scatter")
 
     def copy_windows(self, arena, src_off, length, dst, dst_off, pad, stream=None):
         """Packed private copies on the device (pc_copy_windows): window i of `arena` -> dst[dst_off[i]:], padded

@@ -948,6 +948,82 @@ int pc_phase_b_reduce(pc_ctx *c, const int32_t *d_records, int64_t n, int njobs,
     return PC_OK;
 }
 
+int pc_phase_b_select(pc_ctx *c, const int32_t *d_records, int64_t n, int njobs, const int64_t *d_job_record_offset,
+                      const int32_t *d_job_side, const int32_t *d_job_adapter_len, const int32_t *d_job_calls,
+                      const int32_t *d_start_len, const int32_t *d_end_len, int end_size, int min_trim_size,
+                      int extra_end_trim, double end_threshold, int round, double call_level, double call_level_diff,
+                      const uint64_t *d_mask_prev, const int32_t *d_start_trim, const int32_t *d_end_trim,
+                      const double *d_best_full, uint64_t *d_mask_out, uint64_t *d_counts, int32_t *d_ub_trim_out,
+                      double *d_ub_full_out, void *stream_v)
+{
+    if (!c || n < 0 || njobs < 0 || (round != 1 && round != 2)) return PC_ERR_BAD_ARG;
+    if (n == 0 || njobs == 0) return PC_OK;
+    if (!d_records || !d_job_record_offset || !d_job_side || !d_job_adapter_len || !d_job_calls || !d_start_len || !d_end_len ||
+        !d_mask_out || !d_counts)
+        return PC_ERR_BAD_ARG;
+    if (round == 2 && (!d_mask_prev || !d_start_trim || !d_end_trim || (call_level < 1e8 && !d_best_full))) return PC_ERR_BAD_ARG;
+    (void)hipSetDevice(c->device);
+    hipStream_t stream = (stream_v == PC_STREAM_CONTEXT) ? c->stream : (hipStream_t)stream_v;
+    pck::SelectArgs a;
+    memset(&a, 0, sizeof(a));
+    a.records = d_records; a.n = n; a.njobs = njobs; a.job_off = d_job_record_offset;
+    a.job_side = d_job_side; a.job_len = d_job_adapter_len; a.job_call = d_job_calls;
+    a.start_len = d_start_len; a.end_len = d_end_len;
+    a.end_size = end_size; a.min_trim_size = min_trim_size; a.extra_end_trim = extra_end_trim;
+    a.match = c->match; a.gap_open = c->gap_open; a.gap_extend = c->gap_extend;
+    a.pen_max = std::max(std::max(-c->mismatch, -c->gap_open), std::max(-c->gap_extend, 0));
+    const double tau = (end_threshold - 1e-6) / 100.0;
+    a.ident_c = tau * (double)c->match - (1.0 - tau) * (double)a.pen_max;
+    a.round = round; a.call_level = call_level; a.call_level_diff = call_level_diff;
+    a.mask_prev = (const unsigned long long *)d_mask_prev; a.start_trim = d_start_trim; a.end_trim = d_end_trim;
+    a.best_full = d_best_full;
+    a.mask_out = (unsigned long long *)d_mask_out; a.words = (n + 63) / 64; a.counts = (unsigned long long *)d_counts;
+    a.ub_trim_out = round == 1 ? d_ub_trim_out : nullptr; a.ub_full_out = round == 1 ? d_ub_full_out : nullptr;
+    HIP_TRY(hipMemsetAsync(d_counts, 0, (size_t)njobs * 8, stream));
+    ScopedTimer tm(c, stream, 6, n * (int64_t)njobs);
+    return pck::launch_select(a, stream) ? PC_ERR_NO_DEVICE : PC_OK;
+}
+
+int pc_phase_b_gather(pc_ctx *c, const uint64_t *d_mask, int64_t n, int njobs, const int64_t *d_job_first, uint64_t *d_cursor,
+                      const int64_t *d_job_record_offset, const int32_t *d_job_side, const int64_t *d_start_off,
+                      const int32_t *d_start_len, const int64_t *d_end_off, const int32_t *d_end_len, int64_t *d_win_off,
+                      int32_t *d_win_len, int64_t *d_dest, int32_t *d_pair_job, int64_t *d_pair_read, void *stream_v)
+{
+    if (!c || n < 0 || njobs < 0) return PC_ERR_BAD_ARG;
+    if (n == 0 || njobs == 0) return PC_OK;
+    if (!d_mask || !d_job_first || !d_cursor || !d_job_record_offset || !d_job_side || !d_start_off || !d_start_len || !d_end_off ||
+        !d_end_len || !d_win_off || !d_win_len || !d_dest || !d_pair_job || !d_pair_read || njobs > 65535)
+        return PC_ERR_BAD_ARG;
+    (void)hipSetDevice(c->device);
+    hipStream_t stream = (stream_v == PC_STREAM_CONTEXT) ? c->stream : (hipStream_t)stream_v;
+    pck::GatherArgs a;
+    memset(&a, 0, sizeof(a));
+    a.mask = (const unsigned long long *)d_mask; a.words = (n + 63) / 64; a.njobs = njobs;
+    a.first = d_job_first; a.cursor = (unsigned long long *)d_cursor; a.job_off = d_job_record_offset; a.job_side = d_job_side;
+    a.start_off = d_start_off; a.end_off = d_end_off; a.start_len = d_start_len; a.end_len = d_end_len;
+    a.win_off = d_win_off; a.win_len = d_win_len; a.dest = d_dest; a.pair_job = d_pair_job; a.pair_read = d_pair_read;
+    HIP_TRY(hipMemsetAsync(d_cursor, 0, (size_t)njobs * 8, stream));
+    ScopedTimer tm(c, stream, 6, n * (int64_t)njobs);
+    return pck::launch_gather(a, stream) ? PC_ERR_NO_DEVICE : PC_OK;
+}
+
+int pc_phase_b_scatter(pc_ctx *c, const int32_t *d_traced, int64_t count, const int64_t *d_dest, const int32_t *d_pair_job,
+                       const int64_t *d_pair_read, int32_t *d_records, const int32_t *d_job_side, const int32_t *d_job_calls,
+                       double *d_best_full, int64_t n, void *stream_v)
+{
+    if (!c || count < 0 || n < 0) return PC_ERR_BAD_ARG;
+    if (count == 0) return PC_OK;
+    if (!d_traced || !d_dest || !d_pair_job || !d_pair_read || !d_records || !d_job_side || !d_job_calls) return PC_ERR_BAD_ARG;
+    (void)hipSetDevice(c->device);
+    hipStream_t stream = (stream_v == PC_STREAM_CONTEXT) ? c->stream : (hipStream_t)stream_v;
+    pck::ScatterArgs a;
+    memset(&a, 0, sizeof(a));
+    a.traced = d_traced; a.count = count; a.dest = d_dest; a.pair_job = d_pair_job; a.pair_read = d_pair_read;
+    a.records = d_records; a.job_side = d_job_side; a.job_call = d_job_calls; a.best_full = d_best_full; a.n = n;
+    ScopedTimer tm(c, stream, 6, count);
+    return pck::launch_scatter(a, stream) ? PC_ERR_NO_DEVICE : PC_OK;
+}
+
 int pc_copy_windows(pc_ctx *c, const void *d_arena, const int64_t *d_src_off, const int32_t *d_len, int64_t n,
                     void *d_dst, const int64_t *d_dst_off, int pad, void *stream_v)
 {

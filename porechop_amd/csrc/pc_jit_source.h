@@ -226,13 +226,23 @@ extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P
             o = __shfl_xor(tfmax, s); tfmax = o > tfmax ? o : tfmax;
         }
 
-        // Read bytes are fetched a dword (4 columns) at a time, one dword ahead; the substitution
-        // terms S[] of column j+1 are fetched from the LDS table while column j computes (two
-        // register sets, the column loop statically unrolled by 4), so neither the global load nor
-        // the LDS read latency sits on the column's critical path.
-        auto load_dw = [&](const unsigned char *w, int n, int col) -> u32 {   // dword holding 0-based columns col..col+3
-            const int k = (col < n) ? col : (n > 0 ? ((n - 1) & ~3) : 0);      // finished streams re-read their last dword
-            return *(const u32_unaligned *)(w + k);
+        // Read bytes are fetched 16 columns at a time into q_lo / q_hi and handed to the column loop a dword
+        // (4 columns) at a time, one dword ahead; the substitution terms S[] of column j+1 are fetched from
+        // the LDS table while column j computes (two register sets, the column loop statically unrolled by
+        // 4), so neither the global load nor the LDS read latency sits on the column's critical path.
+        // Why 16 bytes: every lane reads its own window, so a load instruction touches 64 (two streams: 128)
+        // different cache lines, and the lines a CU's waves have open (12 waves x 128 x 128 B) are far more
+        // than its L1 holds -- each load is an L2 request per lane.  With a dword per load a tile of two read
+        // streams asked L2 for 32 x the bytes it used and ran at a third of the one-stream tiles' rate
+        // (measured, 150-column windows: 3.6 vs 9.8 TCUPS); 16 bytes per load is a quarter of the requests.
+        auto load_q = [&](const unsigned char *w, int n, int col) -> uint4 {   // the 16 columns from 0-based column col
+            const int k = (col < n) ? col : (n > 0 ? ((n - 1) & ~15) : 0);     // finished streams re-read their last block
+            uint4 v;
+            __builtin_memcpy(&v, w + k, 16);                                   // any alignment: one global_load_dwordx4
+            return v;
+        };
+        auto pick_dw = [&](const uint4 &q, int k) -> u32 {                     // k is wave-uniform
+            return k == 0 ? q.x : k == 1 ? q.y : k == 2 ? q.z : q.w;
         };
 #if PC_CHECK_RANGE
         // debug build (PC_JIT_CHECK_RANGE=1): every column takes the one-column path and the extremes of EVERY value
@@ -519,12 +529,21 @@ extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P
             for (int r = 0; r < R; ++r) { vmax = pk_max(vmax, pk_max(T[r], U[r])); vmin = pk_min(vmin, T[r]); }
         };
 #endif
-        u32 cur_lo = load_dw(w_lo, n_lo, 0), cur_hi = one_stream ? 0u : load_dw(w_hi, n_hi, 0);
-        u32 nxt_lo = load_dw(w_lo, n_lo, 4), nxt_hi = one_stream ? 0u : load_dw(w_hi, n_hi, 4);
+        uint4 q_lo = load_q(w_lo, n_lo, 0), q_hi = one_stream ? make_uint4(0u, 0u, 0u, 0u) : load_q(w_hi, n_hi, 0);
+        u32 cur_lo = q_lo.x, cur_hi = q_hi.x;
+        u32 nxt_lo = q_lo.y, nxt_hi = q_hi.y;
         u32 SA[K], SB[K], SC[K], SD[K];
         fetch_S(SA, cur_lo & 0xFF, cur_hi & 0xFF);
         int jj = 0;                                           // columns since the last renormalisation
         for (int j0 = 1; j0 <= nmax; j0 += 4) {
+            // the dword this block hands on at its end is the one two blocks ahead (0-based column j0 + 7); when
+            // that opens a new 16-column block, the old one is used up -- its last dword is already in nxt -- and
+            // the new one is requested here, a whole 4-column block of arithmetic before it is needed
+            const int kq = ((j0 + 7) >> 2) & 3;
+            if (kq == 0) {
+                q_lo = load_q(w_lo, n_lo, j0 + 7);
+                if (!one_stream) q_hi = load_q(w_hi, n_hi, j0 + 7);
+            }
             if (jj >= PC_KREN) {
                 const u32 DK = pack2(PC_KREN * PC_EPS);
 #pragma clang loop unroll(full)
@@ -586,8 +605,8 @@ extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P
             }
             jj += 4;
             cur_lo = nxt_lo; cur_hi = nxt_hi;
-            nxt_lo = load_dw(w_lo, n_lo, j0 + 7);
-            if (!one_stream) nxt_hi = load_dw(w_hi, n_hi, j0 + 7);
+            nxt_lo = pick_dw(q_lo, kq);
+            if (!one_stream) nxt_hi = pick_dw(q_hi, kq);
         }
         if (packed_ahead) unpack_best();
         // ---- the reads' last columns, all lanes at once: rolled re-run of the column from the parked

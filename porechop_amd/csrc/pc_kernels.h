@@ -149,6 +149,46 @@ constexpr int kSeedBitmapWords = (1 << 16) / 32 + (1 << 14) / 32 + (1 << 12) / 3
 int launch_seed_scan(const SeedScanArgs &a, void *stream);
 int launch_seed_verify(const SeedVerifyArgs &a, int64_t ncand, void *stream);
 
+// exact pruning of phase B (pc_select.hip): which end-window pairs have to be traced
+struct SelectArgs {
+    const int32_t *records;          // score records (-2, Jc, I, 0, S, 0, 0, 0) -- or traced ones (round 2), 8 ints each
+    int64_t n;                       // reads
+    int32_t njobs;
+    const int64_t *job_off;          // [njobs] first record of the job (device)
+    const int32_t *job_side, *job_len, *job_call;   // [njobs] 0 = start window / 1 = end window, adapter length, feeds a barcode call (device)
+    const int32_t *start_len, *end_len;             // [n] window lengths
+    int32_t end_size, min_trim_size, extra_end_trim;
+    int32_t match, gap_open, gap_extend, pen_max;   // pen_max: the dearest non-matching column
+    double ident_c;                  // tau match - (1 - tau) pen_max, tau = (end_threshold - 1e-6) / 100
+    int32_t round;                   // 1 or 2
+    int32_t lds_counts;              // set by the launcher
+    double call_level, call_level_diff;             // barcode threshold - diff, diff; call_level >= 1e8: no barcode call
+    const unsigned long long *mask_prev;            // round 2: the pairs of round 1
+    const int32_t *start_trim, *end_trim;           // round 2: trims so far [n]
+    const double *best_full;         // round 2: [2][n] best traced full identity of a barcode pair per side
+    unsigned long long *mask_out;    // [njobs][words]: bit r % 64 of word r / 64 = trace pair (job, r)
+    int64_t words;
+    unsigned long long *counts;      // [njobs], zeroed by the caller
+    int32_t *ub_trim_out;            // optional [njobs][n] (round 1): the bounds themselves, for the tests
+    double *ub_full_out;
+};
+int launch_select(const SelectArgs &a, void *stream);
+struct GatherArgs {
+    const unsigned long long *mask; int64_t words; int32_t njobs;
+    const int64_t *first;            // [njobs] first window of the job in the lists (exclusive prefix of counts)
+    unsigned long long *cursor;      // [njobs], zeroed by the caller
+    const int64_t *job_off; const int32_t *job_side;
+    const int64_t *start_off, *end_off; const int32_t *start_len, *end_len;   // [n]
+    int64_t *win_off; int32_t *win_len;             // the traced scan's windows
+    int64_t *dest; int32_t *pair_job; int64_t *pair_read;   // record index / job / read of each
+};
+int launch_gather(const GatherArgs &a, void *stream);
+struct ScatterArgs {
+    const int32_t *traced; int64_t count; const int64_t *dest; const int32_t *pair_job; const int64_t *pair_read;
+    int32_t *records; const int32_t *job_side, *job_call; double *best_full; int64_t n;
+};
+int launch_scatter(const ScatterArgs &a, void *stream);
+
 constexpr int TRACE_OUT_INTS = 8;
 constexpr int SCORE_OUT_INTS = 4;
 

@@ -810,9 +810,27 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(R <= 30 ? 4 
             st_best[0][lane] = b_lo.score; st_best[1][lane] = b_lo.I; st_best[2][lane] = b_lo.J; st_best[3][lane] = b_lo.tie;
             st_best[4][lane] = b_hi.score; st_best[5][lane] = b_hi.I; st_best[6][lane] = b_hi.J; st_best[7][lane] = b_hi.tie;
         };
-        auto load_dw = [&](const uint8_t *w, int n, int col) -> u32 {   // dword holding 0-based columns col..col+3
-            const int k = (col < n) ? col : (n > 0 ? ((n - 1) & ~3) : 0);
-            return load_u32_unaligned(w + k);
+        // Read bytes come 16 columns per load (q_lo / q_hi) and are handed on a dword at a time: every lane reads its
+        // own window, so each load is an L2 request per lane whatever its width -- a dword per load asked L2 for
+        // 32 x the bytes used (see pc_jit_source.h).  The next 16 columns are requested when the last dword of the
+        // current ones has been taken, four columns before their first byte is needed.
+        auto load_q = [&](const uint8_t *w, int n, int col) -> uint4 {  // the 16 columns from 0-based column col
+            const int k = (col < n) ? col : (n > 0 ? ((n - 1) & ~15) : 0);
+            uint4 v;
+            __builtin_memcpy(&v, w + k, 16);                                   // any alignment: one global_load_dwordx4
+            return v;
+        };
+        uint4 q_lo = load_q(w_lo, n_lo, 0), q_hi = one_stream ? make_uint4(0u, 0u, 0u, 0u) : load_q(w_hi, n_hi, 0);
+        auto pick_dw = [&](const uint4 &q, int k) -> u32 { return k == 0 ? q.x : k == 1 ? q.y : k == 2 ? q.z : q.w; };
+        u32 cur_lo = q_lo.x, cur_hi = q_hi.x;
+        auto next_dword = [&](int j) {                                  // j % 4 == 0: the dword of 0-based columns j..j+3
+            const int kq = (j >> 2) & 3;
+            cur_lo = pick_dw(q_lo, kq);
+            if (!one_stream) cur_hi = pick_dw(q_hi, kq);
+            if (kq == 3) {
+                q_lo = load_q(w_lo, n_lo, j + 4);
+                if (!one_stream) q_hi = load_q(w_hi, n_hi, j + 4);
+            }
         };
         auto row_of = [&](u32 bl, u32 bh) -> int {                      // table row (dword offset) of a column's byte pair
             return one_stream ? (int)lut_lo[bl] + (int)lut_hi[bl] : (int)lut_lo[bl] + (int)lut_hi[bh];
@@ -838,7 +856,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(R <= 30 ? 4 
                 U[r] = (U[r] & keep) | (NEG2 & (ml | mh));
             }
         };
-        u32 cur_lo = load_dw(w_lo, n_lo, 0), cur_hi = one_stream ? 0u : load_dw(w_hi, n_hi, 0);
         int trow = row_of(cur_lo & 0xFF, cur_hi & 0xFF);
         u32 vmax = H_NEGINF2, vmin = H_POSINF2;
         auto note = [&](u32 x) { vmax = hk_max(vmax, x); vmin = hk_min(vmin, x); };      // CHECK builds only
@@ -849,7 +866,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(R <= 30 ? 4 
         for (; j_first <= notrace_upto; ++j_first) {
             const int trow_j = trow;
             cur_lo >>= 8; cur_hi >>= 8;
-            if ((j_first & 3) == 0) { cur_lo = load_dw(w_lo, n_lo, j_first); if (!one_stream) cur_hi = load_dw(w_hi, n_hi, j_first); }
+            if ((j_first & 3) == 0) next_dword(j_first);
             trow = row_of(cur_lo & 0xFF, cur_hi & 0xFF);
             const u32 topn = hk_add(top, EPS2);
             const uint4 *srow = (const uint4 *)(s_tab + trow_j);
@@ -879,7 +896,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(R <= 30 ? 4 
             const int trow_j = trow;
             // next column's bytes / table row, one column ahead of their use
             cur_lo >>= 8; cur_hi >>= 8;
-            if ((j & 3) == 0) { cur_lo = load_dw(w_lo, n_lo, j); if (!one_stream) cur_hi = load_dw(w_hi, n_hi, j); }
+            if ((j & 3) == 0) next_dword(j);
             trow = row_of(cur_lo & 0xFF, cur_hi & 0xFF);
 
             const bool fin_lo = (j == n_lo), fin_hi = (j == n_hi);

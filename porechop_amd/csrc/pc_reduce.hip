@@ -10,7 +10,8 @@
 //
 // Identities are the doubles Python sees: (100.0 * matches) / length printed with %f and parsed
 // back, i.e. rounded half-to-even at 6 decimals (porechop/src/alignment.cpp:113-121,
-// nanopore_read.py:476-491); a failed alignment (field 0 == -1) scores 0.0.
+// nanopore_read.py:476-491); a failed alignment (field 0 == -1) scores 0.0, and so does a score-only record
+// (field 0 == -2) that the exact pruning of phase B proved irrelevant and left untraced (pc_select.hip).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -37,7 +38,7 @@ __device__ __forceinline__ double identity(int matches, int len)
 
 __device__ __forceinline__ double full_identity(const Rec &r)
 {
-    return r.rs == -1 ? 0.0 : identity(r.matches, r.full_len);
+    return r.rs < 0 ? 0.0 : identity(r.matches, r.full_len);
 }
 
 }  // namespace
@@ -50,7 +51,7 @@ __global__ __launch_bounds__(256) void reduce_kernel(ReduceArgs a)
     int start_trim = 0, end_trim = 0;
     for (int j = 0; j < a.njobs; ++j) {
         const Rec rec = load_rec(a.records, a.job_off[j] + r);
-        if (rec.rs == -1) continue;
+        if (rec.rs < 0) continue;                      // -1: no alignment; -2: a score record left untraced (pc_select.hip)
         const double partial = identity(rec.matches, rec.aligned_len);
         const int rs = rec.rs, re = rec.re + 1;
         if (!(partial > a.end_threshold) || re - rs < a.min_trim_size) continue;

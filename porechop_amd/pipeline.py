@@ -20,6 +20,10 @@ import torch
 
 from .batch import MODE_SCORE, MODE_TRACE, MODE_TWO_PASS, Aligner, RESULT_INTS
 
+# phase B is pruned (exactly: see "Exact pruning of phase B" below) from this many (sequence, side) jobs on; measured on
+# MI355X, 1 M reads: 198 jobs 192 -> 122 ms; with the 4-6 jobs of a run without barcodes tracing everything is faster
+PRUNE_MIN_JOBS = 24
+
 
 @dataclass
 class AdapterSet:
@@ -454,98 +458,94 @@ class Pipeline:
         return ub, ub_full
 
     def _phase_b_pruned_records(self, reads, jobs, where, call_sets, call_level, reduce_trims, call_level_diff=0.0):
-        """Dense [J * R, 8] records of phase B with only the pairs that can matter traced (see above); the others are the
-        "no alignment" record.  call_sets: set indices whose full identities feed a barcode call (traced whenever they can
-        reach call_level = threshold - diff, or come within call_level_diff of the best traced on their side).  reduce_trims(records, rec_off) -> (start_trim, end_trim) runs the exact reduction.
+        """Records of phase B with only the pairs that can matter traced (see above); the others keep their score-only
+        record, which the reduction reads as "no alignment".  call_sets: set indices whose full identities feed a barcode
+        call (traced whenever they can reach call_level = threshold - diff, or come within call_level_diff of the best
+        traced on their side).  reduce_trims(records, rec_off) -> (start_trim, end_trim) runs the exact reduction.
+        The selection runs on the device (pc_select.hip); the host reads back one count per job and round.
+        self.debug_bounds (tests): a dict that receives the bounds and the untouched score records.
         -> (records, rec_off)"""
         p = self.p
         dev = self.device
+        al = self.aligner
+        bounds_out = getattr(self, "debug_bounds", None)
         R, J = reads.n, len(jobs)
         so, sl = self._end_windows(reads, None, "start")
         eo, el = self._end_windows(reads, None, "end")
-        score_rec = torch.stack(self._scan_jobs(reads.arena, jobs, MODE_SCORE, p.end_size, fuse=False))        # [J, R, 8]
-        ub, ub_full = self._phase_b_bounds(score_rec, jobs, where, sl, el)
-        score_S = score_rec[:, :, 4].to(torch.int64)
-        del score_rec
-        is_end = torch.tensor([w[0] for w in where], dtype=torch.bool, device=dev)
-        calls = torch.tensor([w[1] in call_sets for w in where], dtype=torch.bool, device=dev)[:, None]
-        fail = torch.tensor([-1, 0, -1, 0, -2147483648, 0, 0, 0], dtype=torch.int32, device=dev)
-        dense = fail.repeat(J * R, 1).view(J, R, RESULT_INTS)
-        rec_off = [k * R for k in range(J)]
-
+        so, eo = so.contiguous(), eo.contiguous()
+        sl, el = sl.to(torch.int32).contiguous(), el.to(torch.int32).contiguous()
+        # every sequence alone: the single-sequence score kernels ship with the library (porechop_amd/aot.py)
+        _, rec, rec_off = self._scan_jobs(reads.arena, jobs, MODE_SCORE, p.end_size, with_layout=True, fuse=False)
+        job_off = torch.tensor(rec_off, dtype=torch.int64, device=dev)
+        job_side = torch.tensor([w[0] for w in where], dtype=torch.int32, device=dev)
+        job_len = torch.tensor([len(self.seqs[j[0]]) for j in jobs], dtype=torch.int32, device=dev)
+        job_calls = torch.tensor([1 if w[1] in call_sets else 0 for w in where], dtype=torch.int32, device=dev)
+        job_adapter = np.array([j[0] for j in jobs], dtype=np.int32)
+        words = (R + 63) // 64
         best_full = torch.zeros((2, R), dtype=torch.float64, device=dev)   # best traced full identity of a call pair, per side
-        calls_j = calls.flatten()
 
-        def trace(need):
-            hit = torch.nonzero(need)                                   # [C, 2] (job, read), job-major
-            counts = torch.bincount(hit[:, 0], minlength=J).cpu().numpy()
-            if hit.shape[0] == 0:
+        def trace(mask, counts):
+            cnt = counts.cpu().numpy()                                   # the round's one host round trip
+            total = int(cnt.sum())
+            if total == 0:
                 return 0
-            jj, rr = hit[:, 0], hit[:, 1]
-            e = is_end[jj]
-            off = torch.where(e, eo[rr], so[rr])
-            ln = torch.where(e, el[rr], sl[rr])
-            cjobs, pos = [], 0
-            for k in range(J):
-                c = int(counts[k])
-                if c:
-                    cjobs.append((jobs[k][0], off[pos:pos + c], ln[pos:pos + c]))
-                    pos += c
-            recs = torch.cat(self._scan_jobs(reads.arena, cjobs, MODE_TRACE, p.end_size))
-            dense[jj, rr] = recs
-            cm = calls_j[jj]
-            if bool(cm.any()):
-                rc = recs[cm]
-                full, _ = _identities(rc)
-                full = torch.where(rc[:, 0] == -1, torch.zeros_like(full), torch.nan_to_num(full, nan=0.0))
-                best_full.view(-1).scatter_reduce_(0, e[cm].to(torch.int64) * R + rr[cm], full, reduce="amax")
-            return int(hit.shape[0])
+            first = torch.cumsum(counts, 0) - counts
+            woff = torch.empty(total, dtype=torch.int64, device=dev)
+            wlen = torch.empty(total, dtype=torch.int32, device=dev)
+            dest = torch.empty(total, dtype=torch.int64, device=dev)
+            pjob = torch.empty(total, dtype=torch.int32, device=dev)
+            pread = torch.empty(total, dtype=torch.int64, device=dev)
+            cursor = torch.empty(J, dtype=torch.int64, device=dev)
+            al.phase_b_gather(mask, R, first, cursor, job_off, job_side, so, sl, eo, el, woff, wlen, dest, pjob, pread)
+            live = np.nonzero(cnt)[0]
+            starts = np.zeros(len(live) + 1, dtype=np.int64)
+            starts[1:] = np.cumsum(cnt[live])
+            traced = torch.empty((total, RESULT_INTS), dtype=torch.int32, device=dev)
+            al.set_length_hint(0)
+            al.scan_device(reads.arena, woff, wlen, job_adapter[live], starts, p.end_size, traced, MODE_TRACE)
+            al.phase_b_scatter(traced, dest, pjob, pread, rec, job_side, job_calls, best_full, R)
+            return total
 
-        def top2_by_score(rows_mask, eligible):
-            """per read: the two best-scoring pairs among the jobs of rows_mask that are `eligible`"""
-            pick_all = torch.zeros_like(eligible)
-            rows = torch.nonzero(rows_mask).flatten()
-            if rows.numel():
-                sub = torch.where(eligible[rows], score_S[rows], torch.full_like(score_S[rows], -1))    # [Js, R]
-                top = torch.topk(sub, min(2, int(rows.numel())), dim=0)
-                pick = torch.zeros_like(sub, dtype=torch.bool)
-                pick.scatter_(0, top.indices, top.values >= 0)
-                pick_all[rows] = pick
-            return pick_all
+        def select(rnd, mask_prev=None, trims=(None, None)):
+            mask = torch.empty((J, words), dtype=torch.int64, device=dev)
+            counts = torch.empty(J, dtype=torch.int64, device=dev)
+            ub_t = ub_f = None
+            if rnd == 1 and bounds_out is not None:
+                ub_t = torch.empty((J, R), dtype=torch.int32, device=dev)
+                ub_f = torch.empty((J, R), dtype=torch.float64, device=dev)
+                bounds_out.update(ub_trim=ub_t, ub_full=ub_f, score_records=rec.clone(), rec_off=list(rec_off))
+            al.phase_b_select(rec, R, job_off, job_side, job_len, job_calls, sl, el, p.end_size, p.min_trim_size,
+                              p.extra_end_trim, p.end_threshold, rnd, call_level, call_level_diff, mask, counts,
+                              mask_prev=mask_prev, start_trim=trims[0], end_trim=trims[1], best_full=best_full,
+                              ub_trim_out=ub_t, ub_full_out=ub_f)
+            return mask, counts
 
         # round 1: per read and side the two best-SCORING pairs that can trim at all (the real adapter and the real barcode,
         # where the read has them) and the two best-scoring barcode pairs (they fix the level a rival would have to reach)
-        need1 = torch.zeros_like(ub, dtype=torch.bool)
-        for side in (False, True):
-            need1 |= top2_by_score(is_end == side, ub > 0)
-            if call_level < 1e8:
-                need1 |= top2_by_score((is_end == side) & calls_j, torch.ones_like(need1))
-        n1 = trace(need1)
-        st1, et1 = reduce_trims(dense.view(J * R, RESULT_INTS), rec_off)
-        so_far = torch.where(is_end[:, None], et1[None, :].to(torch.int64), st1[None, :].to(torch.int64))
-        need2 = ~need1 & (ub > so_far)
-        if call_level < 1e8:
-            # A barcode pair left untraced counts as identity 0.  That changes no call as long as its identity is below
-            # max(best traced on its side, --barcode_threshold) - --barcode_diff: it can then neither become the best nor come
-            # within the difference of it.  An identity of t needs the geometric bound >= t AND S >= m (t match - (1 - t) P).
-            level = torch.clamp(best_full, min=call_level + call_level_diff) - call_level_diff      # [2, R]
-            lvl = torch.where(is_end[:, None], level[1][None, :], level[0][None, :]) - 1e-6
-            mj = torch.tensor([len(self.seqs[j[0]]) for j in jobs], dtype=torch.float64, device=dev)[:, None]
-            Pc = float(max(-p.scores[1], -p.scores[2], -p.scores[3], 0))
-            smin = torch.floor(mj * ((lvl / 100.0) * (p.scores[0] + Pc) - Pc) - 1e-9)
-            need2 |= ~need1 & calls & (ub_full >= lvl) & (score_S.to(torch.float64) >= smin)
-        n2 = trace(need2)
+        mask1, counts1 = select(1)
+        n1 = trace(mask1, counts1)
+        st1, et1 = reduce_trims(rec, rec_off)
+        # round 2: whatever could still beat the trims so far or change the call
+        mask2, counts2 = select(2, mask_prev=mask1, trims=(st1, et1))
+        n2 = trace(mask2, counts2)
         self.stats["pairs_end"] += J * R
         self.stats["pairs_end_traced_after_pruning"] = self.stats.get("pairs_end_traced_after_pruning", 0) + n1 + n2
-        return dense.view(J * R, RESULT_INTS), rec_off
+        return rec, rec_off
 
     @property
     def can_prune_phase_b(self):
-        """Needs the reduction kernel and score records that carry the end cell (the GPU library's do)."""
-        return self.native_reduce and getattr(self.aligner, "score_end_cell", False)
+        """Needs the reduction and selection kernels and score records that carry the end cell (the GPU library's do)."""
+        return self.native_reduce and hasattr(self.aligner, "phase_b_select") and getattr(self.aligner, "score_end_cell", False)
+
+    def _prune_b(self, prune, njobs):
+        """prune=None: the exact pruning of phase B where it pays -- a barcode panel's worth of jobs (with a handful of
+        adapters the score pass, two selections and two host round trips cost more than tracing everything)."""
+        if prune is None:
+            return self.can_prune_phase_b and njobs >= PRUNE_MIN_JOBS
+        return bool(prune) and self.can_prune_phase_b
 
     def phase_b_demux(self, reads: DeviceReads, matching: List[int], bins, barcode_threshold, barcode_diff, require_two,
-                      prune: bool = False):
+                      prune: Optional[bool] = None):
         """Phase B of a demultiplexing run: trims + the barcode call of every read.
         bins: one (start set index or None, end set index or None) per barcode bin, in the order the
         reference inserts the names into its score dicts (nanopore_read.py:185-187,206-208)
@@ -568,7 +568,7 @@ class Pipeline:
         jobs, where = self._phase_b_jobs(reads, matching)
         if jobs and R:
             sides = [w[0] for w in where]
-            if prune and self.can_prune_phase_b:
+            if self._prune_b(prune, len(jobs)):
                 def trims(records, offs):
                     a = torch.zeros(R, dtype=torch.int32, device=self.device)
                     b = torch.zeros(R, dtype=torch.int32, device=self.device)
@@ -590,7 +590,7 @@ class Pipeline:
                                         require_two=require_two, call=call)
         return start_trim, end_trim, call.to(torch.int64).cpu().numpy()
 
-    def phase_b(self, reads: DeviceReads, matching: List[int], full_for=(), prune: bool = False):
+    def phase_b(self, reads: DeviceReads, matching: List[int], full_for=(), prune: Optional[bool] = None):
         """-> (start_trim[R], end_trim[R]) int32: nanopore_read.py:166-208 for every read.
         full_for: set indices whose full-adapter identities are wanted too (barcode calling,
         nanopore_read.py:185-187,206-208) -> third result {(set, side): float64[R]}, side 0 = start."""
@@ -604,7 +604,7 @@ class Pipeline:
             return (start_trim, end_trim, fulls) if full_for else (start_trim, end_trim)
         if self.native_reduce and not full_for and R:
             sides = [w[0] for w in where]
-            if prune and self.can_prune_phase_b:
+            if self._prune_b(prune, len(jobs)):
                 def trims(records, offs):
                     a = torch.zeros(R, dtype=torch.int32, device=self.device)
                     b = torch.zeros(R, dtype=torch.int32, device=self.device)

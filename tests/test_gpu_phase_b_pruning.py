@@ -26,10 +26,25 @@ def check_bounds_and_results(pl, reads, matching, bins, opts):
     jobs, where = pl._phase_b_jobs(reads, matching)
     so, sl = pl._end_windows(reads, None, "start")
     eo, el = pl._end_windows(reads, None, "end")
-    score = torch.stack(pl._scan_jobs(reads.arena, jobs, MODE_SCORE, p.end_size, fuse=False))
     full_rec = torch.stack(pl._scan_jobs(reads.arena, jobs, MODE_TRACE, p.end_size))
     pl.aligner.sync()
-    ub, ub_full = pl._phase_b_bounds(score, jobs, where, sl, el)
+    # the pruned run, with the device's bounds and its untouched score records handed out
+    pl.stats["pairs_end"] = 0
+    pl.stats["pairs_end_traced_after_pruning"] = 0
+    pl.debug_bounds = {}
+    if bins is not None:
+        b = pl.phase_b_demux(reads, matching, bins, opts.barcode_threshold, opts.barcode_diff, opts.require_two_barcodes, prune=True)
+    else:
+        b = pl.phase_b(reads, matching, prune=True)
+    pl.aligner.sync()
+    probe, pl.debug_bounds = pl.debug_bounds, None
+    assert probe["rec_off"] == [k * reads.n for k in range(len(jobs))]
+    score = probe["score_records"].view(len(jobs), reads.n, 8)
+    ub, ub_full = probe["ub_trim"].to(torch.int64), probe["ub_full"]
+    # the same bounds in torch (Pipeline._phase_b_bounds: the readable statement of them)
+    ub_t, ub_full_t = pl._phase_b_bounds(score, jobs, where, sl, el)
+    assert torch.equal(ub, ub_t), "device and torch bounds differ"
+    assert float((ub_full - ub_full_t).abs().max()) < 1e-9
     full, partial = _identities(full_rec)
     ok = full_rec[..., 0] != -1
     rs = full_rec[..., 0].to(torch.int64)
@@ -48,15 +63,11 @@ def check_bounds_and_results(pl, reads, matching, bins, opts):
                                 [(bj, br, float(fullv[bj, br]), float(ub_full[bj, br]), score[bj, br].tolist(), full_rec[bj, br].tolist())
                                  for bj, br in badf[:4].tolist()])
     # results
-    pl.stats["pairs_end"] = 0
-    pl.stats["pairs_end_traced_after_pruning"] = 0
     if bins is not None:
         a = pl.phase_b_demux(reads, matching, bins, opts.barcode_threshold, opts.barcode_diff, opts.require_two_barcodes)
-        b = pl.phase_b_demux(reads, matching, bins, opts.barcode_threshold, opts.barcode_diff, opts.require_two_barcodes, prune=True)
         assert np.array_equal(a[2], b[2])
     else:
         a = pl.phase_b(reads, matching)
-        b = pl.phase_b(reads, matching, prune=True)
     pl.aligner.sync()
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
     print("phase B pruning: %d pairs, %d traced (%.1f %%), %d with a trim of their own" % (

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """One leg of bench.py, alone, for the profiler: every launch in the process then belongs to that leg, so rocprofv3's
 per-kernel numbers can be attributed to it.  `steps` identical steps, nothing else (no CPU legs, no cross-checks).
-usage: run_leg.py headline|prefilter|configs1|configs2|configs4|configs4_prefilter [steps]"""
+usage: run_leg.py headline|prefilter|configs1|configs2|configs2_pruned|configs4|configs4_prefilter [steps]"""
 import argparse
 import os
 import sys
@@ -28,16 +28,20 @@ if leg in ("headline", "prefilter"):
 elif leg == "configs1":
     reads = make_reads(100_000, 8000, seed=1, start_frac=0.9, end_frac=0.5, chimera_frac=0.0, device=dev)
     step = lambda: bench.step_end_trim(pl, reads, p.check_reads)
-elif leg == "configs2":
+elif leg in ("configs2", "configs2_pruned"):
     reads = make_reads(1_000_000, 8000, seed=2, start_frac=0.9, end_frac=0.5, chimera_frac=0.0, device=dev, **bc)
-    step = lambda: bench.step_demux(pl, reads, p.check_reads, opts)
+    step = lambda: bench.step_demux(pl, reads, p.check_reads, opts, prune=(leg == "configs2_pruned"))
 elif leg in ("configs4", "configs4_prefilter"):
     reads = make_reads(int(os.environ.get("PC_LEG_READS4", "1250000")), 8000, seed=4, start_frac=0.9, end_frac=0.5, chimera_frac=0.01, device=dev, **bc)
-    step = lambda: bench.step_configs4(pl, reads, p.check_reads, opts, prefilter=(leg == "configs4_prefilter"))
+    step = lambda: bench.step_configs4(pl, reads, p.check_reads, opts, prefilter=(leg == "configs4_prefilter"), prune_b=(leg == "configs4_prefilter"))
 else:
     raise SystemExit("unknown leg " + leg)
+import time  # noqa: E402
 for _ in range(steps):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
     step()
+    torch.cuda.synchronize()
+    print("%s: %.1f ms / step, %.3f M reads/s" % (leg, 1e3 * (time.perf_counter() - t0), reads.n / (time.perf_counter() - t0) / 1e6), file=sys.stderr)
     pl.aligner.sync()
 torch.cuda.synchronize()
 print("LEG", leg, "steps", steps, "library_sha1", bench.library_fingerprint())

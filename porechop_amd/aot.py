@@ -49,6 +49,21 @@ def panel_kernel_pairs(panel, full_native=range(1, 13), full_rapid=range(1, 13))
             if x is not None and (x[1], None) not in seen:
                 seen.add((x[1], None))
                 pairs.append((x[1], None))
+    # the barcode pairs of the pruned phase B's score pass (panel.phase_b_pair_key): start with start, end with end
+    by_key = {}
+    for s in panel:
+        k = rules.phase_b_pair_key(s)
+        if k is not None:
+            by_key.setdefault(k, []).append(s)
+    for group in by_key.values():
+        if len(group) == 2:
+            for side in ("start", "end"):
+                x, y = getattr(group[0], side), getattr(group[1], side)
+                if x is not None and y is not None and x[1] != y[1]:
+                    p = canonical_pair(x[1], y[1])
+                    if p not in seen:
+                        seen.add(p)
+                        pairs.append(p)
     for i in full_native:
         add(rules.full_native_barcode(panel, i))
     for i in full_rapid:

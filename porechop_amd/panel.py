@@ -74,6 +74,18 @@ def barcode_direction(s: AdapterSet) -> str:
     return "reverse" if "_rev" in s.start[0] else "forward"
 
 
+def phase_b_pair_key(s: AdapterSet):
+    """Barcode sets whose end-window score passes share a kernel in the pruned phase B (Pipeline._phase_b_pruned_records):
+    barcodes 2k-1 and 2k of one direction -- two 24-mers scanned over the same windows read them once and run the
+    one-stream kernel.  The pairing is a constant of the panel, so the pair kernels are built ahead of time
+    (porechop_amd/aot.py).  -> a hashable key, None for a set that is scanned alone."""
+    import re
+    m = re.match(r"Barcode (\d+) \((forward|reverse)\)$", s.name)
+    if not m:
+        return None
+    return (m.group(2), (int(m.group(1)) - 1) // 2)
+
+
 def barcode_name(s: AdapterSet) -> str:
     """Shortest of the set name and its sequence names (first wins ties), spaces -> '_'."""
     names = [s.name]

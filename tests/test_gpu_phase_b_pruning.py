@@ -38,8 +38,7 @@ def check_bounds_and_results(pl, reads, matching, bins, opts):
         b = pl.phase_b(reads, matching, prune=True)
     pl.aligner.sync()
     probe, pl.debug_bounds = pl.debug_bounds, None
-    assert probe["rec_off"] == [k * reads.n for k in range(len(jobs))]
-    score = probe["score_records"].view(len(jobs), reads.n, 8)
+    score = torch.stack([probe["score_records"][o:o + reads.n] for o in probe["rec_off"]])
     ub, ub_full = probe["ub_trim"].to(torch.int64), probe["ub_full"]
     # the same bounds in torch (Pipeline._phase_b_bounds: the readable statement of them)
     ub_t, ub_full_t = pl._phase_b_bounds(score, jobs, where, sl, el)

@@ -368,7 +368,7 @@ int chunks_for(int64_t tile_count, int capacity, int max_len, int max_window)
 
 struct ScopedTimer {
     pc_ctx *c; hipStream_t s; bool on; pc_ctx::Timed t;
-    ScopedTimer(pc_ctx *c_, hipStream_t s_, int kind, int64_t pairs) : c(c_), s(s_), on(c_->timing)
+    ScopedTimer(pc_ctx *c_, hipStream_t s_, int kind, int64_t pairs) : c(c_), s(s_), on(c_ && c_->timing)     // c_ == null: untimed
     {
         if (!on) return;
         t.kind = kind; t.pairs = pairs;
@@ -675,7 +675,7 @@ int pc_scan_device(pc_ctx *c, const void *d_arena, const int64_t *d_win_off, con
     // single-pass groups get slab / last-column regions of their own (they run concurrently); two-pass groups
     // run one after the other and share the region behind them
     size_t slab_bytes = 0, fin_bytes = 0, slab_single = 0, fin_single = 0;
-    std::vector<size_t> slab_off(c->groups.size(), 0), fin_off(c->groups.size(), 0);
+    std::vector<size_t> slab_off(c->groups.size(), 0), fin_off(c->groups.size(), 0), fin_region(c->groups.size(), 0);
     bool any_two = false;
     int max_chunks = 1, n_single = 0;
     for (const Group &g : c->groups) {
@@ -696,7 +696,9 @@ int pc_scan_device(pc_ctx *c, const void *d_arena, const int64_t *d_win_off, con
         // score pass: chunked launches, and the chunked tails of big jobs (at most 8 chunks x resident waves)
         const int grid1 = grid_for(c, g, std::max<size_t>(g.tile_count * (size_t)chunks, (size_t)c->ncu * 64), 1, nullptr);
         // (x2: the specialised score kernel parks the two halves of a lane separately)
-        fin_bytes = std::max(fin_bytes, (size_t)std::max(grid, grid1) * (size_t)std::max(1, g.rows ? g.rows : g.gen_max_rows) * 64 * 8 * 2);
+        // (x2 again for a score-only call: its launches alternate between two streams, each with a region of its own)
+        fin_region[(size_t)(&g - &c->groups[0])] = (size_t)std::max(grid, grid1) * (size_t)std::max(1, g.rows ? g.rows : g.gen_max_rows) * 64 * 8 * 2;
+        fin_bytes = std::max(fin_bytes, fin_region[(size_t)(&g - &c->groups[0])] * (mode == PC_MODE_SCORE ? 2 : 1));
         any_two |= g.two_pass;
     }
     for (size_t gi = 0; gi < c->groups.size(); ++gi)
@@ -794,9 +796,33 @@ int pc_scan_device(pc_ctx *c, const void *d_arena, const int64_t *d_win_off, con
             a.slab = nullptr; a.slab_cols = 0; a.slab_stride = 0;
             a.ad_span = c->d_ad_span.as<int32_t>();
             const size_t gi = (size_t)(&g - &c->groups[0]);
+            // A score-only call over short windows (phase B's pruning pass: ~100 launches of 150-column windows, one per
+            // adapter pair) cannot cut its tails into column chunks, and every launch would end with a round of tiles that
+            // fills a fraction of the chip (15 625 tiles on 3072 resident waves: 15 % of the launch).  Its launches
+            // alternate between the caller's stream and the context's: the next kernel's first tiles fill the CUs the
+            // previous one's last round leaves idle.  Timed as ONE region.
+            const bool sfork = mode == PC_MODE_SCORE && !fork && stream != c->stream && score_plan[gi].size() >= 2 &&
+                               !ragged_lengths(c, max_len) && max_len / 2 < std::max(128, g.max_window / 2) && !getenv("PC_NO_SCORE_FORK");
+            const size_t fin_alt = fin_region[gi];
+            pc_ctx::Timed region;
+            bool region_timed = false;
+            size_t launch_in_group = 0;
+            if (sfork) {
+                bool any_spec = false;
+                for (const ScoreLaunch &L : score_plan[gi]) any_spec |= L.spec != nullptr;
+                if (c->timing && hipEventCreate(&region.e0) == hipSuccess && hipEventCreate(&region.e1) == hipSuccess) {
+                    region.kind = any_spec ? 3 : 0; region.pairs = np; region_timed = true;
+                    (void)hipEventRecord(region.e0, stream);
+                }
+                HIP_TRY(hipEventRecord(c->ev_fork, stream));
+                HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_fork, 0));
+            }
             for (const ScoreLaunch &L : score_plan[gi]) {
                 const int chunk_len = (max_len + L.chunks - 1) / L.chunks;
                 int grid = grid_for(c, g, L.count * (size_t)L.chunks, 1, nullptr);
+                const bool alt = sfork && (launch_in_group++ & 1);
+                hipStream_t stream_k = alt ? c->stream : stream;
+                uint32_t *fin_k = (uint32_t *)((char *)a.fin_scratch + (alt ? fin_alt : 0));
                 // windows of very different lengths: exactly the resident workgroups, every further unit drawn from
                 // the counter in launch order -- longest first.  (With a larger grid the first workgroups would stay
                 // resident drawing the short units while the long ones waited for a slot until the very end.)
@@ -804,27 +830,33 @@ int pc_scan_device(pc_ctx *c, const void *d_arena, const int64_t *d_win_off, con
                     grid = (int)std::min<size_t>((size_t)grid, L.spec ? (size_t)c->ncu * (size_t)L.spec->blocks_per_cu
                                                                       : (size_t)resident_waves(c, g));
                 const int64_t sub_pairs = group_pairs(g, L.begin, L.begin + L.count);
-                ScopedTimer tm(c, stream, L.spec ? 3 : 0, sub_pairs);       // one timed region per kernel launch
+                ScopedTimer tm(sfork ? nullptr : c, stream, L.spec ? 3 : 0, sub_pairs);       // one timed region per kernel launch
                 if (L.spec) {
                     pcj::SpecArgs sa;
                     memset(&sa, 0, sizeof(sa));
                     sa.arena = a.arena; sa.win_off = a.win_off; sa.win_len = a.win_len;
                     sa.tiles = a.tiles + L.begin; sa.ntiles = (int32_t)L.count;
-                    sa.out = c->d_k1.as<int32_t>() + L.k1_ints; sa.fin_scratch = a.fin_scratch;
+                    sa.out = c->d_k1.as<int32_t>() + L.k1_ints; sa.fin_scratch = fin_k;
                     sa.gap_open = c->gap_open; sa.gap_extend = c->gap_extend;
                     sa.chunks = L.chunks; sa.chunk_len = chunk_len;
                     sa.span = std::max(c->ad_span[L.adapter_lo], c->ad_span[L.adapter_hi]);
                     sa.err = a.err;
                     sa.work_counter = c->d_work.as<uint32_t>() + score_launch_no++;
-                    if (pcj::launch(L.spec, sa, grid, stream)) return PC_ERR_NO_DEVICE;
+                    if (pcj::launch(L.spec, sa, grid, stream_k)) return PC_ERR_NO_DEVICE;
                 } else {
                     pck::ScanArgs b = a;
                     b.tiles = a.tiles + L.begin; b.ntiles = (int32_t)L.count;
                     b.out = c->d_k1.as<int32_t>() + L.k1_ints;
                     b.chunks = L.chunks; b.chunk_len = chunk_len;
+                    b.fin_scratch = fin_k;
                     b.work_counter = c->d_work.as<uint32_t>() + score_launch_no++;
-                    if ((rc = pck::launch_score(b, g.rows, g.pad, grid, stream))) return PC_ERR_NO_DEVICE;
+                    if ((rc = pck::launch_score(b, g.rows, g.pad, grid, stream_k))) return PC_ERR_NO_DEVICE;
                 }
+            }
+            if (sfork) {
+                HIP_TRY(hipEventRecord(c->ev_join, c->stream));
+                HIP_TRY(hipStreamWaitEvent(stream, c->ev_join, 0));
+                if (region_timed) { (void)hipEventRecord(region.e1, stream); c->timed.push_back(region); }
             }
             // plan the bounded windows, per launch (the [pair][chunk] layout is the launch's)
             pck::PlanArgs pl;

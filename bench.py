@@ -406,6 +406,14 @@ def leg_configs2(dev, args, workers):
            "roofline": trace_roofline(timing, 2 * n + 2 * nchk, pairs + pairs_a, cells + cells_a, steps,
                                       pl.aligner.trace_ops_per_2_cells(), leg="configs2")}
     if pruned:
+        kms = pruned["kernel_ms_per_step"]
+        score_ms = kms.get("score_spec", 0.0) + kms.get("score", 0.0)
+        if score_ms > 0:
+            pruned["score_pass"] = {"ms_per_step": score_ms, "cells_per_step": cells,
+                                    "tcups": cells / (score_ms / 1e3) / 1e12,
+                                    "packed_ops_per_2_cells": 5.0,
+                                    "what": "score-only kernels (barcodes 2k-1 and 2k share a pass; launches alternate between two "
+                                            "streams and are timed as one region per row class)"}
         out["exact_pruning"] = pruned
     if args.cpu_seconds > 0:
         seqs, ln = host_seqs(reads, min(n, 4096))

@@ -7,7 +7,7 @@
 # Only the filtered summaries are kept under gpurun_out/prof_<tag>/<leg>/ ; tools/summarize_profile3.py turns them into
 # profiles/<round>_summary.json (+ the CSVs it was made from).
 TAG=${1:-r03}; shift
-LEGS=${@:-headline prefilter configs1 configs2 configs4 configs4_prefilter}
+LEGS=${@:-headline prefilter configs1 configs2 configs2_pruned configs4 configs4_prefilter}
 VALU_LEGS=${VALU_LEGS:-headline prefilter configs2}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG

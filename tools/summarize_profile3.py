@@ -16,7 +16,8 @@ import sys
 
 # MI355X_MICROARCH.md, "HBM": on gfx950 rocprofv3's FETCH_SIZE reports exactly half of the bytes of a wide (16 B per lane)
 # streaming read -- "double it before comparing with a byte count".  That is the access pattern of the two prefilter kernels
-# (aligned dwordx4 per lane); the DP kernels gather 4 bytes per lane, for which the guide gives no calibration: as reported.
+# (aligned dwordx4 per lane, consecutive lanes consecutive addresses).  The DP kernels GATHER -- every lane reads 16 bytes of
+# its own window, 64-128 different cache lines per load -- an access pattern the guide gives no calibration for: as reported.
 FETCH_CORRECTION = {"seed_scan_kernel": 2.0, "prefilter_kernel": 2.0}
 
 tag, rnd = sys.argv[1], sys.argv[2]
@@ -25,7 +26,7 @@ src = os.path.join("gpurun_out", "prof_" + tag)
 
 def family(name):
     m = re.search(r"(pc_spec_score|trace16_kernel|seed_scan_kernel|seed_verify_kernel|(?<![a-z_])scan_kernel<[^,>]*,[^,>]*, *(?:true|false)>|(?<![a-z_])scan_kernel|prefilter_kernel|plan_kernel|reduce_kernel|"
-                  r"expand_tiles_kernel|copy_windows_kernel)", name)
+                  r"expand_tiles_kernel|copy_windows_kernel|select_kernel|gather_kernel|scatter_kernel)", name)
     if not m:
         return None
     f = m.group(1)

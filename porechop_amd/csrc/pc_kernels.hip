@@ -180,11 +180,17 @@ __device__ __forceinline__ void column_step(u32 (&T)[R], u32 (&U)[R], u32 h2,
 // and the fp16 traced kernels (same slab layout: [column][word][lane], 16 bits per 4 rows per half,
 // first row of a group in the highest nibble).
 // ---------------------------------------------------------------------------------------------
+// COUNT (the range-checking builds): the matches are also counted from the bases on the walk's diagonal steps and must
+// equal the count pc_walk.h derives from the score -- with match - mismatch = 1 a wrong end-cell score would otherwise turn
+// into a wrong identity without tripping finish()'s divisibility check.
+template <bool COUNT = false>
 __device__ __forceinline__ void traceback_pairs(const ScanArgs &a, const u32 *slab, const int rows, const int NW, const int lane,
                                                 const Best b_lo, const Best b_hi, const int pad_lo, const int pad_hi,
                                                 const bool have_lo, const bool have_hi, const int n_lo, const int n_hi,
                                                 const int c0_lo, const int c0_hi, const int m_lo, const int m_hi,
-                                                const int64_t p_lo, const int64_t p_hi, const int notrace_upto)
+                                                const int64_t p_lo, const int64_t p_hi, const int notrace_upto,
+                                                const uint8_t *w_lo = nullptr, const uint8_t *w_hi = nullptr,
+                                                const int ad_lo = 0, const int ad_hi = 0)
 {
     // end-aligned windows: a negative col0 is the lead-in before the read's column 0
     const int cmin_lo = c0_lo < 0 ? -c0_lo : 0, cmin_hi = c0_hi < 0 ? -c0_hi : 0;
@@ -214,6 +220,7 @@ __device__ __forceinline__ void traceback_pairs(const ScanArgs &a, const u32 *sl
     if (!have_lo) wk_lo.done = 1;
     if (!have_hi) wk_hi.done = 1;
     int left_trace = 0;
+    int seen_lo = 0, seen_hi = 0;                      // COUNT: matches counted from the bases
     // (a path has at most rows + columns steps: the cap turns a corrupted trace into a reported error, not a hang)
     int steps_left = 2 * (rows + (n_lo > n_hi ? n_lo : n_hi)) + 8;
     while (!(wk_lo.done & wk_hi.done)) {
@@ -229,8 +236,17 @@ __device__ __forceinline__ void traceback_pairs(const ScanArgs &a, const u32 *sl
         const int nb_lo = fetch(0, pad_lo, wk_lo.col > 1 ? wk_lo.col : 1, wk_lo.row > 1 ? wk_lo.row : 1);
         const int nb_hi = fetch(1, pad_hi, wk_hi.col > 1 ? wk_hi.col : 1, wk_hi.row > 1 ? wk_hi.row : 1);
         (void)cmin_lo; (void)cmin_hi;
-        wk_lo.step(nb_lo, go_lo);
-        wk_hi.step(nb_hi, go_hi);
+        if constexpr (COUNT) {
+            const int d_lo = wk_lo.ndiag, d_hi = wk_hi.ndiag;
+            const int cl = wk_lo.col, rl = wk_lo.row, ch = wk_hi.col, rh = wk_hi.row;
+            wk_lo.step(nb_lo, go_lo);
+            wk_hi.step(nb_hi, go_hi);
+            if (wk_lo.ndiag != d_lo) seen_lo += dna5_code(w_lo[cl - 1]) == (int)a.ad_codes[ad_lo * 128 + rl - 1] ? 1 : 0;
+            if (wk_hi.ndiag != d_hi) seen_hi += dna5_code(w_hi[ch - 1]) == (int)a.ad_codes[ad_hi * 128 + rh - 1] ? 1 : 0;
+        } else {
+            wk_lo.step(nb_lo, go_lo);
+            wk_hi.step(nb_hi, go_hi);
+        }
     }
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf) {
@@ -243,6 +259,7 @@ __device__ __forceinline__ void traceback_pairs(const ScanArgs &a, const u32 *sl
         int err = wk.finish(dg, a.match, a.mismatch, a.gap_open, a.init_extend);
         if (a.force_score && a.force_score[p] != b.score) err = 1;
         if (left_trace) err = 1;
+        if constexpr (COUNT) { if (dg.matches != (hf ? seen_hi : seen_lo)) err = 1; }
         if (err) atomicAdd(a.err, 1u);
         int4 o0 = {dg.read_start, dg.read_end, dg.adapter_start, dg.adapter_end};
         int4 o1 = {dg.score, dg.matches, dg.aligned_len, dg.full_len};
@@ -1062,8 +1079,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(R <= 30 ? 4 
             if (have_hi) a.out[p_hi * TRACE_OUT_INTS + 4] = b_hi.score;
             continue;
         }
-        traceback_pairs(a, slab, R, NW, lane, b_lo, b_hi, pad_lo, pad_hi,
-                        have_lo, have_hi, n_lo, n_hi, c0_lo, c0_hi, m_lo, m_hi, p_lo, p_hi, notrace_upto);
+        traceback_pairs<CHECK>(a, slab, R, NW, lane, b_lo, b_hi, pad_lo, pad_hi,
+                               have_lo, have_hi, n_lo, n_hi, c0_lo, c0_hi, m_lo, m_hi, p_lo, p_hi, notrace_upto,
+                               w_lo, w_hi, tile.adapter_lo, tile.adapter_hi);
     }
 }
 #undef PC_ROW16_FULL

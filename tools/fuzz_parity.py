@@ -31,6 +31,12 @@ t0 = time.time()
 for blk in range(blocks):
     while True:
         sc = (rng.randint(1, 30), -rng.randint(0, 40), -rng.randint(1, 40), -rng.randint(1, 40))
+        if blk % 5 == 4:
+            # match - mismatch of 1 or 2: the match count pc_walk.h derives from the score then divides by almost nothing,
+            # so a wrong end-cell score would pass its divisibility check -- the range-checking builds count the matches
+            # from the bases as well (traceback_pairs<COUNT>) and these schemes are where that matters
+            mt = rng.randint(1, 6)
+            sc = (mt, mt - rng.choice([1, 2]), sc[2], sc[3])
         if sc[0] > sc[1]:
             try:
                 ads = ["".join(rng.choice("ACGT") for _ in range(rng.choice([1, 5, 22, 24, 24, 28, 33, 38, 50, 64, 87, 120]))) for _ in range(6)]

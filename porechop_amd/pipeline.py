@@ -879,9 +879,11 @@ class Pipeline:
                     outs_r = self._scan_jobs(dirty, [(aidx[a], o_act, l_act, hint[a]) for a in range(a0, A)], MODE_TWO_PASS, dmax,
                                              sort_lengths=ragged, typ_len=dtyp)
                 scheduled = (A - a0) * int(act.numel())
-                for a, o in zip(range(a0, A), outs_r):
-                    rec_all[a, act] = o
-                    full_all[a, act] = torch.nan_to_num(identity_of(o), nan=0.0)
+                if not torch.is_tensor(outs_r):
+                    outs_r = torch.stack(outs_r)                     # [A - a0, active, 8]
+                # (all adapters at once: a loop over the 196 sequences of a barcode panel is ~2 000 tiny launches a round)
+                rec_all[a0:, act] = outs_r
+                full_all[a0:, act] = torch.nan_to_num(identity_of(outs_r), nan=0.0)
         self.stats["pairs_middle"] += n_align
         self.stats["pairs_middle_speculative"] = self.stats.get("pairs_middle_speculative", 0) + n_spec
         if not H_read:

@@ -43,7 +43,7 @@ def build_ref():
 class _Result(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int) for n in (
         "read_start", "read_end", "adapter_start", "adapter_end", "score",
-        "aligned_matches", "aligned_len", "full_matches", "full_len", "path_len", "failed")]
+        "aligned_matches", "aligned_len", "full_matches", "full_len", "path_len", "failed", "end_i", "end_j")]
 
 
 class Oracle:

@@ -12,6 +12,9 @@ typedef struct {
     int aligned_matches, aligned_len, full_matches, full_len;
     int path_len;
     int failed; /* 1 => reference prints read_start == -1 (empty input) */
+    int end_i, end_j; /* the scout's end cell: adapter bases / read columns consumed where the traceback starts
+                         (dp_scout.h:165-179) -- what the GPU's score-only records carry, and what the bounds of
+                         the pruned phase B are derived from (tests/test_phase_b_bounds.py) */
 } pc_oracle_result;
 
 /* returns 0 on success, -1 on allocation failure.  gap_open == gap_extend follows the reference's

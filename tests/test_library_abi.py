@@ -58,3 +58,17 @@ def test_no_gpu_means_loud_failure_not_fallback():
         porechop_amd.Aligner(["ACGT"])
     with pytest.raises(RuntimeError):
         porechop_amd.adapter_alignment("ACGT", "ACGT", [3, -6, -5, -2])
+
+
+def test_context_functions_refuse_a_null_context():
+    """Every batch entry point checks its context before it touches the device (no compute without a GPU here): the
+    round's new ones -- the exact prefilter and the three kernels of phase B's exact pruning -- included."""
+    lib = porechop_amd.load_library()
+    BAD = -3                                                     # PC_ERR_BAD_ARG (include/porechop_amd.h)
+    assert lib.pc_phase_b_select(None, None, 0, 0, None, None, None, None, None, None, 150, 4, 2, 75.0, 1, 1e9, 0.0,
+                                 None, None, None, None, None, None, None, None, None) == BAD
+    assert lib.pc_phase_b_gather(None, None, 0, 0, *([None] * 14)) == BAD
+    assert lib.pc_phase_b_scatter(None, None, 0, None, None, None, None, None, None, None, 0, None) == BAD
+    assert lib.pc_phase_b_reduce(None, None, 0, 0, None, None, 150, 4, 2, 75.0, None, None, 0, None, None, 0.0, 0.0, 0, None, None) == BAD
+    assert lib.pc_prefilter_device(None, None, None, None, 0, 0, None, None, 0, None, None) == BAD
+    assert lib.pc_strerror(BAD).decode() == "bad argument"

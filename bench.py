@@ -19,10 +19,13 @@ Prints ONE JSON line on rank 0 (see the contract in the task statement) with ext
                   way with its own end-scan roofline, CPU sample and parity count:
                   configs1 = 100 k reads, end-trim only (--no_split): phases A + B
                   configs2 = 1 M barcoded reads, full panel, end-trim + demultiplexing:
-                             phases A + kit choice + B + barcode calls
+                             phases A + kit choice + B + barcode calls; every end-window pair traced, and beside it
+                             `exact_pruning`: the same step with phase B pruned exactly (score-only pass + bounds from
+                             the end cell, selection on the device: pc_select.hip) -- same trims and calls
   config.also_measured.configs4_per_gpu (every N) -- the per-GPU shape of BASELINE configs[4] (full panel with the
                   96 barcodes AND the middle scan over every matching set's sequences, 1 % chimeras), run by every
-                  rank on its own shard: its own roofline, CPU sample, parity, and the exact-prefilter variant
+                  rank on its own shard: its own roofline, CPU sample, parity, and the variant behind the exact
+                  prefilter with phase B pruned
   config.exact_prefilter -- the headline step with the middle scan behind the exact bit-parallel prefilter
                   (pc_prefilter_device); identical hits, reported BESIDE `value`, which computes every record
   parity.device_crosscheck -- packed-int16 kernels against the packed-fp16 ones over ALL pairs of the headline batch

@@ -184,6 +184,103 @@ def cpu_baseline(reads, pl, matching, st, et, hits, seconds, workers):
     return base, parity
 
 
+def write_fastq(reads, n, path, first=0):
+    """Reads first .. first + n of a uniform-length resident batch as a plain 4-line FASTQ file (names r<index>,
+    qualities '5': SURVEY.md 8d)."""
+    L = int(reads.length[0].item())
+    seq = reads.arena[first * L:(first + n) * L].view(n, L).cpu().numpy()
+    name_w = 9
+    rec = np.empty((n, 1 + name_w + 1 + L + 3 + L + 1), dtype=np.uint8)
+    rec[:, 0] = ord("@"); rec[:, 1] = ord("r")
+    rec[:, 2:1 + name_w] = (np.arange(first, first + n)[:, None] // (10 ** np.arange(name_w - 2, -1, -1))[None, :]) % 10 + ord("0")
+    c = 1 + name_w
+    rec[:, c] = 10
+    rec[:, c + 1:c + 1 + L] = seq
+    rec[:, c + 1 + L:c + 4 + L] = np.frombuffer(b"\n+\n", dtype=np.uint8)
+    rec[:, c + 4 + L:c + 4 + 2 * L] = ord("5")
+    rec[:, -1] = 10
+    rec.tofile(path)
+    return int(rec.size)
+
+
+def file_md5(path):
+    import hashlib
+    h = hashlib.md5()
+    with open(path, "rb") as f:
+        for blk in iter(lambda: f.read(1 << 22), b""):
+            h.update(blk)
+    return h.hexdigest()
+
+
+def run_ref_cli(fastq, out, threads, dropin=False, extra=()):
+    """tests/ref_cli.py in a fresh interpreter: the staged, unchanged porechop.porechop.main() (what porechop-runner.py
+    calls), phases timed from outside; dropin=True installs porechop_amd.dropin first (INTEGRATION.md mode B).
+    -> (report dict, wall seconds of the whole process incl. interpreter start)."""
+    import subprocess
+    import tempfile
+    rep = tempfile.mktemp(prefix="pc_cli_", suffix=".json")
+    cmd = [sys.executable, os.path.join(REPO, "tests", "ref_cli.py")] + (["--dropin"] if dropin else []) + \
+          ["--report", rep, "--", "-i", fastq, "-o", out, "--threads", str(threads), "-v", "0"] + list(extra)
+    t0 = time.perf_counter()
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    wall = time.perf_counter() - t0
+    if res.returncode != 0:
+        raise RuntimeError("ref_cli.py failed: " + res.stderr[-1500:])
+    with open(rep) as f:
+        report = json.load(f)
+    os.remove(rep)
+    return report, wall
+
+
+def leg_reference_cli(reads, args, workers, work):
+    """BASELINE.md's B1 -- Porechop's OWN --threads CLI (porechop/porechop.py:86,108,484-509,575-591), unchanged, over its
+    own compiled cpp_functions.so, on the first --cli-reads of the benchmark's reads written as FASTQ, on this box's host
+    cores, in this run: --threads 1 and --threads min(cores, 16) (the CLI's default cap)."""
+    n = min(args.cli_reads, reads.n)
+    fq = os.path.join(work, "cli_reads.fastq")
+    write_fastq(reads, n, fq)
+    out = {"kind": "reference CLI", "reads": n, "read_len": int(reads.length[0].item())}
+    best = 0.0
+    for t in sorted({1, min(workers, 16)}):
+        o = os.path.join(work, "cli_out_t%d.fastq" % t)
+        rep, wall = run_ref_cli(fq, o, t)
+        out["threads_%d" % t] = {"reads_per_s": n / rep["main_s"], "main_s": rep["main_s"], "process_s": wall,
+                                 "phase_s": {k: round(v, 3) for k, v in rep["phase_s"].items()}}
+        out["output_md5"] = file_md5(o) if "output_md5" not in out else out["output_md5"]
+        out["same_output_all_threads"] = out.get("same_output_all_threads", True) and file_md5(o) == out["output_md5"]
+        best = max(best, n / rep["main_s"])
+    out["best_reads_per_s"] = best
+    return out, fq
+
+
+def leg_dropin(reads, args, work, cli, cli_fastq):
+    """What a Porechop user gets from the drop-in: the unchanged reference Python + porechop_amd.dropin.install(pp)
+    (INTEGRATION.md mode B) with the real library.  (1) the reference CLI leg's FASTQ again: output md5 must equal the
+    CPU reference's, zero memo misses; (2) --dropin-reads reads for the rate (the reference's own Python loops bound it)."""
+    out = {}
+    o = os.path.join(work, "dropin_small.fastq")
+    rep, _ = run_ref_cli(cli_fastq, o, 1, dropin=True)
+    out["md5_equal"] = bool(cli and file_md5(o) == cli.get("output_md5"))
+    out["md5_checked_reads"] = cli["reads"] if cli else 0
+    out["misses"] = rep["dropin"]["misses"]
+    n = min(args.dropin_reads, reads.n)
+    fq = os.path.join(work, "dropin_reads.fastq")
+    write_fastq(reads, n, fq)
+    for t in sorted({1, args.dropin_threads}):
+        o = os.path.join(work, "dropin_big_t%d.fastq" % t)
+        rep, wall = run_ref_cli(fq, o, t, dropin=True)
+        r = {"reads_per_s": n / rep["main_s"], "main_s": rep["main_s"], "process_s": wall,
+             "phase_s": {k: round(v, 3) for k, v in rep["phase_s"].items()},
+             "prefetch_s": round(rep["dropin"]["prefetch_s"], 3), "gpu_batch_calls_s": round(rep["dropin"]["backend_s"], 3),
+             "lookups": rep["dropin"]["hits"], "misses": rep["dropin"]["misses"], "pairs_batched": rep["dropin"]["batched"]}
+        out["threads_%d" % t] = r
+        out["misses"] += rep["dropin"]["misses"]
+        if r["reads_per_s"] > out.get("reads_per_s", 0.0):
+            out["reads_per_s"], out["threads"] = r["reads_per_s"], t
+    out["reads"] = n
+    return out
+
+
 def cpu_phase_a_check(reads, pl, workers, nreads=1024):
     """Phase A re-derived on the host for the first `nreads` reads (the reference's align_adapter_set over the whole
     119-set panel, nanopore_read.py:149-164, through the compiled reference) against the GPU's phase A over the same
@@ -806,23 +903,10 @@ def leg_end_to_end(dev, args):
     os.makedirs(work, exist_ok=True)
     try:
         reads = make_reads(n, L, seed=9, start_frac=0.9, end_frac=0.5, chimera_frac=args.chimera, device=dev)
-        seq = reads.arena[: n * L].view(n, L).cpu().numpy()
+        inp = os.path.join(work, "in.fastq")
+        in_bytes = write_fastq(reads, n, inp)
         del reads
         torch.cuda.empty_cache()
-        name_w = 9
-        rec = np.empty((n, 1 + name_w + 1 + L + 3 + L + 1), dtype=np.uint8)
-        rec[:, 0] = ord("@"); rec[:, 1] = ord("r")
-        rec[:, 2:1 + name_w] = np.arange(n)[:, None] // (10 ** np.arange(name_w - 2, -1, -1))[None, :] % 10 + ord("0")
-        c = 1 + name_w
-        rec[:, c] = 10
-        rec[:, c + 1:c + 1 + L] = seq
-        rec[:, c + 1 + L:c + 4 + L] = np.frombuffer(b"\n+\n", dtype=np.uint8)
-        rec[:, c + 4 + L:c + 4 + 2 * L] = ord("5")
-        rec[:, -1] = 10
-        inp = os.path.join(work, "in.fastq")
-        rec.tofile(inp)
-        in_bytes = int(rec.size)
-        del rec, seq
         runs = []
         out_s = os.path.join(work, "out_streamed.fastq")
         for _ in range(3):
@@ -903,6 +987,169 @@ def leg_ragged(dev, args, workers, uniform_bp_per_s):
     return out
 
 
+def _r(x, sig=6):
+    """Numbers of the printed line: 6 significant digits."""
+    if isinstance(x, bool) or x is None or isinstance(x, (int, str)):
+        return x
+    try:
+        return float("%.*g" % (sig, float(x)))
+    except Exception:
+        return x
+
+
+def _pick(d, *path, default=None):
+    for k in path:
+        if not isinstance(d, dict) or k not in d:
+            return default
+        d = d[k]
+    return d
+
+
+def compact_line(full):
+    """The ONE line bench.py prints: every leg's numbers, no prose, under 8 KB (the driver keeps the last 8 KB of stdout and,
+    in its parsed copy, only scalars one level deep) -- so every leg's rate, parity count and roofline fraction is ALSO a flat
+    scalar in `config`.  What the keys mean is in DESIGN.md section 9; the unabridged record goes to --full-json."""
+    cfg, roof, cpu = full.get("config", {}), full.get("roofline") or {}, full.get("cpu_baseline") or {}
+    also = cfg.get("also_measured", {})
+    legs = {}
+
+    def leg(name, **kw):
+        legs[name] = {k: _r(v) for k, v in kw.items() if v is not None}
+
+    c1 = also.get("configs1", {})
+    if c1:
+        leg("configs1", failed=c1.get("failed"), reads_per_s=c1.get("reads_per_s"), ms_per_step=c1.get("ms_per_step"),
+            phase_b_reads_per_s=_pick(c1, "phase_b", "reads_per_s"), parity_checked=_pick(c1, "parity", "checked"),
+            mismatches=_pick(c1, "parity", "mismatches"), roofline_frac=_pick(c1, "roofline", "frac"),
+            valu_frac=_pick(c1, "roofline", "valu", "frac"), avg_launch_ms=_pick(c1, "roofline", "avg_launch_ms"),
+            traffic=_pick(c1, "roofline", "traffic"), alg_bytes_per_launch=_pick(c1, "roofline", "algorithmic_bytes_per_launch"),
+            cpu_reads_per_s=_pick(c1, "cpu_baseline", "value"))
+    c2 = also.get("configs2", {})
+    if c2:
+        leg("configs2", failed=c2.get("failed"), reads_per_s=c2.get("reads_per_s"), ms_per_step=c2.get("ms_per_step"),
+            pairs_per_read=c2.get("pairs_per_read"), binned_to_planted=c2.get("reads_binned_to_their_planted_barcode"),
+            pruned_reads_per_s=_pick(c2, "exact_pruning", "reads_per_s"), pruned_ms_per_step=_pick(c2, "exact_pruning", "ms_per_step"),
+            pruned_same=_pick(c2, "exact_pruning", "same_trims_and_calls_as_tracing_every_pair"),
+            pruned_traced_fraction=_pick(c2, "exact_pruning", "pairs_traced_fraction"),
+            score_pass_tcups=_pick(c2, "exact_pruning", "score_pass", "tcups"),
+            parity_checked=_pick(c2, "parity", "checked"), mismatches=_pick(c2, "parity", "mismatches"),
+            crosscheck_pairs=_pick(c2, "parity", "device_crosscheck", "device_crosscheck_pairs"),
+            crosscheck_differing=_pick(c2, "parity", "device_crosscheck", "records_differing"),
+            roofline_frac=_pick(c2, "roofline", "frac"), valu_frac=_pick(c2, "roofline", "valu", "frac"),
+            avg_launch_ms=_pick(c2, "roofline", "avg_launch_ms"), traffic=_pick(c2, "roofline", "traffic"),
+            alg_bytes_per_launch=_pick(c2, "roofline", "algorithmic_bytes_per_launch"),
+            cpu_reads_per_s=_pick(c2, "cpu_baseline", "value"))
+    c4 = also.get("configs4_per_gpu", {})
+    if c4:
+        leg("configs4_per_gpu", failed=c4.get("failed"), n_gpus=c4.get("n_gpus"), reads_per_gpu=c4.get("reads_per_gpu"),
+            reads_per_s=c4.get("reads_per_s"), ms_per_step=c4.get("ms_per_step"), middle_adapters=c4.get("middle_adapters"),
+            binned_to_planted=c4.get("reads_binned_to_their_planted_barcode"),
+            fast_reads_per_s=_pick(c4, "exact_prefilter", "reads_per_s"), fast_ms_per_step=_pick(c4, "exact_prefilter", "ms_per_step"),
+            fast_same=_pick(c4, "exact_prefilter", "same_trims_calls_and_middle_hits"),
+            kernels_compiled=_pick(c4, "specialised_kernels", "compiled_in_this_process"),
+            kernels_loaded=_pick(c4, "specialised_kernels", "loaded_from_the_kernel_cache"),
+            parity_checked=_pick(c4, "parity", "checked"), mismatches=_pick(c4, "parity", "mismatches"),
+            roofline_frac=_pick(c4, "roofline", "frac"), valu_frac=_pick(c4, "roofline", "valu", "frac"),
+            avg_launch_ms=_pick(c4, "roofline", "avg_launch_ms"), traffic=_pick(c4, "roofline", "traffic"),
+            seed_scan_hbm_frac=_pick(c4, "exact_prefilter", "roofline", "frac"),
+            cpu_reads_per_s=_pick(c4, "cpu_baseline", "value"))
+    pf = cfg.get("exact_prefilter", {})
+    if pf:
+        leg("exact_prefilter", reads_per_s=pf.get("reads_per_s"), ms_per_step=pf.get("ms_per_step"),
+            same=pf.get("same_trims_and_middle_hits"), seed_scan_gb_per_s=_pick(pf, "roofline", "achieved"),
+            seed_scan_hbm_frac=_pick(pf, "roofline", "frac"), seed_scan_ms=_pick(pf, "roofline", "avg_launch_ms"),
+            seed_scan_traffic=_pick(pf, "roofline", "traffic"), seed_scan_alg_bytes=_pick(pf, "roofline", "algorithmic_bytes_per_launch"))
+    pr = cfg.get("optional_exact_pruning", {})
+    if pr:
+        leg("proven_middle_scan", reads_per_s=pr.get("reads_per_s"), ms_per_step=pr.get("ms_per_step"), same=pr.get("same_middle_hits"))
+    rg = also.get("ragged_lengths", {})
+    if rg:
+        leg("ragged_lengths", failed=rg.get("failed"), reads_per_s=rg.get("reads_per_s"), read_bp_per_s=rg.get("read_bp_per_s"),
+            bp_vs_uniform=rg.get("bp_per_s_vs_uniform_lengths"), parity_checked=_pick(rg, "parity", "checked"),
+            mismatches=_pick(rg, "parity", "mismatches"))
+    hb = also.get("from_host_memory", {})
+    if hb:
+        leg("from_host_memory", failed=hb.get("failed"), reads_per_s=hb.get("reads_per_s"), ms_per_step=hb.get("ms_per_step"),
+            h2d_gb_per_s=hb.get("h2d_gb_per_s_alone"), h2d_ms=hb.get("h2d_ms_alone"), packed=hb.get("packed"))
+    ee = also.get("end_to_end", {})
+    if ee:
+        leg("end_to_end", failed=ee.get("failed"), reads_per_s=ee.get("reads_per_s"), wall_s=ee.get("wall_s"),
+            input_gb_per_s=ee.get("input_gb_per_s"), streamed_equals_whole=ee.get("streamed_output_identical_to_whole_file_output"),
+            whole_file_reads_per_s=_pick(ee, "whole_file_path", "reads_per_s"))
+    b1 = cpu.get("b1_cli") or {}
+    dr = full.get("dropin") or {}
+    par = full.get("parity") or {}
+    flat = {}
+    short = {"configs1": "c1", "configs2": "c2", "configs4_per_gpu": "c4", "exact_prefilter": "pf", "ragged_lengths": "ragged",
+             "from_host_memory": "h2d", "end_to_end": "e2e", "proven_middle_scan": "proven"}
+    for name, d in legs.items():
+        for k in ("reads_per_s", "parity_checked", "mismatches", "roofline_frac", "valu_frac", "cpu_reads_per_s",
+                  "pruned_reads_per_s", "fast_reads_per_s", "seed_scan_hbm_frac", "same", "pruned_same", "fast_same"):
+            if k in d:
+                flat["%s_%s" % (short[name], k)] = d[k]
+    out = {k: _r(full.get(k)) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                        "scaling", "vs_baseline", "dtype", "data", "read_bp_per_s", "value_incl_h2d")}
+    out["config"] = {"workload": cfg.get("workload"), "reads_per_gpu": cfg.get("reads_per_gpu"), "read_len": cfg.get("read_len"),
+                     "parallelism": cfg.get("parallelism"), "world_size": cfg.get("world_size"), "backend": cfg.get("backend"),
+                     "library_sha1": cfg.get("library_sha1"), "middle_hits_per_step": cfg.get("middle_hits_per_step"),
+                     "mask_rounds": cfg.get("mask_rounds"), "matching_sets": ",".join(cfg.get("matching_sets") or []),
+                     "speedup_vs_cpu_baseline": _r(cfg.get("speedup_vs_cpu_baseline")),
+                     "speedup_vs_reference_cli": _r(full["value"] / b1["best_reads_per_s"]) if b1.get("best_reads_per_s") else None,
+                     "region_ms_min": _r(_pick(full, "repeats", "min")), "region_ms_median": _r(_pick(full, "repeats", "median")),
+                     "region_ms_max": _r(_pick(full, "repeats", "max")),
+                     "ms_per_step_by_rank": [_r(x) for x in cfg.get("ms_per_step_by_rank") or []]}
+    out["config"].update({"kernel_ms_" + k: _r(v) for k, v in (cfg.get("kernel_ms_per_step") or {}).items() if v})
+    out["config"].update(flat)
+    if dr:
+        out["config"].update({"dropin_reads_per_s": _r(dr.get("reads_per_s")), "dropin_md5_equal": dr.get("md5_equal"),
+                              "dropin_misses": dr.get("misses")})
+    out["roofline"] = None
+    if roof:
+        out["roofline"] = {"bound": roof.get("bound"), "kernel": (roof.get("kernel") or "").split(" ")[0],
+                           "achieved": _r(roof.get("achieved")), "peak": roof.get("peak"), "unit": roof.get("unit"),
+                           "frac": _r(roof.get("frac")), "traffic": _r(roof.get("traffic")),
+                           "traffic_measured_in_this_run": False, "traffic_source": (roof.get("traffic_source") or "").split(" ")[0] or None,
+                           "launches": roof.get("launches"), "avg_launch_ms": _r(roof.get("avg_launch_ms")),
+                           "algorithmic_bytes_per_launch": _r(roof.get("algorithmic_bytes_per_launch")),
+                           "valu_gcups": _r(_pick(roof, "valu", "achieved_gcups")), "valu_peak_gcups": _r(_pick(roof, "valu", "peak_gcups")),
+                           "valu_frac": _r(_pick(roof, "valu", "frac")), "ops_per_2_cells": _pick(roof, "valu", "ops_per_2_cells")}
+    if cpu:
+        out["cpu_baseline"] = {"value": _r(cpu.get("value")), "unit": cpu.get("unit"), "cores": cpu.get("cores"), "kind": cpu.get("kind"),
+                               "sample": cpu.get("sample")}
+        if b1:
+            c = out["cpu_baseline"]
+            c["b1_cli_kind"] = b1.get("kind", "reference CLI")
+            c["b1_cli_failed"] = b1.get("failed")
+            c["b1_cli_reads"] = b1.get("reads")
+            for k, v in b1.items():
+                if k.startswith("threads_") and isinstance(v, dict):
+                    c["b1_cli_%s_reads_per_s" % k] = _r(v.get("reads_per_s"))
+            c["b1_cli"] = {k: ({kk: (_r(vv) if not isinstance(vv, dict) else {a: _r(b) for a, b in vv.items()}) for kk, vv in v.items()}
+                               if isinstance(v, dict) else _r(v)) for k, v in b1.items()}
+            out["cpu_baseline"] = {k: v for k, v in c.items() if v is not None}
+    out["parity"] = {"checked": par.get("checked"), "mismatches": par.get("mismatches"),
+                     "phase_a_reads": _pick(par, "phase_a_rederived_on_cpu", "reads"),
+                     "phase_a_entries_differing": _pick(par, "phase_a_rederived_on_cpu", "entries_differing"),
+                     "phase_a_same_matching_sets": _pick(par, "phase_a_rederived_on_cpu", "same_matching_sets"),
+                     "crosscheck_pairs": _pick(par, "device_crosscheck", "device_crosscheck_pairs"),
+                     "crosscheck_differing": _pick(par, "device_crosscheck", "records_differing")}
+    if dr:
+        out["dropin"] = {k: ({kk: (_r(vv) if not isinstance(vv, dict) else {a: _r(b) for a, b in vv.items()}) for kk, vv in v.items()}
+                             if isinstance(v, dict) else _r(v)) for k, v in dr.items()}
+    out["legs"] = legs
+    line = json.dumps(out, separators=(",", ":"))
+    for victim in (("dropin", "threads_1", "phase_s"), ("cpu_baseline", "b1_cli", "threads_1", "phase_s"), ("config", "ms_per_step_by_rank")):
+        if len(line) <= 7600:
+            break
+        d = out
+        for k in victim[:-1]:
+            d = d.get(k, {}) if isinstance(d, dict) else {}
+        if isinstance(d, dict):
+            d.pop(victim[-1], None)
+        line = json.dumps(out, separators=(",", ":"))
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -918,6 +1165,11 @@ def main():
     ap.add_argument("--chimera", type=float, default=0.01)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="0 disables the CPU baseline / parity legs")
     ap.add_argument("--no-extra", action="store_true", help="headline only (skip the configs[1] / configs[2] legs)")
+    ap.add_argument("--cli-reads", type=int, default=2000, help="reads of the reference-CLI baseline (B1); 0 disables it and the drop-in leg")
+    ap.add_argument("--dropin-reads", type=int, default=20000, help="reads of the drop-in leg (unchanged reference Python over the HIP library)")
+    ap.add_argument("--dropin-threads", type=int, default=16, help="--threads of the drop-in leg's second run (the first uses 1)")
+    ap.add_argument("--full-json", default=os.environ.get("PC_BENCH_FULL", ""), help="also write the unabridged record here "
+                    "(default: gpurun_out/bench_full.json under the repo)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -1092,8 +1344,9 @@ def main():
             "repeats": {"ms_per_step": region_ms, "median": srt[len(srt) // 2], "min": srt[0], "max": srt[-1],
                         "note": "%d timed regions of %d steps each, back to back; `value` is the FIRST (the contract's) region"
                                 % (len(region_ms), args.steps)},
-            "config": {"workload": "BASELINE configs[3]: %d synthetic %d-bp reads per GPU, %.0f%% chimeras, "
-                                   "phases A (119-set panel, %d check reads) + B + C (middle scan on)"
+            "config": {"workload": "BASELINE configs[3] shape: %d synthetic %d-bp reads per GPU, %.0f%% chimeras, phases A (119-set "
+                                   "panel, %d check reads) + B + C (middle scan on); generator porechop_amd/synth.py: bodies from a "
+                                   "torch generator, adapter copies drawn from a pool of 4096 pre-mutated instances"
                                    % (args.reads, args.read_len, args.chimera * 100, params.check_reads),
                        "reads_per_gpu": args.reads, "read_len": args.read_len, "parallelism": "reads sharded x%d" % world,
                        "world_size": dist.get_world_size() if world > 1 else 1,
@@ -1122,6 +1375,32 @@ def main():
                 out.setdefault("parity", {})["phase_a_rederived_on_cpu"] = cpu_phase_a_check(reads, pl, host_cores())
             except Exception as e:
                 out.setdefault("parity", {})["phase_a_rederived_on_cpu"] = {"failed": repr(e)}
+        if args.cpu_seconds > 0 and world == 1 and args.cli_reads > 0:
+            from tests.ref_cli import staged
+            if staged():
+                import shutil
+                import tempfile
+                work = tempfile.mkdtemp(prefix="pc_bench_cli_")
+                try:
+                    cli = fq = None
+                    try:
+                        note("leg reference_cli")
+                        cli, fq = leg_reference_cli(reads, args, host_cores(), work)
+                        out["cpu_baseline"]["b1_cli"] = cli
+                    except Exception as e:
+                        out["cpu_baseline"]["b1_cli"] = {"failed": repr(e)}
+                    try:
+                        note("leg dropin")
+                        if fq is None:
+                            fq = os.path.join(work, "cli_reads.fastq")
+                            write_fastq(reads, min(args.cli_reads, reads.n), fq)
+                        out["dropin"] = leg_dropin(reads, args, work, cli, fq)
+                    except Exception as e:
+                        out["dropin"] = {"failed": repr(e)}
+                finally:
+                    shutil.rmtree(work, ignore_errors=True)
+            else:
+                out["cpu_baseline"]["b1_cli"] = {"failed": "no staged reference under oracle/_ref/porechop_ref (make -C oracle ref)"}
         if world == 1 and not args.no_extra:
             try:
                 out.setdefault("parity", {})["device_crosscheck"] = device_crosscheck(pl, reads, matching, st, et, dev)
@@ -1161,7 +1440,14 @@ def main():
                 out["value_incl_h2d"] = also["from_host_memory"]["reads_per_s"]
         if also:
             out["config"]["also_measured"] = also
-        print(json.dumps(out))
+        full_path = args.full_json or os.path.join(REPO, "gpurun_out", "bench_full.json")
+        try:
+            os.makedirs(os.path.dirname(os.path.abspath(full_path)), exist_ok=True)
+            with open(full_path, "w") as f:
+                json.dump(out, f, indent=1)
+        except Exception:
+            pass
+        print(json.dumps(compact_line(out), separators=(",", ":")))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -141,6 +141,7 @@ int pc_sync(pc_ctx *ctx, void *stream);
  * phase B's exact pruning: pc_phase_b_select / _gather / _scatter) the summed duration in milliseconds, the number
  * of launches and the number of pairs they covered, and resets the accumulators.  Each array
  * holds PC_KERNEL_KINDS entries. */
+/* (PC_KERNEL_KINDS grew from 4 to 7 in round 3: a caller built against the older header must enlarge its three arrays.) */
 #define PC_KERNEL_KINDS 7
 int pc_set_timing(pc_ctx *ctx, int enabled);
 int pc_get_timing(pc_ctx *ctx, void *stream, double *ms, int64_t *launches, int64_t *pairs);
@@ -228,8 +229,12 @@ int pc_copy_windows(pc_ctx *ctx, const void *d_arena, const int64_t *d_src_off, 
  * a longer adapter is represented by its first 32 bases with the same bound when max_edits <= 8, and otherwise cut into
  * ceil(m / 32) pieces, surviving when one piece lies within floor(max_edits / pieces) edits (pigeonhole) -- a superset
  * either way.  max_edits[j] < 0 = do not filter adapter j (bit set for every non-empty window).
- * adapters[] indexes the table of pc_set_adapters; max_len bounds every win_len; the arena must be readable 16 bytes
- * past its last window.  Asynchronous on `stream`; honours pc_set_length_hint. */
+ * adapters[] indexes the table of pc_set_adapters; max_len bounds every win_len (a longer window is flagged on the
+ * device and reported by pc_sync as PC_ERR_INTERNAL: its tail would otherwise go unscanned and look "proven"); the arena
+ * must be readable 16 bytes past its last window, and -- because the kernels fetch whole aligned 16-byte blocks
+ * (exhaustive kernel) and 128-byte lines (seed scan) -- from the 128-byte boundary at or below d_arena: d_arena itself
+ * should be 128-byte aligned (hipMalloc and torch allocations are 256-byte aligned), or sit inside an allocation that
+ * starts at or below that boundary.  Asynchronous on `stream`; honours pc_set_length_hint. */
 int pc_prefilter_max_edits(int adapter_len, double threshold_percent);
 int pc_prefilter_device(pc_ctx *ctx, const void *d_arena, const int64_t *d_win_off, const int32_t *d_win_len,
                         int64_t nwindows, int max_len, const int32_t *adapters, const int32_t *max_edits,
@@ -273,6 +278,10 @@ void pc_jit_stats(int64_t *compiled, int64_t *from_disk);
 
 /* Format one result record exactly as the reference prints it; buf must hold >= 160 bytes. */
 int pc_format_result(const int32_t *rec, char *buf, size_t buflen);
+/* The same for n records at once: the strings back to back in buf, each followed by '\n'; *used = bytes written.
+ * buflen >= 161 * n always suffices.  (The drop-in's prefetch turns millions of records into the strings the
+ * reference's Python parses, porechop/nanopore_read.py:476-491: one call instead of one per record.) */
+int pc_format_results(const int32_t *recs, int64_t n, char *buf, int64_t buflen, int64_t *used);
 
 /* Prefetch memo for the per-call symbol: compute these pairs on the GPU now and remember the
  * answers, keyed by (window bytes, adapter bytes, scores), so that later adapterAlignment()

@@ -14,7 +14,7 @@ EXPORTS = [
     "adapterAlignment", "freeCString",
     "pc_version", "pc_strerror", "pc_scores_supported", "pc_create", "pc_destroy",
     "pc_set_scores", "pc_set_adapters", "pc_align_batch_host", "pc_scan_device", "pc_sync",
-    "pc_format_result", "pc_jit_async", "pc_jit_shutdown", "pc_jit_precompile", "pc_jit_stats", "pc_prefilter_max_edits", "pc_prefilter_device", "pc_prefetch", "pc_memo_clear", "pc_memo_stats", "pc_set_timing", "pc_get_timing", "pc_set_length_hint", "pc_set_int16_only", "pc_copy_windows", "pc_trace_ops_x100", "pc_phase_b_reduce", "pc_phase_b_select", "pc_phase_b_gather", "pc_phase_b_scatter", "pc_debug_value_range",
+    "pc_format_result", "pc_format_results", "pc_jit_async", "pc_jit_shutdown", "pc_jit_precompile", "pc_jit_stats", "pc_prefilter_max_edits", "pc_prefilter_device", "pc_prefetch", "pc_memo_clear", "pc_memo_stats", "pc_set_timing", "pc_get_timing", "pc_set_length_hint", "pc_set_int16_only", "pc_copy_windows", "pc_trace_ops_x100", "pc_phase_b_reduce", "pc_phase_b_select", "pc_phase_b_gather", "pc_phase_b_scatter", "pc_debug_value_range",
     "pc_readset_load", "pc_readset_free", "pc_readset_error", "pc_readset_count", "pc_readset_is_fastq",
     "pc_readset_arena", "pc_readset_offsets", "pc_readset_lengths", "pc_readset_name", "pc_readset_quals",
     "pc_readset_is_rna", "pc_readset_load_many", "pc_readset_file_index", "pc_readset_write",
@@ -113,6 +113,8 @@ def load_library():
     atexit.register(L.pc_jit_shutdown)       # no worker thread inside hiprtc while the process is torn down
     L.pc_format_result.argtypes = [c_vp, c_cp, ctypes.c_size_t]
     L.pc_format_result.restype = c_int
+    L.pc_format_results.argtypes = [c_vp, c_i64, c_vp, c_i64, ctypes.POINTER(c_i64)]
+    L.pc_format_results.restype = c_int
     L.pc_prefetch.argtypes = [c_vp, c_i64, c_vp, c_vp, ctypes.POINTER(c_cp), c_vp, c_i64, c_int, c_int, c_int, c_int]
     L.pc_prefetch.restype = c_int
     L.pc_readset_load.argtypes = [c_cp, ctypes.POINTER(c_vp)]

@@ -25,6 +25,21 @@ def format_result(rec):
     return buf.value.decode()
 
 
+def format_results(recs):
+    """[n, 8] int32 records -> list of the reference's 7-field strings (pc_format_results: one call for all)."""
+    recs = np.ascontiguousarray(recs, dtype=np.int32).reshape(-1, RESULT_INTS)
+    n = int(recs.shape[0])
+    if n == 0:
+        return []
+    lib = load_library()
+    buf = ctypes.create_string_buffer(161 * n)
+    used = ctypes.c_int64()
+    check(lib.pc_format_results(recs.ctypes.data, n, buf, 161 * n, ctypes.byref(used)), "pc_format_results")
+    out = buf.raw[:used.value].decode("ascii").split("\n")
+    out.pop()
+    return out
+
+
 def records_to_fields(recs):
     """[n,8] int32 -> what porechop/nanopore_read.py:476-491 (align_adapter) derives per call:
     full_adapter_identity, aligned_identity (float64), read_start, read_end (= field1 + 1)."""

@@ -1097,6 +1097,9 @@ int pc_prefilter_device(pc_ctx *c, const void *d_arena, const int64_t *d_win_off
     std::vector<int32_t> key(adapters, adapters + nadapters);
     key.insert(key.end(), max_edits, max_edits + nadapters);
     if (key != c->pf_key) {
+        // the cached seed / table state is rebuilt member by member below: until ALL of it is in place (the key is set last)
+        // no key may name it -- a failed upload half-way must not leave the old key over mixed tables
+        c->pf_key.clear();
         // Pieces.  An adapter of at most 32 bases is one piece with its own bound.  A longer one that allows at most 8
         // edits is represented by its FIRST 32 BASES with the same bound (within k edits of a substring, so is every
         // substring of it: still a proof, and a 32-mer within <= 8 edits of random text is rare).  Beyond that it is cut
@@ -1313,6 +1316,7 @@ int pc_prefilter_device(pc_ctx *c, const void *d_arena, const int64_t *d_win_off
     a.arena = (const uint8_t *)d_arena; a.win_off = d_win_off; a.win_len = d_win_len; a.nwindows = nwindows;
     a.chunks = (int32_t)chunks; a.chunk_len = chunk_len; a.warm = c->pf_warm;
     a.mask = d_mask; a.words = words;
+    a.max_len = max_len; a.err = c->d_err.as<uint32_t>();
     auto exhaustive = [&](const std::vector<pc_ctx::PfLaunch> &ls) -> int {
         for (const pc_ctx::PfLaunch &L : ls) {
             a.tables = c->d_pf_tables.as<uint32_t>() + L.table_off; a.piece_meta = c->d_pf_meta.as<int32_t>() + L.meta_off;
@@ -1345,6 +1349,7 @@ int pc_prefilter_device(pc_ctx *c, const void *d_arena, const int64_t *d_win_off
     for (int t = 0; t < 3; ++t) sa.q[t] = c->sd_q[t];
     sa.bitmaps = c->d_sd_bitmaps.as<uint32_t>();
     sa.cand = c->d_sd_cand.as<uint32_t>(); sa.count = c->d_sd_count.as<unsigned long long>(); sa.cap = cap;
+    sa.max_len = max_len; sa.err = c->d_err.as<uint32_t>();
     {
         ScopedTimer ts(c, stream, 5, nwindows);     // the scan alone (pairs = windows)
         if (pck::launch_seed_scan(sa, stream)) return PC_ERR_NO_DEVICE;
@@ -1531,6 +1536,19 @@ int pc_format_result(const int32_t *r, char *buf, size_t buflen)
     const double pa = 100.0 * m / al;
     const double pf = 100.0 * m / fl;
     return snprintf(buf, buflen, "%d,%d,%d,%d,%d,%f,%f", r[0], r[1], r[2], r[3], r[4], pa, pf);
+}
+
+int pc_format_results(const int32_t *recs, int64_t n, char *buf, int64_t buflen, int64_t *used)
+{
+    if (n < 0 || (n && (!recs || !buf))) return PC_ERR_BAD_ARG;
+    int64_t pos = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        if (buflen - pos < 161) return PC_ERR_BAD_ARG;
+        pos += pc_format_result(recs + i * PC_RESULT_INTS, buf + pos, 160);
+        buf[pos++] = '\n';
+    }
+    if (used) *used = pos;
+    return PC_OK;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -211,12 +211,22 @@ uint64_t fnv64(const void *p, size_t n, uint64_t h)
     return h;
 }
 
-const char kCacheMagic[] = "PCJK2\n";
+const char kCacheMagic[] = "PCJK3\n";
+
+// The toolchain a cached code object belongs to: the HIP / clang versions THIS LIBRARY was compiled with (hipcc and
+// hiprtc of one ROCm install share their compiler; the library is built in-tree by that install).  Part of the file
+// name's hash and of the header a load checks, so code objects in ~/.cache/porechop_amd or in a copied kernel_cache/
+// do not survive a toolchain upgrade: they simply stop being found and are recompiled.
+#define PC_STR2(x) #x
+#define PC_STR(x) PC_STR2(x)
+const char kToolchainTag[] = "toolchain=hip-" PC_STR(HIP_VERSION_MAJOR) "." PC_STR(HIP_VERSION_MINOR) "." PC_STR(HIP_VERSION_PATCH)
+                             "/clang-" __clang_version__;
 
 std::string joined(const std::vector<std::string> &opts)
 {
     std::string s;
     for (const std::string &o : opts) { s += o; s += ' '; }
+    s += kToolchainTag;
     return s;
 }
 

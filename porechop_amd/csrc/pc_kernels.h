@@ -110,6 +110,8 @@ struct PrefilterArgs {
     const int32_t *piece_meta;       // [ngroups][P][4]: piece length (0 = unused slot), max edits, mask word, mask bit
     uint32_t *mask;                  // [nwindows][words], zeroed by the host; bit set = the pair survives
     int32_t words;
+    int32_t max_len;                 // the caller's bound on win_len: a longer window is a contract violation, flagged in
+    uint32_t *err;                   // err[0] (a clear bit means PROVEN not a hit: an unscanned tail must never look like one)
 };
 int launch_prefilter(const PrefilterArgs &a, int pieces_per_lane, int ngroups, void *stream);
 
@@ -127,6 +129,8 @@ struct SeedScanArgs {
     uint32_t *cand;                      // candidates, 2 words each: window, column of the seed's last base | class << 28
     unsigned long long *count;           // appended so far (may exceed cap: then the host falls back to the exhaustive kernel)
     int64_t cap;
+    int32_t max_len;                     // as in PrefilterArgs
+    uint32_t *err;
 };
 struct SeedVerifyArgs {
     const uint8_t *arena;

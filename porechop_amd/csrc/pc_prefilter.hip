@@ -126,6 +126,7 @@ __global__ __launch_bounds__(256) void prefilter_kernel(PrefilterArgs a)
     const uint8_t *p = a.arena;
     if (w < a.nwindows) {
         const int len = a.win_len[w];
+        if (chunk == 0 && len > a.max_len) atomicAdd(a.err, 1u);      // columns beyond chunks * chunk_len would go unscanned
         const int c0 = chunk * a.chunk_len;
         if (c0 < len) {
             const int start = c0 > a.warm ? c0 - a.warm : 0;
@@ -267,6 +268,7 @@ __global__ __launch_bounds__(256) void seed_scan_kernel(SeedScanArgs a)
     const uint8_t *p = a.arena;
     if (w < a.nwindows) {
         const int len = a.win_len[w];
+        if (chunk == 0 && len > a.max_len) atomicAdd(a.err, 1u);
         c0 = chunk * a.chunk_len;
         if (c0 < len) {
             start = c0 > a.warm ? c0 - a.warm : 0;

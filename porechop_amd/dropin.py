@@ -23,31 +23,57 @@ The backend is any object with ``align(pairs, scores) -> list[str]`` (pairs = [(
 the default is the GPU library.  There is no CPU backend in this package; tests inject the oracle.
 """
 import functools
+import time
 
 
 class GpuBackend:
-    """(read, adapter) string pairs -> the reference's 7-field strings, through the C ABI."""
+    """(read, adapter) string pairs -> the reference's 7-field strings, through the C ABI (pc_align_batch_host +
+    pc_format_results).  Every distinct read string goes into the arena once, however many adapters it meets; one
+    context per scoring scheme is kept for the life of the backend."""
 
     def __init__(self):
         self._aligners = {}
 
+    def _aligner(self, adapters, scores):
+        from .batch import Aligner
+        al = self._aligners.get(scores)
+        if al is None:
+            al = self._aligners[scores] = Aligner(adapters, scores)
+        else:
+            al.set_adapters(adapters)
+        return al
+
     def align(self, pairs, scores):
-        from .batch import Aligner, format_result
+        import numpy as np
+        from .batch import format_results
         if not pairs:
             return []
-        ads, idx = [], {}
-        items = []
-        for rd, ad in pairs:
-            if ad not in idx:
-                idx[ad] = len(ads)
+        ads, ad_idx, rd_idx = [], {}, {}
+        chunks, pos = [], 0
+        n = len(pairs)
+        offs = np.empty(n, dtype=np.int64)
+        lens = np.empty(n, dtype=np.int32)
+        idx = np.empty(n, dtype=np.int32)
+        for p, (rd, ad) in enumerate(pairs):
+            ai = ad_idx.get(ad)
+            if ai is None:
+                ai = ad_idx[ad] = len(ads)
                 ads.append(ad)
-            items.append((rd, idx[ad]))
-        al = Aligner(ads, tuple(scores))
-        try:
-            recs = al.align_pairs(items)
-        finally:
+            where = rd_idx.get(rd)
+            if where is None:
+                b = rd.encode()
+                where = rd_idx[rd] = (pos, len(b))
+                chunks.append(b)
+                pos += len(b)
+            offs[p], lens[p] = where
+            idx[p] = ai
+        al = self._aligner(ads, tuple(int(x) for x in scores))
+        return format_results(al.align_host(b"".join(chunks), offs, lens, idx))
+
+    def close(self):
+        for al in self._aligners.values():
             al.close()
-        return [format_result(r) for r in recs]
+        self._aligners = {}
 
 
 class _State:
@@ -57,8 +83,17 @@ class _State:
         self.hits = 0
         self.misses = 0
         self.batched = 0
+        self.prefetch_seconds = 0.0       # wall clock inside prefetch(), of which ...
+        self.backend_seconds = 0.0        # ... inside the backend's batch calls
 
     def prefetch(self, pairs, scores):
+        t0 = time.perf_counter()
+        try:
+            self._prefetch(pairs, scores)
+        finally:
+            self.prefetch_seconds += time.perf_counter() - t0
+
+    def _prefetch(self, pairs, scores):
         key_scores = tuple(scores)
         todo, seen = [], set()
         for rd, ad in pairs:
@@ -68,7 +103,9 @@ class _State:
                 todo.append((rd, ad))
         if not todo:
             return
+        t0 = time.perf_counter()
         out = self.backend.align(todo, key_scores)
+        self.backend_seconds += time.perf_counter() - t0
         self.batched += len(todo)
         for (rd, ad), res in zip(todo, out):
             self.memo[(rd, ad, key_scores)] = res

@@ -49,7 +49,7 @@ class ScanParams:
 @dataclass
 class DeviceReads:
     """Reads resident in HBM: one byte per base as delivered (upper-cased ASCII), read r at
-    arena[off[r] : off[r] + length[r]].  The arena must have >= 8 readable bytes after the last
+    arena[off[r] : off[r] + length[r]].  The arena must have >= 16 readable bytes after the last
     read (the kernels fetch bases a dword at a time)."""
     arena: torch.Tensor    # uint8 [bytes]
     off: torch.Tensor      # int64 [R]

@@ -637,7 +637,7 @@ def run(input_path, output=None, barcode_dir=None, options: Options = None, devi
         reads = None
         if R:
             a0 = int(rs.offsets[lo_r])
-            a1 = min(int(rs.offsets[hi_r - 1]) + int(rs.lengths[hi_r - 1]) + 64, rs.arena.size)   # >= 8 readable bytes past the end
+            a1 = min(int(rs.offsets[hi_r - 1]) + int(rs.lengths[hi_r - 1]) + 64, rs.arena.size)   # >= 16 readable bytes past the end (the kernels fetch 16 columns per load)
             reads = DeviceReads(torch.from_numpy(rs.arena[a0:a1]).to(dev), torch.from_numpy(rs.offsets[lo_r:hi_r] - a0).to(dev),
                                 torch.from_numpy(rs.lengths[lo_r:hi_r].copy()).to(dev))
         lap("upload", sync=True)

@@ -612,7 +612,7 @@ def leg_configs4(dev, args, workers, world, rank, barrier):
     fw = [a for a in load_panel_json() if a["name"].startswith("Barcode ") and "(forward)" in a["name"]]
     reads = make_reads(n, args.read_len, seed=4 + 1000 * rank, start_frac=0.9, end_frac=0.5, chimera_frac=args.chimera, device=dev,
                        barcodes_start=[a["start"][1] for a in fw], barcodes_end=[a["end"][1] for a in fw])
-    n_check = max(1, p.check_reads // world)
+    n_check = p.check_reads // world + (1 if rank < p.check_reads % world else 0)
 
     def run(steps, prefilter, prune_b=False):
         out = None
@@ -645,13 +645,17 @@ def leg_configs4(dev, args, workers, world, rank, barrier):
     (_, _, _, st_p, et_p, calls_p, hits_p), dt_p = timed_region(psteps, True, True)
     timing_p = pl.aligner.get_timing()
     pl.aligner.set_timing(False)
-    if rank != 0:
-        pl.close()
-        return None
     same = bool(hits_p.read.numel() == hits.read.numel() and torch.equal(hits_p.read, hits.read) and
                 torch.equal(hits_p.adapter, hits.adapter) and torch.equal(hits_p.start, hits.start) and
                 torch.equal(hits_p.end, hits.end) and torch.equal(st_p, st) and torch.equal(et_p, et) and
                 np.array_equal(calls_p, calls))
+    if world > 1:                                            # EVERY rank's fast variant must equal its own full computation
+        flag = torch.tensor([1 if same else 0], dtype=torch.int64, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        same = bool(flag.item())
+    if rank != 0:
+        pl.close()
+        return None
     ads = pl.middle_adapter_list(matching)
     A = len(ads)
     mean_trim_len = float((reads.length.to(torch.float64) - st.to(torch.float64) - et.to(torch.float64)).mean().item())
@@ -798,10 +802,13 @@ def profile_traffic(leg, kernel, launches_per_step=None):
 
 
 def leg_host_buffers(dev, args):
-    """The headline workload with the reads starting in (pinned) HOST memory: every step uploads all read bytes
-    over PCIe again.  Reads go up in batches on a copy stream into two device buffers while the previous batch
-    is being scanned on the compute stream (phase A runs on the first batch, which holds the check reads).
+    """The headline workload with the reads starting in (pinned) HOST memory: every step uploads all reads over PCIe again,
+    in batches on a copy stream into two device buffers while the previous batch is being scanned on the compute stream
+    (phase A runs on the first batch, which holds the check reads).  Twice: the reads held at 2 BITS per base, the form
+    pc_pack_reads gives them once at ingest (north_star: "2-bit-packed read windows"; pc_unpack_device turns a batch into
+    the byte arena on the GPU) -- `reads_per_s` -- and at one byte per base as earlier rounds did (`bytes_per_base_1`).
     This is the PCIe-inclusive rate of DESIGN.md section 6 -- never `value`, which is measured HBM-resident."""
+    from porechop_amd.io import pack_reads
     from porechop_amd.pipeline import Pipeline, ScanParams, DeviceReads
     from porechop_amd.synth import make_reads
     p = ScanParams()
@@ -817,14 +824,27 @@ def leg_host_buffers(dev, args):
     per = (n + nb - 1) // nb
     bounds = [(i, min(n, i + per)) for i in range(0, n, per)]
     first = [int(h_off[a]) for a, _ in bounds] + [int(h_off[n - 1]) + int(h_len[n - 1])]
-    cap = max(first[k + 1] - first[k] for k in range(len(bounds))) + 64
+    cap = (max(first[k + 1] - first[k] for k in range(len(bounds))) + 64 + 15) // 16 * 16
     bufs = [torch.empty(cap, dtype=torch.uint8, device=dev) for _ in range(2)]
     offs = [torch.empty(per, dtype=torch.int64, device=dev) for _ in range(2)]
     lens = [torch.empty(per, dtype=torch.int32, device=dev) for _ in range(2)]
+    # the 2-bit form of every batch, packed once (ingest-time work, timed and reported, not part of a step)
+    t0 = time.perf_counter()
+    h_pk, h_exc = [], []
+    for k in range(len(bounds)):
+        nbases = first[k + 1] - first[k]
+        out = torch.empty((nbases + 15) // 16 * 4, dtype=torch.uint8, pin_memory=True)
+        _, exc = pack_reads(h_arena.numpy()[first[k]:first[k + 1]], nbases, out=out.numpy())
+        h_pk.append(out)
+        h_exc.append(torch.from_numpy(exc).pin_memory() if exc.size else None)
+    pack_s = time.perf_counter() - t0
+    d_pk = [torch.empty(max(int(x.numel()) for x in h_pk), dtype=torch.uint8, device=dev) for _ in range(2)]
+    d_exc = [torch.empty(max([1] + [int(x.numel()) for x in h_exc if x is not None]), dtype=torch.int64, device=dev) for _ in range(2)]
     copy_stream = torch.cuda.Stream(device=dev)
     main = torch.cuda.current_stream(dev)
     uploaded = [torch.cuda.Event() for _ in range(2)]
     scanned = [torch.cuda.Event() for _ in range(2)]
+    packed, prefilter = [True], [False]
 
     def upload(k):
         a, b = bounds[k]
@@ -832,8 +852,16 @@ def leg_host_buffers(dev, args):
         with torch.cuda.stream(copy_stream):
             copy_stream.wait_event(scanned[s])                      # the scan of batch k-2 is done with this buffer
             nbytes = first[k + 1] - first[k]
-            bufs[s][:nbytes].copy_(h_arena[first[k]:first[k + 1]], non_blocking=True)
-            bufs[s][nbytes:nbytes + 64].fill_(ord("N"))
+            if packed[0]:
+                d_pk[s][:h_pk[k].numel()].copy_(h_pk[k], non_blocking=True)
+                ne = 0 if h_exc[k] is None else int(h_exc[k].numel())
+                if ne:
+                    d_exc[s][:ne].copy_(h_exc[k], non_blocking=True)
+                pl.aligner.unpack_device(d_pk[s], nbytes, d_exc[s][:ne] if ne else None, arena=bufs[s], pad=64,
+                                         stream=copy_stream.cuda_stream)
+            else:
+                bufs[s][:nbytes].copy_(h_arena[first[k]:first[k + 1]], non_blocking=True)
+                bufs[s][nbytes:nbytes + 64].fill_(ord("N"))
             offs[s][:b - a].copy_(h_off[a:b], non_blocking=True)
             lens[s][:b - a].copy_(h_len[a:b], non_blocking=True)
             uploaded[s].record(copy_stream)
@@ -851,7 +879,7 @@ def leg_host_buffers(dev, args):
                 bs, be = pl.phase_a(batch, torch.arange(min(p.check_reads, b - a), device=dev))
                 matching = pl.matching_sets(bs, be)
             st, et = pl.phase_b(batch, matching)
-            hits = pl.phase_c(batch, st, et, matching)
+            hits = pl.phase_c(batch, st, et, matching, prefilter=prefilter[0])
             hits_n += int(hits.read.numel())
             scanned[s].record(main)
         return matching, hits_n
@@ -859,23 +887,45 @@ def leg_host_buffers(dev, args):
     def sync():
         pl.aligner.sync()
         torch.cuda.synchronize()
+
+    def upload_alone():
+        sync()
+        t0 = time.perf_counter()
+        with torch.cuda.stream(copy_stream):
+            for k in range(len(bounds)):
+                if packed[0]:
+                    d_pk[k & 1][:h_pk[k].numel()].copy_(h_pk[k], non_blocking=True)
+                    pl.aligner.unpack_device(d_pk[k & 1], first[k + 1] - first[k], None, arena=bufs[k & 1], pad=64,
+                                             stream=copy_stream.cuda_stream)
+                else:
+                    bufs[k & 1][:first[k + 1] - first[k]].copy_(h_arena[first[k]:first[k + 1]], non_blocking=True)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+
     for e in scanned:
         e.record(main)
     steps = max(1, min(args.steps, 5))
-    (matching, hits_n), dt = timed(step, steps, max(1, min(args.warmup, 2)), sync)
-    # the upload alone, for reference
-    sync()
-    t0 = time.perf_counter()
-    with torch.cuda.stream(copy_stream):
-        for k in range(len(bounds)):
-            bufs[k & 1][:first[k + 1] - first[k]].copy_(h_arena[first[k]:first[k + 1]], non_blocking=True)
-    torch.cuda.synchronize()
-    dt_up = time.perf_counter() - t0
-    out = {"workload": "BASELINE configs[3] from pinned host memory: %d reads x %d bp uploaded every step in %d batches, upload of "
-                       "batch k+1 overlapping the scan of batch k (two device buffers, two streams)" % (n, args.read_len, len(bounds)),
-           "reads_per_s": n * steps / dt, "ms_per_step": dt / steps * 1e3, "steps": steps,
-           "h2d_gb_per_s_alone": total / dt_up / 1e9, "h2d_ms_alone": dt_up * 1e3,
-           "middle_hits_per_step": hits_n, "matching_sets": [pl.sets[i].name for i in matching]}
+    res = {}
+    for mode in (False, True):
+        packed[0] = mode
+        (matching, hits_n), dt = timed(step, steps, max(1, min(args.warmup, 2)), sync)
+        dt_up = upload_alone()
+        sent = sum(int(x.numel()) for x in h_pk) if mode else total
+        res[mode] = {"reads_per_s": n * steps / dt, "ms_per_step": dt / steps * 1e3, "h2d_ms_alone": dt_up * 1e3,
+                     "h2d_gb_per_s_alone": sent / dt_up / 1e9, "bytes_uploaded_per_step": sent, "middle_hits_per_step": hits_n}
+    out = {"workload": "BASELINE configs[3] from pinned host memory: %d reads x %d bp uploaded every step in %d batches at 2 bits per "
+                       "base (pc_pack_reads once at ingest; pc_unpack_device per batch), upload of batch k+1 overlapping the scan of "
+                       "batch k" % (n, args.read_len, len(bounds)),
+           "packed": True, "steps": steps, "pack_once_s": pack_s, "pack_gb_per_s": total / pack_s / 1e9,
+           "exceptions": sum(0 if x is None else int(x.numel()) for x in h_exc),
+           "same_hits_both_forms": res[True]["middle_hits_per_step"] == res[False]["middle_hits_per_step"],
+           "bytes_per_base_1": res[False], "matching_sets": [pl.sets[i].name for i in matching]}
+    out.update(res[True])
+    # the same, the middle scan behind the exact prefilter (config.exact_prefilter's step, fed from the host)
+    prefilter[0] = True
+    (_, hits_f), dt_f = timed(step, steps, 1, sync)
+    out["exact_prefilter"] = {"reads_per_s": n * steps / dt_f, "ms_per_step": dt_f / steps * 1e3,
+                              "same_hits": hits_f == res[True]["middle_hits_per_step"]}
     pl.close()
     return out
 
@@ -1070,7 +1120,11 @@ def compact_line(full):
     hb = also.get("from_host_memory", {})
     if hb:
         leg("from_host_memory", failed=hb.get("failed"), reads_per_s=hb.get("reads_per_s"), ms_per_step=hb.get("ms_per_step"),
-            h2d_gb_per_s=hb.get("h2d_gb_per_s_alone"), h2d_ms=hb.get("h2d_ms_alone"), packed=hb.get("packed"))
+            h2d_gb_per_s=hb.get("h2d_gb_per_s_alone"), h2d_ms=hb.get("h2d_ms_alone"), packed_2bit=hb.get("packed"),
+            bytes_per_step=hb.get("bytes_uploaded_per_step"), pack_once_s=hb.get("pack_once_s"),
+            unpacked_reads_per_s=_pick(hb, "bytes_per_base_1", "reads_per_s"), unpacked_h2d_ms=_pick(hb, "bytes_per_base_1", "h2d_ms_alone"),
+            same_hits_both_forms=hb.get("same_hits_both_forms"), prefiltered_reads_per_s=_pick(hb, "exact_prefilter", "reads_per_s"),
+            prefiltered_same_hits=_pick(hb, "exact_prefilter", "same_hits"))
     ee = also.get("end_to_end", {})
     if ee:
         leg("end_to_end", failed=ee.get("failed"), reads_per_s=ee.get("reads_per_s"), wall_s=ee.get("wall_s"),
@@ -1097,7 +1151,8 @@ def compact_line(full):
                      "speedup_vs_reference_cli": _r(full["value"] / b1["best_reads_per_s"]) if b1.get("best_reads_per_s") else None,
                      "region_ms_min": _r(_pick(full, "repeats", "min")), "region_ms_median": _r(_pick(full, "repeats", "median")),
                      "region_ms_max": _r(_pick(full, "repeats", "max")),
-                     "ms_per_step_by_rank": [_r(x) for x in cfg.get("ms_per_step_by_rank") or []]}
+                     "ms_per_step_by_rank": [_r(x) for x in cfg.get("ms_per_step_by_rank") or []],
+                     "check_reads": cfg.get("check_reads"), "check_reads_by_rank": cfg.get("check_reads_by_rank")}
     out["config"].update({"kernel_ms_" + k: _r(v) for k, v in (cfg.get("kernel_ms_per_step") or {}).items() if v})
     out["config"].update(flat)
     if dr:
@@ -1199,7 +1254,8 @@ def main():
     # seed 3 = BASELINE config 4; every rank draws its own shard (rank-dependent seed)
     reads = make_reads(args.reads, args.read_len, seed=3 + 1000 * rank, start_frac=0.9, end_frac=0.5,
                        chimera_frac=args.chimera, device=dev)
-    n_check = max(1, params.check_reads // world)   # each rank checks its share of the first 10 000
+    # each rank checks its share of the first 10 000 (porechop.py:86 --check_reads): the shares sum to exactly that
+    n_check = params.check_reads // world + (1 if rank < params.check_reads % world else 0)
 
     def barrier():
         torch.cuda.synchronize()
@@ -1223,6 +1279,11 @@ def main():
         rank_s = [float(x) for x in tall.cpu()]
         return out, max(rank_s), rank_s
 
+    shares = torch.zeros(world, dtype=torch.int64, device=dev)
+    shares[rank] = min(n_check, args.reads)
+    if world > 1:
+        dist.all_reduce(shares, op=dist.ReduceOp.SUM)
+    check_shares = [int(x) for x in shares.cpu()]
     matching = None
     for _ in range(args.warmup):
         matching, st, et, hits = one_step(pl, reads, n_check, world)
@@ -1352,6 +1413,7 @@ def main():
                        "world_size": dist.get_world_size() if world > 1 else 1,
                        "backend": (dist.get_backend() if world > 1 else "none (single process)"),
                        "ms_per_step_by_rank": [s_ / args.steps * 1e3 for s_ in rank_s],
+                       "check_reads": params.check_reads, "check_reads_by_rank": check_shares,
                        "matching_sets": [pl.sets[i].name for i in matching],
                        "middle_hits_per_step": int(hits.read.numel()), "mask_rounds": hits.rounds,
                        "kernel_ms_per_step": kern_ms,

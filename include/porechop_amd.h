@@ -216,6 +216,24 @@ int pc_phase_b_scatter(pc_ctx *ctx, const int32_t *d_traced, int64_t count, cons
 int pc_copy_windows(pc_ctx *ctx, const void *d_arena, const int64_t *d_src_off, const int32_t *d_len,
                     int64_t n, void *d_dst, const int64_t *d_dst_off, int pad, void *stream);
 
+/* Reads cross PCIe at 2 bits per base (north_star: "2-bit-packed read windows"; a read set is 8 GB of bases per million
+ * 8-kb reads and the link moves ~57 GB/s, so at one byte per base the upload, not the scan, bounds a run).
+ * pc_pack_reads (host, all cores the caller may use: pc_io_set_thread_limit): base i of arena[0 .. nbases) -- one byte per
+ * base as pc_readset_arena delivers them -- becomes bits 2*(i%4).. of packed[i/4] ((nbases + 3) / 4 bytes; keep the
+ * buffer a multiple of 4 bytes long): SeqAn's Dna ordinal values, A 0, C 1, G 2, T/U 3, either case
+ * (porechop/include/seqan/basic/alphabet_residue_tabs.h:113-140).  Every other byte ('N', '-', IUPAC codes ...: all of
+ * them Dna5 'N' to the alignment, which is what the reference's conversion makes of them) is an EXCEPTION: code 0 in
+ * the plane and its position appended to exc_pos (ascending).  *nexc = the number of exceptions; if that exceeds
+ * exc_cap nothing is listed and PC_ERR_BAD_ARG is returned (call again with room for *nexc entries).
+ * pc_unpack_device is the inverse on the device, into the byte arena every scan entry point takes: d_arena[i] = 'A' /
+ * 'C' / 'G' / 'T', 'N' at the exceptions, then pad_bytes bytes of 'N' (the 16 readable bytes the scans need past the last
+ * window, say).  Alignment-equivalent to the original bytes: Dna5(original) == Dna5(unpacked) for every base.
+ * d_packed 4-byte aligned, d_arena 16-byte aligned, room for nbases + pad_bytes bytes.  HBM-bound (0.25 B in, 1 B out per
+ * base), asynchronous on `stream`. */
+int pc_pack_reads(const char *arena, int64_t nbases, uint8_t *packed, int64_t *exc_pos, int64_t exc_cap, int64_t *nexc);
+int pc_unpack_device(pc_ctx *ctx, const void *d_packed, int64_t nbases, const int64_t *d_exc_pos, int64_t nexc,
+                     void *d_arena, int pad_bytes, void *stream);
+
 /* Exact bit-parallel prefilter of the whole-read ("middle") scan.  Porechop keeps a whole-read alignment only when
  * its full-adapter identity reaches --middle_threshold (porechop/nanopore_read.py:224-241); such an alignment has at
  * most pc_prefilter_max_edits(adapter length, threshold) non-matching columns inside the adapter's span, so the

@@ -18,7 +18,7 @@ EXPORTS = [
     "pc_readset_load", "pc_readset_free", "pc_readset_error", "pc_readset_count", "pc_readset_is_fastq",
     "pc_readset_arena", "pc_readset_offsets", "pc_readset_lengths", "pc_readset_name", "pc_readset_quals",
     "pc_readset_is_rna", "pc_readset_load_many", "pc_readset_file_index", "pc_readset_write",
-    "pc_readset_load_segment", "pc_readset_write_at", "pc_io_set_thread_limit",
+    "pc_readset_load_segment", "pc_readset_write_at", "pc_io_set_thread_limit", "pc_pack_reads", "pc_unpack_device",
 ]
 
 
@@ -153,6 +153,10 @@ def load_library():
     L.pc_readset_write_at.restype = c_int
     L.pc_io_set_thread_limit.argtypes = [c_int]
     L.pc_io_set_thread_limit.restype = None
+    L.pc_pack_reads.argtypes = [c_vp, c_i64, c_vp, c_vp, c_i64, ctypes.POINTER(c_i64)]
+    L.pc_pack_reads.restype = c_int
+    L.pc_unpack_device.argtypes = [c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_int, c_vp]
+    L.pc_unpack_device.restype = c_int
     L.pc_memo_clear.argtypes = []
     L.pc_memo_clear.restype = None
     L.pc_memo_stats.argtypes = [ctypes.POINTER(c_i64)] * 3

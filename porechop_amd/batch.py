@@ -245,6 +245,25 @@ class Aligner:
         check(self.lib.pc_copy_windows(self._ctx, arena.data_ptr(), src_off.data_ptr(), length.data_ptr(), n, dst.data_ptr(),
                                        dst_off.data_ptr(), int(pad), ctypes.c_void_p(s)), "pc_copy_windows")
 
+    def unpack_device(self, packed, nbases, exceptions, arena=None, pad=64, stream=None):
+        """2 bits per base -> the byte arena the scans take, on the device (pc_unpack_device).  packed: uint8 CUDA tensor
+        (io.pack_reads' plane, uploaded); exceptions: int64 CUDA tensor of the non-ACGT positions; arena: optional
+        preallocated uint8 CUDA tensor of >= nbases + pad bytes.  -> the arena (nbases bases + `pad` bytes of 'N')."""
+        import torch
+        assert packed.is_cuda and packed.dtype == torch.uint8 and packed.is_contiguous()
+        nbases = int(nbases)
+        assert int(packed.numel()) * 4 >= nbases
+        if arena is None:
+            arena = torch.empty(nbases + pad, dtype=torch.uint8, device=packed.device)
+        assert arena.is_cuda and arena.dtype == torch.uint8 and int(arena.numel()) >= nbases + pad
+        ne = 0 if exceptions is None else int(exceptions.numel())
+        if ne:
+            assert exceptions.is_cuda and exceptions.dtype == torch.int64 and exceptions.is_contiguous()
+        s = stream if stream is not None else torch.cuda.current_stream().cuda_stream
+        check(self.lib.pc_unpack_device(self._ctx, packed.data_ptr(), nbases, exceptions.data_ptr() if ne else None, ne,
+                                        arena.data_ptr(), int(pad), ctypes.c_void_p(s)), "pc_unpack_device")
+        return arena
+
     def max_edits(self, adapter_len, threshold_percent):
         """Most non-matching columns an alignment of an adapter_len-base adapter can have inside the adapter's span if
         its full-adapter identity reaches threshold_percent (pc_prefilter_max_edits)."""

@@ -1067,6 +1067,18 @@ int pc_copy_windows(pc_ctx *c, const void *d_arena, const int64_t *d_src_off, co
     return pck::launch_copy_windows((const uint8_t *)d_arena, d_src_off, d_len, n, (uint8_t *)d_dst, d_dst_off, pad, stream) ? PC_ERR_NO_DEVICE : PC_OK;
 }
 
+int pc_unpack_device(pc_ctx *c, const void *d_packed, int64_t nbases, const int64_t *d_exc_pos, int64_t nexc, void *d_arena,
+                     int pad_bytes, void *stream_v)
+{
+    if (!c || nbases < 0 || nexc < 0 || pad_bytes < 0) return PC_ERR_BAD_ARG;
+    if (nbases + pad_bytes == 0) return PC_OK;
+    if (!d_arena || (nbases && !d_packed) || (nexc && !d_exc_pos)) return PC_ERR_BAD_ARG;
+    if (((uintptr_t)d_packed & 3u) || ((uintptr_t)d_arena & 15u)) return PC_ERR_BAD_ARG;
+    (void)hipSetDevice(c->device);
+    hipStream_t stream = (stream_v == PC_STREAM_CONTEXT) ? c->stream : (hipStream_t)stream_v;
+    return pck::launch_unpack(d_packed, nbases, d_exc_pos, nexc, d_arena, pad_bytes, stream) ? PC_ERR_NO_DEVICE : PC_OK;
+}
+
 int pc_prefilter_max_edits(int adapter_len, double threshold_percent)
 {
     // A hit has full-adapter identity 100 M / L >= threshold after the reference's %f rounding (six decimals;

@@ -540,6 +540,57 @@ int pc_readset_is_rna(const pc_readset *rs, int64_t i)
 }
 const int32_t *pc_readset_file_index(const pc_readset *rs) { return rs ? rs->file_index.data() : nullptr; }
 
+// ---- 2-bit packing of the read bases for the trip over PCIe (include/porechop_amd.h, pc_pack_reads) ---------------
+// Codes are SeqAn's Dna ordinal values (seqan/basic/alphabet_residue_tabs.h:113-140: A 0, C 1, G 2, T/U 3, either case);
+// every other byte is an exception (Dna5 'N' for the alignment) whose POSITION is listed.  Threads take spans that are
+// multiples of 64 bases, so no two threads share a byte of the plane; the exception lists of the spans are concatenated
+// in span order, which leaves them sorted.
+int pc_pack_reads(const char *arena, int64_t nbases, uint8_t *packed, int64_t *exc_pos, int64_t exc_cap, int64_t *nexc)
+{
+    if (nbases < 0 || (nbases && (!arena || !packed)) || !nexc) return PC_ERR_BAD_ARG;
+    static const struct Tab { uint8_t t[256]; Tab() { memset(t, 4, sizeof t); t['A'] = t['a'] = 0; t['C'] = t['c'] = 1; t['G'] = t['g'] = 2;
+                                                      t['T'] = t['t'] = t['U'] = t['u'] = 3; } } tab;
+    const int64_t blocks = (nbases + 63) / 64;
+    const int T = (int)std::max<int64_t>(1, std::min<int64_t>(usable_threads(), blocks / 4096 + 1));
+    std::vector<std::vector<int64_t>> exc((size_t)T);
+    auto work = [&](int t) {
+        const int64_t b0 = blocks * t / T * 64, b1 = std::min<int64_t>(nbases, blocks * (t + 1) / T * 64);
+        const unsigned char *src = (const unsigned char *)arena;
+        std::vector<int64_t> &mine = exc[(size_t)t];
+        int64_t i = b0;
+        for (; i + 4 <= b1; i += 4) {
+            const unsigned a = tab.t[src[i]], b = tab.t[src[i + 1]], c = tab.t[src[i + 2]], d = tab.t[src[i + 3]];
+            if ((a | b | c | d) & 4u) {
+                if (a & 4u) mine.push_back(i);
+                if (b & 4u) mine.push_back(i + 1);
+                if (c & 4u) mine.push_back(i + 2);
+                if (d & 4u) mine.push_back(i + 3);
+            }
+            packed[i >> 2] = (uint8_t)((a & 3u) | (b & 3u) << 2 | (c & 3u) << 4 | (d & 3u) << 6);
+        }
+        if (i < b1) {                                   // the last, partial byte of the plane (only the last span has one)
+            unsigned v = 0;
+            for (int k = 0; i + k < b1; ++k) {
+                const unsigned a = tab.t[src[i + k]];
+                if (a & 4u) mine.push_back(i + k);
+                v |= (a & 3u) << (2 * k);
+            }
+            packed[i >> 2] = (uint8_t)v;
+        }
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < T; ++t) th.emplace_back(work, t);
+    work(0);
+    for (auto &x : th) x.join();
+    int64_t total = 0;
+    for (auto &v : exc) total += (int64_t)v.size();
+    *nexc = total;
+    if (total > exc_cap || (total && !exc_pos)) return PC_ERR_BAD_ARG;        // *nexc says how many entries are needed
+    int64_t at = 0;
+    for (auto &v : exc) { if (!v.empty()) memcpy(exc_pos + at, v.data(), v.size() * 8); at += (int64_t)v.size(); }
+    return PC_OK;
+}
+
 static int write_pieces(const pc_readset *rs, int64_t npieces, const int64_t *piece_read, const int32_t *piece_start,
                         const int32_t *piece_len, const int32_t *piece_number, const int32_t *piece_file, int nfiles,
                         const char *const *file_paths, int fastq, int64_t *bytes_written, int64_t *file_pos);

@@ -225,4 +225,7 @@ int launch_trace16(const ScanArgs &a, int rows, int grid, void *stream);   // pa
 int launch_plan(const PlanArgs &a, void *stream);
 int trace_words_per_col(int rows);   // NW
 
+// 2-bit plane (+ exception positions) -> bytes 'A','C','G','T' / 'N', followed by `pad` bytes of 'N' (pc_reduce.hip)
+int launch_unpack(const void *packed, int64_t nbases, const int64_t *exc_pos, int64_t nexc, void *arena, int pad, void *stream);
+
 }  // namespace pck

@@ -179,4 +179,56 @@ int launch_copy_windows(const uint8_t *arena, const int64_t *src_off, const int3
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 
+// ---- pc_unpack_device: 2 bits per base (+ the positions of the non-ACGT bases) -> one byte per base ------------------
+// HBM-bound: a thread turns one dword of the plane (16 bases) into one 16-byte store; 0.25 B read + 1 B written per base.
+__global__ __launch_bounds__(256) void unpack_kernel(const uint32_t *packed, int64_t nbases, uint8_t *arena, int pad)
+{
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;      // group of 16 bases
+    const int64_t base = g * 16;
+    if (base >= nbases + pad) return;
+    uint32_t out[4];
+    if (base + 16 <= nbases) {
+        const uint32_t w = packed[g];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            uint32_t v = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t code = (w >> (2 * (4 * q + k))) & 3u;
+                v |= ((0x54474341u >> (8 * code)) & 0xFFu) << (8 * k);      // "ACGT"
+            }
+            out[q] = v;
+        }
+        *(uint4 *)(arena + base) = uint4{out[0], out[1], out[2], out[3]};
+        return;
+    }
+    // the tail: the plane's last (possibly partial) dword is read a byte at a time, then `pad` bytes of 'N'
+    const uint8_t *pb = (const uint8_t *)packed;
+    for (int k = 0; k < 16 && base + k < nbases + pad; ++k) {
+        const int64_t i = base + k;
+        arena[i] = i < nbases ? (uint8_t)((0x54474341u >> (8 * ((pb[i >> 2] >> (2 * (i & 3))) & 3u))) & 0xFFu) : (uint8_t)'N';
+    }
+}
+
+__global__ __launch_bounds__(256) void unpack_exceptions_kernel(const int64_t *exc_pos, int64_t nexc, int64_t nbases, uint8_t *arena)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nexc) return;
+    const int64_t p = exc_pos[i];
+    if (p >= 0 && p < nbases) arena[p] = (uint8_t)'N';
+}
+
+int launch_unpack(const void *packed, int64_t nbases, const int64_t *exc_pos, int64_t nexc, void *arena, int pad, void *stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t groups = (nbases + pad + 15) / 16;
+    if (groups > 0)
+        hipLaunchKernelGGL(unpack_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, st, (const uint32_t *)packed, nbases,
+                           (uint8_t *)arena, pad);
+    if (nexc > 0)
+        hipLaunchKernelGGL(unpack_exceptions_kernel, dim3((unsigned)((nexc + 255) / 256)), dim3(256), 0, st, exc_pos, nexc, nbases,
+                           (uint8_t *)arena);
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+
 }  // namespace pck

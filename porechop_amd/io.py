@@ -8,6 +8,39 @@ import numpy as np
 from ._lib import load_library
 
 
+def pack_reads(arena, nbases=None, out=None):
+    """One byte per base -> 2 bits per base + the positions of the non-ACGT(U) bases (pc_pack_reads; all host cores).
+    arena: uint8 numpy array (or bytes); nbases: how many of its bytes are bases (default: all).
+    -> (packed uint8 [ceil(nbases / 16) * 4], exceptions int64 [E], ascending).  `out` may be a preallocated uint8 array
+    (pinned memory, say) of at least that many bytes."""
+    lib = load_library()
+    a = np.frombuffer(arena, dtype=np.uint8) if isinstance(arena, (bytes, bytearray)) else np.ascontiguousarray(arena, dtype=np.uint8)
+    n = int(a.size if nbases is None else nbases)
+    assert 0 <= n <= a.size
+    nb = (n + 15) // 16 * 4
+    packed = np.zeros(nb, dtype=np.uint8) if out is None else out
+    assert packed.dtype == np.uint8 and packed.size >= nb and packed.flags["C_CONTIGUOUS"]
+    nexc = ctypes.c_int64()
+    exc = np.zeros(max(16, n // 4096), dtype=np.int64)
+    rc = lib.pc_pack_reads(a.ctypes.data, n, packed.ctypes.data, exc.ctypes.data, exc.size, ctypes.byref(nexc))
+    if rc != 0 and nexc.value > exc.size:
+        exc = np.zeros(nexc.value, dtype=np.int64)
+        rc = lib.pc_pack_reads(a.ctypes.data, n, packed.ctypes.data, exc.ctypes.data, exc.size, ctypes.byref(nexc))
+    if rc != 0:
+        raise RuntimeError("pc_pack_reads failed (%d)" % rc)
+    return packed[:nb], exc[:nexc.value].copy()
+
+
+def unpack_reads_host(packed, nbases, exc):
+    """The inverse of pack_reads in numpy (what pc_unpack_device writes, without the padding): for tests and hosts
+    that want the canonical bytes back."""
+    p = np.ascontiguousarray(packed, dtype=np.uint8)
+    codes = ((p[:, None] >> np.array([0, 2, 4, 6], dtype=np.uint8)[None, :]) & 3).reshape(-1)[:nbases]
+    out = np.frombuffer(b"ACGT", dtype=np.uint8)[codes].copy()
+    out[np.asarray(exc, dtype=np.int64)] = ord("N")
+    return out
+
+
 class ReadSet:
     """Reads of one file -- or of several files, in order (Albacore directory input) -- normalised
     like NanoporeRead.__init__, as numpy views over one arena."""
@@ -75,13 +108,20 @@ class ReadSet:
     def is_rna(self, i):
         return bool(self.lib.pc_readset_is_rna(self._h, i))
 
-    def to_device(self, device="cuda"):
-        """-> porechop_amd.pipeline.DeviceReads (one upload of the packed arena)."""
+    def to_device(self, device="cuda", packed=False, aligner=None):
+        """-> porechop_amd.pipeline.DeviceReads.  packed=True sends the bases over PCIe at 2 bits each (pack_reads on the
+        host, pc_unpack_device on the GPU; `aligner` = any porechop_amd.Aligner of that device) -- a quarter of the bytes,
+        alignment-equivalent contents (non-ACGT bases arrive as 'N')."""
         import torch
         from .pipeline import DeviceReads
         dev = torch.device(device)
-        return DeviceReads(torch.from_numpy(self.arena.copy()).to(dev), torch.from_numpy(self.offsets.copy()).to(dev),
-                           torch.from_numpy(self.lengths.copy()).to(dev))
+        off = torch.from_numpy(self.offsets.copy()).to(dev)
+        ln = torch.from_numpy(self.lengths.copy()).to(dev)
+        if not packed:
+            return DeviceReads(torch.from_numpy(self.arena.copy()).to(dev), off, ln)
+        nbases = int(self.offsets[-1] + self.lengths[-1]) if self.count else 0
+        pk, exc = pack_reads(self.arena, nbases)
+        return DeviceReads.from_packed(aligner, torch.from_numpy(pk).to(dev), nbases, torch.from_numpy(exc).to(dev), off, ln)
 
     def write(self, piece_read, piece_start, piece_len, piece_number, piece_file, file_paths, fastq):
         """Write pieces of reads (see pc_readset_write in include/porechop_amd.h) -> bytes written."""

@@ -59,6 +59,12 @@ class DeviceReads:
     def n(self):
         return int(self.off.shape[0])
 
+    @classmethod
+    def from_packed(cls, aligner, packed, nbases, exceptions, off, length, arena=None):
+        """Reads that crossed PCIe at 2 bits per base (io.pack_reads) -> the resident byte arena (pc_unpack_device:
+        'A' / 'C' / 'G' / 'T', 'N' at the listed exceptions, 64 bytes of 'N' behind the last read)."""
+        return cls(aligner.unpack_device(packed, nbases, exceptions, arena=arena), off, length)
+
 
 @dataclass
 class MiddleHits:

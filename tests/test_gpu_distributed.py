@@ -78,7 +78,30 @@ def test_one_rank_launcher_equals_plain_bench():
         assert a[k] == b[k], k
     for k in ("workload", "matching_sets", "middle_hits_per_step", "mask_rounds", "world_size"):
         assert a["config"][k] == b["config"][k], k
-    assert a["config"]["exact_prefilter"]["same_trims_and_middle_hits"] and b["config"]["exact_prefilter"]["same_trims_and_middle_hits"]
+    assert a["legs"]["exact_prefilter"]["same"] is True and b["legs"]["exact_prefilter"]["same"] is True
+    assert a["config"]["pf_same"] is True and b["config"]["pf_same"] is True          # the flat copy the driver's record keeps
+    assert len(plain.stdout.strip().splitlines()[-1]) < 8000                          # the whole line fits the driver's 8 KB tail
     # (a sanity band only: these are 3-step runs of a fifth of the benchmark's batch, the first of them on a cold box --
     # observed 0.71 on a fresh box; bench.py's own repeats are the place where throughput is compared)
     assert 1 / 3 < a["value"] / b["value"] < 3, (a["value"], b["value"])
+
+
+def test_two_ranks_on_one_gpu_emit_the_configs4_leg_for_both_ranks():
+    """Multi-GPU readiness (no curve): `bench.py --gpus 2` over gloo, both ranks on the box's one GPU.  The line must carry the
+    per-GPU configs[4] shape run by BOTH ranks (n_gpus 2, the exact-prefilter + pruned variant giving the same trims, calls
+    and middle hits as the full computation on every rank), both ranks' timed regions, and phase A's check-read shares must
+    sum to --check_reads (porechop.py:86)."""
+    args = ["--gpus", "2", "--steps", "1", "--warmup", "1", "--reads", "60000", "--reads4", "30000", "--cpu-seconds", "0", "--repeats", "1"]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", PC_DIST_BACKEND="gloo")
+    run = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(_free_port()), "bench.py"] + args, cwd=REPO, env=env, capture_output=True, text=True, timeout=1500)
+    assert run.returncode == 0, run.stderr[-3000:]
+    line = [l for l in run.stdout.strip().splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["config"]["world_size"] == 2 and d["config"]["backend"] == "gloo"
+    assert len(d["config"]["ms_per_step_by_rank"]) == 2
+    assert sum(d["config"]["check_reads_by_rank"]) == d["config"]["check_reads"] == 10000
+    c4 = d["legs"]["configs4_per_gpu"]
+    assert c4["n_gpus"] == 2 and c4["reads_per_gpu"] == 30000
+    assert c4["fast_same"] is True and d["config"]["c4_fast_same"] is True
+    assert c4["reads_per_s"] > 0 and c4["fast_reads_per_s"] > c4["reads_per_s"]

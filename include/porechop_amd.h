@@ -27,8 +27,9 @@ extern "C" {
  *   "readStart,readEnd,adapterStart,adapterEnd,rawScore,alignedRegion%id,fullAdapter%id"
  * formatted exactly like porechop/src/alignment.cpp:113-121 ("%d" ints, "%f" doubles;
  * "-1,..." when either sequence is empty).  Served from the prefetch memo (Part 2) when the
- * pair was prefetched, otherwise by a single-pair GPU launch.  Never throws; on an
- * unsupported scoring scheme or a device error it prints to stderr and returns NULL. */
+ * pair was prefetched, otherwise by a single-pair GPU launch.  Any four integer scores (up to 2^20 in magnitude) and
+ * adapters up to PC_MAX_ADAPTER_ANY bases are computed, as the reference computes them.  Never throws; on a device
+ * error (or beyond those limits) it prints to stderr and returns NULL. */
 char *adapterAlignment(char *readSeq, char *adapterSeq, int matchScore, int mismatchScore,
                        int gapOpenScore, int gapExtensionScore);
 
@@ -44,13 +45,14 @@ typedef struct pc_ctx pc_ctx;
 enum {
     PC_OK = 0,
     PC_ERR_NO_DEVICE = -1,          /* no HIP device / HIP call failed */
-    PC_ERR_UNSUPPORTED_SCORES = -2, /* scheme outside the exact int16 path (see pc_scores_supported) */
+    PC_ERR_UNSUPPORTED_SCORES = -2, /* a score above 2^20 in magnitude, or sums that leave the 32-bit range */
     PC_ERR_BAD_ARG = -3,
-    PC_ERR_ADAPTER_TOO_LONG = -4,   /* adapter longer than PC_MAX_ADAPTER */
+    PC_ERR_ADAPTER_TOO_LONG = -4,   /* adapter longer than PC_MAX_ADAPTER_ANY */
     PC_ERR_INTERNAL = -5            /* a kernel reported an inconsistency (never expected) */
 };
 
-#define PC_MAX_ADAPTER 128
+#define PC_MAX_ADAPTER 128        /* the packed 16-bit kernels' limit; longer adapters take the plain-int32 kernel ... */
+#define PC_MAX_ADAPTER_ANY 4096   /* ... up to this many bases */
 #define PC_RESULT_INTS 8   /* readStart, readEnd, adapterStart, adapterEnd, rawScore,
                               matches, alignedRegionLength, fullAdapterLength.
                               identities are (100.0*matches)/length in double, as the reference
@@ -73,10 +75,14 @@ enum {
 const char *pc_version(void);
 const char *pc_strerror(int code);
 
-/* 1 if (match, mismatch, gap_open, gap_extend) is handled exactly by the GPU path for adapters
- * up to max_adapter_len bases; 0 otherwise (non-negative gap scores, match <= mismatch, or
- * magnitudes that overflow the int16 lanes).  gap_open == gap_extend is supported: it selects the
- * reference's linear-gap recurrence (seqan/align/global_alignment_unbanded.h:217-220). */
+/* 1 if (match, mismatch, gap_open, gap_extend) with adapters of up to max_adapter_len bases runs the PACKED 16-bit
+ * kernels (match > 0, match > mismatch, negative gap scores, magnitudes that fit the int16 / fp16 lanes, adapters up to
+ * PC_MAX_ADAPTER; gap_open == gap_extend selects the reference's linear-gap recurrence,
+ * seqan/align/global_alignment_unbanded.h:217-220).  0: such pairs run the PLAIN-INT32 kernel (csrc/pc_slow.hip: one
+ * lane per pair, every cell's trace kept) -- the same answers as the reference for ANY four integers up to 2^20 in
+ * magnitude and adapters up to PC_MAX_ADAPTER_ANY, as porechop/porechop.py:145,196-202 accepts them, only about a
+ * hundred times slower per cell and without the batch pipeline's exact prunings (PC_MODE_SCORE is refused there).
+ * Nothing is ever approximated, and nothing runs on the CPU. */
 int pc_scores_supported(int match, int mismatch, int gap_open, int gap_extend, int max_adapter_len);
 
 /* device < 0: current device.  The context owns its stream-ordered scratch buffers. */

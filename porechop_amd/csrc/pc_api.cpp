@@ -22,6 +22,7 @@
 
 #include "../../include/porechop_amd.h"
 #include "pc_bounds.h"
+#include "pc_slow.h"
 #include "pc_jit.h"
 #include "pc_kernels.h"
 
@@ -131,6 +132,14 @@ struct pc_ctx {
     // cached job table (bench loops repeat the same one: skip the re-upload).  The tile table itself only
     // exists on the device: it is expanded there from the groups' runs (one per job and shape).
     std::vector<Group> groups;
+    // jobs the packed 16-bit kernels cannot take (scheme outside pcb::scores_supported, adapter above pcb::MAX_ADAPTER):
+    // they run the plain-int32 kernel of pc_slow.hip after the tiles, each with its place in the output kept
+    struct SlowJob { int64_t win_start, n, out_base; int adapter; };
+    std::vector<SlowJob> slow_jobs;
+    bool slow_scheme = false;                // the scoring scheme itself is outside the packed kernels' exact range
+    std::vector<char> ad_slow;               // per adapter: takes the plain-int32 kernel
+    std::vector<int64_t> slow_ad_off;        // offsets of the adapters' Dna5 codes in d_slow_ad
+    DevBuf d_slow_ad, d_slow_state, d_slow_trace;
     std::vector<int32_t> last_job_adapter, last_job_adapter_b;
     std::vector<int64_t> last_job_start;
     int last_max_len = -1, last_mode = -1;
@@ -175,19 +184,32 @@ int upload_panel(pc_ctx *c)
     c->ad_window.assign(std::max(n, 1), 0);
     c->ad_span.assign(std::max(n, 1), 0);
     int maxm = 1;
+    // Adapters above pcb::MAX_ADAPTER bases, and every adapter under a scheme outside the packed kernels' exact range,
+    // take the plain-int32 kernel (pc_slow.hip): the reference accepts any adapter and any four integers.
+    c->ad_slow.assign(std::max(n, 1), 0);
+    c->slow_ad_off.assign(std::max(n, 1) + 1, 0);
+    std::vector<uint8_t> raw;
     for (int i = 0; i < n; ++i) {
         const std::string &s = c->adapters[i];
-        if ((int)s.size() > pcb::MAX_ADAPTER) return PC_ERR_ADAPTER_TOO_LONG;
+        if ((int)s.size() > pcs::MAX_ADAPTER) return PC_ERR_ADAPTER_TOO_LONG;
         c->ad_len[i] = (int)s.size();
+        c->slow_ad_off[i] = (int64_t)raw.size();
+        for (char ch : s) raw.push_back((uint8_t)dna5((unsigned char)ch));
+        if ((int)s.size() > pcb::MAX_ADAPTER) { c->ad_slow[i] = 1; continue; }
         maxm = std::max(maxm, (int)s.size());
         for (size_t k = 0; k < s.size(); ++k) codes[(size_t)i * pcb::MAX_ADAPTER + k] = (uint32_t)dna5((unsigned char)s[k]);
     }
-    if (!pcb::scores_supported(c->match, c->mismatch, c->gap_open, c->gap_extend, maxm))
-        return PC_ERR_UNSUPPORTED_SCORES;
+    c->slow_ad_off[std::max(n, 1)] = (int64_t)raw.size();
+    if (!pcs::fits(0, 0, c->match, c->mismatch, c->gap_open, c->gap_extend)) return PC_ERR_UNSUPPORTED_SCORES;
+    c->slow_scheme = !pcb::scores_supported(c->match, c->mismatch, c->gap_open, c->gap_extend, maxm);
     for (int i = 0; i < n; ++i) {
         pcb::Bounds b;
-        if (!pcb::compute_bounds(c->match, c->mismatch, c->gap_open, c->gap_extend, std::max(1, c->ad_len[i]), b))
-            return PC_ERR_UNSUPPORTED_SCORES;
+        if (c->slow_scheme || c->ad_slow[i] ||
+            !pcb::compute_bounds(c->match, c->mismatch, c->gap_open, c->gap_extend, std::max(1, c->ad_len[i]), b)) {
+            c->ad_slow[i] = 1;
+            c->ad_window[i] = 0; c->ad_span[i] = 0;
+            continue;
+        }
         c->ad_window[i] = b.window;
         c->ad_span[i] = b.SPAN;
     }
@@ -200,6 +222,8 @@ int upload_panel(pc_ctx *c)
         (rc = c->d_ad_window.ensure(c->ad_window.size() * 4)) || (rc = c->d_ad_span.ensure(c->ad_span.size() * 4)))
         return rc;
     HIP_TRY(hipMemcpy(c->d_ad_codes.p, codes.data(), codes.size() * 4, hipMemcpyHostToDevice));
+    if ((rc = c->d_slow_ad.ensure(raw.size() + 16))) return rc;
+    if (!raw.empty()) HIP_TRY(hipMemcpy(c->d_slow_ad.p, raw.data(), raw.size(), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(c->d_ad_len.p, c->ad_len.data(), c->ad_len.size() * 4, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(c->d_ad_window.p, c->ad_window.data(), c->ad_window.size() * 4, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(c->d_ad_span.p, c->ad_span.data(), c->ad_span.size() * 4, hipMemcpyHostToDevice));
@@ -231,6 +255,7 @@ int build_tiles(pc_ctx *c, const int32_t *job_adapter, const int32_t *job_adapte
 
     std::map<std::pair<int, int>, std::vector<pck::TileRun>> by_group;   // (rows*2+pad, two_pass) -> runs
     std::map<std::pair<int, int>, int> group_window;
+    std::vector<pc_ctx::SlowJob> slow;
     int64_t out_pos = 0;
     for (int k = 0; k < njobs; ++k) {
         const int ad = job_adapter[k], adb = jb[k];
@@ -238,9 +263,15 @@ int build_tiles(pc_ctx *c, const int32_t *job_adapter, const int32_t *job_adapte
         if (ad < 0 || ad >= nad || adb >= nad) return PC_ERR_BAD_ARG;
         const int m = c->ad_len[ad], mb = adb >= 0 ? c->ad_len[adb] : m;
         if (m <= 0 || mb <= 0) return PC_ERR_BAD_ARG;
-        if (m > pcb::MAX_ADAPTER || mb > pcb::MAX_ADAPTER) return PC_ERR_ADAPTER_TOO_LONG;
         const int64_t ws = job_start[k], n = job_start[k + 1] - job_start[k];
         if (n < 0) return PC_ERR_BAD_ARG;
+        if (c->ad_slow[ad] || (adb >= 0 && c->ad_slow[adb])) {
+            // no tiles: the plain-int32 kernel runs this job after them (adapter A's records first, then B's)
+            if (n > 0) slow.push_back({ws, n, out_pos, ad});
+            out_pos += n;
+            if (adb >= 0) { if (n > 0) slow.push_back({ws, n, out_pos, adb}); out_pos += n; }
+            continue;
+        }
         // the register variants run in drifting coordinates: linear-gap schemes (extension made
         // impossible, pc_bounds.h) and schemes whose gap extension is too large to drift in int16 take
         // the generic kernel
@@ -292,6 +323,7 @@ int build_tiles(pc_ctx *c, const int32_t *job_adapter, const int32_t *job_adapte
     c->tiles_uploaded = false;
     c->last_max_len = -1;
     c->groups.clear();
+    c->slow_jobs.swap(slow);
     std::vector<pck::TileRun> all_runs;
     size_t ntiles = 0;
     for (auto &kv : by_group) {
@@ -548,9 +580,9 @@ const char *pc_strerror(int code)
     switch (code) {
         case PC_OK: return "ok";
         case PC_ERR_NO_DEVICE: return "no usable HIP device / HIP runtime error";
-        case PC_ERR_UNSUPPORTED_SCORES: return "scoring scheme outside the exact GPU path";
+        case PC_ERR_UNSUPPORTED_SCORES: return "scores beyond the 32-bit-safe range of the GPU path (|score| <= 2^20; PC_MODE_SCORE needs the packed kernels' schemes)";
         case PC_ERR_BAD_ARG: return "bad argument";
-        case PC_ERR_ADAPTER_TOO_LONG: return "adapter longer than PC_MAX_ADAPTER";
+        case PC_ERR_ADAPTER_TOO_LONG: return "adapter longer than PC_MAX_ADAPTER_ANY (or its trace too large)";
         case PC_ERR_INTERNAL: return "kernel reported an internal inconsistency";
         default: return "unknown error";
     }
@@ -608,7 +640,8 @@ void pc_destroy(pc_ctx *c)
                       &c->d_runs_slot[0], &c->d_runs_slot[1], &c->d_slab, &c->d_fin, &c->d_k1, &c->d_woff2,
                       &c->d_wlen2, &c->d_col0, &c->d_ntot, &c->d_frow, &c->d_fscore, &c->d_err, &c->d_arena,
                       &c->d_woff, &c->d_wlen, &c->d_out, &c->d_red_slot[0], &c->d_red_slot[1], &c->d_work, &c->d_pf_tables, &c->d_pf_meta, &c->d_sd_bitmaps, &c->d_sd_first,
-                      &c->d_sd_entries, &c->d_sd_meta, &c->d_sd_eq, &c->d_sd_cand, &c->d_sd_count};
+                      &c->d_sd_entries, &c->d_sd_meta, &c->d_sd_eq, &c->d_sd_cand, &c->d_sd_count, &c->d_slow_ad, &c->d_slow_state,
+                      &c->d_slow_trace};
     if (c->h_sd_count) (void)hipHostFree(c->h_sd_count);
     for (DevBuf *b : bufs) b->release();
     (void)hipStreamDestroy(c->stream);
@@ -618,7 +651,9 @@ void pc_destroy(pc_ctx *c)
 int pc_set_scores(pc_ctx *c, int match, int mismatch, int gap_open, int gap_extend)
 {
     if (!c) return PC_ERR_BAD_ARG;
-    if (!pcb::scores_supported(match, mismatch, gap_open, gap_extend, 1)) return PC_ERR_UNSUPPORTED_SCORES;
+    // any four integers the reference's int arithmetic can hold: schemes outside pcb::scores_supported run the
+    // plain-int32 kernel (pc_slow.hip); only magnitudes above 2^20 are refused
+    if (!pcs::fits(0, 0, match, mismatch, gap_open, gap_extend)) return PC_ERR_UNSUPPORTED_SCORES;
     if (match != c->match || mismatch != c->mismatch || gap_open != c->gap_open || gap_extend != c->gap_extend) {
         c->match = match; c->mismatch = mismatch; c->gap_open = gap_open; c->gap_extend = gap_extend;
         c->panel_dirty = true;
@@ -647,7 +682,7 @@ int pc_set_adapters(pc_ctx *c, const char *const *seqs, int n)
     for (int i = 0; i < n; ++i) {
         if (!seqs[i]) return PC_ERR_BAD_ARG;
         v.emplace_back(seqs[i]);
-        if (v.back().size() > (size_t)pcb::MAX_ADAPTER) return PC_ERR_ADAPTER_TOO_LONG;
+        if (v.back().size() > (size_t)pcs::MAX_ADAPTER) return PC_ERR_ADAPTER_TOO_LONG;
     }
     c->adapters.swap(v);
     c->panel_dirty = true;
@@ -668,6 +703,11 @@ int pc_scan_device(pc_ctx *c, const void *d_arena, const int64_t *d_win_off, con
     if (rc) return rc;
     int64_t npairs = 0;
     if ((rc = build_tiles(c, job_adapter, job_adapter_b, job_start, njobs, max_len, mode, &npairs))) return rc;
+    if (mode == PC_MODE_SCORE && !c->slow_jobs.empty()) {
+        // score-only records (the end cell) feed bounds that are derived for the packed kernels' schemes (pc_select.hip)
+        fprintf(stderr, "porechop_amd: PC_MODE_SCORE is not available for scoring schemes / adapters that take the plain-int32 kernel\n");
+        return PC_ERR_UNSUPPORTED_SCORES;
+    }
     hipStream_t stream = (stream_v == PC_STREAM_CONTEXT) ? c->stream : (hipStream_t)stream_v;
     if (stream != c->stream) HIP_TRY(hipStreamWaitEvent(stream, c->table_ready, 0));   // the table is built on the context's stream
 
@@ -902,6 +942,41 @@ int pc_scan_device(pc_ctx *c, const void *d_arena, const int64_t *d_win_off, con
             HIP_TRY(hipStreamWaitEvent(stream, c->ev_join, 0));
         }
         if (fork_timed) { (void)hipEventRecord(fork_timer.e1, stream); c->timed.push_back(fork_timer); }
+    }
+    // ---- jobs outside the packed kernels' range: plain int32, one lane per pair (pc_slow.hip) -----------------------
+    for (const pc_ctx::SlowJob &J : c->slow_jobs) {
+        const int m = c->ad_len[J.adapter];
+        if (!pcs::fits(max_len, m, c->match, c->mismatch, c->gap_open, c->gap_extend)) {
+            fprintf(stderr, "porechop_amd: scores %d,%d,%d,%d over windows of up to %d bases and an adapter of %d leave the 32-bit range\n",
+                    c->match, c->mismatch, c->gap_open, c->gap_extend, max_len, m);
+            return PC_ERR_UNSUPPORTED_SCORES;
+        }
+        static const size_t budget = [] { const char *e = getenv("PC_SLOW_SCRATCH_MB"); return (size_t)(e && atol(e) > 0 ? atol(e) : 2048) << 20; }();
+        const bool lds = m <= 128;
+        const size_t per_pair = (size_t)std::max(1, max_len) * (size_t)m + (lds ? 0 : (size_t)m * 8);
+        int64_t P = (int64_t)(budget / per_pair) / 64 * 64;
+        if (P < 64) P = 64;
+        if ((size_t)P * per_pair > ((size_t)16 << 30)) {
+            fprintf(stderr, "porechop_amd: a window of %d bases against an adapter of %d needs %zu bytes of trace per pair: too large for the plain-int32 path\n",
+                    max_len, m, per_pair);
+            return PC_ERR_ADAPTER_TOO_LONG;
+        }
+        P = std::min<int64_t>(P, (J.n + 63) / 64 * 64);
+        if ((rc = c->d_slow_trace.ensure((size_t)P * (size_t)std::max(1, max_len) * (size_t)m + 256))) return rc;
+        if (!lds && (rc = c->d_slow_state.ensure((size_t)P * (size_t)m * 8 + 256))) return rc;
+        pck::SlowArgs sa;
+        memset(&sa, 0, sizeof sa);
+        sa.arena = (const uint8_t *)d_arena; sa.win_off = d_win_off; sa.win_len = d_win_len;
+        sa.adapter = c->d_slow_ad.as<uint8_t>() + c->slow_ad_off[J.adapter];
+        sa.m = m; sa.max_len = max_len;
+        sa.match = c->match; sa.mismatch = c->mismatch; sa.gap_open = c->gap_open; sa.gap_extend = c->gap_extend;
+        sa.out = d_out; sa.state = lds ? nullptr : c->d_slow_state.as<int32_t>(); sa.trace = c->d_slow_trace.as<uint8_t>();
+        sa.P = P; sa.err = c->d_err.as<uint32_t>();
+        ScopedTimer tm(c, stream, 2, J.n);
+        for (int64_t first = 0; first < J.n; first += P) {
+            sa.first_window = J.win_start + first; sa.count = std::min<int64_t>(P, J.n - first); sa.out_base = J.out_base + first;
+            if (pck::launch_slow(sa, stream)) return PC_ERR_NO_DEVICE;
+        }
     }
     HIP_TRY(hipEventRecord(c->slot_free[c->slot], stream));      // the last launch that reads this table slot
     return PC_OK;
@@ -1669,7 +1744,7 @@ int intern_adapters(const char *const *seqs, int n, std::vector<int> &idx)
         std::lock_guard<std::mutex> lk(g.mu);
         for (int i = 0; i < n; ++i) {
             std::string s(seqs[i]);
-            if (s.size() > (size_t)PC_MAX_ADAPTER) return PC_ERR_ADAPTER_TOO_LONG;
+            if (s.size() > (size_t)PC_MAX_ADAPTER_ANY) return PC_ERR_ADAPTER_TOO_LONG;
             auto it = g.ad_index.find(s);
             if (it == g.ad_index.end()) { it = g.ad_index.emplace(s, (int)g.ad_list.size()).first; g.ad_list.push_back(s); grew = true; }
             idx[i] = it->second;
@@ -1775,13 +1850,12 @@ char *adapterAlignment(char *readSeq, char *adapterSeq, int matchScore, int mism
             const int64_t off = 0; const int32_t len = (int32_t)n, aidx = rc ? 0 : gidx[0];
             if (!rc) rc = pc_align_batch_host(c, readSeq, (int64_t)n, &off, &len, &aidx, 1, PC_MODE_AUTO, rec);
             if (rc) {
-                // The reference accepts any scheme and any adapter length; this library refuses what it
-                // cannot compute exactly.  The unchanged Python wrapper dereferences the NULL below
+                // Only a missing / failing device, scores above 2^20 in magnitude or an adapter above PC_MAX_ADAPTER_ANY
+                // bases end here.  The unchanged Python wrapper dereferences the NULL below
                 // (cpp_function_wrappers.py:56-63), so say clearly why before it does.
-                fprintf(stderr, "porechop_amd: adapterAlignment cannot be computed on the GPU: %s (scores %d,%d,%d,%d; adapter of %zu bases, "
-                                "limit %d).  Supported: match > 0, match > mismatch, negative gap scores within the 16-bit range "
-                                "(pc_scores_supported), adapters up to %d bases, a visible MI355X.  Returning NULL.\n",
-                        pc_strerror(rc), matchScore, mismatchScore, gapOpenScore, gapExtensionScore, m, PC_MAX_ADAPTER, PC_MAX_ADAPTER);
+                fprintf(stderr, "porechop_amd: adapterAlignment cannot be computed on the GPU: %s (scores %d,%d,%d,%d; read of %zu, adapter of "
+                                "%zu bases; limits: |score| <= 2^20, adapters up to %d bases, a visible MI355X).  Returning NULL.\n",
+                        pc_strerror(rc), matchScore, mismatchScore, gapOpenScore, gapExtensionScore, n, m, PC_MAX_ADAPTER_ANY);
                 return nullptr;
             }
         }

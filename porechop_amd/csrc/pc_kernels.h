@@ -228,4 +228,22 @@ int trace_words_per_col(int rows);   // NW
 // 2-bit plane (+ exception positions) -> bytes 'A','C','G','T' / 'N', followed by `pad` bytes of 'N' (pc_reduce.hip)
 int launch_unpack(const void *packed, int64_t nbases, const int64_t *exc_pos, int64_t nexc, void *arena, int pad, void *stream);
 
+// the plain-int32 kernel of pc_slow.hip: windows first_window .. first_window + count of the caller's table against ONE
+// adapter (m Dna5 codes at `adapter`), records to out[(out_base + i) * 8]; state == nullptr: column state in LDS (m <= 128)
+struct SlowArgs {
+    const uint8_t *arena;
+    const int64_t *win_off;
+    const int32_t *win_len;
+    int64_t first_window, count, out_base;
+    const uint8_t *adapter;
+    int32_t m, max_len;
+    int32_t match, mismatch, gap_open, gap_extend;
+    int32_t *out;
+    int32_t *state;              // [2 * m][P] ints, or nullptr
+    uint8_t *trace;              // [max_len][m][P] bytes
+    int64_t P;                   // pairs of a launch (stride of the scratch)
+    uint32_t *err;
+};
+int launch_slow(const SlowArgs &a, void *stream);
+
 }  // namespace pck

@@ -138,11 +138,18 @@ struct Walk {
     }
     // match, mismatch, gap_open, gap_extend: the scheme's real scores (linear mode: gap_extend = gap_open)
     PC_HD int finish(Digest &out, int match, int mismatch, int gap_open, int gap_extend) {
-        if (row > 0 && col == cmin && col0 + cmin > 0) err = 1;   // left the window: bound violated
         const int gaps = nsteps - ndiag;
         const int num = score - mismatch * ndiag - nopen * gap_open - (gaps - nopen) * gap_extend;
         const int matches = num / (match - mismatch);
         if (num != matches * (match - mismatch) || matches < 0 || matches > ndiag) err = 1;   // the path does not realise the score
+        return finish_with(out, matches);
+    }
+    // The digest with the matches COUNTED along the path (consume() with the bases): what the plain-coordinate kernel of
+    // pc_slow.h uses -- valid for every scoring scheme, match == mismatch included, where the score equation above has no
+    // unique solution.
+    PC_HD int finish_counted(Digest &out) { return finish_with(out, matches_seen); }
+    PC_HD int finish_with(Digest &out, int matches) {
+        if (row > 0 && col == cmin && col0 + cmin > 0) err = 1;   // left the window: bound violated
         if (!changed) { first_type = cur_type; first_len = cur_len; second_type = 0; }
         const int a = col0 + col, b = row;                    // head: read bases / adapter rows before the path
         const int c = n_total - (col0 + J), d = m - I;        // tail

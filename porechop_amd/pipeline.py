@@ -174,6 +174,19 @@ class Pipeline:
             self.aligner.set_adapters(self.seqs)
         self.stats = {"pairs_end": 0, "pairs_middle": 0, "cells_end": 0, "cells_middle": 0}
 
+    def packed_kernels(self):
+        """True when every pair of this pipeline runs the packed 16-bit kernels (pc_scores_supported): the exact prunings
+        below (score bounds, PC_MODE_SCORE records) are derived for those schemes.  Any other scheme -- the reference takes
+        any four integers -- and adapters above 128 bases run the library's plain-int32 kernel: same answers, every record
+        computed, no pruning."""
+        lib = getattr(self.aligner, "lib", None)
+        if lib is None or not hasattr(lib, "pc_scores_supported"):
+            # test stand-ins (no library): the sign conditions the bounds' derivations rest on
+            match, mismatch, go, ge = [int(x) for x in self.p.scores]
+            return match > 0 and match > mismatch and go < 0 and ge < 0
+        longest = max([len(x) for x in self.seqs] + [1])
+        return bool(lib.pc_scores_supported(*[int(x) for x in self.p.scores], int(longest)))
+
     def _register(self, sets):
         # one adapter table for everything (deduplicated sequences)
         for s in sets:
@@ -331,7 +344,7 @@ class Pipeline:
                 jobs.append((self.seq_index[s.start[1]], so, sl)); where.append((si, 0))
             if s.end is not None:
                 jobs.append((self.seq_index[s.end[1]], eo, el)); where.append((si, 1))
-        if prune:
+        if prune and self.packed_kernels():
             return self._phase_a_pruned(reads, jobs, where, best_start, best_end)
         outs = self._scan_jobs(reads.arena, jobs, MODE_TRACE, self.p.end_size)
         # one vectorised reduction for all jobs (they all cover the same n check reads)
@@ -549,7 +562,8 @@ class Pipeline:
     @property
     def can_prune_phase_b(self):
         """Needs the reduction and selection kernels and score records that carry the end cell (the GPU library's do)."""
-        return self.native_reduce and hasattr(self.aligner, "phase_b_select") and getattr(self.aligner, "score_end_cell", False)
+        return self.native_reduce and hasattr(self.aligner, "phase_b_select") and getattr(self.aligner, "score_end_cell", False) and \
+            self.packed_kernels()
 
     def _prune_b(self, prune, njobs):
         """prune=None: the exact pruning of phase B where it pays -- a barcode panel's worth of jobs (with a handful of
@@ -745,6 +759,7 @@ class Pipeline:
         pass, on the set's ahead-of-time kernel).  Hits, masks, rounds and alignment counts are identical."""
         p = self.p
         dev = self.device
+        prove = prove and self.packed_kernels()                # the score bound is derived for the packed kernels' schemes
         ads_sets = self._middle_adapters_with_sets(matching)
         ads = [a for a, _ in ads_sets]
         hint = [("set", si) for _, si in ads_sets]

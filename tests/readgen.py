@@ -267,4 +267,9 @@ RUNNER_CASES = [
     ("albacore_bins_check30", "albacore", "b", ["--check_reads", "30"]),
     ("albacore_file_out", "albacore", "o:out.fastq", []),
     ("bc_tie_bins", "bc_tie", "b", []),
+    # schemes the packed 16-bit kernels do not take (the reference takes any four integers, porechop.py:145,196-202):
+    # the default scheme x 100 (same alignments, magnitudes beyond 16 bits), a zero gap extension, a positive gap opening
+    ("ligation_wide_scheme", "ligation", "o:out.fastq", ["--scoring_scheme", "300,-600,-500,-200"]),
+    ("ligation_zero_extend_scheme", "ligation", "o:out.fastq", ["--scoring_scheme", "4,-5,-3,0"]),
+    ("edge_posgap_scheme", "edge", "o:out.fastq", ["--scoring_scheme", "5,-7,1,-3"]),
 ]

@@ -159,15 +159,44 @@ def test_linear_gap_schemes_vs_oracle(pa, oracle):
         assert not bad, (sc, len(bad), bad[:3])
 
 
-def test_unsupported_scores_fail_loudly(pa):
+def test_any_scheme_and_any_adapter_length_is_computed(pa, oracle):
+    """The reference takes any four integers and any adapter (porechop.py:145,196-202): what the packed 16-bit kernels
+    refuse -- non-negative gap scores, match <= mismatch, magnitudes beyond 16 bits, adapters above 128 bases -- runs the
+    plain-int32 kernel (csrc/pc_slow.hip) and gives the oracle's strings (the oracle is pinned on the compiled reference
+    for such schemes too: tests/test_oracle_vs_ref.py).  End windows and whole reads, the batch API and the per-call
+    symbol."""
+    rng = random.Random(4242)
+    schemes = [(3, -6, 5, -2), (3, 4, -5, -2), (3000, -6, -5, -2), (0, 0, 0, 0), (1, -1, 0, 0), (2, -3, 1, 2), (-2, 3, -1, -4),
+               (5, -4, 3, 3), (100000, -70000, -90000, -30000), (3, 3, -5, -2), (1, 1, 1, 1), (4, -5, -3, 0)]
+    for sc in schemes:
+        cases = [random_case(rng) for _ in range(400)]
+        cases += [random_case(rng, n=rng.choice([900, 2500]), m=rng.choice([22, 28, 33])) for _ in range(12)]
+        cases += [("", "ACGT"), ("ACGT", "")]
+        got = run_batch(pa, cases, sc)
+        bad = [(rd, ad, g, oracle.adapter_alignment(rd, ad, sc)) for (rd, ad), g in zip(cases, got)
+               if comparable(g) != comparable(oracle.adapter_alignment(rd, ad, sc))]
+        assert not bad, (sc, len(bad), bad[:3])
+        assert comparable(pa.adapter_alignment("TTTTACGTTTTT", "ACGT", list(sc))) == comparable(oracle.adapter_alignment("TTTTACGTTTTT", "ACGT", sc))
+    # long adapters under the default scheme, mixed with short ones in one batch (the short ones keep the packed kernels)
+    sc = (3, -6, -5, -2)
+    cases = []
+    for _ in range(150):
+        rd, ad = random_case(rng, n=rng.choice([150, 600, 1500]), m=rng.choice([129, 200, 333, 700]))
+        cases.append((rd, ad))
+    cases += [random_case(rng) for _ in range(300)]
+    rng.shuffle(cases)
+    got = run_batch(pa, cases, sc)
+    bad = [(len(rd), len(ad), g) for (rd, ad), g in zip(cases, got) if comparable(g) != comparable(oracle.adapter_alignment(rd, ad, sc))]
+    assert not bad, (len(bad), bad[:3])
+
+
+def test_scores_beyond_the_32_bit_safe_range_fail_loudly(pa):
     with pytest.raises(RuntimeError):
-        pa.Aligner(["ACGT"], scores=(3, -6, 5, -2))       # positive gap score
+        pa.Aligner(["ACGT"], scores=(3, -6, -5, -(1 << 21)))
     with pytest.raises(RuntimeError):
-        pa.Aligner(["ACGT"], scores=(3, 4, -5, -2))       # match <= mismatch
+        pa.Aligner(["A" * 5000])                             # beyond PC_MAX_ADAPTER_ANY
     with pytest.raises(RuntimeError):
-        pa.Aligner(["ACGT" * 8], scores=(3000, -6, -5, -2))   # overflows the int16 lanes
-    with pytest.raises(RuntimeError):
-        pa.adapter_alignment("ACGT", "ACGT", [3, -6, 5, -2])
+        pa.adapter_alignment("ACGT", "ACGT", [1 << 22, -6, -5, -2])
 
 
 def test_specialised_kernel_matches_generic(pa, oracle):

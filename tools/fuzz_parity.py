@@ -3,6 +3,7 @@
 millions of end-window pairs and tens of thousands of whole reads, over random valid scoring
 schemes and adapters of 1..120 bases.  Prints one line per block and a final tally.
     python tools/fuzz_parity.py [blocks] [seed]
+PC_FUZZ_UNRESTRICTED=1 draws ANY four integers as the scheme and adapters up to 400 bases (the plain-int32 kernel's ground).
 With PC_CHECK_RANGE=1 PC_JIT_CHECK_RANGE=1 PC_JIT_MIN_CELLS=1 in the environment the range-checking builds of the 16-bit
 kernels run (every row class of the packed-fp16 traced kernel, the specialised score kernel of every adapter pair met):
 each block then also prints the extremes of every value those kernels formed (pc_debug_value_range; the exactness argument
@@ -28,8 +29,25 @@ bad = total = 0
 checking = os.environ.get("PC_CHECK_RANGE", "0") not in ("", "0") or os.environ.get("PC_JIT_CHECK_RANGE", "0") not in ("", "0")
 worst = [0, 0]
 t0 = time.time()
+unrestricted = os.environ.get("PC_FUZZ_UNRESTRICTED", "0") not in ("", "0")
 for blk in range(blocks):
-    while True:
+    while unrestricted:
+        # ANY four integers, as the reference takes them (porechop.py:145,196-202): positive / zero gap scores, match <=
+        # mismatch, magnitudes far beyond 16 bits; adapters up to 400 bases.  These run the plain-int32 kernel
+        # (csrc/pc_slow.hip) wherever the packed kernels refuse; smaller blocks, it is ~100x slower per cell.
+        kind = blk % 4
+        if kind == 0:
+            sc = tuple(rng.randint(-12, 12) for _ in range(4))
+        elif kind == 1:
+            sc = tuple(rng.randint(-100000, 100000) for _ in range(4))
+        elif kind == 2:
+            sc = (rng.randint(1, 8), rng.randint(-8, 0), rng.randint(0, 6), rng.randint(0, 6))
+        else:
+            sc = (rng.randint(1, 30), -rng.randint(0, 40), -rng.randint(1, 40), -rng.randint(1, 40))
+        ads = ["".join(rng.choice("ACGT") for _ in range(rng.choice([1, 5, 22, 24, 28, 33, 64, 120, 129, 200, 400]))) for _ in range(6)]
+        al = porechop_amd.Aligner(ads, scores=sc)
+        break
+    while not unrestricted:
         sc = (rng.randint(1, 30), -rng.randint(0, 40), -rng.randint(1, 40), -rng.randint(1, 40))
         if blk % 5 == 4:
             # match - mismatch of 1 or 2: the match count pc_walk.h derives from the score then divides by almost nothing,
@@ -46,7 +64,10 @@ for blk in range(blocks):
                 continue
     whole = blk % 4 == 3
     n = 2000 if whole else 100_000
-    lens = nrng.choice([3000, 8000], size=n) if whole else nrng.choice([1, 7, 60, 149, 150, 150, 150, 151], size=n)
+    if unrestricted:
+        whole = blk % 8 == 7
+        n = 300 if whole else 20_000
+    lens = nrng.choice([3000, 8000] if not unrestricted else [900, 2500], size=n) if whole else nrng.choice([1, 7, 60, 149, 150, 150, 150, 151], size=n)
     lens = lens.astype(np.int32)
     offs = np.concatenate([[0], np.cumsum(lens[:-1].astype(np.int64))]).astype(np.int64)
     alphabet = np.frombuffer(rng.choice([b"ACGT", b"ACGT", b"ACGTN", b"AC", b"ACGT-", b"acgtACGTUu"]), dtype=np.uint8)

@@ -72,6 +72,15 @@ enum {
                              * reference's end cell (row I of the adapter, window column J) and raw
                              * score, no traceback (pc_scan_device only) */
 
+#define PC_MODE_TRACE_AT 4  /* the traced alignment of pairs whose END CELL is already known: on entry d_out holds, for
+                             * every pair, the PC_MODE_SCORE record of the same (window, adapter) pair; on return the
+                             * traced record.  Only the columns the path can occupy are traced (the last W + 2 before
+                             * the end cell, W the exact bound of csrc/pc_bounds.h), the columns before them run the
+                             * bare recurrence, the columns after the end cell are not run at all -- the machinery of
+                             * PC_MODE_TWO_PASS's second pass, for windows of any length (phase B's exact pruning traces
+                             * its few selected end-window pairs this way).  The score the window reproduces must equal
+                             * the record's, or the pair is flagged (pc_sync: PC_ERR_INTERNAL).  pc_scan_device only. */
+
 const char *pc_version(void);
 const char *pc_strerror(int code);
 

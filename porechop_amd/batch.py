@@ -10,7 +10,7 @@ import numpy as np
 from ._lib import check, load_library
 
 RESULT_INTS = 8      # readStart, readEnd, adapterStart, adapterEnd, rawScore, matches, alignedLen, fullLen
-MODE_AUTO, MODE_TRACE, MODE_TWO_PASS, MODE_SCORE = 0, 1, 2, 3
+MODE_AUTO, MODE_TRACE, MODE_TWO_PASS, MODE_SCORE, MODE_TRACE_AT = 0, 1, 2, 3, 4
 DEFAULT_SCORES = (3, -6, -5, -2)   # porechop/porechop.py:145
 INT_MIN = -2147483648
 
@@ -61,6 +61,7 @@ class Aligner:
     """One GPU context: a scoring scheme + an adapter panel + scratch buffers."""
     fast_prefilter = True      # prefilter_rows is the device's exact prefilter (callers may put it in front of the middle scan)
     score_end_cell = True      # MODE_SCORE records carry the reference's end cell (row, column) besides the score
+    trace_at = True            # MODE_TRACE_AT: the traced record of a pair whose MODE_SCORE record (its end cell) is known
 
     def __init__(self, adapters, scores=DEFAULT_SCORES, device=-1):
         self.lib = load_library()

@@ -280,7 +280,11 @@ int build_tiles(pc_ctx *c, const int32_t *job_adapter, const int32_t *job_adapte
             bool pad = false;
             int rows = pck::pick_rows(ma, mbb, &pad);         // 0 => generic LDS-state kernel
             if (no_drift) { rows = 0; pad = true; }
-            const bool two = (mode == PC_MODE_TWO_PASS) || (mode == PC_MODE_SCORE) || (mode == PC_MODE_AUTO && max_len > 2 * window + 64);
+            const bool two = (mode == PC_MODE_TWO_PASS) || (mode == PC_MODE_SCORE) || (mode == PC_MODE_TRACE_AT) ||
+                             (mode == PC_MODE_AUTO && max_len > 2 * window + 64);
+            // PC_MODE_TRACE_AT over short windows: a traced window never needs to be longer than the windows themselves
+            // (one that holds its read's column 0 starts from the true column 0: no warm-up before it)
+            if (mode == PC_MODE_TRACE_AT) window = std::min(window, std::max(1, max_len));
             auto key = std::make_pair(rows * 2 + (pad ? 1 : 0), two ? 1 : 0);
             group_window[key] = std::max(group_window[key], window);
             *rows_out = rows;
@@ -294,7 +298,8 @@ int build_tiles(pc_ctx *c, const int32_t *job_adapter, const int32_t *job_adapte
             if (n > 0) v.push_back(pck::TileRun{ws, out_base, n, 0, a1, a1, rows ? rows : m1, 0});
         };
         const int window = std::max(c->ad_window[ad], adb >= 0 ? c->ad_window[adb] : 0);
-        const bool two_pass_job = (mode == PC_MODE_TWO_PASS) || (mode == PC_MODE_SCORE) || (mode == PC_MODE_AUTO && max_len > 2 * window + 64);
+        const bool two_pass_job = (mode == PC_MODE_TWO_PASS) || (mode == PC_MODE_SCORE) || (mode == PC_MODE_TRACE_AT) ||
+                                  (mode == PC_MODE_AUTO && max_len > 2 * window + 64);
         // A dual tile runs both halves with the longer adapter's rows and saves nothing but the second
         // read stream -- which matters for whole reads (8 kB per window), not for 150-byte end windows:
         // there, two adapters of different row classes cost fewer rows as two single-adapter jobs
@@ -768,7 +773,7 @@ int pc_scan_device(pc_ctx *c, const void *d_arena, const int64_t *d_win_off, con
         const bool lin = pcb::is_linear(c->gap_open, c->gap_extend);
         for (size_t gi = 0; gi < c->groups.size(); ++gi) {
             const Group &g = c->groups[gi];
-            if (!g.two_pass) continue;
+            if (!g.two_pass || mode == PC_MODE_TRACE_AT) continue;           // (TRACE_AT: the end cells are the caller's)
             group_chunks[gi] = group_chunks_for(c, g, max_len);
             size_t need = 0;
             score_plan[gi] = plan_score_launches(c, g, max_len, npairs, lin, group_chunks[gi], &need);
@@ -912,11 +917,17 @@ int pc_scan_device(pc_ctx *c, const void *d_arena, const int64_t *d_win_off, con
                 pcb::F16Plan fp_;
                 pl.end_align = trace16_plan(c, g.rows, g.max_window + 1, &fp_) ? 1 : 0;
             }
+            pl.err = a.err;
             {
                 ScopedTimer tm(c, stream, 1, np);
                 for (const ScoreLaunch &L : score_plan[gi]) {
                     pl.k1 = c->d_k1.as<int32_t>() + L.k1_ints;
                     pl.tiles = a.tiles + L.begin; pl.ntiles = (int32_t)L.count; pl.chunks = L.chunks;
+                    if ((rc = pck::launch_plan(pl, stream))) return PC_ERR_NO_DEVICE;
+                }
+                if (mode == PC_MODE_TRACE_AT) {         // the caller's score records, read before pass 2 overwrites them
+                    pl.k1 = nullptr; pl.end_records = d_out; pl.window_cap = std::max(1, max_len);
+                    pl.tiles = a.tiles; pl.ntiles = (int32_t)g.tile_count; pl.chunks = 1;
                     if ((rc = pck::launch_plan(pl, stream))) return PC_ERR_NO_DEVICE;
                 }
             }

@@ -77,6 +77,11 @@ struct PlanArgs {
                                                         // adapters' windows), a window that would start before the read's column 0
                                                         // by a lead-in of the bytes before the read (col0 < 0): all windows then END
                                                         // in the same local column and share their trace-free warm-up (trace16_kernel)
+    const int32_t *end_records;                         // PC_MODE_TRACE_AT: the end cells come from the caller's PC_MODE_SCORE records
+                                                        // ([npairs][8], indexed like k1 by output slot) instead of a score pass
+    int32_t window_cap;                                 // > 0: no traced window longer than this (PC_MODE_TRACE_AT: the caller's max_len --
+                                                        // a window that holds its read's column 0 needs no warm-up before it)
+    uint32_t *err;
 };
 
 // per-read reduction of the end-window records (pc_reduce.hip)

@@ -1100,10 +1100,21 @@ __global__ void plan_kernel(PlanArgs a)
     const int64_t w = (hi ? tile.win_hi : tile.win_lo) + i;      // its whole-read window
     // merge the per-chunk maxima in the reference's visiting order (strict '>', earlier chunk wins)
     const int nch = a.chunks > 1 ? a.chunks : 1;
-    int score = a.k1[(p * nch) * 4 + 0], I = a.k1[(p * nch) * 4 + 1], J = a.k1[(p * nch) * 4 + 2];
-    for (int c = 1; c < nch; ++c) {
-        const int sc = a.k1[(p * nch + c) * 4 + 0];
-        if (sc > score) { score = sc; I = a.k1[(p * nch + c) * 4 + 1]; J = a.k1[(p * nch + c) * 4 + 2]; }
+    int score, I, J;
+    if (a.end_records) {
+        // PC_MODE_TRACE_AT: the caller's score record of this very pair, (-2, J, I, 0, score, ...)
+        const int4 r0 = ((const int4 *)(a.end_records + p * TRACE_OUT_INTS))[0];
+        score = a.end_records[p * TRACE_OUT_INTS + 4]; I = r0.z; J = r0.y;
+        if (r0.x != -2 || J < 0 || J > a.win_len[w] || I < 0) {       // not a score record of this window: loud, never guessed
+            atomicAdd(a.err, 1u);
+            I = 0; J = 0;
+        }
+    } else {
+        score = a.k1[(p * nch) * 4 + 0]; I = a.k1[(p * nch) * 4 + 1]; J = a.k1[(p * nch) * 4 + 2];
+        for (int c = 1; c < nch; ++c) {
+            const int sc = a.k1[(p * nch + c) * 4 + 0];
+            if (sc > score) { score = sc; I = a.k1[(p * nch + c) * 4 + 1]; J = a.k1[(p * nch + c) * 4 + 2]; }
+        }
     }
     if (a.score_out) {       // score-only request: the end cell and its score are the whole answer
         int4 *o = (int4 *)(a.score_out + p * TRACE_OUT_INTS);
@@ -1112,12 +1123,14 @@ __global__ void plan_kernel(PlanArgs a)
         return;
     }
     int window = a.ad_window[hi ? tile.adapter_hi : tile.adapter_lo];
+    if (a.window_cap > 0 && window > a.window_cap) window = a.window_cap;
     int c0 = J - window;
     if (a.end_align && J > 0) {             // (J == 0: the end cell is the corner (m, 0) -- nothing to run, nothing to align)
         // (a longer warm-up is still exact; the lead-in columns are garbage the kernel discards when it reaches
         // the read's column 0 -- they only have to be readable: not before the arena's first byte)
         const int wl = a.ad_window[tile.adapter_lo], wh = a.ad_window[tile.adapter_hi];
         window = wl > wh ? wl : wh;
+        if (a.window_cap > 0 && window > a.window_cap) window = a.window_cap;
         c0 = J - window;
         const int64_t room = a.win_off[w];
         if (c0 < 0 && (int64_t)(-c0) > room) c0 = -(int)room;

@@ -15,10 +15,12 @@ PyTorch is plumbing here: it owns the HBM buffers and the stream.
 from dataclasses import dataclass, field
 from typing import List, Optional, Tuple
 
+import os
+
 import numpy as np
 import torch
 
-from .batch import MODE_SCORE, MODE_TRACE, MODE_TWO_PASS, Aligner, RESULT_INTS
+from .batch import MODE_SCORE, MODE_TRACE, MODE_TRACE_AT, MODE_TWO_PASS, Aligner, RESULT_INTS
 
 # phase B is pruned (exactly: see "Exact pruning of phase B" below) from this many (sequence, side) jobs on; measured on
 # MI355X, 1 M reads: 198 jobs 192 -> 122 ms; with the 4-6 jobs of a run without barcodes tracing everything is faster
@@ -510,6 +512,7 @@ class Pipeline:
         job_adapter = np.array([j[0] for j in jobs], dtype=np.int32)
         words = (R + 63) // 64
         best_full = torch.zeros((2, R), dtype=torch.float64, device=dev)   # best traced full identity of a call pair, per side
+        trace_at = getattr(al, "trace_at", False) and os.environ.get("PC_NO_TRACE_AT", "0") in ("", "0")
 
         def trace(mask, counts):
             cnt = counts.cpu().numpy()                                   # the round's one host round trip
@@ -527,9 +530,15 @@ class Pipeline:
             live = np.nonzero(cnt)[0]
             starts = np.zeros(len(live) + 1, dtype=np.int64)
             starts[1:] = np.cumsum(cnt[live])
-            traced = torch.empty((total, RESULT_INTS), dtype=torch.int32, device=dev)
             al.set_length_hint(0)
-            al.scan_device(reads.arena, woff, wlen, job_adapter[live], starts, p.end_size, traced, MODE_TRACE)
+            if trace_at:
+                # the end cell of every selected pair is known from its score record: only the columns its path can occupy
+                # are traced (PC_MODE_TRACE_AT: the second pass of the whole-read scan, for end windows)
+                traced = rec.index_select(0, dest)
+                al.scan_device(reads.arena, woff, wlen, job_adapter[live], starts, p.end_size, traced, MODE_TRACE_AT)
+            else:
+                traced = torch.empty((total, RESULT_INTS), dtype=torch.int32, device=dev)
+                al.scan_device(reads.arena, woff, wlen, job_adapter[live], starts, p.end_size, traced, MODE_TRACE)
             al.phase_b_scatter(traced, dest, pjob, pread, rec, job_side, job_calls, best_full, R)
             return total
 

@@ -11,7 +11,7 @@ for WHAT in "$@"; do
       timeout 1500 python -m pytest tests/test_gpu_dropin.py -m gpu -x -q > $OUT/${TAG}_gpu_dropin.log 2>&1; echo "dropin tests rc=$?" | tee -a $OUT/${TAG}_gpu_dropin.log
       tail -8 $OUT/${TAG}_gpu_dropin.log ;;
     tests)
-      timeout 1800 python -m pytest tests -m gpu -x -q > $OUT/${TAG}_gpu_tests.log 2>&1; echo "gpu tests rc=$?" | tee -a $OUT/${TAG}_gpu_tests.log
+      timeout 2400 python -m pytest tests -m gpu -q > $OUT/${TAG}_gpu_tests.log 2>&1; echo "gpu tests rc=$?" | tee -a $OUT/${TAG}_gpu_tests.log
       tail -6 $OUT/${TAG}_gpu_tests.log
       timeout 300 python __graft_entry__.py smoke 2>&1 | tail -1 ;;
     bench*)

@@ -216,6 +216,10 @@ int pc_phase_b_gather(pc_ctx *ctx, const uint64_t *d_mask, int64_t n, int njobs,
                       const int64_t *d_start_off, const int32_t *d_start_len, const int64_t *d_end_off,
                       const int32_t *d_end_len, int64_t *d_win_off, int32_t *d_win_len, int64_t *d_dest,
                       int32_t *d_pair_job, int64_t *d_pair_read, void *stream);
+/* d_out[k] = d_records[d_index[k]] (PC_RESULT_INTS each): the score records of the gathered pairs (d_index = d_dest) in the
+ * order of the traced scan's windows -- what PC_MODE_TRACE_AT expects in its output buffer on entry. */
+int pc_gather_records(pc_ctx *ctx, const int32_t *d_records, const int64_t *d_index, int64_t count, int32_t *d_out,
+                      void *stream);
 /* The traced records of the gathered windows over the score records they replace; d_best_full (may be NULL) is
  * raised to the full identity of every traced barcode pair. */
 int pc_phase_b_scatter(pc_ctx *ctx, const int32_t *d_traced, int64_t count, const int64_t *d_dest,
@@ -386,6 +390,23 @@ int pc_readset_write(const pc_readset *rs, int64_t npieces, const int64_t *piece
 int pc_readset_write_at(const pc_readset *rs, int64_t npieces, const int64_t *piece_read, const int32_t *piece_start,
                         const int32_t *piece_len, const int32_t *piece_number, const int32_t *piece_file, int nfiles,
                         const char *const *file_paths, int fastq, int64_t *file_pos);
+
+/* A sharded run (one process per GPU) over ONE plain FASTQ file: every rank parses only its own byte range and writes its
+ * own span of the shared output files.
+ * pc_fastq_find_record: the first record start at or after byte_pos (the cut pc_readset_load_segment would choose), or the
+ * file size when none is left; rank r of W takes [find(size * r / W), find(size * (r + 1) / W)).  "Not streamable" (gzip,
+ * FASTA, an irregular record near byte_pos) is PC_ERR_UNSUPPORTED_SCORES, as for pc_readset_load_segment.
+ * pc_readset_write_sizes: the bytes pc_readset_write would put into each file, nothing written -- the ranks exchange them
+ * and take the prefix sums as their positions.
+ * pc_readset_write_shared: pc_readset_write_at for files other processes write disjoint spans of: opened without
+ * truncation whatever the position (create / truncate them once, before any rank writes). */
+int pc_fastq_find_record(const char *path, int64_t byte_pos, int64_t *record_start);
+int pc_readset_write_sizes(const pc_readset *rs, int64_t npieces, const int64_t *piece_read, const int32_t *piece_start,
+                           const int32_t *piece_len, const int32_t *piece_number, const int32_t *piece_file, int nfiles,
+                           int fastq, int64_t *bytes_per_file);
+int pc_readset_write_shared(const pc_readset *rs, int64_t npieces, const int64_t *piece_read, const int32_t *piece_start,
+                            const int32_t *piece_len, const int32_t *piece_number, const int32_t *piece_file, int nfiles,
+                            const char *const *file_paths, int fastq, int64_t *file_pos);
 
 #ifdef __cplusplus
 }

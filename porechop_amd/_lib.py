@@ -14,11 +14,11 @@ EXPORTS = [
     "adapterAlignment", "freeCString",
     "pc_version", "pc_strerror", "pc_scores_supported", "pc_create", "pc_destroy",
     "pc_set_scores", "pc_set_adapters", "pc_align_batch_host", "pc_scan_device", "pc_sync",
-    "pc_format_result", "pc_format_results", "pc_jit_async", "pc_jit_shutdown", "pc_jit_precompile", "pc_jit_stats", "pc_prefilter_max_edits", "pc_prefilter_device", "pc_prefetch", "pc_memo_clear", "pc_memo_stats", "pc_set_timing", "pc_get_timing", "pc_set_length_hint", "pc_set_int16_only", "pc_copy_windows", "pc_trace_ops_x100", "pc_phase_b_reduce", "pc_phase_b_select", "pc_phase_b_gather", "pc_phase_b_scatter", "pc_debug_value_range",
+    "pc_format_result", "pc_format_results", "pc_jit_async", "pc_jit_shutdown", "pc_jit_precompile", "pc_jit_stats", "pc_prefilter_max_edits", "pc_prefilter_device", "pc_prefetch", "pc_memo_clear", "pc_memo_stats", "pc_set_timing", "pc_get_timing", "pc_set_length_hint", "pc_set_int16_only", "pc_copy_windows", "pc_trace_ops_x100", "pc_phase_b_reduce", "pc_phase_b_select", "pc_phase_b_gather", "pc_phase_b_scatter", "pc_gather_records", "pc_debug_value_range",
     "pc_readset_load", "pc_readset_free", "pc_readset_error", "pc_readset_count", "pc_readset_is_fastq",
     "pc_readset_arena", "pc_readset_offsets", "pc_readset_lengths", "pc_readset_name", "pc_readset_quals",
     "pc_readset_is_rna", "pc_readset_load_many", "pc_readset_file_index", "pc_readset_write",
-    "pc_readset_load_segment", "pc_readset_write_at", "pc_io_set_thread_limit", "pc_pack_reads", "pc_unpack_device",
+    "pc_readset_load_segment", "pc_readset_write_at", "pc_io_set_thread_limit", "pc_pack_reads", "pc_unpack_device", "pc_fastq_find_record", "pc_readset_write_sizes", "pc_readset_write_shared",
 ]
 
 
@@ -97,6 +97,8 @@ def load_library():
     L.pc_phase_b_gather.restype = c_int
     L.pc_phase_b_scatter.argtypes = [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]
     L.pc_phase_b_scatter.restype = c_int
+    L.pc_gather_records.argtypes = [c_vp, c_vp, c_vp, c_i64, c_vp, c_vp]
+    L.pc_gather_records.restype = c_int
     L.pc_jit_async.argtypes = [c_int]
     L.pc_jit_async.restype = None
     L.pc_jit_shutdown.argtypes = []
@@ -151,6 +153,13 @@ def load_library():
     L.pc_readset_write_at.argtypes = [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, ctypes.POINTER(c_cp), c_int,
                                       ctypes.POINTER(c_i64)]
     L.pc_readset_write_at.restype = c_int
+    L.pc_fastq_find_record.argtypes = [c_cp, c_i64, ctypes.POINTER(c_i64)]
+    L.pc_fastq_find_record.restype = c_int
+    L.pc_readset_write_sizes.argtypes = [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_vp]
+    L.pc_readset_write_sizes.restype = c_int
+    L.pc_readset_write_shared.argtypes = [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, ctypes.POINTER(c_cp), c_int,
+                                          ctypes.POINTER(c_i64)]
+    L.pc_readset_write_shared.restype = c_int
     L.pc_io_set_thread_limit.argtypes = [c_int]
     L.pc_io_set_thread_limit.restype = None
     L.pc_pack_reads.argtypes = [c_vp, c_i64, c_vp, c_vp, c_i64, ctypes.POINTER(c_i64)]

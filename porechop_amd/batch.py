@@ -224,6 +224,18 @@ class Aligner:
                                          dest.data_ptr(), pair_job.data_ptr(), pair_read.data_ptr(), ctypes.c_void_p(s)),
               "pc_phase_b_gather")
 
+    def gather_records(self, records, index, out=None, stream=None):
+        """out[k] = records[index[k]] on the device (pc_gather_records); records int32 [*, 8], index int64 [count]."""
+        import torch
+        assert records.dtype == torch.int32 and records.is_contiguous() and index.dtype == torch.int64 and index.is_contiguous()
+        n = int(index.shape[0])
+        if out is None:
+            out = torch.empty((n, RESULT_INTS), dtype=torch.int32, device=records.device)
+        s = stream if stream is not None else torch.cuda.current_stream().cuda_stream
+        check(self.lib.pc_gather_records(self._ctx, records.data_ptr(), index.data_ptr(), n, out.data_ptr(), ctypes.c_void_p(s)),
+              "pc_gather_records")
+        return out
+
     def phase_b_scatter(self, traced, dest, pair_job, pair_read, records, job_side, job_calls, best_full, n, stream=None):
         """Traced records over the score records they replace (pc_phase_b_scatter)."""
         import torch

@@ -1125,6 +1125,17 @@ int pc_phase_b_gather(pc_ctx *c, const uint64_t *d_mask, int64_t n, int njobs, c
     return pck::launch_gather(a, stream) ? PC_ERR_NO_DEVICE : PC_OK;
 }
 
+int pc_gather_records(pc_ctx *c, const int32_t *d_records, const int64_t *d_index, int64_t count, int32_t *d_out, void *stream_v)
+{
+    if (!c || count < 0) return PC_ERR_BAD_ARG;
+    if (count == 0) return PC_OK;
+    if (!d_records || !d_index || !d_out) return PC_ERR_BAD_ARG;
+    (void)hipSetDevice(c->device);
+    hipStream_t stream = (stream_v == PC_STREAM_CONTEXT) ? c->stream : (hipStream_t)stream_v;
+    ScopedTimer tm(c, stream, 6, count);
+    return pck::launch_gather_records(d_records, d_index, count, d_out, stream) ? PC_ERR_NO_DEVICE : PC_OK;
+}
+
 int pc_phase_b_scatter(pc_ctx *c, const int32_t *d_traced, int64_t count, const int64_t *d_dest, const int32_t *d_pair_job,
                        const int64_t *d_pair_read, int32_t *d_records, const int32_t *d_job_side, const int32_t *d_job_calls,
                        double *d_best_full, int64_t n, void *stream_v)

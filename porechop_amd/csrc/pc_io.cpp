@@ -514,6 +514,37 @@ int pc_readset_load_segment(const char *path, int64_t byte_begin, int64_t target
     return rc;
 }
 
+// The first record start at or after byte_pos of a plain 4-line FASTQ file -- the `cut` pc_readset_load_segment would
+// choose for byte_begin + target_bytes == byte_pos -- or the file's size when no record starts there any more.  Lets the
+// ranks of a sharded run find their own byte ranges without reading anything else of the file.
+int pc_fastq_find_record(const char *path, int64_t byte_pos, int64_t *record_start)
+{
+    if (!path || !record_start || byte_pos < 0) return PC_ERR_BAD_ARG;
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) return PC_ERR_BAD_ARG;
+    struct stat st;
+    if (fstat(fd, &st) != 0 || st.st_size <= 0) { close(fd); return PC_ERR_UNSUPPORTED_SCORES; }
+    const size_t size = (size_t)st.st_size;
+    if ((size_t)byte_pos >= size) { close(fd); *record_start = (int64_t)size; return PC_OK; }
+    void *m = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
+    close(fd);
+    if (m == MAP_FAILED) return PC_ERR_UNSUPPORTED_SCORES;
+    const char *base = (const char *)m, *fend = base + size;
+    int rc = PC_OK;
+    if (base[0] != '@') rc = PC_ERR_UNSUPPORTED_SCORES;
+    if (rc == PC_OK) {
+        const char *e = find_record_start(base + byte_pos, base, fend);
+        if (!e) {
+            const char *q = next_line(base + byte_pos - 1, fend);
+            for (int tries = 0; tries < 8 && q < fend; ++tries) q = next_line(q, fend);
+            if (q >= fend) e = fend; else rc = PC_ERR_UNSUPPORTED_SCORES;
+        }
+        if (rc == PC_OK) *record_start = (int64_t)(e - base);
+    }
+    munmap(m, size);
+    return rc;
+}
+
 void pc_readset_free(pc_readset *rs) { delete rs; }
 const char *pc_readset_error(const pc_readset *rs) { return rs ? rs->error.c_str() : "null readset"; }
 int64_t pc_readset_count(const pc_readset *rs) { return rs ? (int64_t)rs->off.size() : 0; }
@@ -593,7 +624,8 @@ int pc_pack_reads(const char *arena, int64_t nbases, uint8_t *packed, int64_t *e
 
 static int write_pieces(const pc_readset *rs, int64_t npieces, const int64_t *piece_read, const int32_t *piece_start,
                         const int32_t *piece_len, const int32_t *piece_number, const int32_t *piece_file, int nfiles,
-                        const char *const *file_paths, int fastq, int64_t *bytes_written, int64_t *file_pos);
+                        const char *const *file_paths, int fastq, int64_t *bytes_written, int64_t *file_pos,
+                        int shared = 0, int64_t *sizes_only = nullptr);
 
 void pc_io_set_thread_limit(int nthreads) { t_thread_limit = nthreads > 0 ? (nthreads > 64 ? 64 : nthreads) : 0; }
 
@@ -616,9 +648,34 @@ int pc_readset_write_at(const pc_readset *rs, int64_t npieces, const int64_t *pi
                         nullptr, file_pos);
 }
 
+// The write of one rank of a sharded run: like pc_readset_write_at, but the files are SHARED with other processes writing
+// disjoint spans -- they are opened without truncation whatever the position (the caller creates / truncates them once,
+// before any rank writes).
+int pc_readset_write_shared(const pc_readset *rs, int64_t npieces, const int64_t *piece_read, const int32_t *piece_start,
+                            const int32_t *piece_len, const int32_t *piece_number, const int32_t *piece_file, int nfiles,
+                            const char *const *file_paths, int fastq, int64_t *file_pos)
+{
+    if (!file_pos) return PC_ERR_BAD_ARG;
+    return write_pieces(rs, npieces, piece_read, piece_start, piece_len, piece_number, piece_file, nfiles, file_paths, fastq,
+                        nullptr, file_pos, 1);
+}
+
+// How many bytes pc_readset_write would put into each file (bytes_per_file[nfiles]); nothing is written or created.
+int pc_readset_write_sizes(const pc_readset *rs, int64_t npieces, const int64_t *piece_read, const int32_t *piece_start,
+                           const int32_t *piece_len, const int32_t *piece_number, const int32_t *piece_file, int nfiles,
+                           int fastq, int64_t *bytes_per_file)
+{
+    if (!bytes_per_file || nfiles < 0) return PC_ERR_BAD_ARG;
+    for (int f = 0; f < nfiles; ++f) bytes_per_file[f] = 0;
+    std::vector<const char *> dummy((size_t)std::max(nfiles, 1), "");
+    return write_pieces(rs, npieces, piece_read, piece_start, piece_len, piece_number, piece_file, nfiles, dummy.data(), fastq,
+                        nullptr, nullptr, 0, bytes_per_file);
+}
+
 static int write_pieces(const pc_readset *rs, int64_t npieces, const int64_t *piece_read, const int32_t *piece_start,
                         const int32_t *piece_len, const int32_t *piece_number, const int32_t *piece_file, int nfiles,
-                        const char *const *file_paths, int fastq, int64_t *bytes_written, int64_t *file_pos)
+                        const char *const *file_paths, int fastq, int64_t *bytes_written, int64_t *file_pos, int shared,
+                        int64_t *sizes_only)
 {
     if (!rs || npieces < 0 || nfiles < 0 || (npieces > 0 && (!piece_read || !piece_start || !piece_len || !piece_file || !file_paths)))
         return PC_ERR_BAD_ARG;
@@ -690,6 +747,7 @@ static int write_pieces(const pc_readset *rs, int64_t npieces, const int64_t *pi
         std::vector<size_t> at(idx.size() + 1, 0);
         for (size_t i = 0; i < idx.size(); ++i) at[i + 1] = at[i] + size_of(idx[i]);
         const size_t bytes = at.back();
+        if (sizes_only) { sizes_only[f] = (int64_t)bytes; continue; }
         if (to_stdout) {
             std::vector<char> buf;
             for (size_t i = 0; i < idx.size() && rc == PC_OK; ) {
@@ -705,7 +763,8 @@ static int write_pieces(const pc_readset *rs, int64_t npieces, const int64_t *pi
             fflush(stdout);
         } else {
             const size_t base_pos = file_pos ? (size_t)file_pos[f] : 0;
-            const int fd = open(path, base_pos ? O_RDWR : (O_RDWR | O_CREAT | O_TRUNC), 0666);
+            // shared: several processes write disjoint spans of one file (a sharded run): never truncate, whatever the position
+            const int fd = open(path, shared ? (O_RDWR | O_CREAT) : (base_pos ? O_RDWR : (O_RDWR | O_CREAT | O_TRUNC)), 0666);
             if (fd < 0) { rc = PC_ERR_BAD_ARG; break; }
             // Threads format their spans in parallel; their pwrite()s take turns on a mutex of ours.  Writes to ONE file
             // are serialised by the inode's lock anyway, and on the GPU box 16 threads fighting over that lock move

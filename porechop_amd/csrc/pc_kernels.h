@@ -197,6 +197,7 @@ struct ScatterArgs {
     int32_t *records; const int32_t *job_side, *job_call; double *best_full; int64_t n;
 };
 int launch_scatter(const ScatterArgs &a, void *stream);
+int launch_gather_records(const int32_t *records, const int64_t *index, int64_t count, int32_t *out, void *stream);
 
 constexpr int TRACE_OUT_INTS = 8;
 constexpr int SCORE_OUT_INTS = 4;

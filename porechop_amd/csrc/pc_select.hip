@@ -223,6 +223,25 @@ int launch_gather(const GatherArgs &a, void *stream)
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
+// out[k] = records[index[k]]: the score records of the selected pairs, in the order of the traced scan's windows
+// (PC_MODE_TRACE_AT reads their end cells from its output buffer)
+__global__ __launch_bounds__(256) void gather_records_kernel(const int32_t *records, const int64_t *index, int64_t count, int32_t *out)
+{
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= count) return;
+    const int4 *s = (const int4 *)(records + index[k] * TRACE_OUT_INTS);
+    int4 *d = (int4 *)(out + k * TRACE_OUT_INTS);
+    const int4 lo = s[0], hi = s[1];
+    d[0] = lo; d[1] = hi;
+}
+
+int launch_gather_records(const int32_t *records, const int64_t *index, int64_t count, int32_t *out, void *stream)
+{
+    if (count <= 0) return 0;
+    hipLaunchKernelGGL(gather_records_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, (hipStream_t)stream, records, index, count, out);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
 // Traced records over the score records they replace; the best full identity of the barcode pairs per (side, read)
 // is kept as the bit pattern of a non-negative double (ordered like the value).
 __global__ __launch_bounds__(256) void scatter_kernel(ScatterArgs a)

@@ -74,3 +74,33 @@ def gather_in_order(local, group=None):
     parts = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(parts, pad, group=group)
     return torch.cat([p[: int(s.item())] for p, s in zip(parts, sizes)])
+
+
+def _staging_device(device=None):
+    """Where small host-side values must live to take part in a collective: RCCL ("nccl") only moves device tensors."""
+    if dist.get_backend() == "nccl":
+        return torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+    return torch.device("cpu")
+
+
+def all_gather_ints(values, device=None):
+    """Small per-rank integer vectors of EQUAL length -> int64 tensor [world, len] on the host (same on every rank)."""
+    dev = _staging_device(device)
+    mine = torch.as_tensor(values, dtype=torch.int64).reshape(-1).to(dev)
+    parts = [torch.empty_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(parts, mine)
+    return torch.stack(parts).cpu()
+
+
+def all_agree(flag, device=None):
+    """True iff `flag` is true on EVERY rank (MIN all-reduce of one integer)."""
+    t = torch.tensor([1 if flag else 0], dtype=torch.int64, device=_staging_device(device))
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return bool(t.item())
+
+
+def all_gather_objects(obj):
+    """Small picklable per-rank values -> list over ranks (same on every rank)."""
+    out = [None] * dist.get_world_size()
+    dist.all_gather_object(out, obj)
+    return out

@@ -41,6 +41,15 @@ def unpack_reads_host(packed, nbases, exc):
     return out
 
 
+def fastq_record_start(path, byte_pos):
+    """First record start at or after byte_pos of a plain 4-line FASTQ file (the file size when none is left), or None when
+    the file is not streamable there (gzip, FASTA, an irregular record): pc_fastq_find_record."""
+    lib = load_library()
+    out = ctypes.c_int64()
+    rc = lib.pc_fastq_find_record(str(path).encode(), int(byte_pos), ctypes.byref(out))
+    return int(out.value) if rc == 0 else None
+
+
 class ReadSet:
     """Reads of one file -- or of several files, in order (Albacore directory input) -- normalised
     like NanoporeRead.__init__, as numpy views over one arena."""
@@ -154,6 +163,36 @@ class ReadSet:
         rc = self.lib.pc_readset_write_at(self._h, pr.shape[0], pr.ctypes.data, ps.ctypes.data, pl.ctypes.data,
                                           pn.ctypes.data, pf.ctypes.data, len(file_paths), paths, 1 if fastq else 0,
                                           file_pos.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)))
+        if rc != 0:
+            raise OSError("Error: could not write the output reads")
+
+    def write_sizes(self, piece_read, piece_start, piece_len, piece_number, piece_file, nfiles, fastq):
+        """Bytes write() would put into each of nfiles files (numpy int64 [nfiles]); nothing is written (pc_readset_write_sizes)."""
+        pr = np.ascontiguousarray(piece_read, dtype=np.int64)
+        ps = np.ascontiguousarray(piece_start, dtype=np.int32)
+        pl = np.ascontiguousarray(piece_len, dtype=np.int32)
+        pn = np.ascontiguousarray(piece_number, dtype=np.int32)
+        pf = np.ascontiguousarray(piece_file, dtype=np.int32)
+        out = np.zeros(max(1, nfiles), dtype=np.int64)
+        rc = self.lib.pc_readset_write_sizes(self._h, pr.shape[0], pr.ctypes.data, ps.ctypes.data, pl.ctypes.data, pn.ctypes.data,
+                                             pf.ctypes.data, int(nfiles), 1 if fastq else 0, out.ctypes.data)
+        if rc != 0:
+            raise OSError("Error: could not size the output reads")
+        return out[:nfiles]
+
+    def write_shared(self, piece_read, piece_start, piece_len, piece_number, piece_file, file_paths, fastq, file_pos):
+        """write_at() into files that other processes write disjoint spans of (a sharded run): never truncates
+        (pc_readset_write_shared)."""
+        pr = np.ascontiguousarray(piece_read, dtype=np.int64)
+        ps = np.ascontiguousarray(piece_start, dtype=np.int32)
+        pl = np.ascontiguousarray(piece_len, dtype=np.int32)
+        pn = np.ascontiguousarray(piece_number, dtype=np.int32)
+        pf = np.ascontiguousarray(piece_file, dtype=np.int32)
+        assert file_pos.dtype == np.int64 and file_pos.flags["C_CONTIGUOUS"] and file_pos.shape[0] == len(file_paths)
+        paths = (ctypes.c_char_p * max(1, len(file_paths)))(*[str(p).encode() for p in file_paths])
+        rc = self.lib.pc_readset_write_shared(self._h, pr.shape[0], pr.ctypes.data, ps.ctypes.data, pl.ctypes.data,
+                                              pn.ctypes.data, pf.ctypes.data, len(file_paths), paths, 1 if fastq else 0,
+                                              file_pos.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)))
         if rc != 0:
             raise OSError("Error: could not write the output reads")
 

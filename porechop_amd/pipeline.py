@@ -534,7 +534,7 @@ class Pipeline:
             if trace_at:
                 # the end cell of every selected pair is known from its score record: only the columns its path can occupy
                 # are traced (PC_MODE_TRACE_AT: the second pass of the whole-read scan, for end windows)
-                traced = rec.index_select(0, dest)
+                traced = al.gather_records(rec, dest) if hasattr(al, "gather_records") else rec.index_select(0, dest)
                 al.scan_device(reads.arena, woff, wlen, job_adapter[live], starts, p.end_size, traced, MODE_TRACE_AT)
             else:
                 traced = torch.empty((total, RESULT_INTS), dtype=torch.int32, device=dev)

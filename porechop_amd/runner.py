@@ -575,6 +575,156 @@ def run_streamed(input_path, output, barcode_dir, opts: Options, device=None, al
     return res
 
 
+def run_sharded(input_path, output, barcode_dir, opts: Options, device=None, aligner=None,
+                adapter_panel: List[AdapterSet] = None) -> Optional[RunResult]:
+    """One plain FASTQ file over the ranks of a torch.distributed job WITHOUT any rank touching the whole file: rank r
+    parses the records that start in its W-th of the file's bytes (pc_fastq_find_record / pc_readset_load_segment),
+    scans them on its GPU and writes its own span of the shared output files (pc_readset_write_sizes, exchanged, give
+    every rank its positions; pc_readset_write_shared).  The collectives: phase A's presence table (MAX), read counts,
+    output sizes, the names of the bins in use.  The files are the single-process ones byte for byte -- Porechop's
+    decisions are per read once the presence table is known (porechop.py:224-273,607-734).
+    -> None when this route does not apply on EVERY rank (input not a streamable plain FASTQ file; output to stdout; the
+    ranks were given different paths): run() then falls back to every rank loading the input and rank 0 writing."""
+    import torch.distributed as dist
+    from .distributed import all_agree, all_gather_ints, all_gather_objects
+    from .io import fastq_record_start
+    rank, world = dist.get_rank(), dist.get_world_size()
+    t_start = time.perf_counter()
+    target_dir_or_file = os.path.abspath(barcode_dir if barcode_dir is not None else output) if (barcode_dir or output) else None
+    ok = os.path.isfile(input_path) and target_dir_or_file is not None
+    # the same files on every rank?  (tests run the ranks on private copies: those runs gather to rank 0 as before)
+    seen = all_gather_objects((os.path.abspath(input_path), target_dir_or_file, os.path.getsize(input_path) if ok else -1))
+    ok = ok and all(x == seen[0] for x in seen)
+    rs, b0, b1 = None, 0, 0
+    if ok:
+        size = os.path.getsize(input_path)
+        b0 = 0 if rank == 0 else fastq_record_start(input_path, size * rank // world)
+        b1 = size if rank == world - 1 else fastq_record_start(input_path, size * (rank + 1) // world)
+        if b0 is None or b1 is None:
+            ok = False
+        elif b1 > b0:
+            rs, nxt = ReadSet.segment(input_path, b0, b1 - b0)
+            if rs is None or nxt != b1:
+                ok = False
+    if not all_agree(ok, device if aligner is None else None):
+        if rs is not None:
+            rs.close()
+        return None
+    discard_middle = opts.discard_middle or barcode_dir is not None
+    R = rs.count if rs is not None else 0
+    counts = all_gather_ints([R], device if aligner is None else None)[:, 0].numpy()
+    first_read, total = int(counts[:rank].sum()), int(counts.sum())
+    res = RunResult(n_reads=total, read_type="FASTQ")
+    res.seconds["load"] = time.perf_counter() - t_start
+    check_idx = np.arange(max(0, min(R, max(0, opts.check_reads) - first_read)), dtype=np.int64)
+
+    panel = list(adapter_panel) if adapter_panel is not None else panel_rules.load_panel()
+    params = ScanParams(end_size=opts.end_size, min_trim_size=opts.min_trim_size, extra_end_trim=opts.extra_end_trim,
+                        end_threshold=opts.end_threshold, middle_threshold=opts.middle_threshold,
+                        adapter_threshold=opts.adapter_threshold, check_reads=opts.check_reads,
+                        scores=tuple(int(x) for x in opts.scoring_scheme))
+    pl = Pipeline(panel, params, device=device, aligner=aligner)
+    dev = pl.device
+    if aligner is None:
+        pl.aligner.lib.pc_jit_async(1)
+    coll_dev = dev if aligner is None else None
+    try:
+        t0 = time.perf_counter()
+        reads = None
+        if R:
+            reads = DeviceReads(torch.from_numpy(rs.arena).to(dev), torch.from_numpy(rs.offsets.copy()).to(dev),
+                                torch.from_numpy(rs.lengths.copy()).to(dev))
+        matching, match_idx, orientation = _find_sets(pl, panel, reads, check_idx, opts, barcode_dir, sharded=True)
+        res.matching_sets = [s.name for s in matching]
+        res.barcode_orientation = orientation
+        start_trim, end_trim, ci, hits, _ = _scan_reads(pl, reads, R, match_idx, opts, barcode_dir, orientation)
+        if hasattr(pl.aligner, "sync"):
+            pl.aligner.sync()
+        if hits is not None and hits.read.numel():
+            h = torch.stack([hits.read, hits.adapter.to(torch.int64), hits.start.to(torch.int64),
+                             hits.end.to(torch.int64)], dim=1).cpu().numpy()
+        else:
+            h = np.zeros((0, 4), dtype=np.int64)
+        st, et = start_trim.cpu().numpy(), end_trim.cpu().numpy()
+        calls = None
+        if barcode_dir is not None:
+            names_all = _barcode_bin_names(pl, match_idx, orientation)
+            calls = [names_all[k] if k >= 0 else "none" for k in ci]
+        res.start_trim, res.end_trim, res.barcode_calls = st, et, calls          # this rank's reads
+        res.seconds["scan"] = time.perf_counter() - t0
+
+        # ---- this rank's pieces, the files they go to, and where ------------------------------------------
+        t0 = time.perf_counter()
+        fmt, gz = _resolve_format(opts, output, barcode_dir, res.read_type, input_path)
+        res.out_format = fmt
+        fastq = fmt != "fasta"
+        lengths = rs.lengths if R else np.zeros(0, dtype=np.int32)
+        pr, ps_, pn_, num, tlen, n_split = _plan_pieces(opts, lengths, st, et, h, calls, barcode_dir, discard_middle,
+                                                       matching, pl, match_idx)
+        res.middle_hit_reads = int(all_gather_ints([n_split], coll_dev)[:, 0].sum())
+        if barcode_dir is not None:
+            mine = sorted({calls[r] for r in pr.tolist()})
+            bins = sorted(set().union(*all_gather_objects(mine)))
+            index = {b: k for k, b in enumerate(bins)}
+            paths = [os.path.join(barcode_dir, b + "." + fmt) for b in bins]
+            pf = np.fromiter((index[calls[r]] for r in pr.tolist()), dtype=np.int32, count=int(pr.size))
+            finals = [p + (".gz" if gz else "") for p in paths]
+        else:
+            if gz:
+                name = None
+                if rank == 0:
+                    tmp = tempfile.NamedTemporaryFile(prefix="porechop_amd_", suffix="." + fmt, delete=False,
+                                                      dir=os.path.dirname(os.path.abspath(output)))
+                    tmp.close()
+                    name = tmp.name
+                name = all_gather_objects(name)[0]
+                paths = [name]
+            else:
+                paths = [output]
+            pf = np.zeros(pr.size, dtype=np.int32)
+            finals = [output]
+        nf = len(paths)
+        sizes = rs.write_sizes(pr, ps_, pn_, num, pf, nf, fastq) if (R and nf) else np.zeros(nf, dtype=np.int64)
+        # per file: bytes, reads and bases of every rank (the reference counts reads, not pieces, and for bins their
+        # end-trimmed -- or whole -- lengths)
+        per_file = np.zeros((nf, 3), dtype=np.int64)
+        per_file[:, 0] = sizes
+        for k in range(nf):
+            sel = pf == k
+            rr = np.unique(pr[sel])
+            per_file[k, 1] = rr.size
+            per_file[k, 2] = int((lengths[rr] if opts.untrimmed else tlen[rr]).sum()) if barcode_dir is not None else int(pn_[sel].sum())
+        everyone = all_gather_ints(per_file.reshape(-1), coll_dev).numpy().reshape(world, nf, 3) if nf else np.zeros((world, 0, 3), dtype=np.int64)
+        pos = everyone[:rank, :, 0].sum(axis=0).astype(np.int64)
+        if rank == 0:
+            if barcode_dir is not None:
+                os.makedirs(barcode_dir, exist_ok=True)
+            for path in paths:
+                open(path, "wb").close()                 # created / truncated ONCE, before any rank writes its span
+        dist.barrier()
+        if R and pr.size:
+            rs.write_shared(pr, ps_, pn_, num, pf, paths, fastq, np.ascontiguousarray(pos))
+        dist.barrier()
+        totals = everyone.sum(axis=0)
+        if rank == 0:
+            for k, path in enumerate(paths):
+                if gz:
+                    if barcode_dir is not None and os.path.isfile(path + ".gz"):
+                        os.remove(path + ".gz")
+                    _gzip_file(path, finals[k])
+        for k in range(nf):
+            res.files[finals[k]] = (int(totals[k, 1]), int(totals[k, 2]))
+        dist.barrier()
+        res.seconds["write"] = time.perf_counter() - t0
+        res.seconds["wall"] = time.perf_counter() - t_start
+        return res
+    finally:
+        if aligner is None:
+            pl.close()
+        if rs is not None:
+            rs.close()
+
+
 def run(input_path, output=None, barcode_dir=None, options: Options = None, device=None, aligner=None,
         adapter_panel: List[AdapterSet] = None) -> RunResult:
     """Porechop's main() on arrays.  output=None and barcode_dir=None writes to stdout.
@@ -601,6 +751,11 @@ def run(input_path, output=None, barcode_dir=None, options: Options = None, devi
         streamed = run_streamed(input_path, output, barcode_dir, opts, device=device, aligner=aligner, adapter_panel=adapter_panel)
         if streamed is not None:
             return streamed
+
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        shared = run_sharded(input_path, output, barcode_dir, opts, device=device, aligner=aligner, adapter_panel=adapter_panel)
+        if shared is not None:
+            return shared
 
     t_last = [time.perf_counter()]
 

@@ -62,6 +62,65 @@ def test_two_ranks_on_one_gpu_write_the_reference_files(tmp_path):
         assert got[1][name] == {}, name          # only rank 0 writes
 
 
+def _shared_worker(rank, world, port, workdir, q):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    from porechop_amd import runner
+    from tests import readgen
+    from tests.runner_cases import load_cases, options_from_argv
+    cases = load_cases()
+    out, shares = {}, {}
+    for name in SHARED_CASES:
+        case = cases[name]
+        box = [readgen.build_dataset(case["dataset"], os.path.join(workdir, "datasets_" + name)) if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        work = os.path.join(workdir, "run_" + name)
+        if rank == 0:
+            os.makedirs(work)
+        dist.barrier()
+        target = os.path.join(work, "bins" if case["mode"] == "b" else case["mode"][2:])
+        kw = {"options": options_from_argv(case["argv"]), "device": "cuda:0"}
+        res = runner.run(box[0], barcode_dir=target, **kw) if case["mode"] == "b" else runner.run(box[0], output=target, **kw)
+        dist.barrier()
+        out[name] = readgen.output_md5s(target) if rank == 0 else {}
+        shares[name] = (len(res.start_trim), res.n_reads)
+    q.put((rank, out, shares))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+SHARED_CASES = ["native_default", "native_bins", "native_gz_out", "ligation_default"]
+
+
+def test_two_ranks_share_one_file_and_each_writes_its_own_span(tmp_path):
+    """runner.run_sharded with the real library: both ranks are given the SAME input file and output path (what a multi-GPU
+    node does); each parses only the records that start in its half of the bytes and writes its own span of the output.
+    The files are the reference CLI's; neither rank held every read."""
+    from tests.runner_cases import load_cases
+    cases = load_cases()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_shared_worker, args=(r, 2, port, str(tmp_path), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(2):
+        rank, out, shares = q.get(timeout=600)
+        got[rank] = (out, shares)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for name in SHARED_CASES:
+        assert got[0][0][name] == cases[name]["outputs"], (name, got[0][0][name])
+        mine = [got[r][1][name][0] for r in range(2)]
+        assert sum(mine) == got[0][1][name][1] and max(mine) < got[0][1][name][1], (name, mine)
+
+
 def test_one_rank_launcher_equals_plain_bench():
     """`python -m torch.distributed.run --nproc-per-node 1 bench.py --gpus 1` (the driver's launch line) and plain
     `python bench.py`: the same workload, the same results (matching sets, hits, parity), throughput of the same order."""

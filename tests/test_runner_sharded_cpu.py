@@ -1,0 +1,101 @@
+"""World-size-2 run of the runner over ONE shared plain FASTQ file (gloo, CPU; the oracle stands in for the GPU through
+tests/cpu_aligner.py): neither rank loads the whole file -- each parses the records that start in its half of the bytes --
+and each writes its own span of the shared output files (runner.run_sharded).  The files must be the single-process ones,
+i.e. the reference CLI's (tests/golden/runner_goldens.json): one file, barcode bins, FASTA and gzip outputs, a run in
+which nothing is found, and a three-rank run whose ranks get very uneven shares."""
+import os
+import socket
+
+import pytest
+import torch.multiprocessing as mp
+
+CASES = {2: ["native_default", "native_bins_gz", "native_to_fasta", "edge_bins", "nothing_found", "native_bins_untrimmed", "ligation_default"],
+         3: ["native_gz_out", "native_bins", "edge_default"]}
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, workdir, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle.oracle import Oracle
+    from porechop_amd import runner
+    from tests import readgen
+    from tests.cpu_aligner import OracleAligner
+    from tests.runner_cases import load_cases, options_from_argv
+    oracle = Oracle()
+    cases = load_cases()
+    out, shares = {}, {}
+    seen_sharded = []
+    orig = runner.run_sharded
+
+    def spy(*a, **kw):
+        r = orig(*a, **kw)
+        seen_sharded.append(r is not None)
+        return r
+    runner.run_sharded = spy
+    built = {}
+    for name in CASES[world]:
+        case = cases[name]
+        if rank == 0 and case["dataset"] not in built:            # ONE copy of the input, shared by the ranks
+            built[case["dataset"]] = readgen.build_dataset(case["dataset"], os.path.join(workdir, "datasets"))
+            assert readgen.dataset_sha1(built[case["dataset"]]) == case["input_sha1"]
+        box = [built.get(case["dataset"])]
+        dist.broadcast_object_list(box, src=0)
+        inp = box[0]
+        built[case["dataset"]] = inp
+        opts = options_from_argv(case["argv"])
+        work = os.path.join(workdir, "run_" + name)
+        if rank == 0:
+            os.makedirs(work)
+        dist.barrier()
+        target = os.path.join(work, "bins" if case["mode"] == "b" else case["mode"][2:])
+        kw = {"options": opts, "aligner": OracleAligner(oracle, opts.scoring_scheme)}
+        try:
+            res = runner.run(inp, barcode_dir=target, **kw) if case["mode"] == "b" else runner.run(inp, output=target, **kw)
+        except runner.UsageError as e:       # the reference ends such runs with sys.exit(message): same message on every rank
+            assert case["exit"] == str(e), (name, case["exit"], str(e))
+            seen_sharded.append(True)
+            res = None
+        dist.barrier()
+        out[name] = readgen.output_md5s(target) if (rank == 0 and os.path.exists(target)) else {}
+        shares[name] = (len(res.start_trim), res.n_reads, dict(res.files)) if res is not None else None
+    q.put((rank, out, shares, seen_sharded))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_runs_write_the_reference_files(tmp_path, world):
+    from tests.runner_cases import load_cases
+    cases = load_cases()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, str(tmp_path), q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(world):
+        rank, out, shares, seen = q.get(timeout=900)
+        got[rank] = (out, shares, seen)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for name in CASES[world]:
+        assert got[0][0][name] == cases[name]["outputs"], (name, got[0][0][name])
+        if cases[name]["exit"] is not None:
+            continue
+        total = got[0][1][name][1]
+        mine = [got[r][1][name][0] for r in range(world)]
+        assert sum(mine) == total and max(mine) < total, (name, mine, total)          # no rank held every read
+        assert all(got[r][1][name][2] == got[0][1][name][2] for r in range(world))   # every rank reports the same file statistics
+    assert all(all(got[r][2]) and len(got[r][2]) == len(CASES[world]) for r in range(world))  # every run took the sharded route

@@ -821,16 +821,26 @@ def leg_host_buffers(dev, args):
     h_off, h_len = reads.off.cpu().pin_memory(), reads.length.cpu().pin_memory()
     del reads
     torch.cuda.empty_cache()
-    per = (n + nb - 1) // nb
-    bounds = [(i, min(n, i + per)) for i in range(0, n, per)]
-    first = [int(h_off[a]) for a, _ in bounds] + [int(h_off[n - 1]) + int(h_len[n - 1])]
-    cap = (max(first[k + 1] - first[k] for k in range(len(bounds))) + 64 + 15) // 16 * 16
+    # Batches: at one byte per base the upload (140 ms) bounds the step and eight batches hide all but the first behind scans;
+    # at 2 bits per base the scan bounds it, and fewer, larger batches keep its launches at full size (a 125 k-read batch
+    # runs phases B and C at ~0.7 of the rate of a 333 k-read one: launch tails, one host round trip per mask round).
+    nb_packed = int(os.environ.get("PC_BENCH_H2D_BATCHES_PACKED", "3"))
+
+    def layout(k_batches):
+        per_ = (n + k_batches - 1) // k_batches
+        bounds_ = [(i, min(n, i + per_)) for i in range(0, n, per_)]
+        first_ = [int(h_off[a]) for a, _ in bounds_] + [int(h_off[n - 1]) + int(h_len[n - 1])]
+        return per_, bounds_, first_
+    lay = {False: layout(nb), True: layout(nb_packed)}
+    per = max(lay[False][0], lay[True][0])
+    cap = (max(f[k + 1] - f[k] for _, b, f in lay.values() for k in range(len(b))) + 64 + 15) // 16 * 16
     bufs = [torch.empty(cap, dtype=torch.uint8, device=dev) for _ in range(2)]
     offs = [torch.empty(per, dtype=torch.int64, device=dev) for _ in range(2)]
     lens = [torch.empty(per, dtype=torch.int32, device=dev) for _ in range(2)]
     # the 2-bit form of every batch, packed once (ingest-time work, timed and reported, not part of a step)
     t0 = time.perf_counter()
     h_pk, h_exc = [], []
+    _, bounds, first = lay[True]
     for k in range(len(bounds)):
         nbases = first[k + 1] - first[k]
         out = torch.empty((nbases + 15) // 16 * 4, dtype=torch.uint8, pin_memory=True)
@@ -847,6 +857,7 @@ def leg_host_buffers(dev, args):
     packed, prefilter = [True], [False]
 
     def upload(k):
+        _, bounds, first = lay[packed[0]]
         a, b = bounds[k]
         s = k & 1
         with torch.cuda.stream(copy_stream):
@@ -867,6 +878,7 @@ def leg_host_buffers(dev, args):
             uploaded[s].record(copy_stream)
 
     def step():
+        _, bounds, first = lay[packed[0]]
         matching, hits_n = None, 0
         upload(0)
         for k, (a, b) in enumerate(bounds):
@@ -889,6 +901,7 @@ def leg_host_buffers(dev, args):
         torch.cuda.synchronize()
 
     def upload_alone():
+        _, bounds, first = lay[packed[0]]
         sync()
         t0 = time.perf_counter()
         with torch.cuda.stream(copy_stream):
@@ -912,10 +925,11 @@ def leg_host_buffers(dev, args):
         dt_up = upload_alone()
         sent = sum(int(x.numel()) for x in h_pk) if mode else total
         res[mode] = {"reads_per_s": n * steps / dt, "ms_per_step": dt / steps * 1e3, "h2d_ms_alone": dt_up * 1e3,
-                     "h2d_gb_per_s_alone": sent / dt_up / 1e9, "bytes_uploaded_per_step": sent, "middle_hits_per_step": hits_n}
+                     "h2d_gb_per_s_alone": sent / dt_up / 1e9, "bytes_uploaded_per_step": sent, "middle_hits_per_step": hits_n,
+                     "batches": len(lay[mode][1])}
     out = {"workload": "BASELINE configs[3] from pinned host memory: %d reads x %d bp uploaded every step in %d batches at 2 bits per "
                        "base (pc_pack_reads once at ingest; pc_unpack_device per batch), upload of batch k+1 overlapping the scan of "
-                       "batch k" % (n, args.read_len, len(bounds)),
+                       "batch k" % (n, args.read_len, len(lay[True][1])),
            "packed": True, "steps": steps, "pack_once_s": pack_s, "pack_gb_per_s": total / pack_s / 1e9,
            "exceptions": sum(0 if x is None else int(x.numel()) for x in h_exc),
            "same_hits_both_forms": res[True]["middle_hits_per_step"] == res[False]["middle_hits_per_step"],
@@ -1187,7 +1201,9 @@ def compact_line(full):
                      "phase_a_entries_differing": _pick(par, "phase_a_rederived_on_cpu", "entries_differing"),
                      "phase_a_same_matching_sets": _pick(par, "phase_a_rederived_on_cpu", "same_matching_sets"),
                      "crosscheck_pairs": _pick(par, "device_crosscheck", "device_crosscheck_pairs"),
-                     "crosscheck_differing": _pick(par, "device_crosscheck", "records_differing")}
+                     "crosscheck_differing": _pick(par, "device_crosscheck", "records_differing"),
+                     "runner_vs_reference_cli_reads": _pick(par, "runner_vs_reference_cli", "reads"),
+                     "runner_vs_reference_cli_md5_equal": _pick(par, "runner_vs_reference_cli", "md5_equal")}
     if dr:
         out["dropin"] = {k: ({kk: (_r(vv) if not isinstance(vv, dict) else {a: _r(b) for a, b in vv.items()}) for kk, vv in v.items()}
                              if isinstance(v, dict) else _r(v)) for k, v in dr.items()}
@@ -1451,6 +1467,16 @@ def main():
                         out["cpu_baseline"]["b1_cli"] = cli
                     except Exception as e:
                         out["cpu_baseline"]["b1_cli"] = {"failed": repr(e)}
+                    try:
+                        # the batch runner (no reference Python at all) on the same file: the reference CLI's output, byte for byte
+                        from porechop_amd import runner
+                        o_run = os.path.join(work, "runner_out.fastq")
+                        t0 = time.perf_counter()
+                        runner.run(fq, output=o_run, device=dev)
+                        out.setdefault("parity", {})["runner_vs_reference_cli"] = {
+                            "reads": cli["reads"], "md5_equal": bool(file_md5(o_run) == cli["output_md5"]), "runner_s": time.perf_counter() - t0}
+                    except Exception as e:
+                        out.setdefault("parity", {})["runner_vs_reference_cli"] = {"failed": repr(e)}
                     try:
                         note("leg dropin")
                         if fq is None:

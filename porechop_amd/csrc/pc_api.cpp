@@ -750,7 +750,9 @@ int pc_scan_device(pc_ctx *c, const void *d_arena, const int64_t *d_win_off, con
         if (c->groups[gi].two_pass) { slab_off[gi] = slab_single; fin_off[gi] = fin_single; }
     slab_bytes += slab_single; fin_bytes += fin_single;
     if ((rc = c->d_slab.ensure(slab_bytes + 256)) || (rc = c->d_fin.ensure(fin_bytes + 256))) return rc;
-    const bool fork = n_single >= 2 && stream != c->stream;
+    // (PC_NO_TRACE_FORK=1 keeps them on one stream: a profile whose per-kernel durations add up to the step)
+    static const bool no_trace_fork = [] { const char *e = getenv("PC_NO_TRACE_FORK"); return e && *e && *e != '0'; }();
+    const bool fork = n_single >= 2 && stream != c->stream && !no_trace_fork;
     int forked = 0;
     pc_ctx::Timed fork_timer;
     bool fork_timed = false;

@@ -23,6 +23,7 @@ The backend is any object with ``align(pairs, scores) -> list[str]`` (pairs = [(
 the default is the GPU library.  There is no CPU backend in this package; tests inject the oracle.
 """
 import functools
+import itertools
 import time
 
 
@@ -70,6 +71,22 @@ class GpuBackend:
         al = self._aligner(ads, tuple(int(x) for x in scores))
         return format_results(al.align_host(b"".join(chunks), offs, lens, idx))
 
+    def align_product(self, reads, adapters, scores):
+        """Every read against every adapter (distinct strings each) -> the strings in read-major order.  No per-pair Python:
+        the arena holds each read once, the pair table is numpy repeat / tile."""
+        import numpy as np
+        from .batch import format_results
+        if not reads or not adapters:
+            return []
+        enc = [r.encode() for r in reads]
+        lens1 = np.fromiter((len(b) for b in enc), dtype=np.int64, count=len(enc))
+        offs1 = np.concatenate([[0], np.cumsum(lens1[:-1])]).astype(np.int64)
+        A = len(adapters)
+        al = self._aligner(list(adapters), tuple(int(x) for x in scores))
+        recs = al.align_host(b"".join(enc), np.repeat(offs1, A), np.repeat(lens1, A).astype(np.int32),
+                             np.tile(np.arange(A, dtype=np.int32), len(enc)))
+        return format_results(recs)
+
     def close(self):
         for al in self._aligners.values():
             al.close()
@@ -109,6 +126,28 @@ class _State:
         self.batched += len(todo)
         for (rd, ad), res in zip(todo, out):
             self.memo[(rd, ad, key_scores)] = res
+
+    def prefetch_product(self, reads, adapters, scores):
+        """prefetch() of every read x every adapter -- the shape of phase A, phase B and round 0 of phase C -- without a
+        Python-level loop over the pairs when the backend has align_product (the GPU backend does)."""
+        if not hasattr(self.backend, "align_product"):
+            return self.prefetch([(r, a) for r in reads for a in adapters], scores)
+        t0 = time.perf_counter()
+        try:
+            ks = tuple(scores)
+            adapters = list(dict.fromkeys(adapters))
+            memo = self.memo
+            # reads of which some pair is still unknown (a read is usually either wholly new or wholly known)
+            reads = [r for r in dict.fromkeys(reads) if any((r, a, ks) not in memo for a in adapters)]
+            if not reads or not adapters:
+                return
+            t1 = time.perf_counter()
+            out = self.backend.align_product(reads, adapters, ks)
+            self.backend_seconds += time.perf_counter() - t1
+            self.batched += len(out)
+            memo.update(zip(itertools.product(reads, adapters, (ks,)), out))
+        finally:
+            self.prefetch_seconds += time.perf_counter() - t0
 
     def lookup(self, read_sequence, adapter_sequence, scoring_scheme_vals):
         k = (read_sequence, adapter_sequence, tuple(scoring_scheme_vals))
@@ -154,30 +193,22 @@ def install(pp, backend=None):
 
     @functools.wraps(orig_a)
     def find_matching_adapter_sets(check_reads, verbosity, end_size, scoring_scheme_vals, *args, **kw):
-        pairs = []
         search = [a for a in pp.ADAPTERS if '(full sequence)' not in a.name]      # porechop.py:296
-        for read in check_reads:
-            start, end = read.seq[:end_size], read.seq[-end_size:]                # nanopore_read.py:155,160
-            for s in search:
-                if s.start_sequence:
-                    pairs.append((start, s.start_sequence[1]))
-                if s.end_sequence:
-                    pairs.append((end, s.end_sequence[1]))
-        st.prefetch(pairs, scoring_scheme_vals)
+        # nanopore_read.py:155,160: every check read's start window x every start sequence, end window x every end sequence
+        st.prefetch_product([read.seq[:end_size] for read in check_reads],
+                            [s.start_sequence[1] for s in search if s.start_sequence], scoring_scheme_vals)
+        st.prefetch_product([read.seq[-end_size:] for read in check_reads],
+                            [s.end_sequence[1] for s in search if s.end_sequence], scoring_scheme_vals)
         return orig_a(check_reads, verbosity, end_size, scoring_scheme_vals, *args, **kw)
 
     @functools.wraps(orig_b)
     def find_adapters_at_read_ends(reads, matching_sets, verbosity, end_size, extra_trim_size, end_threshold,
                                    scoring_scheme_vals, *args, **kw):
-        pairs = []
-        for read in reads:
-            start, end = read.seq[:end_size], read.seq[-end_size:]                # nanopore_read.py:174,196
-            for s in matching_sets:
-                if s.start_sequence:
-                    pairs.append((start, s.start_sequence[1]))
-                if s.end_sequence:
-                    pairs.append((end, s.end_sequence[1]))
-        st.prefetch(pairs, scoring_scheme_vals)
+        # nanopore_read.py:174,196
+        st.prefetch_product([read.seq[:end_size] for read in reads],
+                            [s.start_sequence[1] for s in matching_sets if s.start_sequence], scoring_scheme_vals)
+        st.prefetch_product([read.seq[-end_size:] for read in reads],
+                            [s.end_sequence[1] for s in matching_sets if s.end_sequence], scoring_scheme_vals)
         return orig_b(reads, matching_sets, verbosity, end_size, extra_trim_size, end_threshold,
                       scoring_scheme_vals, *args, **kw)
 
@@ -194,7 +225,7 @@ def install(pp, backend=None):
         key_scores = tuple(scoring_scheme_vals)
         seqs = [r.get_seq_with_start_end_adapters_trimmed() for r in reads]       # nanopore_read.py:216
         # round 0: every adapter against every unmasked trimmed read
-        st.prefetch([(s, a) for s in seqs for a in adapters], scoring_scheme_vals)
+        st.prefetch_product(seqs, adapters, scoring_scheme_vals)
         # replay nanopore_read.py:217-243 on the memo to learn what else will be asked
         active = []                       # [masked_seq, adapter index] of reads still in the loop
         for s in seqs:

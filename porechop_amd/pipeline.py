@@ -24,7 +24,7 @@ from .batch import MODE_SCORE, MODE_TRACE, MODE_TRACE_AT, MODE_TWO_PASS, Aligner
 
 # phase B is pruned (exactly: see "Exact pruning of phase B" below) from this many (sequence, side) jobs on; measured on
 # MI355X, 1 M reads: 198 jobs 192 -> 122 ms; with the 4-6 jobs of a run without barcodes tracing everything is faster
-PRUNE_MIN_JOBS = 24
+PRUNE_MIN_JOBS = int(os.environ.get("PC_PRUNE_MIN_JOBS", "24"))
 
 
 @dataclass

@@ -30,6 +30,14 @@ class OracleBackend:
         return [self.oracle.adapter_alignment(r, a, tuple(scores)) for r, a in pairs]
 
 
+class OracleProductBackend(OracleBackend):
+    """... with the product entry point the GPU backend has: every read x every adapter, read-major."""
+
+    def align_product(self, reads, adapters, scores):
+        self.calls += 1
+        return [self.oracle.adapter_alignment(r, a, tuple(scores)) for r in reads for a in adapters]
+
+
 def md5_of(path):
     h = hashlib.md5()
     if os.path.isdir(path):
@@ -60,16 +68,17 @@ def staged_reference():
     shutil.rmtree(tmp, ignore_errors=True)
 
 
+@pytest.mark.parametrize("backend_cls", [OracleBackend, OracleProductBackend])
 @pytest.mark.parametrize("run", ["one_default", "one_mid97", "one_nosplit", "two_default", "barcodes_default",
                                  "albacore_mid85"])
-def test_unchanged_reference_with_prefetching_dropin(staged_reference, goldens, oracle, run):
+def test_unchanged_reference_with_prefetching_dropin(staged_reference, goldens, oracle, run, backend_cls):
     pp, tmp = staged_reference
     import porechop.adapters as adapters_mod
     import porechop_amd.dropin as dropin
     info = goldens["runs"][run]
     for a in adapters_mod.ADAPTERS:            # fresh-process state
         a.best_start_score, a.best_end_score = 0.0, 0.0
-    backend = OracleBackend(oracle)
+    backend = backend_cls(oracle)
     st = dropin.install(pp, backend)
     out = os.path.join(tmp, "out_" + run)
     argv = ["porechop", "-i", os.path.join(REFERENCE, "test", info["fixture"]), "-v", "0"]

@@ -824,7 +824,7 @@ def leg_host_buffers(dev, args):
     # Batches: at one byte per base the upload (140 ms) bounds the step and eight batches hide all but the first behind scans;
     # at 2 bits per base the scan bounds it, and fewer, larger batches keep its launches at full size (a 125 k-read batch
     # runs phases B and C at ~0.7 of the rate of a 333 k-read one: launch tails, one host round trip per mask round).
-    nb_packed = int(os.environ.get("PC_BENCH_H2D_BATCHES_PACKED", "3"))
+    nb_packed = int(os.environ.get("PC_BENCH_H2D_BATCHES_PACKED", "2"))
 
     def layout(k_batches):
         per_ = (n + k_batches - 1) // k_batches
@@ -855,11 +855,15 @@ def leg_host_buffers(dev, args):
     uploaded = [torch.cuda.Event() for _ in range(2)]
     scanned = [torch.cuda.Event() for _ in range(2)]
     packed, prefilter = [True], [False]
+    # A continuous stream of batches: uploads run ONE BATCH AHEAD of the scans, across step boundaries too (the first batch
+    # of step s+1 crosses the link under the last scan of step s); buffers alternate by a global batch counter.
+    seq = {"next_upload": 0, "next_scan": 0, "primed": False}
 
     def upload(k):
         _, bounds, first = lay[packed[0]]
         a, b = bounds[k]
-        s = k & 1
+        s = seq["next_upload"] & 1
+        seq["next_upload"] += 1
         with torch.cuda.stream(copy_stream):
             copy_stream.wait_event(scanned[s])                      # the scan of batch k-2 is done with this buffer
             nbytes = first[k + 1] - first[k]
@@ -880,11 +884,13 @@ def leg_host_buffers(dev, args):
     def step():
         _, bounds, first = lay[packed[0]]
         matching, hits_n = None, 0
-        upload(0)
+        if not seq["primed"]:
+            upload(0)
+            seq["primed"] = True
         for k, (a, b) in enumerate(bounds):
-            s = k & 1
-            if k + 1 < len(bounds):
-                upload(k + 1)                                       # in flight while batch k is scanned
+            s = seq["next_scan"] & 1
+            seq["next_scan"] += 1
+            upload((k + 1) % len(bounds))                           # in flight while batch k is scanned (k = last: the next step's first)
             main.wait_event(uploaded[s])
             batch = DeviceReads(bufs[s], offs[s][:b - a] - first[k], lens[s][:b - a])
             if k == 0:
@@ -919,8 +925,16 @@ def leg_host_buffers(dev, args):
         e.record(main)
     steps = max(1, min(args.steps, 5))
     res = {}
+    def restart():
+        sync()
+        seq.update(next_upload=0, next_scan=0, primed=False)
+        for e in scanned:
+            e.record(main)
+        sync()
+
     for mode in (False, True):
         packed[0] = mode
+        restart()
         (matching, hits_n), dt = timed(step, steps, max(1, min(args.warmup, 2)), sync)
         dt_up = upload_alone()
         sent = sum(int(x.numel()) for x in h_pk) if mode else total
@@ -928,8 +942,8 @@ def leg_host_buffers(dev, args):
                      "h2d_gb_per_s_alone": sent / dt_up / 1e9, "bytes_uploaded_per_step": sent, "middle_hits_per_step": hits_n,
                      "batches": len(lay[mode][1])}
     out = {"workload": "BASELINE configs[3] from pinned host memory: %d reads x %d bp uploaded every step in %d batches at 2 bits per "
-                       "base (pc_pack_reads once at ingest; pc_unpack_device per batch), upload of batch k+1 overlapping the scan of "
-                       "batch k" % (n, args.read_len, len(lay[True][1])),
+                       "base (pc_pack_reads once at ingest; pc_unpack_device per batch), uploads one batch ahead of the scans, across "
+                       "step boundaries too" % (n, args.read_len, len(lay[True][1])),
            "packed": True, "steps": steps, "pack_once_s": pack_s, "pack_gb_per_s": total / pack_s / 1e9,
            "exceptions": sum(0 if x is None else int(x.numel()) for x in h_exc),
            "same_hits_both_forms": res[True]["middle_hits_per_step"] == res[False]["middle_hits_per_step"],
@@ -937,6 +951,7 @@ def leg_host_buffers(dev, args):
     out.update(res[True])
     # the same, the middle scan behind the exact prefilter (config.exact_prefilter's step, fed from the host)
     prefilter[0] = True
+    restart()
     (_, hits_f), dt_f = timed(step, steps, 1, sync)
     out["exact_prefilter"] = {"reads_per_s": n * steps / dt_f, "ms_per_step": dt_f / steps * 1e3,
                               "same_hits": hits_f == res[True]["middle_hits_per_step"]}

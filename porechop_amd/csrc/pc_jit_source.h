@@ -96,7 +96,7 @@ struct SpecArgs {
     const unsigned char *arena; const i64 *win_off; const int *win_len;
     const Tile *tiles; int ntiles;
     int *out;                 // [npairs * chunks][4]: score, I, J, 0
-    uint2 *fin_scratch;       // [grid][R*64]
+    uint2 *fin_scratch;       // [grid][R][64]: row-major, lane fastest -- a store / load instruction of a wave is 512 contiguous bytes
     const u32 *s_table;       // [25 = code_lo * 5 + code_hi][PC_K]
     int m_lo, m_hi, gap_open, gap_extend;
     int chunks, chunk_len, span;
@@ -280,12 +280,12 @@ extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P
                 if (any_fin) {
                     if (fin_lo) {
 #pragma clang loop unroll(full)
-                        for (int r = 0; r < R; ++r) fin[lane * R + r] = make_uint2(T[r], U[r]);
+                        for (int r = 0; r < R; ++r) fin[r * 64 + lane] = make_uint2(T[r], U[r]);
                     }
 #if !PC_DUAL
                     if (fin_hi) {
 #pragma clang loop unroll(full)
-                        for (int r = 0; r < R; ++r) fin_hi_buf[lane * R + r] = make_uint2(T[r], U[r]);
+                        for (int r = 0; r < R; ++r) fin_hi_buf[r * 64 + lane] = make_uint2(T[r], U[r]);
                     }
 #endif
                     ftop = (fin_lo ? (top & 0xFFFFu) : (ftop & 0xFFFFu)) | (fin_hi ? (top & 0xFFFF0000u) : (ftop & 0xFFFF0000u));
@@ -623,11 +623,11 @@ extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P
                 const u32 rowbase = 4 * ((u32)lut_lo[bl] + (u32)lut_hi[bh]);
 #pragma unroll 1
                 for (int r = 0; r < R; ++r) {
-                    const uint2 ol = ev_lo ? fin[lane * R + r] : make_uint2(0u, 0u);
+                    const uint2 ol = ev_lo ? fin[r * 64 + lane] : make_uint2(0u, 0u);
 #if PC_DUAL
                     const uint2 old = ol;
 #else
-                    const uint2 oh = ev_hi ? fin_hi_buf[lane * R + r] : make_uint2(0u, 0u);
+                    const uint2 oh = ev_hi ? fin_hi_buf[r * 64 + lane] : make_uint2(0u, 0u);
                     const uint2 old = make_uint2((ol.x & 0xFFFFu) | (oh.x & 0xFFFF0000u), (ol.y & 0xFFFFu) | (oh.y & 0xFFFF0000u));
 #endif
                     const u32 s = srow[rowbase + COMBO[r]];

@@ -531,7 +531,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((R > 0 && R 
                     // some pair reaches its last column: keep the previous column for the scan below
                     if (fin_lo || fin_hi) {
 #pragma clang loop unroll(full)
-                        for (int r = 0; r < R; ++r) fin[lane * RS + r] = make_uint2(T[r], U[r]);
+                        for (int r = 0; r < R; ++r) fin[r * 64 + lane] = make_uint2(T[r], U[r]);
                     }
                 }
                 u32 trw[(RS + 3) / 4];
@@ -551,7 +551,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((R > 0 && R 
                     u32 dq = topD, Tup = topT_col, Vprev = k.NEG2;
 #pragma unroll 1
                     for (int r = 0; r < R; ++r) {
-                        const uint2 old = (fin_lo || fin_hi) ? fin[lane * RS + r] : make_uint2(0u, 0u);
+                        const uint2 old = (fin_lo || fin_hi) ? fin[r * 64 + lane] : make_uint2(0u, 0u);
                         const uint2 c = lds_const[r];
                         const u32 z = pk_minu(pk_sub(h2, c.x), c.y);
                         const u32 d = pk_sub(dq, z);
@@ -921,7 +921,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(R <= 30 ? 4 
             if (any_fin) limit2 = track_limit(j);
             if (any_fin && (fin_lo || fin_hi)) {
 #pragma clang loop unroll(full)
-                for (int r = 0; r < R; ++r) fin[lane * R + r] = make_uint2(T[r], U[r]);
+                for (int r = 0; r < R; ++r) fin[r * 64 + lane] = make_uint2(T[r], U[r]);
             }
             const u32 topn = hk_add(top, EPS2);                   // T~(0, j)
             const uint4 *srow = (const uint4 *)(s_tab + trow_j);
@@ -1045,7 +1045,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(R <= 30 ? 4 
                 u32 dq = top, Tu2 = topn, Vp2 = NEG2;
 #pragma unroll 1
                 for (int r = 0; r < R; ++r) {
-                    const uint2 old = (fin_lo || fin_hi) ? fin[lane * R + r] : make_uint2(0u, 0u);
+                    const uint2 old = (fin_lo || fin_hi) ? fin[r * 64 + lane] : make_uint2(0u, 0u);
                     const u32 sv = s_tab[trow_j + r];
                     const u32 d = hk_add(dq, sv);
                     const u32 Hs = hk_max(old.y, old.x);

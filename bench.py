@@ -9,26 +9,24 @@ mask-and-realign rounds for reads with middle hits).  Headline workload = BASELI
 ("1M synthetic 8 kb reads with 1% chimeras, middle scan enabled") per GPU; reads are sharded
 over ranks with no data-path collective (weak scaling).
 
-Prints ONE JSON line on rank 0 (see the contract in the task statement) with extra objects:
-  roofline     -- the dominant kernel (score-only whole-read scan), timed with HIP events on its
-                  launch stream inside the timed region (pc_get_timing)
-  cpu_baseline -- the same phases B+C on a bounded sample of the same reads on the host cores,
-                  through the compiled reference (oracle/_ref) when present, else the oracle port
-  parity       -- the per-read results of that CPU sample compared with the GPU's for the same reads
-  config.also_measured (N=1 only) -- the two other single-GPU BASELINE configs, each timed the same
-                  way with its own end-scan roofline, CPU sample and parity count:
-                  configs1 = 100 k reads, end-trim only (--no_split): phases A + B
-                  configs2 = 1 M barcoded reads, full panel, end-trim + demultiplexing:
-                             phases A + kit choice + B + barcode calls; every end-window pair traced, and beside it
-                             `exact_pruning`: the same step with phase B pruned exactly (score-only pass + bounds from
-                             the end cell, selection on the device: pc_select.hip) -- same trims and calls
-  config.also_measured.configs4_per_gpu (every N) -- the per-GPU shape of BASELINE configs[4] (full panel with the
-                  96 barcodes AND the middle scan over every matching set's sequences, 1 % chimeras), run by every
-                  rank on its own shard: its own roofline, CPU sample, parity, and the variant behind the exact
-                  prefilter with phase B pruned
-  config.exact_prefilter -- the headline step with the middle scan behind the exact bit-parallel prefilter
-                  (pc_prefilter_device); identical hits, reported BESIDE `value`, which computes every record
-  parity.device_crosscheck -- packed-int16 kernels against the packed-fp16 ones over ALL pairs of the headline batch
+Prints ONE JSON line on rank 0, under 8 KB, numbers only (DESIGN.md section 9 names every key; the unabridged record goes
+to --full-json, default gpurun_out/bench_full.json):
+  roofline     -- the dominant kernel (score-only whole-read scan), timed with HIP events on its launch stream inside the
+                  timed region (pc_get_timing); traffic from profiles/<round>_summary.json when that profile was taken with
+                  the library now loaded (traffic_measured_in_this_run is always false)
+  cpu_baseline -- phases B+C of a bounded sample of the same reads on the host cores through the compiled reference
+                  (oracle/_ref; BASELINE.md's B2), and b1_cli*: Porechop's OWN --threads CLI, unchanged (tests/ref_cli.py runs
+                  the staged porechop.porechop.main()), on the first --cli-reads of the same reads, --threads 1 and 16
+  parity       -- the CPU sample's per-read results vs the GPU's; phase A re-derived on the CPU; int16 vs fp16 kernels over ALL
+                  pairs; the batch runner's output file vs the reference CLI's on the same reads
+  dropin       -- the unchanged reference Python + porechop_amd.dropin over the HIP library: md5 vs the CPU reference, memo
+                  misses, reads/s on --dropin-reads reads
+  legs (+ flat config.<leg>_* copies; N=1 only, except configs4_per_gpu which every rank runs):
+                  configs1 (100 k reads, end-trim only), configs2 (1 M barcoded reads: every end-window pair traced, and
+                  pruned_* = phase B pruned exactly), configs4_per_gpu (1.25 M reads, barcodes + chimeras + 196 middle adapters:
+                  every record, and fast_* = exact prefilter + pruned phase B), exact_prefilter (the headline step behind the
+                  prefilter), proven_middle_scan, ragged_lengths, from_host_memory (2 bits per base over PCIe, steady state;
+                  unpacked_* = 1 B/base), end_to_end (FASTQ file -> FASTQ file)
 """
 import argparse
 import json

@@ -225,6 +225,12 @@ extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P
             o = __shfl_xor(nmin, s); nmin = o < nmin ? o : nmin;
             o = __shfl_xor(tfmax, s); tfmax = o > tfmax ? o : tfmax;
         }
+        // Every stream of the tile ends in the SAME column (equal-length windows: the 150-column end windows of phase B's
+        // score pass, the uniform reads of the benchmark): the column loop then stops exactly there and the last column's
+        // cells are scanned straight from the registers.  Otherwise (ragged tiles) a lane that ends parks the state its last
+        // column starts from in fin_scratch and the column is re-run from there after the loop.  (The parked state costs
+        // R*64*8 B per half and tile, out and back in: 37 GB per step of a 196-job phase B, for nothing.)
+        const bool uniform_fin = nmax > 0 && nmin == nmax && __all((!have_lo || tail_lo) && (!have_hi || tail_hi));
 
         // Read bytes are fetched 16 columns at a time into q_lo / q_hi and handed to the column loop a dword
         // (4 columns) at a time, one dword ahead; the substitution terms S[] of column j+1 are fetched from
@@ -275,7 +281,7 @@ extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P
                 // A read's LAST column is scanned row by row (every cell of it is an end candidate,
                 // dp_scout.h:165-179) -- after the column loop, for all lanes of the tile at once: here the
                 // lanes that end in this column only park the state the column starts from.
-                fin_lo = (j == n_lo) && tail_lo; fin_hi = (j == n_hi) && tail_hi;
+                fin_lo = (j == n_lo) && tail_lo && !uniform_fin; fin_hi = (j == n_hi) && tail_hi && !uniform_fin;
                 any_fin = __any(fin_lo || fin_hi);
                 if (any_fin) {
                     if (fin_lo) {
@@ -592,14 +598,22 @@ extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P
 #define PC_NOTE
 #endif
                 if (packed_ahead) unpack_best();
+                // (a tile whose streams all end in column nmax computes no column beyond it: T[] then IS the last column)
+                const int last = uniform_fin ? nmax : 0x7FFFFFFF;
                 fetch_S(SB, (cur_lo >> 8) & 0xFF, (cur_hi >> 8) & 0xFF);
                 column(SlowT{}, j0, SA); PC_NOTE
-                fetch_S(SA, (cur_lo >> 16) & 0xFF, (cur_hi >> 16) & 0xFF);
-                column(SlowT{}, j0 + 1, SB); PC_NOTE
-                fetch_S(SB, cur_lo >> 24, cur_hi >> 24);
-                column(SlowT{}, j0 + 2, SA); PC_NOTE
-                fetch_S(SA, nxt_lo & 0xFF, nxt_hi & 0xFF);
-                column(SlowT{}, j0 + 3, SB); PC_NOTE
+                if (j0 + 1 <= last) {
+                    fetch_S(SA, (cur_lo >> 16) & 0xFF, (cur_hi >> 16) & 0xFF);
+                    column(SlowT{}, j0 + 1, SB); PC_NOTE
+                    if (j0 + 2 <= last) {
+                        fetch_S(SB, cur_lo >> 24, cur_hi >> 24);
+                        column(SlowT{}, j0 + 2, SA); PC_NOTE
+                        if (j0 + 3 <= last) {
+                            fetch_S(SA, nxt_lo & 0xFF, nxt_hi & 0xFF);
+                            column(SlowT{}, j0 + 3, SB); PC_NOTE
+                        }
+                    }
+                }
                 best2 = packbest(bs_lo, bs_hi);
                 pos2 = ((u32)bj_lo & 0xFFFFu) | ((u32)bj_hi << 16);
             }
@@ -612,7 +626,21 @@ extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P
         // ---- the reads' last columns, all lanes at once: rolled re-run of the column from the parked
         // state, cells visited top to bottom with strict '>' (dp_scout.h:165-179).  The last column is the
         // last one the reference visits, so doing it after the loop keeps the visiting order.
-        {
+        if (uniform_fin) {
+            // T[r] = T~(r+1, n) of the tile's common last column n, top = T~(0, n): the candidates (rho, n), rho = 1..R, top to
+            // bottom, strict '>' -- what the rolled re-run below derives from the parked state, read off the registers
+#pragma clang loop unroll(full)
+            for (int r = 0; r < R; ++r) {
+                const u32 c = pk_sub(T[r], top);                     // M(rho, n) + rho*eps
+#if PC_CHECK_RANGE
+                PC_NOTE_V(c)
+#endif
+                const int il = r - pad_lo + 1, ih = r - pad_hi + 1;
+                const int cl = lo16(c) - (r + 1) * PC_EPS, ch = hi16(c) - (r + 1) * PC_EPS;
+                if (have_lo && il >= 1 && cl > bs_lo) { bs_lo = cl; bi_lo = il; bj_lo = n_lo; }
+                if (have_hi && ih >= 1 && ch > bs_hi) { bs_hi = ch; bi_hi = ih; bj_hi = n_hi; }
+            }
+        } else {
             const bool ev_lo = have_lo && tail_lo && n_lo > 0, ev_hi = have_hi && tail_hi && n_hi > 0;
             if (__any(ev_lo || ev_hi)) {
                 const u32 topn = pk_add(ftop, EPS2);

@@ -889,6 +889,8 @@ int pc_scan_device(pc_ctx *c, const void *d_arena, const int64_t *d_win_off, con
                     sa.span = std::max(c->ad_span[L.adapter_lo], c->ad_span[L.adapter_hi]);
                     sa.err = a.err;
                     sa.work_counter = c->d_work.as<uint32_t>() + score_launch_no++;
+                    // a score-only request over whole windows: the kernel writes the records itself (no planner launch)
+                    sa.rec_out = (mode == PC_MODE_SCORE && L.chunks == 1) ? d_out : nullptr;
                     if (pcj::launch(L.spec, sa, grid, stream_k)) return PC_ERR_NO_DEVICE;
                 } else {
                     pck::ScanArgs b = a;
@@ -923,6 +925,7 @@ int pc_scan_device(pc_ctx *c, const void *d_arena, const int64_t *d_win_off, con
             {
                 ScopedTimer tm(c, stream, 1, np);
                 for (const ScoreLaunch &L : score_plan[gi]) {
+                    if (mode == PC_MODE_SCORE && L.chunks == 1 && L.spec) continue;      // records written by the kernel itself
                     pl.k1 = c->d_k1.as<int32_t>() + L.k1_ints;
                     pl.tiles = a.tiles + L.begin; pl.ntiles = (int32_t)L.count; pl.chunks = L.chunks;
                     if ((rc = pck::launch_plan(pl, stream))) return PC_ERR_NO_DEVICE;

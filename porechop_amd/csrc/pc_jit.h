@@ -29,6 +29,8 @@ struct SpecArgs {
     uint32_t *err;
     uint32_t *work_counter;      // units beyond the grid are handed out by this counter (zeroed by the host); null = fixed stride
     uint32_t one2;               // 0x00010001 (set by launch())
+    int32_t *rec_out;            // PC_MODE_SCORE with whole windows (chunks == 1): the pairs' 8-int score records, written by the
+                                 // kernel itself -- (-2, J, I, 0, score, 0, 0, 0) at rec_out[p * 8] -- instead of by the planner
 };
 
 bool disabled();

@@ -103,6 +103,7 @@ struct SpecArgs {
     u32 *err;
     u32 *work_counter;
     u32 one2;                 // 0x00010001, kept opaque to the compiler (with a literal it turns min_u16(x, 1) into compare / select chains)
+    int *rec_out;             // score-only request over whole windows: [npairs][8] records (-2, J, I, 0, score, 0, 0, 0), else null
 };
 struct FastT { static constexpr bool fast = true; };
 struct SlowT { static constexpr bool fast = false; };
@@ -686,8 +687,14 @@ extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P
             }
         }
 #endif
-        if (have_lo) { int4 o = {bs_lo, bi_lo, bj_lo + c0_lo, 0}; *(int4 *)(a.out + (p_lo * nchunks + chunk) * 4) = o; }
-        if (have_hi) { int4 o = {bs_hi, bi_hi, bj_hi + c0_hi, 0}; *(int4 *)(a.out + (p_hi * nchunks + chunk) * 4) = o; }
+        if (a.rec_out) {
+            // (nchunks == 1: the end cell and its score are the whole answer -- what plan_kernel would make of the line below)
+            if (have_lo) { int4 *o = (int4 *)(a.rec_out + p_lo * 8); o[0] = int4{-2, bj_lo + c0_lo, bi_lo, 0}; o[1] = int4{bs_lo, 0, 0, 0}; }
+            if (have_hi) { int4 *o = (int4 *)(a.rec_out + p_hi * 8); o[0] = int4{-2, bj_hi + c0_hi, bi_hi, 0}; o[1] = int4{bs_hi, 0, 0, 0}; }
+        } else {
+            if (have_lo) { int4 o = {bs_lo, bi_lo, bj_lo + c0_lo, 0}; *(int4 *)(a.out + (p_lo * nchunks + chunk) * 4) = o; }
+            if (have_hi) { int4 o = {bs_hi, bi_hi, bj_hi + c0_hi, 0}; *(int4 *)(a.out + (p_hi * nchunks + chunk) * 4) = o; }
+        }
     }
 }
 )PCJIT";

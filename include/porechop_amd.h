@@ -181,6 +181,18 @@ int pc_phase_b_reduce(pc_ctx *ctx, const int32_t *d_records, int64_t n, int njob
                       double barcode_threshold, double barcode_diff, int require_two_barcodes,
                       int32_t *d_call, void *stream);
 
+/* pc_phase_b_reduce for records most of which are PC_MODE_SCORE records left untraced by the exact pruning below:
+ * d_traced_mask[njobs][(n + 63) / 64] (bit r % 64 of word r / 64 of row j) says which pairs hold a traced record -- the union
+ * of the selection rounds' masks; a pair whose bit is clear is read as "no alignment" without its record being loaded (the
+ * reduction would skip it anyway: 94 % of the records of a barcoded batch).  NULL = pc_phase_b_reduce. */
+int pc_phase_b_reduce_masked(pc_ctx *ctx, const int32_t *d_records, int64_t n, int njobs,
+                             const int64_t *job_record_offset, const int32_t *job_side, int end_size,
+                             int min_trim_size, int extra_end_trim, double end_threshold,
+                             int32_t *d_start_trim, int32_t *d_end_trim, int nbins,
+                             const int32_t *bin_start_job, const int32_t *bin_end_job,
+                             double barcode_threshold, double barcode_diff, int require_two_barcodes,
+                             int32_t *d_call, const uint64_t *d_traced_mask, void *stream);
+
 /* Exact pruning of phase B: of the ~200 end-window alignments a barcoded read gets, two or three decide its trims and
  * its barcode call; a score-only pass (PC_MODE_SCORE, 5 instead of 13.25 packed operations per two cells, no trace)
  * gives every alignment's end cell and score, and those bound what the alignment can contribute (the bounds and

@@ -61,6 +61,7 @@ class Aligner:
     """One GPU context: a scoring scheme + an adapter panel + scratch buffers."""
     fast_prefilter = True      # prefilter_rows is the device's exact prefilter (callers may put it in front of the middle scan)
     score_end_cell = True      # MODE_SCORE records carry the reference's end cell (row, column) besides the score
+    reduce_takes_mask = True   # phase_b_reduce(traced_mask=...): pairs whose bit is clear are skipped without a load
     trace_at = True            # MODE_TRACE_AT: the traced record of a pair whose MODE_SCORE record (its end cell) is known
 
     def __init__(self, adapters, scores=DEFAULT_SCORES, device=-1):
@@ -167,7 +168,7 @@ class Aligner:
 
     def phase_b_reduce(self, records, n, job_record_offset, job_side, end_size, min_trim_size, extra_end_trim,
                        end_threshold, start_trim, end_trim, bins=None, barcode_threshold=0.0, barcode_diff=0.0,
-                       require_two=False, call=None, stream=None):
+                       require_two=False, call=None, stream=None, traced_mask=None):
         """Per-read reduction of end-window records on the device (pc_phase_b_reduce): records int32[*,8]
         written by scan_device for len(job_side) jobs over the same n reads; start_trim / end_trim (and call,
         when bins = [(start job or -1, end job or -1), ...] is given) are int32[n] CUDA tensors."""
@@ -182,11 +183,17 @@ class Aligner:
         if nb:
             assert call is not None and call.is_cuda and call.dtype == torch.int32
         s = stream if stream is not None else torch.cuda.current_stream().cuda_stream
-        check(self.lib.pc_phase_b_reduce(self._ctx, records.data_ptr(), int(n), len(side), off.ctypes.data, side.ctypes.data,
-                                         int(end_size), int(min_trim_size), int(extra_end_trim), float(end_threshold),
-                                         start_trim.data_ptr(), end_trim.data_ptr(), nb, bs.ctypes.data, be.ctypes.data,
-                                         float(barcode_threshold), float(barcode_diff), 1 if require_two else 0,
-                                         call.data_ptr() if nb else None, ctypes.c_void_p(s)), "pc_phase_b_reduce")
+        if traced_mask is not None:
+            # traced_mask int64 [njobs, (n + 63) // 64]: the union of the selection rounds' masks (pc_phase_b_reduce_masked)
+            assert traced_mask.is_cuda and traced_mask.dtype == torch.int64 and traced_mask.is_contiguous()
+            assert tuple(traced_mask.shape) == (len(side), (int(n) + 63) // 64)
+        check(self.lib.pc_phase_b_reduce_masked(self._ctx, records.data_ptr(), int(n), len(side), off.ctypes.data, side.ctypes.data,
+                                                int(end_size), int(min_trim_size), int(extra_end_trim), float(end_threshold),
+                                                start_trim.data_ptr(), end_trim.data_ptr(), nb, bs.ctypes.data, be.ctypes.data,
+                                                float(barcode_threshold), float(barcode_diff), 1 if require_two else 0,
+                                                call.data_ptr() if nb else None,
+                                                traced_mask.data_ptr() if traced_mask is not None else None, ctypes.c_void_p(s)),
+              "pc_phase_b_reduce")
 
     def phase_b_select(self, records, n, job_off, job_side, job_len, job_calls, start_len, end_len, end_size, min_trim_size,
                        extra_end_trim, end_threshold, rnd, call_level, call_level_diff, mask_out, counts, mask_prev=None,

@@ -1024,6 +1024,17 @@ int pc_phase_b_reduce(pc_ctx *c, const int32_t *d_records, int64_t n, int njobs,
                       const int32_t *bin_end_job, double barcode_threshold, double barcode_diff, int require_two,
                       int32_t *d_call, void *stream_v)
 {
+    return pc_phase_b_reduce_masked(c, d_records, n, njobs, job_record_offset, job_side, end_size, min_trim_size, extra_end_trim,
+                                    end_threshold, d_start_trim, d_end_trim, nbins, bin_start_job, bin_end_job, barcode_threshold,
+                                    barcode_diff, require_two, d_call, nullptr, stream_v);
+}
+
+int pc_phase_b_reduce_masked(pc_ctx *c, const int32_t *d_records, int64_t n, int njobs, const int64_t *job_record_offset,
+                             const int32_t *job_side, int end_size, int min_trim_size, int extra_end_trim, double end_threshold,
+                             int32_t *d_start_trim, int32_t *d_end_trim, int nbins, const int32_t *bin_start_job,
+                             const int32_t *bin_end_job, double barcode_threshold, double barcode_diff, int require_two,
+                             int32_t *d_call, const uint64_t *d_traced_mask, void *stream_v)
+{
     if (!c || n < 0 || njobs < 0 || nbins < 0) return PC_ERR_BAD_ARG;
     if (n == 0) return PC_OK;
     if (!d_start_trim || !d_end_trim || (njobs > 0 && (!d_records || !job_record_offset || !job_side))) return PC_ERR_BAD_ARG;
@@ -1066,6 +1077,7 @@ int pc_phase_b_reduce(pc_ctx *c, const int32_t *d_records, int64_t n, int njobs,
     a.nbins = nbins; a.bin_start = a.job_side + njobs; a.bin_end = a.bin_start + nbins;
     a.barcode_threshold = barcode_threshold; a.barcode_diff = barcode_diff; a.require_two = require_two ? 1 : 0;
     a.call = d_call;
+    a.traced_mask = (const unsigned long long *)d_traced_mask; a.mask_words = (n + 63) / 64;
     if (pck::launch_reduce(a, stream)) return PC_ERR_NO_DEVICE;
     HIP_TRY(hipEventRecord(c->red_done[sl], stream));
     return PC_OK;

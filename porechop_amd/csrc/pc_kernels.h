@@ -99,6 +99,9 @@ struct ReduceArgs {
     double barcode_threshold, barcode_diff;
     int32_t require_two;
     int32_t *call;                   // [n] bin index or -1
+    const unsigned long long *traced_mask;   // optional [njobs][mask_words]: bit r % 64 of word r / 64 of row j set = pair (j, r) holds
+    int64_t mask_words;                      // a traced record; a clear bit = "no alignment" WITHOUT loading the record (pruned phase B:
+                                             // 94 % of the records are score records the reduction would only skip)
 };
 int launch_reduce(const ReduceArgs &a, void *stream);
 int launch_copy_windows(const uint8_t *arena, const int64_t *src_off, const int32_t *len, int64_t n, uint8_t *dst,

@@ -49,7 +49,12 @@ __global__ __launch_bounds__(256) void reduce_kernel(ReduceArgs a)
     if (r >= a.n) return;
     // ---- trims: every job, in job order (the order is irrelevant to a max) -----------------
     int start_trim = 0, end_trim = 0;
+    // (a wave's 64 reads share one mask word per job: a single broadcast load decides for all of them)
+    auto untraced = [&](int j) -> bool {
+        return a.traced_mask && !((a.traced_mask[(int64_t)j * a.mask_words + (r >> 6)] >> (r & 63)) & 1ull);
+    };
     for (int j = 0; j < a.njobs; ++j) {
+        if (untraced(j)) continue;
         const Rec rec = load_rec(a.records, a.job_off[j] + r);
         if (rec.rs < 0) continue;                      // -1: no alignment; -2: a score record left untraced (pc_select.hip)
         const double partial = identity(rec.matches, rec.aligned_len);
@@ -71,7 +76,7 @@ __global__ __launch_bounds__(256) void reduce_kernel(ReduceArgs a)
     // scores the entry inserted first wins -- start entries before end entries, bins in order.
     auto score_of = [&](const int32_t *jobs, int k) -> double {
         const int j = jobs[k];
-        return j < 0 ? 0.0 : full_identity(load_rec(a.records, a.job_off[j] + r));
+        return (j < 0 || untraced(j)) ? 0.0 : full_identity(load_rec(a.records, a.job_off[j] + r));
     };
     int call = -1;
     if (a.require_two) {

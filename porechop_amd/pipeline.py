@@ -487,10 +487,11 @@ class Pipeline:
         traced on their side).  reduce_trims(records, rec_off) -> (start_trim, end_trim) runs the exact reduction.
         The selection runs on the device (pc_select.hip); the host reads back one count per job and round.
         self.debug_bounds (tests): a dict that receives the bounds and the untouched score records.
-        -> (records, rec_off)"""
+        -> (records, rec_off); self._traced_mask = the pairs that hold a traced record (int64 [J, words])"""
         p = self.p
         dev = self.device
         al = self.aligner
+        self._traced_mask = None
         bounds_out = getattr(self, "debug_bounds", None)
         R, J = reads.n, len(jobs)
         so, sl = self._end_windows(reads, None, "start")
@@ -560,13 +561,21 @@ class Pipeline:
         # where the read has them) and the two best-scoring barcode pairs (they fix the level a rival would have to reach)
         mask1, counts1 = select(1)
         n1 = trace(mask1, counts1)
-        st1, et1 = reduce_trims(rec, rec_off)
+        st1, et1 = reduce_trims(rec, rec_off, mask1)
         # round 2: whatever could still beat the trims so far or change the call
         mask2, counts2 = select(2, mask_prev=mask1, trims=(st1, et1))
         n2 = trace(mask2, counts2)
         self.stats["pairs_end"] += J * R
         self.stats["pairs_end_traced_after_pruning"] = self.stats.get("pairs_end_traced_after_pruning", 0) + n1 + n2
+        # which pairs hold a traced record: the reductions skip the others without loading them (pc_phase_b_reduce_masked)
+        self._traced_mask = torch.bitwise_or(mask1, mask2)
         return rec, rec_off
+
+    def _masked_kw(self, mask):
+        """Keyword for phase_b_reduce: the traced-pairs mask, where the aligner's reduction takes one (the GPU library's does)."""
+        if mask is None or not getattr(self.aligner, "reduce_takes_mask", False) or os.environ.get("PC_NO_REDUCE_MASK", "0") not in ("", "0"):
+            return {}
+        return {"traced_mask": mask.contiguous()}
 
     @property
     def can_prune_phase_b(self):
@@ -603,18 +612,21 @@ class Pipeline:
         end_trim = torch.zeros(R, dtype=torch.int32, device=self.device)
         call = torch.full((R,), -1, dtype=torch.int32, device=self.device)
         jobs, where = self._phase_b_jobs(reads, matching)
+        masked = self._masked_kw
+        tmask = None
         if jobs and R:
             sides = [w[0] for w in where]
             if self._prune_b(prune, len(jobs)):
-                def trims(records, offs):
+                def trims(records, offs, mask=None):
                     a = torch.zeros(R, dtype=torch.int32, device=self.device)
                     b = torch.zeros(R, dtype=torch.int32, device=self.device)
                     self.aligner.phase_b_reduce(records, R, offs, sides, p.end_size, p.min_trim_size, p.extra_end_trim,
-                                                p.end_threshold, a, b)
+                                                p.end_threshold, a, b, **masked(mask))
                     return a, b
                 call_sets = {i for b in bins for i in b if i is not None}
                 out, rec_off = self._phase_b_pruned_records(reads, jobs, where, call_sets, barcode_threshold - barcode_diff, trims,
                                                             call_level_diff=barcode_diff)
+                tmask = self._traced_mask
             else:
                 _, out, rec_off = self._scan_jobs(reads.arena, jobs, MODE_TRACE, p.end_size, with_layout=True)
                 self.stats["pairs_end"] += sum(int(j[1].shape[0]) for j in jobs)
@@ -624,7 +636,7 @@ class Pipeline:
             self.aligner.phase_b_reduce(out, R, rec_off, sides, p.end_size, p.min_trim_size, p.extra_end_trim,
                                         p.end_threshold, start_trim, end_trim, bins=jb if bins else None,
                                         barcode_threshold=barcode_threshold, barcode_diff=barcode_diff,
-                                        require_two=require_two, call=call)
+                                        require_two=require_two, call=call, **masked(tmask))
         return start_trim, end_trim, call.to(torch.int64).cpu().numpy()
 
     def phase_b(self, reads: DeviceReads, matching: List[int], full_for=(), prune: Optional[bool] = None):
@@ -639,21 +651,24 @@ class Pipeline:
         fulls = {}
         if not jobs:
             return (start_trim, end_trim, fulls) if full_for else (start_trim, end_trim)
+        masked = self._masked_kw
+        tmask = None
         if self.native_reduce and not full_for and R:
             sides = [w[0] for w in where]
             if self._prune_b(prune, len(jobs)):
-                def trims(records, offs):
+                def trims(records, offs, mask=None):
                     a = torch.zeros(R, dtype=torch.int32, device=self.device)
                     b = torch.zeros(R, dtype=torch.int32, device=self.device)
                     self.aligner.phase_b_reduce(records, R, offs, sides, p.end_size, p.min_trim_size, p.extra_end_trim,
-                                                p.end_threshold, a, b)
+                                                p.end_threshold, a, b, **masked(mask))
                     return a, b
                 out, rec_off = self._phase_b_pruned_records(reads, jobs, where, set(), 1e9, trims)
+                tmask = self._traced_mask
             else:
                 _, out, rec_off = self._scan_jobs(reads.arena, jobs, MODE_TRACE, p.end_size, with_layout=True)
                 self.stats["pairs_end"] += sum(int(j[1].shape[0]) for j in jobs)
             self.aligner.phase_b_reduce(out, R, rec_off, sides, p.end_size, p.min_trim_size, p.extra_end_trim,
-                                        p.end_threshold, start_trim, end_trim)
+                                        p.end_threshold, start_trim, end_trim, **masked(tmask))
             return start_trim, end_trim
         outs = self._scan_jobs(reads.arena, jobs, MODE_TRACE, p.end_size)
         for (side, si), rec in zip(where, outs):

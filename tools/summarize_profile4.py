@@ -30,7 +30,7 @@ def family(name):
     if not m:
         return None
     f = m.group(1)
-    if f in ("select_kernel", "gather_kernel", "scatter_kernel", "unpack_kernel") and "pck::" not in name:
+    if f in ("select_kernel", "gather_kernel", "scatter_kernel", "unpack_kernel", "reduce_kernel") and "pck::" not in name:
         return None                                # (torch has kernels of these names too)
     if f.startswith("scan_kernel<"):
         f = "scan_kernel<traced>" if f.endswith("true>") else "scan_kernel<score>"

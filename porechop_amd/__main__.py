@@ -73,7 +73,8 @@ def main(argv=None):
         dest = sys.stderr if (a.output is None and a.barcode_dir is None) else sys.stdout
         print("%d reads; adapter sets: %s" % (res.n_reads, ", ".join(res.matching_sets) or "none"), file=dest)
         print("start-trimmed %d, end-trimmed %d, reads with middle adapters %d" %
-              (int((res.start_trim > 0).sum()), int((res.end_trim > 0).sum()), res.middle_hit_reads), file=dest)
+              (res.counts.get("start_trimmed", int((res.start_trim > 0).sum())),
+               res.counts.get("end_trimmed", int((res.end_trim > 0).sum())), res.middle_hit_reads), file=dest)
         for path, (n, bases) in sorted(res.files.items()):
             print("  %s: %d reads, %d bases" % (path, n, bases), file=dest)
         print("  " + ", ".join("%s %.2fs" % kv for kv in res.seconds.items()), file=dest)

@@ -73,6 +73,7 @@ class RunResult:
     files: Dict[str, Tuple[int, int]] = field(default_factory=dict)   # path -> (records written, bases)
     out_format: str = "fastq"
     seconds: Dict[str, float] = field(default_factory=dict)      # wall-clock per stage
+    counts: Dict[str, int] = field(default_factory=dict)         # whole-run tallies where start_trim / end_trim hold one rank's reads
 
 
 # (read, adapter) pairs one block of phases B / C may hold at a time: 8 ints each, a few copies -> a few GB of HBM
@@ -661,7 +662,9 @@ def run_sharded(input_path, output, barcode_dir, opts: Options, device=None, ali
         lengths = rs.lengths if R else np.zeros(0, dtype=np.int32)
         pr, ps_, pn_, num, tlen, n_split = _plan_pieces(opts, lengths, st, et, h, calls, barcode_dir, discard_middle,
                                                        matching, pl, match_idx)
-        res.middle_hit_reads = int(all_gather_ints([n_split], coll_dev)[:, 0].sum())
+        tallies = all_gather_ints([n_split, int((st > 0).sum()), int((et > 0).sum())], coll_dev).sum(dim=0)
+        res.middle_hit_reads = int(tallies[0])
+        res.counts = {"start_trimmed": int(tallies[1]), "end_trimmed": int(tallies[2])}
         if barcode_dir is not None:
             mine = sorted({calls[r] for r in pr.tolist()})
             bins = sorted(set().union(*all_gather_objects(mine)))

@@ -102,3 +102,31 @@ def test_pipeline_over_packed_upload_equals_byte_upload():
         assert out[0][4].numel() > 20
     finally:
         pl.close()
+
+
+def test_readset_to_device_packed(aligner, tmp_path):
+    """ReadSet.to_device(packed=True): ingest -> pc_pack_reads -> upload -> pc_unpack_device gives the canonical bytes of the
+    arena ReadSet.to_device() uploads as it is (same offsets and lengths)."""
+    from porechop_amd.io import ReadSet
+    rng = random.Random(9)
+    p = tmp_path / "reads.fastq"
+    with open(p, "w") as f:
+        for i in range(300):
+            L = rng.choice([1, 40, 333, 2000])
+            seq = "".join(rng.choice("ACGTACGTACGTNacgtu-") for _ in range(L))
+            f.write("@r%d\n%s\n+\n%s\n" % (i, seq, "I" * L))
+    rs = ReadSet(str(p))
+    try:
+        plain = rs.to_device("cuda")
+        packed = rs.to_device("cuda", packed=True, aligner=aligner)
+        aligner.sync()
+        assert torch.equal(plain.off, packed.off) and torch.equal(plain.length, packed.length)
+        nb = int(rs.offsets[-1] + rs.lengths[-1])
+        a = plain.arena[:nb].cpu().numpy()
+        want = np.full(nb, ord("N"), dtype=np.uint8)
+        for src, dst in ((b"Aa", "A"), (b"Cc", "C"), (b"Gg", "G"), (b"TtUu", "T")):
+            want[np.isin(a, np.frombuffer(src, dtype=np.uint8))] = ord(dst)
+        assert np.array_equal(packed.arena[:nb].cpu().numpy(), want)
+        assert bool((packed.arena[nb:nb + 16] == ord("N")).all())
+    finally:
+        rs.close()

@@ -323,6 +323,50 @@ int build_tiles(pc_ctx *c, const int32_t *job_adapter, const int32_t *job_adapte
             out_pos += n;
         }
     }
+    // Small single-pass groups run together.  A group is one launch; a handful of jobs of a rare adapter length (phase A:
+    // 217 of the panel's sequences are 24-mers, the other 19 fall into nine row classes of 80-470 tiles each) ends in a
+    // launch that fills a tenth of the chip for the duration of a whole tile, and ten of those in a row cost more than the
+    // 24-mers' launch.  Ascending by rows, groups below kSmallTiles are merged into the next larger small group (its rows,
+    // padded variant: a shorter adapter sits bottom-aligned under padding rows, as in any tile of two different adapters)
+    // until the merged group is large enough; the extra rows are cheap next to an idle chip.  Results do not depend on the
+    // row class a pair runs in (tests/test_gpu_parity.py: ragged / padded classes).
+    {
+        static const bool no_merge = [] { const char *e = getenv("PC_NO_MERGE_SMALL"); return e && *e && *e != '0'; }();
+        const int64_t kSmallTiles = 2048;
+        std::vector<std::pair<int, int>> keys;
+        for (auto &kv : by_group) if (kv.first.second == 0 && kv.first.first / 2 > 0) keys.push_back(kv.first);
+        std::sort(keys.begin(), keys.end(), [](const std::pair<int, int> &x, const std::pair<int, int> &y) {
+            return x.first / 2 != y.first / 2 ? x.first / 2 < y.first / 2 : x.first < y.first; });
+        auto tiles_of = [&](const std::pair<int, int> &k) { int64_t t = 0; for (auto &r : by_group[k]) t += run_tiles(r); return t; };
+        auto padded_class = [](int rows) { for (int r : pck::kPaddedRows) if (r == rows) return true; return false; };
+        bool have_open = false;
+        std::pair<int, int> open;
+        int64_t open_tiles = 0;
+        for (const auto &key : keys) {
+            if (no_merge) break;
+            const int64_t t = tiles_of(key);
+            if (t >= kSmallTiles) continue;                            // large groups stay as they are
+            const int rows_t = key.first / 2;
+            if (!have_open) { have_open = true; open = key; open_tiles = t; continue; }
+            if (!padded_class(rows_t) || rows_t < open.first / 2) continue;   // no padded variant of this class: it stays alone
+            const std::pair<int, int> target(rows_t * 2 + 1, 0);
+            std::vector<pck::TileRun> moved;
+            int window = 0;
+            const std::pair<int, int> olds[2] = {open, key};
+            for (const auto &old : olds) {
+                auto it = by_group.find(old);
+                if (it == by_group.end()) continue;
+                for (auto &r : it->second) { r.rows = rows_t; moved.push_back(r); }
+                window = std::max(window, group_window[old]);
+                by_group.erase(it);
+                group_window.erase(old);
+            }
+            by_group[target] = std::move(moved);
+            group_window[target] = window;
+            open = target; open_tiles += t;
+            if (open_tiles >= kSmallTiles) have_open = false;
+        }
+    }
     // from here on the cached table is being replaced: an error below must not leave the "same job list" fast
     // path pointing at half-built groups or an unbuilt slot
     c->tiles_uploaded = false;

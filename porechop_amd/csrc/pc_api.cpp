@@ -342,12 +342,14 @@ int build_tiles(pc_ctx *c, const int32_t *job_adapter, const int32_t *job_adapte
         bool have_open = false;
         std::pair<int, int> open;
         int64_t open_tiles = 0;
+        int open_min_rows = 0;                                         // (never more than twice the rows a pair needs)
         for (const auto &key : keys) {
             if (no_merge) break;
             const int64_t t = tiles_of(key);
             if (t >= kSmallTiles) continue;                            // large groups stay as they are
             const int rows_t = key.first / 2;
-            if (!have_open) { have_open = true; open = key; open_tiles = t; continue; }
+            if (have_open && key == open) continue;                    // (already the group the smaller classes were merged into)
+            if (!have_open || rows_t > 2 * open_min_rows) { have_open = true; open = key; open_tiles = t; open_min_rows = rows_t; continue; }
             if (!padded_class(rows_t) || rows_t < open.first / 2) continue;   // no padded variant of this class: it stays alone
             const std::pair<int, int> target(rows_t * 2 + 1, 0);
             std::vector<pck::TileRun> moved;
@@ -361,8 +363,11 @@ int build_tiles(pc_ctx *c, const int32_t *job_adapter, const int32_t *job_adapte
                 by_group.erase(it);
                 group_window.erase(old);
             }
-            by_group[target] = std::move(moved);
-            group_window[target] = window;
+            // (the padded group of this class may exist already -- e.g. 27-mers beside exact 28-mers: joined, not replaced)
+            auto &dst = by_group[target];
+            for (auto &r : dst) r.rows = rows_t;
+            dst.insert(dst.end(), moved.begin(), moved.end());
+            group_window[target] = std::max(group_window[target], window);
             open = target; open_tiles += t;
             if (open_tiles >= kSmallTiles) have_open = false;
         }

@@ -23,6 +23,7 @@
 #include <sched.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
+#include <sys/uio.h>
 #include <sys/statvfs.h>
 #include <unistd.h>
 
@@ -216,6 +217,29 @@ struct UpperTable {
 };
 const UpperTable kUpper;
 
+// NanoporeRead.__init__ (nanopore_read.py:23-35) on one read: upper-case copy + the counts of 'U' and 'T' that decide
+// whether it is RNA.  Arithmetic instead of a table, so that the loop vectorises (the table form ran at ~1.5 GB/s per
+// core and was most of the parser's second pass).
+__attribute__((target_clones("avx2", "default")))
+void upper_copy_count(unsigned char *__restrict dst, const unsigned char *__restrict src, size_t n, size_t *nu_out, size_t *nt_out)
+{
+    size_t nu = 0, nt = 0;
+    size_t i = 0;
+    while (i < n) {
+        const size_t stop = n - i > 240 ? i + 240 : n;        // byte-wide partial counts cannot overflow within 240 bases
+        unsigned char u8 = 0, t8 = 0;
+        for (; i < stop; ++i) {
+            unsigned char c = src[i];
+            c = (unsigned char)(c - (((unsigned char)(c - 'a') < 26) ? 32 : 0));
+            dst[i] = c;
+            u8 = (unsigned char)(u8 + (c == 'U'));
+            t8 = (unsigned char)(t8 + (c == 'T'));
+        }
+        nu += u8; nt += t8;
+    }
+    *nu_out = nu; *nt_out = nt;
+}
+
 void add_read(pc_readset *rs, const char *name_b, const char *name_e, const char *seq_b, const char *seq_e,
               const char *q_b, const char *q_e)
 {
@@ -225,11 +249,7 @@ void add_read(pc_readset *rs, const char *name_b, const char *name_e, const char
     rs->arena.resize(o + n);
     unsigned char *dst = (unsigned char *)rs->arena.data() + o;
     size_t nu = 0, nt = 0;
-    for (size_t i = 0; i < n; ++i) {
-        const unsigned char c = kUpper.t[(unsigned char)seq_b[i]];
-        dst[i] = c;
-        nu += (c == 'U'); nt += (c == 'T');
-    }
+    upper_copy_count(dst, (const unsigned char *)seq_b, n, &nu, &nt);
     const bool rna = nu > nt;
     if (rna) for (size_t i = 0; i < n; ++i) if (dst[i] == 'U') dst[i] = 'T';
     rs->off.push_back((int64_t)o);
@@ -362,11 +382,7 @@ bool parse_fastq_range(pc_readset *rs, const char *begin, const char *end, int n
             const size_t n = (size_t)(se - sb), q = (size_t)(qe - qb);
             unsigned char *dst = (unsigned char *)rs->arena.data() + so;
             size_t nu = 0, nt = 0;
-            for (size_t i = 0; i < n; ++i) {
-                const unsigned char c = kUpper.t[(unsigned char)sb[i]];
-                dst[i] = c;
-                nu += (c == 'U'); nt += (c == 'T');
-            }
+            upper_copy_count(dst, (const unsigned char *)sb, n, &nu, &nt);
             const bool rna = nu > nt;
             if (rna) for (size_t i = 0; i < n; ++i) if (dst[i] == 'U') dst[i] = 'T';
             rs->off[r] = (int64_t)so; rs->len[r] = (int32_t)n; rs->rna[r] = rna ? 1 : 0;
@@ -795,6 +811,12 @@ static int write_pieces(const pc_readset *rs, int64_t npieces, const int64_t *pi
             for (int t = 1; t < T; ++t)
                 cut[(size_t)t] = (size_t)(std::lower_bound(at.begin(), at.end(), bytes / (size_t)T * (size_t)t) - at.begin());
             std::vector<int> ok((size_t)T, 1);
+            // the gather path: FASTQ out of a FASTQ read set, no RNA read among the pieces (U for T needs a copy), records
+            // long enough that five vectors per record are few (PC_IO_GATHER=0 switches it off)
+            static const bool gather_off = [] { const char *e = getenv("PC_IO_GATHER"); return e && *e == '0'; }();
+            bool gather_write = !gather_off && fastq && rs->fastq && !map && bytes / idx.size() >= 1024;
+            if (gather_write)
+                for (int64_t k : idx) if (rs->rna[(size_t)piece_read[k]]) { gather_write = false; break; }
             auto work = [&](int t) {
                 std::vector<char> buf;
                 size_t i = cut[(size_t)t];
@@ -803,6 +825,58 @@ static int write_pieces(const pc_readset *rs, int64_t npieces, const int64_t *pi
                     char *o = map + map_lead + at[i];
                     for (size_t q = i; q < stop; ++q) o = format(idx[q], o);
                     if ((size_t)(o - (map + map_lead)) != at[stop]) ok[(size_t)t] = 0;
+                    return;
+                }
+                if (gather_write) {
+                    // FASTQ records of a FASTQ read set: the sequence and quality bytes are written straight from the arenas
+                    // (pwritev), only the header lines are formatted -- one copy of every output byte fewer on a path that
+                    // is bound by memory copies (the page-cache copy of the write itself remains, serialised per file)
+                    static const char sep[] = "\n+\n", nl[] = "\n";
+                    std::vector<struct iovec> iov;
+                    std::vector<char> hdr;
+                    while (i < stop) {
+                        size_t j = i;
+                        while (j < stop && j - i < 200 && at[j + 1] - at[i] <= ((size_t)1 << 24)) ++j;     // 5 vectors per record, IOV_MAX 1024
+                        if (j == i) j = i + 1;
+                        size_t hbytes = 0;
+                        for (size_t q = i; q < j; ++q) hbytes += size_of(idx[q]) - 2 * (size_t)piece_len[idx[q]] - 4;
+                        hdr.resize(hbytes);
+                        iov.clear();
+                        char *o = hdr.data();
+                        for (size_t q = i; q < j; ++q) {
+                            const int64_t k = idx[q];
+                            const size_t r = (size_t)piece_read[k], st = (size_t)piece_start[k], ln = (size_t)piece_len[k];
+                            char tag[24];
+                            const int tl = tag_of(k, tag);
+                            const char *name = rs->name_of(r);
+                            const size_t name_n = strlen(name);
+                            char *h0 = o;
+                            *o++ = '@';
+                            const char *sp = tl ? (const char *)memchr(name, ' ', name_n) : nullptr;
+                            if (tl && sp) { memcpy(o, name, (size_t)(sp - name)); o += sp - name; memcpy(o, tag, (size_t)tl); o += tl; memcpy(o, sp, name_n - (size_t)(sp - name)); o += name_n - (size_t)(sp - name); }
+                            else { memcpy(o, name, name_n); o += name_n; if (tl) { memcpy(o, tag, (size_t)tl); o += tl; } }
+                            *o++ = '\n';
+                            iov.push_back({h0, (size_t)(o - h0)});
+                            if (ln) iov.push_back({(void *)(rs->arena.data() + rs->off[r] + st), ln});
+                            iov.push_back({(void *)sep, 3});
+                            if (ln) iov.push_back({(void *)(rs->qual_of(r) + st), ln});
+                            iov.push_back({(void *)nl, 1});
+                        }
+                        if ((size_t)(o - hdr.data()) != hbytes) { ok[(size_t)t] = 0; return; }
+                        size_t done = 0, first = 0;
+                        const size_t total = at[j] - at[i];
+                        std::lock_guard<std::mutex> turn(write_turn);
+                        while (done < total) {
+                            const ssize_t w = pwritev(fd, iov.data() + first, (int)std::min<size_t>(iov.size() - first, 1024),
+                                                      (off_t)(base_pos + at[i] + done));
+                            if (w <= 0) { ok[(size_t)t] = 0; return; }
+                            done += (size_t)w;
+                            size_t left = (size_t)w;                              // a short write: skip what has been written
+                            while (first < iov.size() && left >= iov[first].iov_len) left -= iov[first++].iov_len;
+                            if (left) { iov[first].iov_base = (char *)iov[first].iov_base + left; iov[first].iov_len -= left; }
+                        }
+                        i = j;
+                    }
                     return;
                 }
                 while (i < stop) {

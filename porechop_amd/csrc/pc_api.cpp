@@ -1936,7 +1936,35 @@ char *adapterAlignment(char *readSeq, char *adapterSeq, int matchScore, int mism
             const char *ads[1] = {adapterSeq};
             if (!rc) rc = intern_adapters(ads, 1, gidx);
             const int64_t off = 0; const int32_t len = (int32_t)n, aidx = rc ? 0 : gidx[0];
-            if (!rc) rc = pc_align_batch_host(c, readSeq, (int64_t)n, &off, &len, &aidx, 1, PC_MODE_AUTO, rec);
+            // Porechop asks for one pair at a time, but never for one pair only: a read's end window meets every sequence
+            // of the panel in turn (phase A: porechop.py:296-322, nanopore_read.py:149-164) and every matching set's in phase
+            // B.  A miss on a short window is therefore answered by ONE launch over that window against every adapter this
+            // process has asked about so far (same scheme; packed kernels only), and all of it goes into the memo: the next
+            // couple of hundred calls are lookups.  This is what makes "swap cpp_functions.so and change nothing else"
+            // (INTEGRATION.md mode A) faster than the CPU instead of ten times slower: a single-pair launch costs ~125 us
+            // whatever its size.  Whole reads (phase C asks for two or three adapters per read) stay single launches.
+            static const bool no_spec = [] { const char *e = getenv("PC_NO_SPECULATION"); return e && *e && *e != '0'; }();
+            bool speculated = false;
+            if (!rc && !no_spec && n <= 1024 && g.ad_list.size() > 1 && g.ad_list.size() <= 1024 && !c->slow_scheme &&
+                (rc = upload_panel(c)) == PC_OK && !c->ad_slow[(size_t)aidx]) {
+                std::vector<int32_t> ai, ln;
+                std::vector<int64_t> of;
+                for (size_t k = 0; k < g.ad_list.size(); ++k)
+                    if (!c->ad_slow[k] && !g.ad_list[k].empty()) { ai.push_back((int32_t)k); ln.push_back((int32_t)n); of.push_back(0); }
+                std::vector<int32_t> recs(ai.size() * PC_RESULT_INTS);
+                rc = pc_align_batch_host(c, readSeq, (int64_t)n, of.data(), ln.data(), ai.data(), (int64_t)ai.size(), PC_MODE_AUTO, recs.data());
+                if (!rc) {
+                    std::lock_guard<std::mutex> lk(g.mu);
+                    for (size_t i = 0; i < ai.size(); ++i) {
+                        const std::string &ad = g.ad_list[(size_t)ai[i]];
+                        const FullKey k2 = make_key(readSeq, n, ad.data(), ad.size(), matchScore, mismatchScore, gapOpenScore, gapExtensionScore);
+                        memo_insert(g, k2, recs.data() + i * PC_RESULT_INTS);
+                        if (ai[i] == aidx) memcpy(rec, recs.data() + i * PC_RESULT_INTS, sizeof(rec));
+                    }
+                    speculated = true;
+                }
+            }
+            if (!rc && !speculated) rc = pc_align_batch_host(c, readSeq, (int64_t)n, &off, &len, &aidx, 1, PC_MODE_AUTO, rec);
             if (rc) {
                 // Only a missing / failing device, scores above 2^20 in magnitude or an adapter above PC_MAX_ADAPTER_ANY
                 // bases end here.  The unchanged Python wrapper dereferences the NULL below

@@ -27,7 +27,10 @@ extern "C" {
  *   "readStart,readEnd,adapterStart,adapterEnd,rawScore,alignedRegion%id,fullAdapter%id"
  * formatted exactly like porechop/src/alignment.cpp:113-121 ("%d" ints, "%f" doubles;
  * "-1,..." when either sequence is empty).  Served from the prefetch memo (Part 2) when the
- * pair was prefetched, otherwise by a single-pair GPU launch.  Any four integer scores (up to 2^20 in magnitude) and
+ * pair is in it; otherwise by a GPU launch -- which, for a window of up to 1024 bases, covers that
+ * window against EVERY adapter this process has asked about so far and memoises all of it (Porechop
+ * walks a read's end window through the whole panel, porechop.py:296-322: one launch, then lookups;
+ * PC_NO_SPECULATION=1 makes every miss a single-pair launch).  Any four integer scores (up to 2^20 in magnitude) and
  * adapters up to PC_MAX_ADAPTER_ANY bases are computed, as the reference computes them.  Never throws; on a device
  * error (or beyond those limits) it prints to stderr and returns NULL. */
 char *adapterAlignment(char *readSeq, char *adapterSeq, int matchScore, int mismatchScore,

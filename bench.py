@@ -1064,6 +1064,60 @@ def leg_ragged(dev, args, workers, uniform_bp_per_s):
     return out
 
 
+def leg_ultralong(dev, args, workers):
+    """Ultra-long reads: the configs[3] shape (phases A + B + C, chimeras) on a log-normal length distribution with a tail
+    far past 65 535 bases (mean 20 kb, sigma 1.2: the longest of 40 000 reads is about a megabase) -- the columns beyond
+    u16 of the score kernels, the chunked launch plan, the prefilter's chunks and the mask-and-realign copies at those
+    lengths.  Parity: the reference's per-read logic over the compiled reference on the LONGEST reads and on the first ones."""
+    from dataclasses import asdict
+    from porechop_amd.pipeline import Pipeline, ScanParams
+    from porechop_amd.synth import make_ragged_reads
+    from tests.cpu_worker import run_chunk
+    p = ScanParams()
+    pl = Pipeline(load_panel_sets(), p, device=dev)
+    n = max(1000, args.reads // 25)
+    reads = make_ragged_reads(n, mean_len=20000, sigma=1.2, min_len=20, seed=9, start_frac=0.9, end_frac=0.5,
+                              chimera_frac=5 * args.chimera, device=dev)
+    bases = int(reads.length.to(torch.int64).sum().item())
+    over = int((reads.length > 65535).sum().item())
+
+    def sync():
+        pl.aligner.sync()
+        torch.cuda.synchronize()
+    steps = max(1, min(args.steps, 3))
+    (matching, st, et, hits), dt = timed(lambda: one_step(pl, reads, p.check_reads, 1), steps, 1, sync)
+    (_, st_f, et_f, hits_f), dt_f = timed(lambda: one_step(pl, reads, p.check_reads, 1, prefilter=True), steps, 1, sync)
+    same = bool(torch.equal(st, st_f) and torch.equal(et, et_f) and hits_f.read.numel() == hits.read.numel() and
+                torch.equal(hits_f.read, hits.read) and torch.equal(hits_f.start, hits.start) and torch.equal(hits_f.end, hits.end))
+    beyond = int((hits.start > 65535).sum().item())
+    out = {"workload": "configs[3] shape on log-normal read lengths with an ultra-long tail: %d reads, mean 20 kb, sigma 1.2 "
+                       "(max %d bp, %d reads above 65 535 bp), %.0f%% chimeras, phases A + B + C"
+                       % (n, int(reads.length.max()), over, 5 * args.chimera * 100),
+           "reads": n, "max_len": int(reads.length.max()), "reads_over_65535": over,
+           "reads_per_s": n * steps / dt, "read_bp_per_s": bases * steps / dt, "ms_per_step": dt / steps * 1e3,
+           "prefiltered_read_bp_per_s": bases * steps / dt_f, "prefiltered_same": same,
+           "middle_hits_per_step": int(hits.read.numel()), "middle_hits_beyond_column_65535": beyond}
+    if args.cpu_seconds > 0:
+        order = torch.argsort(reads.length, descending=True, stable=True)[:24].cpu().tolist()
+        sample = sorted(set(order) | set(range(min(n, 72))))
+        seqs = []
+        for r in sample:
+            o, l = int(reads.off[r]), int(reads.length[r])
+            seqs.append(reads.arena[o:o + l].cpu().numpy().tobytes().decode("ascii"))
+        sets = [(s.name, s.start, s.end) for s in pl.sets]
+        done, dtc, res = cpu_sample(run_chunk, lambda c: (c, sets, matching, asdict(p), True), seqs, 1e9, workers)
+        got = {}
+        for r, a, s_, e_ in zip(hits.read.cpu().tolist(), hits.adapter.cpu().tolist(), hits.start.cpu().tolist(), hits.end.cpu().tolist()):
+            got.setdefault(r, []).append((a, s_, e_))
+        stl, etl = st.cpu().tolist(), et.cpu().tolist()
+        bad = [r for k, r in enumerate(sample[:done]) if (stl[r], etl[r], got.get(r, [])) != (res[k][0], res[k][1], list(res[k][2]))]
+        out["parity"] = {"checked": done, "mismatches": len(bad), "longest_checked_bp": max(len(x) for x in seqs[:done]) if done else 0,
+                         "what": "start trim, end trim, middle hits per read: the 24 longest reads and the first 72",
+                         "first_mismatching_reads": bad[:8]}
+    pl.close()
+    return out
+
+
 def _r(x, sig=6):
     """Numbers of the printed line: 6 significant digits."""
     if isinstance(x, bool) or x is None or isinstance(x, (int, str)):
@@ -1144,6 +1198,13 @@ def compact_line(full):
         leg("ragged_lengths", failed=rg.get("failed"), reads_per_s=rg.get("reads_per_s"), read_bp_per_s=rg.get("read_bp_per_s"),
             bp_vs_uniform=rg.get("bp_per_s_vs_uniform_lengths"), parity_checked=_pick(rg, "parity", "checked"),
             mismatches=_pick(rg, "parity", "mismatches"))
+    ul = also.get("ultralong", {})
+    if ul:
+        leg("ultralong", failed=ul.get("failed"), reads=ul.get("reads"), max_len=ul.get("max_len"), reads_over_65535=ul.get("reads_over_65535"),
+            reads_per_s=ul.get("reads_per_s"), read_bp_per_s=ul.get("read_bp_per_s"), ms_per_step=ul.get("ms_per_step"),
+            prefiltered_read_bp_per_s=ul.get("prefiltered_read_bp_per_s"), same=ul.get("prefiltered_same"),
+            hits_beyond_65535=ul.get("middle_hits_beyond_column_65535"), parity_checked=_pick(ul, "parity", "checked"),
+            mismatches=_pick(ul, "parity", "mismatches"), longest_checked_bp=_pick(ul, "parity", "longest_checked_bp"))
     hb = also.get("from_host_memory", {})
     if hb:
         leg("from_host_memory", failed=hb.get("failed"), reads_per_s=hb.get("reads_per_s"), ms_per_step=hb.get("ms_per_step"),
@@ -1162,7 +1223,7 @@ def compact_line(full):
     par = full.get("parity") or {}
     flat = {}
     short = {"configs1": "c1", "configs2": "c2", "configs4_per_gpu": "c4", "exact_prefilter": "pf", "ragged_lengths": "ragged",
-             "from_host_memory": "h2d", "end_to_end": "e2e", "proven_middle_scan": "proven"}
+             "from_host_memory": "h2d", "end_to_end": "e2e", "proven_middle_scan": "proven", "ultralong": "ul"}
     for name, d in legs.items():
         for k in ("reads_per_s", "parity_checked", "mismatches", "roofline_frac", "valu_frac", "cpu_reads_per_s",
                   "pruned_reads_per_s", "fast_reads_per_s", "seed_scan_hbm_frac", "same", "pruned_same", "fast_same"):
@@ -1528,6 +1589,7 @@ def main():
             legs = (("configs1", lambda: leg_configs1(dev, args, host_cores())),
                     ("configs2", lambda: leg_configs2(dev, args, host_cores())),
                     ("ragged_lengths", lambda: leg_ragged(dev, args, host_cores(), out["read_bp_per_s"])),
+                    ("ultralong", lambda: leg_ultralong(dev, args, host_cores())),
                     ("from_host_memory", lambda: leg_host_buffers(dev, args)),
                     ("end_to_end", lambda: leg_end_to_end(dev, args)))
             for name, leg in legs:

@@ -484,6 +484,13 @@ bool ragged_lengths(const pc_ctx *c, int max_len) { return c->len_hint > 0 && (i
 
 int group_chunks_for(const pc_ctx *c, const Group &g, int max_len)
 {
+    // PC_FORCE_CHUNKS=n (tests): that many column chunks whatever the fill -- 1 runs a whole window in one unit, which a
+    // launch otherwise only does when thousands of tiles fill the chip (tests/test_gpu_ultralong.py: columns beyond 65 535
+    // through the un-chunked branch of the specialised score kernel without a 20 GB batch)
+    if (const char *f = getenv("PC_FORCE_CHUNKS")) {
+        const int n = atoi(f);
+        if (n >= 1) return std::min(n, std::min(kMaxChunks, std::max(1, max_len / std::max(128, g.max_window / 2))));
+    }
     int chunks = chunks_for((int64_t)g.tile_count, resident_waves(c, g), max_len, g.max_window);
     if (ragged_lengths(c, max_len)) {
         const int unit = std::max(c->len_hint, std::max(512, 4 * g.max_window));

@@ -423,6 +423,44 @@ int pc_readset_write_shared(const pc_readset *rs, int64_t npieces, const int64_t
                             const int32_t *piece_len, const int32_t *piece_number, const int32_t *piece_file, int nfiles,
                             const char *const *file_paths, int fastq, int64_t *file_pos);
 
+/* ---- gzip at the speed of the rest (replaces: Python's gzip module on the way in, porechop/misc.py:60-81,151-168; `pigz -p
+ * <threads>` / gzip over a temporary file on the way out, porechop/porechop.py:640-651,685-729) -------------------------------
+ * Output is a chain of independent gzip members of <= 65 280 input bytes, each carrying its compressed size in a 'BC' extra
+ * subfield (the BGZF layout of the SAM specification, 4.1): an ordinary multi-member .gz file to gunzip / zlib / Python, and
+ * one whose members any reader that knows the subfield inflates in parallel.  DEFLATE comes from libdeflate when the
+ * machine has it (dlopen), else zlib.
+ * pc_readset_compress: the pieces pc_readset_write would write, formatted and deflated by all cores into memory (nothing is
+ *   opened); level 1..9 (<= 0: the default -- libdeflate's 3, which already makes smaller files than the zlib level 6 of
+ *   gzip and pigz; zlib's 6 without libdeflate).
+ * pc_gzimage_sizes / pc_gzimage_write: the bytes per file, and the image of every file written at file_pos[f] (updated) --
+ *   a streamed run appends block after block, the ranks of a sharded run exchange the sizes first and write disjoint spans
+ *   (shared = 1: never truncate).  Files whose image is empty are not touched.
+ * pc_gz_finish: the empty last member (28 bytes) that ends such a file; creates the file when there is none.
+ * pc_gzip_file: a whole file, src -> dst, all cores (single_member = 1: ONE member the way pigz builds it, which nobody can
+ *   inflate in parallel -- for tests and benchmarks of the reader's route for ordinary .gz input). */
+typedef struct pc_gzimage pc_gzimage;
+int pc_readset_compress(const pc_readset *rs, int64_t npieces, const int64_t *piece_read, const int32_t *piece_start,
+                        const int32_t *piece_len, const int32_t *piece_number, const int32_t *piece_file, int nfiles,
+                        int fastq, int level, pc_gzimage **out);
+int pc_gzimage_sizes(const pc_gzimage *img, int nfiles, int64_t *compressed_bytes, int64_t *plain_bytes);
+int pc_gzimage_write(const pc_gzimage *img, int nfiles, const char *const *file_paths, int64_t *file_pos, int shared);
+void pc_gzimage_free(pc_gzimage *img);
+int pc_gz_finish(const char *path);
+int pc_gzip_file(const char *src, const char *dst, int level, int single_member);
+
+/* A gzip FASTQ file as a stream of blocks (the streamed route for .gz input): a producer thread inflates ahead of the
+ * caller -- members that carry their size on several cores, any other gzip stream through zlib -- so that inflating block
+ * k+1 overlaps parsing, scanning and writing block k.
+ * pc_gzstream_next: the records that start before the first record start at or after target_bytes of the bytes not yet
+ *   handed out (where pc_readset_load_segment would cut the plain file), at least min_reads of them unless the file ends
+ *   first; *out = NULL and *eof = 1 after the last block.  PC_ERR_UNSUPPORTED_SCORES = "not streamable" (not gzip, not a
+ *   regular 4-line FASTQ, a damaged stream): load the whole file with pc_readset_load, which reproduces the reference's
+ *   behaviour and messages. */
+typedef struct pc_gzstream pc_gzstream;
+int pc_gzstream_open(const char *path, pc_gzstream **out);
+int pc_gzstream_next(pc_gzstream *s, int64_t target_bytes, int64_t min_reads, pc_readset **out, int *eof);
+void pc_gzstream_close(pc_gzstream *s);
+
 #ifdef __cplusplus
 }
 #endif

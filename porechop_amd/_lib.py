@@ -19,6 +19,8 @@ EXPORTS = [
     "pc_readset_arena", "pc_readset_offsets", "pc_readset_lengths", "pc_readset_name", "pc_readset_quals",
     "pc_readset_is_rna", "pc_readset_load_many", "pc_readset_file_index", "pc_readset_write",
     "pc_readset_load_segment", "pc_readset_write_at", "pc_io_set_thread_limit", "pc_pack_reads", "pc_unpack_device", "pc_fastq_find_record", "pc_readset_write_sizes", "pc_readset_write_shared",
+    "pc_readset_compress", "pc_gzimage_sizes", "pc_gzimage_write", "pc_gzimage_free", "pc_gz_finish", "pc_gzip_file",
+    "pc_gzstream_open", "pc_gzstream_next", "pc_gzstream_close",
 ]
 
 
@@ -165,6 +167,24 @@ def load_library():
     L.pc_readset_write_shared.restype = c_int
     L.pc_io_set_thread_limit.argtypes = [c_int]
     L.pc_io_set_thread_limit.restype = None
+    L.pc_readset_compress.argtypes = [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, ctypes.POINTER(c_vp)]
+    L.pc_readset_compress.restype = c_int
+    L.pc_gzimage_sizes.argtypes = [c_vp, c_int, c_vp, c_vp]
+    L.pc_gzimage_sizes.restype = c_int
+    L.pc_gzimage_write.argtypes = [c_vp, c_int, c_vp, c_vp, c_int]
+    L.pc_gzimage_write.restype = c_int
+    L.pc_gzimage_free.argtypes = [c_vp]
+    L.pc_gzimage_free.restype = None
+    L.pc_gz_finish.argtypes = [c_cp]
+    L.pc_gz_finish.restype = c_int
+    L.pc_gzip_file.argtypes = [c_cp, c_cp, c_int, c_int]
+    L.pc_gzip_file.restype = c_int
+    L.pc_gzstream_open.argtypes = [c_cp, ctypes.POINTER(c_vp)]
+    L.pc_gzstream_open.restype = c_int
+    L.pc_gzstream_next.argtypes = [c_vp, c_i64, c_i64, ctypes.POINTER(c_vp), ctypes.POINTER(c_int)]
+    L.pc_gzstream_next.restype = c_int
+    L.pc_gzstream_close.argtypes = [c_vp]
+    L.pc_gzstream_close.restype = None
     L.pc_pack_reads.argtypes = [c_vp, c_i64, c_vp, c_vp, c_i64, ctypes.POINTER(c_i64)]
     L.pc_pack_reads.restype = c_int
     L.pc_unpack_device.argtypes = [c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_int, c_vp]

@@ -28,7 +28,10 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cctype>
+#include <condition_variable>
+#include <deque>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -38,6 +41,7 @@
 #include <vector>
 
 #include "../../include/porechop_amd.h"
+#include "pc_gz.h"
 
 // Big buffers are recycled: a streamed run loads and frees a read set per 256 MB block, and giving 128 MB back to
 // the kernel and faulting 128 MB of fresh zeroed pages in again cost as much as writing the block (measured: 0.8 s of
@@ -122,6 +126,13 @@ struct pc_readset {
     std::string error;
 };
 
+// What pc_readset_compress makes: per file, the compressed members of every formatter thread's span, in order.
+struct pc_gzimage {
+    std::vector<std::vector<std::vector<char>>> parts;      // [file][span]
+    std::vector<int64_t> plain;                             // uncompressed bytes per file
+    int64_t bytes(size_t f) const { int64_t b = 0; for (const auto &v : parts[f]) b += (int64_t)v.size(); return b; }
+};
+
 namespace {
 
 // The bytes of a file: plain files are mapped (no copy), gzip files are inflated into memory.
@@ -130,7 +141,7 @@ struct FileData {
     size_t n = 0;
     void *map = nullptr;
     size_t map_len = 0;
-    std::vector<char> owned;
+    RawBuf owned;
     FileData() = default;
     FileData(const FileData &) = delete;
     ~FileData() { if (map) munmap(map, map_len); }
@@ -138,6 +149,59 @@ struct FileData {
     size_t size() const { return n; }
     bool empty() const { return n == 0; }
 };
+
+int usable_threads();
+
+// A gzip file made of members that carry their own size (pc_gz.h: what this library writes, and bgzip): the members are
+// found by hopping from header to header and inflated by all cores, each into its place.  false = not such a file (or a
+// member that does not check out): the caller inflates it as an ordinary gzip stream.
+bool inflate_sized_members(const char *path, RawBuf &out)
+{
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) return false;
+    struct stat st;
+    if (fstat(fd, &st) != 0 || st.st_size < (off_t)(pcz::kHeader + pcz::kTrailer)) { close(fd); return false; }
+    const size_t size = (size_t)st.st_size;
+    void *m = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
+    close(fd);
+    if (m == MAP_FAILED) return false;
+    const unsigned char *base = (const unsigned char *)m;
+    struct Member { size_t in, in_n, out, out_n; uint32_t crc; };
+    std::vector<Member> mem;
+    size_t at = 0, total = 0;
+    bool ok = true;
+    while (at < size) {
+        size_t payload = 0;
+        const size_t n = pcz::sized_member(base + at, size - at, &payload);
+        if (!n) { ok = false; break; }
+        const size_t isize = pcz::get32(base + at + n - 4);
+        mem.push_back({at + payload, n - payload - pcz::kTrailer, total, isize, pcz::get32(base + at + n - 8)});
+        total += isize;
+        at += n;
+    }
+    if (ok) {
+        out.resize(total);
+        const int T = (int)std::max<size_t>(1, std::min<size_t>((size_t)usable_threads(), mem.size() / 64 + 1));
+        std::atomic<size_t> next{0};
+        std::atomic<bool> good{true};
+        auto work = [&]() {
+            pcz::Inflater inf;
+            for (;;) {
+                const size_t i0 = next.fetch_add(64);
+                if (i0 >= mem.size() || !good.load()) return;
+                for (size_t i = i0; i < std::min(mem.size(), i0 + 64); ++i)
+                    if (!inf.raw(base + mem[i].in, mem[i].in_n, out.data() + mem[i].out, mem[i].out_n, mem[i].crc)) { good.store(false); return; }
+            }
+        };
+        std::vector<std::thread> th;
+        for (int t = 1; t < T; ++t) th.emplace_back(work);
+        work();
+        for (auto &x : th) x.join();
+        ok = good.load();
+    }
+    munmap(m, size);
+    return ok;
+}
 
 bool slurp(const char *path, FileData &data, std::string &err)
 {
@@ -150,7 +214,10 @@ bool slurp(const char *path, FileData &data, std::string &err)
     if (got >= 4 && magic[0] == 0x50 && magic[1] == 0x4b && magic[2] == 0x03 && magic[3] == 0x04) { err = "cannot use zip format - use gzip instead"; return false; }
     // gzopen reads plain files transparently, but the reference decides by magic bytes: do the same
     const bool gz = got >= 3 && magic[0] == 0x1f && magic[1] == 0x8b && magic[2] == 0x08;
-    if (gz) {
+    if (gz && inflate_sized_members(path, data.owned)) {
+        data.p = data.owned.data(); data.n = data.owned.size();
+    } else if (gz) {
+        data.owned.resize(0);
         gzFile g = gzopen(path, "rb");
         if (!g) { err = std::string("could not open ") + path; return false; }
         gzbuffer(g, 1 << 20);
@@ -159,7 +226,7 @@ bool slurp(const char *path, FileData &data, std::string &err)
             const int n = gzread(g, buf.data(), (unsigned)buf.size());
             if (n < 0) { err = "gzip stream error"; gzclose(g); return false; }
             if (n == 0) break;
-            data.owned.insert(data.owned.end(), buf.begin(), buf.begin() + n);
+            data.owned.append(buf.data(), buf.data() + n);
         }
         gzclose(g);
         data.p = data.owned.data(); data.n = data.owned.size();
@@ -561,6 +628,215 @@ int pc_fastq_find_record(const char *path, int64_t byte_pos, int64_t *record_sta
     return rc;
 }
 
+// ---- a gzip FASTQ file as a stream of blocks (the streamed route of runner.py for .gz input) -------------------------
+// A producer thread inflates AHEAD of the consumer into a bounded queue of buffers: members that carry their size
+// (pc_gz.h) a batch at a time on several cores, any other gzip stream (one big member: gzip, pigz; concatenated members)
+// through zlib's inflate.  The consumer (pc_gzstream_next) cuts the inflated bytes exactly where
+// pc_readset_load_segment would cut the plain file -- a block holds the records that start before the first record
+// start at or after `target_bytes` -- and parses it with all cores.
+struct pc_gzstream {
+    std::string path;
+    std::thread producer;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<std::vector<char>> ready;
+    size_t ready_bytes = 0;
+    bool done = false, failed = false, stop = false;
+    RawBuf pending;                      // inflated bytes not yet handed out (starts at a record start)
+    bool eof = false;                    // the producer's last buffer has been taken
+    int inflate_threads = 1;
+    ~pc_gzstream()
+    {
+        { std::lock_guard<std::mutex> lk(mu); stop = true; }
+        cv.notify_all();
+        if (producer.joinable()) producer.join();
+    }
+};
+
+namespace {
+
+constexpr size_t kGzQueueBytes = (size_t)512 << 20;     // inflated bytes the producer may run ahead
+constexpr size_t kGzBuffer = (size_t)32 << 20;
+
+void gz_produce(pc_gzstream *s)
+{
+    auto push = [&](std::vector<char> &&v) -> bool {
+        std::unique_lock<std::mutex> lk(s->mu);
+        s->cv.wait(lk, [&] { return s->stop || s->ready_bytes < kGzQueueBytes; });
+        if (s->stop) return false;
+        s->ready_bytes += v.size();
+        s->ready.push_back(std::move(v));
+        lk.unlock();
+        s->cv.notify_all();
+        return true;
+    };
+    auto finish = [&](bool ok) {
+        { std::lock_guard<std::mutex> lk(s->mu); s->done = true; s->failed = !ok; }
+        s->cv.notify_all();
+    };
+    const int fd = open(s->path.c_str(), O_RDONLY);
+    if (fd < 0) { finish(false); return; }
+    struct stat st;
+    if (fstat(fd, &st) != 0 || st.st_size <= 0) { close(fd); finish(false); return; }
+    const size_t size = (size_t)st.st_size;
+    void *m = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
+    close(fd);
+    if (m == MAP_FAILED) { finish(false); return; }
+    madvise(m, size, MADV_SEQUENTIAL);
+    const unsigned char *base = (const unsigned char *)m;
+    bool ok = true;
+    size_t at = 0;
+    // ---- members that carry their size: batches of about kGzBuffer inflated bytes, several threads -----------------
+    while (ok && at < size) {
+        struct Member { size_t in, in_n, out, out_n; uint32_t crc; };
+        std::vector<Member> mem;
+        size_t total = 0, p = at;
+        while (p < size && total < kGzBuffer) {
+            size_t payload = 0;
+            const size_t n = pcz::sized_member(base + p, size - p, &payload);
+            if (!n) break;
+            const size_t isize = pcz::get32(base + p + n - 4);
+            mem.push_back({p + payload, n - payload - pcz::kTrailer, total, isize, pcz::get32(base + p + n - 8)});
+            total += isize;
+            p += n;
+        }
+        if (mem.empty()) break;                           // an ordinary gzip member from here on
+        std::vector<char> buf(total);
+        const int T = std::max(1, std::min<int>(s->inflate_threads, (int)(mem.size() / 16 + 1)));
+        std::atomic<size_t> next{0};
+        std::atomic<bool> good{true};
+        auto work = [&]() {
+            pcz::Inflater inf;
+            for (;;) {
+                const size_t i0 = next.fetch_add(16);
+                if (i0 >= mem.size() || !good.load()) return;
+                for (size_t i = i0; i < std::min(mem.size(), i0 + 16); ++i)
+                    if (!inf.raw(base + mem[i].in, mem[i].in_n, buf.data() + mem[i].out, mem[i].out_n, mem[i].crc)) { good.store(false); return; }
+            }
+        };
+        std::vector<std::thread> th;
+        for (int t = 1; t < T; ++t) th.emplace_back(work);
+        work();
+        for (auto &x : th) x.join();
+        if (!good.load()) { ok = false; break; }
+        at = p;
+        if (total && !push(std::move(buf))) { munmap(m, size); finish(false); return; }
+    }
+    // ---- the rest (all of an ordinary .gz file): zlib's inflate, member after member -------------------------------
+    if (ok && at < size) {
+        z_stream zs;
+        memset(&zs, 0, sizeof zs);
+        if (inflateInit2(&zs, 15 + 16) != Z_OK) ok = false;
+        std::vector<char> buf;
+        bool ended = false;                               // the last member has ended and nothing follows it
+        while (ok && !ended) {
+            buf.resize(kGzBuffer);
+            zs.next_out = (Bytef *)buf.data(); zs.avail_out = (uInt)buf.size();
+            while (zs.avail_out) {
+                const size_t take = std::min<size_t>(size - at, (size_t)1 << 30);
+                zs.next_in = (Bytef *)(base + at); zs.avail_in = (uInt)take;
+                const int r = inflate(&zs, Z_NO_FLUSH);
+                at += take - zs.avail_in;
+                if (r == Z_STREAM_END) {
+                    // another member may follow (zeros after the last member are padding, as gzip treats them)
+                    while (at < size && base[at] == 0) ++at;
+                    if (at >= size) { ended = true; break; }
+                    if (inflateReset(&zs) != Z_OK) { ok = false; break; }
+                    continue;
+                }
+                if (r == Z_OK) continue;
+                ok = false;                               // Z_BUF_ERROR with room left: the file ends inside a member; or damage
+                break;
+            }
+            if (!ok) break;
+            buf.resize(buf.size() - zs.avail_out);
+            if (!buf.empty() && !push(std::move(buf))) { inflateEnd(&zs); munmap(m, size); finish(false); return; }
+            buf = std::vector<char>();
+        }
+        inflateEnd(&zs);
+    }
+    munmap(m, size);
+    finish(ok);
+}
+
+}  // namespace
+
+// -> PC_ERR_UNSUPPORTED_SCORES ("not streamable") when the file is not gzip
+int pc_gzstream_open(const char *path, pc_gzstream **out)
+{
+    if (!path || !out) return PC_ERR_BAD_ARG;
+    *out = nullptr;
+    FILE *f = fopen(path, "rb");
+    if (!f) return PC_ERR_BAD_ARG;
+    unsigned char magic[3] = {0, 0, 0};
+    const size_t got = fread(magic, 1, 3, f);
+    fclose(f);
+    if (got < 3 || magic[0] != 0x1f || magic[1] != 0x8b || magic[2] != 8) return PC_ERR_UNSUPPORTED_SCORES;
+    pc_gzstream *s = new pc_gzstream();
+    s->path = path;
+    s->inflate_threads = std::max(1, usable_threads() / 2);
+    s->producer = std::thread(gz_produce, s);
+    *out = s;
+    return PC_OK;
+}
+
+// The next block: the records that start before the first record start at or after target_bytes of the bytes not yet
+// handed out, and at least min_reads of them (phase A's check reads must sit in the first block) unless the file ends
+// first.  *out = null and *eof = 1 after the last block.  PC_ERR_UNSUPPORTED_SCORES: not a regular 4-line FASTQ (or a
+// damaged gzip stream): the caller loads the whole file with pc_readset_load, which reproduces the reference's behaviour
+// and messages for such inputs.
+int pc_gzstream_next(pc_gzstream *s, int64_t target_bytes, int64_t min_reads, pc_readset **out, int *eof)
+{
+    if (!s || !out || !eof || target_bytes <= 0) return PC_ERR_BAD_ARG;
+    *out = nullptr; *eof = 0;
+    size_t target = (size_t)target_bytes;
+    const char *cut = nullptr;
+    for (;;) {
+        // enough bytes for a cut after `target`?
+        const char *base = s->pending.data(), *end = base + s->pending.size();
+        if (s->pending.size() && base[0] != '@') return PC_ERR_UNSUPPORTED_SCORES;
+        cut = nullptr;
+        if (s->pending.size() > target) {
+            cut = find_record_start(base + target, base, end);
+            if (cut && min_reads > 0) {
+                int64_t lines = 0;
+                for (const char *q = base; q < cut; ) { const char *nl = (const char *)memchr(q, '\n', (size_t)(cut - q)); if (!nl) break; ++lines; q = nl + 1; }
+                if (lines / 4 < min_reads) { target = std::max(target * 2, (size_t)(cut - base) + 1); cut = nullptr; continue; }
+            }
+        }
+        if (cut) break;
+        if (s->eof) { cut = end; break; }
+        // take what the producer has
+        std::unique_lock<std::mutex> lk(s->mu);
+        s->cv.wait(lk, [&] { return !s->ready.empty() || s->done; });
+        if (s->ready.empty()) {
+            if (s->failed) return PC_ERR_UNSUPPORTED_SCORES;
+            s->eof = true;
+            continue;
+        }
+        std::vector<char> v = std::move(s->ready.front());
+        s->ready.pop_front();
+        s->ready_bytes -= v.size();
+        lk.unlock();
+        s->cv.notify_all();
+        s->pending.append(v.data(), v.data() + v.size());
+    }
+    const char *base = s->pending.data(), *end = base + s->pending.size();
+    if (cut == base) { *eof = 1; return PC_OK; }
+    pc_readset *rs = new pc_readset();
+    rs->fastq = true;
+    if (!parse_fastq_range(rs, base, cut, usable_threads())) { delete rs; return PC_ERR_UNSUPPORTED_SCORES; }
+    rs->file_index.resize(rs->off.size(), 0);
+    rs->arena.fill(64, 'N');
+    const size_t rest = (size_t)(end - cut);
+    if (rest) memmove(s->pending.data(), cut, rest);
+    s->pending.resize(rest);
+    *out = rs;
+    return PC_OK;
+}
+
+void pc_gzstream_close(pc_gzstream *s) { delete s; }
+
 void pc_readset_free(pc_readset *rs) { delete rs; }
 const char *pc_readset_error(const pc_readset *rs) { return rs ? rs->error.c_str() : "null readset"; }
 int64_t pc_readset_count(const pc_readset *rs) { return rs ? (int64_t)rs->off.size() : 0; }
@@ -641,7 +917,7 @@ int pc_pack_reads(const char *arena, int64_t nbases, uint8_t *packed, int64_t *e
 static int write_pieces(const pc_readset *rs, int64_t npieces, const int64_t *piece_read, const int32_t *piece_start,
                         const int32_t *piece_len, const int32_t *piece_number, const int32_t *piece_file, int nfiles,
                         const char *const *file_paths, int fastq, int64_t *bytes_written, int64_t *file_pos,
-                        int shared = 0, int64_t *sizes_only = nullptr);
+                        int shared = 0, int64_t *sizes_only = nullptr, pc_gzimage *image = nullptr, int gz_level = 6);
 
 void pc_io_set_thread_limit(int nthreads) { t_thread_limit = nthreads > 0 ? (nthreads > 64 ? 64 : nthreads) : 0; }
 
@@ -688,10 +964,169 @@ int pc_readset_write_sizes(const pc_readset *rs, int64_t npieces, const int64_t 
                         nullptr, nullptr, 0, bytes_per_file);
 }
 
+// The same pieces, formatted and DEFLATED by all cores into memory (pc_gz.h: independent members that carry their size):
+// what the reference gets from `pigz -p <threads>` over its temporary file (porechop.py:640-651,685-729).  Nothing is
+// opened or written; pc_gzimage_write puts the image of every file where the caller says (a streamed run appends block
+// after block, the ranks of a sharded run exchange pc_gzimage_sizes first), pc_gz_finish ends a file.
+int pc_readset_compress(const pc_readset *rs, int64_t npieces, const int64_t *piece_read, const int32_t *piece_start,
+                        const int32_t *piece_len, const int32_t *piece_number, const int32_t *piece_file, int nfiles,
+                        int fastq, int level, pc_gzimage **out)
+{
+    if (!out || nfiles < 0) return PC_ERR_BAD_ARG;
+    pc_gzimage *img = new pc_gzimage();
+    img->parts.resize((size_t)nfiles);
+    img->plain.assign((size_t)nfiles, 0);
+    *out = img;
+    std::vector<const char *> dummy((size_t)std::max(nfiles, 1), "");
+    return write_pieces(rs, npieces, piece_read, piece_start, piece_len, piece_number, piece_file, nfiles, dummy.data(), fastq,
+                        nullptr, nullptr, 0, nullptr, img, pcz::default_level(level));
+}
+
+int pc_gzimage_sizes(const pc_gzimage *img, int nfiles, int64_t *compressed_bytes, int64_t *plain_bytes)
+{
+    if (!img || nfiles != (int)img->parts.size() || !compressed_bytes) return PC_ERR_BAD_ARG;
+    for (int f = 0; f < nfiles; ++f) {
+        compressed_bytes[f] = img->bytes((size_t)f);
+        if (plain_bytes) plain_bytes[f] = img->plain[(size_t)f];
+    }
+    return PC_OK;
+}
+
+// file_pos[f]: where file f's image goes (0 and not shared: the file is created / truncated), updated to its end.  Files
+// whose image is empty are not touched.
+int pc_gzimage_write(const pc_gzimage *img, int nfiles, const char *const *file_paths, int64_t *file_pos, int shared)
+{
+    if (!img || nfiles != (int)img->parts.size() || (nfiles && (!file_paths || !file_pos))) return PC_ERR_BAD_ARG;
+    int rc = PC_OK;
+    for (int f = 0; f < nfiles && rc == PC_OK; ++f) {
+        const auto &parts = img->parts[(size_t)f];
+        if (img->bytes((size_t)f) == 0) continue;
+        const int64_t base = file_pos[f];
+        const int fd = open(file_paths[f], shared ? (O_RDWR | O_CREAT) : (base ? O_RDWR : (O_RDWR | O_CREAT | O_TRUNC)), 0666);
+        if (fd < 0) return PC_ERR_BAD_ARG;
+        int64_t at = base;
+        for (const auto &v : parts) {
+            size_t done = 0;
+            while (done < v.size()) {
+                const ssize_t w = pwrite(fd, v.data() + done, v.size() - done, (off_t)(at + (int64_t)done));
+                if (w <= 0) { rc = PC_ERR_BAD_ARG; break; }
+                done += (size_t)w;
+            }
+            if (rc != PC_OK) break;
+            at += (int64_t)v.size();
+        }
+        if (close(fd) != 0) rc = PC_ERR_BAD_ARG;
+        file_pos[f] = at;
+    }
+    return rc;
+}
+
+void pc_gzimage_free(pc_gzimage *img) { delete img; }
+
+// The last member of a file of sized members: the empty one (28 bytes).  Creates the file when there is none (the
+// reference always leaves an output file behind: the gzip of nothing).
+int pc_gz_finish(const char *path)
+{
+    if (!path) return PC_ERR_BAD_ARG;
+    const int fd = open(path, O_WRONLY | O_CREAT | O_APPEND, 0666);
+    if (fd < 0) return PC_ERR_BAD_ARG;
+    const bool ok = write(fd, pcz::kEofBlock, sizeof pcz::kEofBlock) == (ssize_t)sizeof pcz::kEofBlock;
+    return (close(fd) == 0 && ok) ? PC_OK : PC_ERR_BAD_ARG;
+}
+
+// A whole file through the same compressor, all cores: src -> dst.  single_member = 0: sized members (pc_gz.h);
+// 1: ONE gzip member the way pigz makes it -- every block deflated on its own, ended at a byte boundary by a sync
+// flush, the blocks concatenated and their CRCs combined -- i.e. input nobody can inflate in parallel (bench / tests:
+// the reader's streamed route for ordinary .gz files).
+int pc_gzip_file(const char *src, const char *dst, int level, int single_member)
+{
+    if (!src || !dst) return PC_ERR_BAD_ARG;
+    level = pcz::default_level(level);
+    const int fd = open(src, O_RDONLY);
+    if (fd < 0) return PC_ERR_BAD_ARG;
+    struct stat st;
+    if (fstat(fd, &st) != 0) { close(fd); return PC_ERR_BAD_ARG; }
+    const size_t size = (size_t)st.st_size;
+    void *m = size ? mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0) : nullptr;
+    close(fd);
+    if (size && m == MAP_FAILED) return PC_ERR_BAD_ARG;
+    const char *base = (const char *)m;
+    const size_t unit = single_member ? ((size_t)1 << 20) : (pcz::kBlockIn * 16);
+    const size_t nunits = (size + unit - 1) / unit;
+    const int T = (int)std::max<size_t>(1, std::min<size_t>((size_t)usable_threads(), nunits));
+    // units are compressed in batches of 4 T, written in order after each batch (memory: a few MB per thread)
+    const int ofd = open(dst, O_WRONLY | O_CREAT | O_TRUNC, 0666);
+    if (ofd < 0) { if (m) munmap(m, size); return PC_ERR_BAD_ARG; }
+    bool ok = true;
+    auto put = [&](const void *p, size_t n) {
+        const char *c = (const char *)p;
+        while (n && ok) { const ssize_t w = write(ofd, c, n); if (w <= 0) { ok = false; break; } c += w; n -= (size_t)w; }
+    };
+    uLong crc = crc32(0L, Z_NULL, 0);
+    if (single_member) { const unsigned char hdr[10] = {0x1f, 0x8b, 8, 0, 0, 0, 0, 0, 0, 0xff}; put(hdr, 10); }
+    const size_t batch = (size_t)T * 4;
+    std::vector<std::vector<char>> outs(batch);
+    std::vector<uLong> crcs(batch, 0);
+    for (size_t u0 = 0; u0 < nunits && ok; u0 += batch) {
+        const size_t u1 = std::min(nunits, u0 + batch);
+        std::atomic<size_t> next{u0};
+        std::atomic<bool> good{true};
+        auto work = [&]() {
+            pcz::Deflater def(level);
+            z_stream zs;
+            memset(&zs, 0, sizeof zs);
+            bool z_ok = single_member && deflateInit2(&zs, level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) == Z_OK;
+            for (;;) {
+                const size_t u = next.fetch_add(1);
+                if (u >= u1) break;
+                const char *in = base + u * unit;
+                const size_t n = std::min(unit, size - u * unit);
+                std::vector<char> &o = outs[u - u0];
+                o.clear();
+                if (!single_member) {
+                    if (!def.usable() || !def.append(in, n, o)) good.store(false);
+                    continue;
+                }
+                if (!z_ok) { good.store(false); continue; }
+                deflateReset(&zs);
+                o.resize(deflateBound(&zs, (uLong)n) + 64);
+                zs.next_in = (Bytef *)in; zs.avail_in = (uInt)n;
+                zs.next_out = (Bytef *)o.data(); zs.avail_out = (uInt)o.size();
+                const bool last = u + 1 == nunits;
+                const int r = deflate(&zs, last ? Z_FINISH : Z_SYNC_FLUSH);
+                if ((last && r != Z_STREAM_END) || (!last && (r != Z_OK || zs.avail_in))) good.store(false);
+                o.resize(o.size() - zs.avail_out);
+                crcs[u - u0] = crc32(crc32(0L, Z_NULL, 0), (const Bytef *)in, (uInt)n);
+            }
+            if (z_ok) deflateEnd(&zs);
+        };
+        std::vector<std::thread> th;
+        for (int t = 1; t < T; ++t) th.emplace_back(work);
+        work();
+        for (auto &x : th) x.join();
+        if (!good.load()) ok = false;
+        for (size_t u = u0; u < u1 && ok; ++u) {
+            put(outs[u - u0].data(), outs[u - u0].size());
+            if (single_member) crc = crc32_combine(crc, crcs[u - u0], (z_off_t)std::min(unit, size - u * unit));
+        }
+    }
+    if (single_member) {
+        if (size == 0) { const unsigned char empty[2] = {3, 0}; put(empty, 2); }
+        unsigned char tr[8];
+        pcz::put32(tr, (uint32_t)crc); pcz::put32(tr + 4, (uint32_t)(size & 0xffffffffu));
+        put(tr, 8);
+    } else {
+        put(pcz::kEofBlock, sizeof pcz::kEofBlock);
+    }
+    if (close(ofd) != 0) ok = false;
+    if (m) munmap(m, size);
+    return ok ? PC_OK : PC_ERR_BAD_ARG;
+}
+
 static int write_pieces(const pc_readset *rs, int64_t npieces, const int64_t *piece_read, const int32_t *piece_start,
                         const int32_t *piece_len, const int32_t *piece_number, const int32_t *piece_file, int nfiles,
                         const char *const *file_paths, int fastq, int64_t *bytes_written, int64_t *file_pos, int shared,
-                        int64_t *sizes_only)
+                        int64_t *sizes_only, pc_gzimage *image, int gz_level)
 {
     if (!rs || npieces < 0 || nfiles < 0 || (npieces > 0 && (!piece_read || !piece_start || !piece_len || !piece_file || !file_paths)))
         return PC_ERR_BAD_ARG;
@@ -764,6 +1199,52 @@ static int write_pieces(const pc_readset *rs, int64_t npieces, const int64_t *pi
         for (size_t i = 0; i < idx.size(); ++i) at[i + 1] = at[i] + size_of(idx[i]);
         const size_t bytes = at.back();
         if (sizes_only) { sizes_only[f] = (int64_t)bytes; continue; }
+        if (image) {
+            // spans of about equal bytes, one thread each: format a chunk, deflate it, append the members to the span's part
+            const int T = (int)std::max<size_t>(1, std::min<size_t>((size_t)nthreads, bytes / ((size_t)1 << 20) + 1));
+            std::vector<size_t> cut((size_t)T + 1, idx.size());
+            cut[0] = 0;
+            for (int t = 1; t < T; ++t)
+                cut[(size_t)t] = (size_t)(std::lower_bound(at.begin(), at.end(), bytes / (size_t)T * (size_t)t) - at.begin());
+            auto &parts = image->parts[(size_t)f];
+            parts.assign((size_t)T, std::vector<char>());
+            image->plain[(size_t)f] = (int64_t)bytes;
+            std::vector<int> ok((size_t)T, 1);
+            auto work = [&](int t) {
+                pcz::Deflater def(gz_level);
+                if (!def.usable()) { ok[(size_t)t] = 0; return; }
+                std::vector<char> buf;
+                std::vector<char> &z = parts[(size_t)t];
+                size_t i = cut[(size_t)t];
+                const size_t stop = std::max(cut[(size_t)t], cut[(size_t)t + 1]);
+                z.reserve((at[stop] - at[i]) / 2 + 4096);
+                // chunks of whole members (16 x 65 280 bytes): only a span's last member is short
+                const size_t chunk = pcz::kBlockIn * 16;
+                size_t have = 0;                                  // bytes of buf not yet deflated
+                buf.resize(chunk + ((size_t)1 << 16));
+                while (i < stop) {
+                    const size_t need = size_of(idx[i]);
+                    if (have + need > buf.size()) buf.resize(std::max(buf.size() * 2, have + need));
+                    char *o = format(idx[i], buf.data() + have);
+                    if ((size_t)(o - (buf.data() + have)) != need) { ok[(size_t)t] = 0; return; }
+                    have += need; ++i;
+                    if (have >= chunk) {
+                        const size_t whole = have / pcz::kBlockIn * pcz::kBlockIn;
+                        if (!def.append(buf.data(), whole, z)) { ok[(size_t)t] = 0; return; }
+                        memmove(buf.data(), buf.data() + whole, have - whole);
+                        have -= whole;
+                    }
+                }
+                if (have && !def.append(buf.data(), have, z)) ok[(size_t)t] = 0;
+            };
+            std::vector<std::thread> th;
+            for (int t = 1; t < T; ++t) th.emplace_back(work, t);
+            work(0);
+            for (auto &x : th) x.join();
+            for (int t = 0; t < T; ++t) if (!ok[(size_t)t]) rc = PC_ERR_BAD_ARG;
+            total += (int64_t)bytes;
+            continue;
+        }
         if (to_stdout) {
             std::vector<char> buf;
             for (size_t i = 0; i < idx.size() && rc == PC_OK; ) {
@@ -793,7 +1274,8 @@ static int write_pieces(const pc_readset *rs, int64_t npieces, const int64_t *pi
             size_t map_len = 0, map_lead = 0;
             static const bool use_mmap = [] { const char *e = getenv("PC_IO_MMAP"); return e && *e && *e != '0'; }();
             std::mutex write_turn;
-            if (use_mmap && bytes >= ((size_t)1 << 22)) {
+            // (never for a file other processes write spans of: the ftruncate below would cut a higher rank's span off)
+            if (use_mmap && !shared && bytes >= ((size_t)1 << 22)) {
                 struct statvfs sv;
                 if (fstatvfs(fd, &sv) == 0 && (unsigned long long)sv.f_bavail * (unsigned long long)sv.f_frsize > (unsigned long long)bytes + ((unsigned long long)256 << 20) &&
                     ftruncate(fd, (off_t)(base_pos + bytes)) == 0) {

@@ -2,6 +2,7 @@
 (the C side is porechop_amd/csrc/pc_io.cpp; semantics of porechop/misc.py:60-168,
 nanopore_read.py:23-35 and, for writing, nanopore_read.py:97-147 + porechop.py:607-734)."""
 import ctypes
+import os
 
 import numpy as np
 
@@ -48,6 +49,89 @@ def fastq_record_start(path, byte_pos):
     out = ctypes.c_int64()
     rc = lib.pc_fastq_find_record(str(path).encode(), int(byte_pos), ctypes.byref(out))
     return int(out.value) if rc == 0 else None
+
+
+GZ_LEVEL = int(os.environ.get("PC_GZ_LEVEL", "0"))      # 0: the library's default (pc_gz.h default_level)
+
+
+def gzip_file(src, dst, level=None, single_member=False):
+    """src -> dst through the library's parallel compressor (pc_gzip_file): sized members, or ONE pigz-style member."""
+    rc = load_library().pc_gzip_file(str(src).encode(), str(dst).encode(), int(level if level is not None else GZ_LEVEL), 1 if single_member else 0)
+    if rc != 0:
+        raise OSError("Error: could not compress " + str(src))
+
+
+def gz_finish(path):
+    """The empty last member of a file of sized members (pc_gz_finish); creates the file when there is none."""
+    if load_library().pc_gz_finish(str(path).encode()) != 0:
+        raise OSError("Error: could not write " + str(path))
+
+
+class GzImage:
+    """The compressed image of some pieces, per file, in memory (pc_readset_compress)."""
+
+    def __init__(self, lib, handle, nfiles):
+        self.lib, self._h, self.nfiles = lib, handle, nfiles
+
+    def sizes(self):
+        """-> (compressed bytes, plain bytes) per file, numpy int64 [nfiles]."""
+        z = np.zeros(max(1, self.nfiles), dtype=np.int64)
+        pl = np.zeros(max(1, self.nfiles), dtype=np.int64)
+        if self.lib.pc_gzimage_sizes(self._h, self.nfiles, z.ctypes.data, pl.ctypes.data) != 0:
+            raise OSError("Error: could not size the compressed output")
+        return z[:self.nfiles], pl[:self.nfiles]
+
+    def write(self, file_paths, file_pos, shared=False):
+        """Every file's image at file_pos[f] (numpy int64, updated in place); shared: other processes write other spans."""
+        assert file_pos.dtype == np.int64 and file_pos.flags["C_CONTIGUOUS"] and file_pos.shape[0] == len(file_paths) == self.nfiles
+        paths = (ctypes.c_char_p * max(1, len(file_paths)))(*[str(p).encode() for p in file_paths])
+        if self.lib.pc_gzimage_write(self._h, self.nfiles, paths, file_pos.ctypes.data, 1 if shared else 0) != 0:
+            raise OSError("Error: could not write the output reads")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.pc_gzimage_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class GzStream:
+    """A gzip FASTQ file as a stream of ReadSet blocks (pc_gzstream_*): inflated ahead of the caller by a producer thread."""
+
+    def __init__(self, path):
+        self.lib = load_library()
+        self.path = str(path)
+        self._h = ctypes.c_void_p()
+        if self.lib.pc_gzstream_open(self.path.encode(), ctypes.byref(self._h)) != 0:
+            self._h = None
+            raise ValueError("not a gzip file: " + self.path)
+
+    def next(self, target_bytes, min_reads=0):
+        """-> a ReadSet; None at the end of the file; False when the input is not streamable (irregular FASTQ, damaged stream)."""
+        h = ctypes.c_void_p()
+        eof = ctypes.c_int()
+        rc = self.lib.pc_gzstream_next(self._h, int(target_bytes), int(min_reads), ctypes.byref(h), ctypes.byref(eof))
+        if rc != 0:
+            return False
+        if eof.value or not h:
+            return None
+        return ReadSet(self.path, _handle=h)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.pc_gzstream_close(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class ReadSet:
@@ -179,6 +263,23 @@ class ReadSet:
         if rc != 0:
             raise OSError("Error: could not size the output reads")
         return out[:nfiles]
+
+    def compress(self, piece_read, piece_start, piece_len, piece_number, piece_file, nfiles, fastq, level=None):
+        """The pieces write() would write, formatted and deflated by all cores into memory -> GzImage (pc_readset_compress)."""
+        pr = np.ascontiguousarray(piece_read, dtype=np.int64)
+        ps = np.ascontiguousarray(piece_start, dtype=np.int32)
+        pl = np.ascontiguousarray(piece_len, dtype=np.int32)
+        pn = np.ascontiguousarray(piece_number, dtype=np.int32)
+        pf = np.ascontiguousarray(piece_file, dtype=np.int32)
+        assert pr.shape == ps.shape == pl.shape == pn.shape == pf.shape
+        h = ctypes.c_void_p()
+        rc = self.lib.pc_readset_compress(self._h, pr.shape[0], pr.ctypes.data, ps.ctypes.data, pl.ctypes.data, pn.ctypes.data,
+                                          pf.ctypes.data, int(nfiles), 1 if fastq else 0, int(level if level is not None else GZ_LEVEL), ctypes.byref(h))
+        img = GzImage(self.lib, h, int(nfiles))
+        if rc != 0:
+            img.close()
+            raise OSError("Error: could not compress the output reads")
+        return img
 
     def write_shared(self, piece_read, piece_start, piece_len, piece_number, piece_file, file_paths, fastq, file_pos):
         """write_at() into files that other processes write disjoint spans of (a sharded run): never truncates

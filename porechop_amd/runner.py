@@ -17,7 +17,6 @@ The alignments come from the GPU library only (Pipeline's default aligner); outp
 byte-identical to the reference's (tests/test_runner_*.py).  Progress tables and coloured
 per-read dumps (verbosity >= 1 in the reference) are not reproduced: run() returns the numbers.
 """
-import gzip
 import os
 import re
 import shutil
@@ -31,7 +30,7 @@ import torch
 
 from . import panel as panel_rules
 from .distributed import gather_in_order, reduce_presence, shard_by_bases
-from .io import ReadSet
+from .io import GzStream, ReadSet, gz_finish
 from .pipeline import AdapterSet, DeviceReads, Pipeline, ScanParams, trimmed_interval
 from .pipeline import call_barcodes as _call_barcodes
 
@@ -74,6 +73,10 @@ class RunResult:
     out_format: str = "fastq"
     seconds: Dict[str, float] = field(default_factory=dict)      # wall-clock per stage
     counts: Dict[str, int] = field(default_factory=dict)         # whole-run tallies where start_trim / end_trim hold one rank's reads
+    # a sharded run (run_sharded): start_trim / end_trim / barcode_calls cover THIS rank's reads only -- reads
+    # [first_read, first_read + local_reads) of the n_reads of the file; everywhere else first_read = 0, local_reads = n_reads
+    first_read: int = 0
+    local_reads: Optional[int] = None
 
 
 # (read, adapter) pairs one block of phases B / C may hold at a time: 8 ints each, a few copies -> a few GB of HBM
@@ -193,10 +196,27 @@ def _resolve_format(opts: Options, output, barcode_dir, read_type, input_path):
     return fmt, gz
 
 
-def _gzip_file(src, dst):
-    with open(src, "rb") as fi, gzip.open(dst, "wb") as fo:
-        shutil.copyfileobj(fi, fo, 1 << 22)
-    os.remove(src)
+def _is_gzip(path):
+    # misc.py:60-81 get_compression_type: by magic bytes, not by name
+    try:
+        with open(path, "rb") as f:
+            return f.read(3) == b"\x1f\x8b\x08"
+    except OSError:
+        return False
+
+
+def _emit(rs, pr, ps_, pn_, num, pf, paths, fastq, file_pos, gz, shared=False):
+    """Pieces of one read set into their files at file_pos (updated): plain bytes (pc_readset_write_at / _shared), or --
+    gz -- formatted and deflated by all cores in memory, then written (pc_readset_compress: what the reference gets from
+    `pigz -p <threads>` over a temporary file, porechop.py:640-651,685-729).  A gz file is ended by io.gz_finish."""
+    if not gz:
+        (rs.write_shared if shared else rs.write_at)(pr, ps_, pn_, num, pf, paths, fastq, file_pos)
+        return
+    img = rs.compress(pr, ps_, pn_, num, pf, len(paths), fastq)
+    try:
+        img.write(paths, file_pos, shared=shared)
+    finally:
+        img.close()
 
 
 def _find_sets(pl, panel, reads, check_idx, opts, barcode_dir, sharded=False):
@@ -360,9 +380,18 @@ def run_streamed(input_path, output, barcode_dir, opts: Options, device=None, al
     block_bytes = block_bytes or _stream_block_bytes()
     size = os.path.getsize(input_path)
     t_start = time.perf_counter()
+    # .gz input: a producer thread inflates ahead (sized members on several cores, anything else through zlib) and hands
+    # over the same blocks the plain file would be cut into (io.GzStream / pc_gzstream_next)
+    gz_in = GzStream(input_path) if _is_gzip(input_path) else None
     # the first block is made large enough to hold the check reads (phase A looks at the first N reads of the file)
     first_bytes = block_bytes
-    while True:
+    pos = 0
+    if gz_in is not None:
+        first = gz_in.next(block_bytes, max(0, opts.check_reads))
+        if first is False or first is None:      # not a regular 4-line FASTQ (FASTA, damaged, empty): the whole-file loader's case
+            gz_in.close()
+            return None
+    while gz_in is None:
         first, pos = ReadSet.segment(input_path, 0, first_bytes)
         if first is None:
             return None
@@ -393,13 +422,9 @@ def run_streamed(input_path, output, barcode_dir, opts: Options, device=None, al
         target = None
     elif output is None:
         target = "-"
-    elif gz:
-        tmp = tempfile.NamedTemporaryFile(prefix="porechop_amd_", suffix="." + fmt, delete=False,
-                                          dir=os.path.dirname(os.path.abspath(output)))
-        tmp.close()
-        target = tmp.name
     else:
-        target = output
+        target = output                  # (gz: written compressed as it goes, no temporary file)
+    ext = "." + fmt + (".gz" if gz else "")
 
     # ---- loader: blocks 1.. (block 0 is in hand) ------------------------------------------------------
     loaded = queue.Queue(maxsize=1)
@@ -423,7 +448,16 @@ def run_streamed(input_path, output, barcode_dir, opts: Options, device=None, al
         p_ = pos
         io_lib.pc_io_set_thread_limit(share)
         try:
-            while p_ < size and not stop.is_set():
+            while gz_in is not None and not stop.is_set():
+                t0 = time.perf_counter()
+                rs_ = gz_in.next(block_bytes)
+                busy["load"] += time.perf_counter() - t0
+                if rs_ is None:
+                    break
+                if rs_ is False:
+                    raise ValueError("Error: " + input_path + " could not be parsed - is it formatted correctly?")
+                loaded.put(rs_)
+            while gz_in is None and p_ < size and not stop.is_set():
                 t0 = time.perf_counter()
                 rs_, nxt = ReadSet.segment(input_path, p_, block_bytes)
                 busy["load"] += time.perf_counter() - t0
@@ -452,12 +486,12 @@ def run_streamed(input_path, output, barcode_dir, opts: Options, device=None, al
                 if barcode_dir is not None:
                     pf = np.zeros(pr.size, dtype=np.int32)
                     for b in sorted(set(bins_of_piece)):
-                        path = os.path.join(barcode_dir, b + "." + fmt)
+                        path = os.path.join(barcode_dir, b + ext)
                         if path not in paths:
                             paths.append(path)
                             file_pos = np.concatenate([file_pos, np.zeros(1, dtype=np.int64)])
                     index = {p_: k for k, p_ in enumerate(paths)}
-                    pf = np.fromiter((index[os.path.join(barcode_dir, b + "." + fmt)] for b in bins_of_piece), dtype=np.int32,
+                    pf = np.fromiter((index[os.path.join(barcode_dir, b + ext)] for b in bins_of_piece), dtype=np.int32,
                                      count=len(bins_of_piece))
                 else:
                     if not paths:
@@ -466,7 +500,7 @@ def run_streamed(input_path, output, barcode_dir, opts: Options, device=None, al
                     pf = np.zeros(pr.size, dtype=np.int32)
                 if pr.size:
                     t1 = time.perf_counter()
-                    rs_.write_at(pr, ps_, pn_, num, pf, paths, fastq, file_pos)
+                    _emit(rs_, pr, ps_, pn_, num, pf, paths, fastq, file_pos, gz)
                     busy["write_call"] = busy.get("write_call", 0.0) + time.perf_counter() - t1
                 for k in np.unique(pf) if pr.size else []:
                     sel = pf == k
@@ -544,10 +578,12 @@ def run_streamed(input_path, output, barcode_dir, opts: Options, device=None, al
                 pass
         if aligner is None:
             pl.close()
+        if gz_in is not None:
+            gz_in.close()
     if failure:
         # a streamed run that fails part-way (a later block that cannot be parsed, a full disk) has already written the
         # earlier blocks: a whole-file run would have written nothing, so nothing is left behind here either
-        for path in list(paths) + ([target] if (output is not None and gz and target) else []):
+        for path in list(paths):
             try:
                 if path and path != "-" and os.path.isfile(path):
                     os.remove(path)
@@ -560,16 +596,14 @@ def run_streamed(input_path, output, barcode_dir, opts: Options, device=None, al
     # ---- what a whole-file run does after writing -------------------------------------------------------
     if barcode_dir is not None:
         for path in paths:
-            res.files[path + (".gz" if gz else "")] = stats.get(path, (0, 0))
+            res.files[path] = stats.get(path, (0, 0))
             if gz:
-                if os.path.isfile(path + ".gz"):
-                    os.remove(path + ".gz")
-                _gzip_file(path, path + ".gz")
+                gz_finish(path)
     elif output is not None:
         if not paths or file_pos[0] == 0:
             open(target, "wb").close()                              # the reference always creates the file
         if gz:
-            _gzip_file(target, output)
+            gz_finish(target)
         res.files[output] = stats.get(target, (0, 0))
     res.seconds = {"wall": time.perf_counter() - t_start, "load_busy": busy["load"], "scan_busy": busy["scan"], "write_busy": busy["write"],
                    "write_call_busy": busy.get("write_call", 0.0), "free_busy": busy.get("free", 0.0)}
@@ -652,6 +686,7 @@ def run_sharded(input_path, output, barcode_dir, opts: Options, device=None, ali
             names_all = _barcode_bin_names(pl, match_idx, orientation)
             calls = [names_all[k] if k >= 0 else "none" for k in ci]
         res.start_trim, res.end_trim, res.barcode_calls = st, et, calls          # this rank's reads
+        res.first_read, res.local_reads = first_read, R
         res.seconds["scan"] = time.perf_counter() - t0
 
         # ---- this rank's pieces, the files they go to, and where ------------------------------------------
@@ -671,23 +706,24 @@ def run_sharded(input_path, output, barcode_dir, opts: Options, device=None, ali
             index = {b: k for k, b in enumerate(bins)}
             paths = [os.path.join(barcode_dir, b + "." + fmt) for b in bins]
             pf = np.fromiter((index[calls[r]] for r in pr.tolist()), dtype=np.int32, count=int(pr.size))
-            finals = [p + (".gz" if gz else "") for p in paths]
+            paths = [p + (".gz" if gz else "") for p in paths]
         else:
-            if gz:
-                name = None
-                if rank == 0:
-                    tmp = tempfile.NamedTemporaryFile(prefix="porechop_amd_", suffix="." + fmt, delete=False,
-                                                      dir=os.path.dirname(os.path.abspath(output)))
-                    tmp.close()
-                    name = tmp.name
-                name = all_gather_objects(name)[0]
-                paths = [name]
-            else:
-                paths = [output]
+            paths = [output]
             pf = np.zeros(pr.size, dtype=np.int32)
-            finals = [output]
+        finals = paths
         nf = len(paths)
-        sizes = rs.write_sizes(pr, ps_, pn_, num, pf, nf, fastq) if (R and nf) else np.zeros(nf, dtype=np.int64)
+        # gz: every rank deflates its own pieces in memory first (independent members: any concatenation of them is a valid
+        # file), the COMPRESSED sizes are what the ranks exchange, and each writes its image at its position
+        img = None
+        failed = None
+        try:
+            if gz and R and nf:
+                img = rs.compress(pr, ps_, pn_, num, pf, nf, fastq)
+                sizes = img.sizes()[0]
+            else:
+                sizes = rs.write_sizes(pr, ps_, pn_, num, pf, nf, fastq) if (R and nf) else np.zeros(nf, dtype=np.int64)
+        except OSError as e:
+            failed, sizes = e, np.zeros(nf, dtype=np.int64)
         # per file: bytes, reads and bases of every rank (the reference counts reads, not pieces, and for bins their
         # end-trimmed -- or whole -- lengths)
         per_file = np.zeros((nf, 3), dtype=np.int64)
@@ -705,16 +741,31 @@ def run_sharded(input_path, output, barcode_dir, opts: Options, device=None, ali
             for path in paths:
                 open(path, "wb").close()                 # created / truncated ONCE, before any rank writes its span
         dist.barrier()
-        if R and pr.size:
-            rs.write_shared(pr, ps_, pn_, num, pf, paths, fastq, np.ascontiguousarray(pos))
-        dist.barrier()
+        # a rank that fails here alone (a full disk, a vanished directory) must not leave the others waiting in the
+        # next collective: the outcome is exchanged, every rank raises, rank 0 removes the partial files
+        try:
+            if failed is None and R and pr.size:
+                if img is not None:
+                    img.write(paths, np.ascontiguousarray(pos), shared=True)
+                else:
+                    rs.write_shared(pr, ps_, pn_, num, pf, paths, fastq, np.ascontiguousarray(pos))
+        except OSError as e:
+            failed = e
+        finally:
+            if img is not None:
+                img.close()
         totals = everyone.sum(axis=0)
-        if rank == 0:
-            for k, path in enumerate(paths):
-                if gz:
-                    if barcode_dir is not None and os.path.isfile(path + ".gz"):
-                        os.remove(path + ".gz")
-                    _gzip_file(path, finals[k])
+        if not all_agree(failed is None, coll_dev):
+            if rank == 0:
+                for path in paths:
+                    try:
+                        os.remove(path)
+                    except OSError:
+                        pass
+            raise failed if failed is not None else OSError("Error: could not write the output reads (another rank failed)")
+        if rank == 0 and gz:
+            for path in paths:
+                gz_finish(path)
         for k in range(nf):
             res.files[finals[k]] = (int(totals[k, 1]), int(totals[k, 2]))
         dist.barrier()
@@ -733,10 +784,12 @@ def run(input_path, output=None, barcode_dir=None, options: Options = None, devi
     """Porechop's main() on arrays.  output=None and barcode_dir=None writes to stdout.
     `aligner` is for tests only (see Pipeline).
 
-    Under torch.distributed (one process per GPU) the reads are sharded over the ranks in
-    contiguous blocks of about equal bases: every rank scans its block, the adapter-set presence
-    table of phase A is MAX-all-reduced (the only cross-read quantity in Porechop), the per-read
-    results are gathered in rank order, and rank 0 alone plans and writes the output -- the files
+    Under torch.distributed (one process per GPU) the reads are sharded over the ranks and the adapter-set presence
+    table of phase A is MAX-all-reduced (the only cross-read quantity in Porechop).  A plain FASTQ file takes
+    run_sharded: every rank parses, scans and WRITES only its own byte range of the input / span of the shared output
+    files, and its RunResult holds its own reads' trims (first_read, local_reads say which).  Anything else (gzip,
+    FASTA, a directory, stdout) falls back to every rank loading the input, contiguous blocks of about equal bases per
+    rank, the per-read results gathered in rank order and rank 0 alone planning and writing.  Either way the files
     are the single-process ones."""
     opts = options or Options()
     if len(tuple(opts.scoring_scheme)) != 4:
@@ -749,7 +802,8 @@ def run(input_path, output=None, barcode_dir=None, options: Options = None, devi
     input_path = str(input_path)
 
     import torch.distributed as dist
-    if (os.path.isfile(input_path) and os.path.getsize(input_path) > 2 * _stream_block_bytes()
+    # (a .gz file holds about three times its size in FASTQ)
+    if (os.path.isfile(input_path) and os.path.getsize(input_path) * (3 if _is_gzip(input_path) else 1) > 2 * _stream_block_bytes()
             and not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)):
         streamed = run_streamed(input_path, output, barcode_dir, opts, device=device, aligner=aligner, adapter_panel=adapter_panel)
         if streamed is not None:
@@ -857,33 +911,23 @@ def run(input_path, output=None, barcode_dir=None, options: Options = None, devi
             remap = np.full(len(all_bins), -1, dtype=np.int32)
             remap[used] = np.arange(used.size, dtype=np.int32)
             pf = remap[bin_of_read[pr]] if pr.size else np.zeros(0, dtype=np.int32)
-            paths = [os.path.join(barcode_dir, b + "." + fmt) for b in bins]
-            rs.write(pr, ps_, pn_, num, pf, paths, fastq)
+            paths = [os.path.join(barcode_dir, b + "." + fmt + (".gz" if gz else "")) for b in bins]
+            _emit(rs, pr, ps_, pn_, num, pf, paths, fastq, np.zeros(len(paths), dtype=np.int64), gz)
             for k, (b, path) in enumerate(zip(bins, paths)):
                 sel = pf == k
                 # the reference counts reads (not pieces) and their end-trimmed (or whole) lengths
                 rr = np.unique(pr[sel])
-                res.files[path + (".gz" if gz else "")] = (int(rr.size), int((rs.lengths[rr] if whole else tlen[rr]).sum()))
+                res.files[path] = (int(rr.size), int((rs.lengths[rr] if whole else tlen[rr]).sum()))
                 if gz:
-                    if os.path.isfile(path + ".gz"):
-                        os.remove(path + ".gz")
-                    _gzip_file(path, path + ".gz")
+                    gz_finish(path)
         elif output is None:
             rs.write(pr, ps_, pn_, num, np.zeros(pr.size, dtype=np.int32), ["-"], fastq)
         else:
+            open(output, "wb").close()                              # the reference always creates the file
+            if pr.size:
+                _emit(rs, pr, ps_, pn_, num, np.zeros(pr.size, dtype=np.int32), [output], fastq, np.zeros(1, dtype=np.int64), gz)
             if gz:
-                tmp = tempfile.NamedTemporaryFile(prefix="porechop_amd_", suffix="." + fmt, delete=False,
-                                                  dir=os.path.dirname(os.path.abspath(output)))
-                tmp.close()
-                target = tmp.name
-            else:
-                target = output
-            if pr.size == 0:
-                open(target, "wb").close()                          # the reference always creates the file
-            else:
-                rs.write(pr, ps_, pn_, num, np.zeros(pr.size, dtype=np.int32), [target], fastq)
-            if gz:
-                _gzip_file(target, output)
+                gz_finish(output)
             res.files[output] = (int(np.unique(pr).size), int(pn_.sum()))
         lap("write")
         return res

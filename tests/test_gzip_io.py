@@ -1,0 +1,221 @@
+"""gzip in and out at the speed of the rest (pc_gz.h / pc_io.cpp; replaces Python's gzip module on the way in,
+porechop/misc.py:60-81,151-168, and `pigz -p <threads>` on the way out, porechop/porechop.py:640-651,685-729).  No GPU.
+
+ * the compressor's two layouts -- sized members (BGZF) and ONE pigz-style member -- inflate to the input with Python's
+   gzip module and with the `gzip` program, with libdeflate and with zlib behind them;
+ * the whole-file loader reads all of them (sized members in parallel) into the same read set as the plain file;
+ * the streamed reader hands over exactly the blocks pc_readset_load_segment cuts the plain file into, whatever the
+   layout, keeps the check reads in its first block, and refuses what the whole-file loader must handle;
+ * runner.run() .fastq.gz -> .fastq.gz through the streamed route equals the plain route's output, byte for byte after
+   gunzip, and a sharded write with PC_IO_MMAP=1 no longer truncates another rank's span."""
+import gzip
+import hashlib
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from porechop_amd import io as pio
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def write_fastq(path, n, seed=1, max_len=3000):
+    rng = np.random.default_rng(seed)
+    with open(path, "w") as f:
+        for i in range(n):
+            L = int(rng.integers(1, max_len))
+            seq = "".join(np.array(list("ACGTN"))[rng.choice(5, L, p=[.245, .245, .245, .245, .02])])
+            q = "".join(chr(33 + int(x)) for x in rng.integers(0, 40, L))
+            f.write("@r%d desc=%d\n%s\n+\n%s\n" % (i, L, seq, q))
+    return path
+
+
+def md5(b):
+    return hashlib.md5(b).hexdigest()
+
+
+@pytest.fixture(scope="module")
+def files(tmp_path_factory):
+    d = tmp_path_factory.mktemp("gz")
+    plain = write_fastq(str(d / "reads.fastq"), 6000)
+    out = {"plain": plain, "dir": str(d)}
+    pio.gzip_file(plain, str(d / "sized.fastq.gz"))
+    pio.gzip_file(plain, str(d / "single.fastq.gz"), single_member=True)
+    subprocess.run("gzip -1 -c %s > %s" % (plain, d / "cli.fastq.gz"), shell=True, check=True)
+    # two members the ordinary way (cat a.gz b.gz), no size subfields
+    data = open(plain, "rb").read()
+    cut = data.index(b"\n@r3000 ") + 1
+    with open(d / "concat.fastq.gz", "wb") as f:
+        f.write(gzip.compress(data[:cut], 1))
+        f.write(gzip.compress(data[cut:], 1))
+    out.update(sized=str(d / "sized.fastq.gz"), single=str(d / "single.fastq.gz"), cli=str(d / "cli.fastq.gz"), concat=str(d / "concat.fastq.gz"))
+    return out
+
+
+def test_compressor_layouts_inflate_to_the_input(files):
+    want = md5(open(files["plain"], "rb").read())
+    for k in ("sized", "single"):
+        assert md5(gzip.open(files[k], "rb").read()) == want, k
+        assert md5(subprocess.run(["gzip", "-dc", files[k]], capture_output=True, check=True).stdout) == want, k
+    raw = open(files["sized"], "rb").read()
+    assert raw[:4] == b"\x1f\x8b\x08\x04" and raw[12:14] == b"BC"
+    assert raw.endswith(bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000"))       # the BGZF end marker
+    # every level, and zlib behind the same interface (a fresh process: the choice is made once)
+    for lvl in (1, 9):
+        dst = os.path.join(files["dir"], "lvl%d.gz" % lvl)
+        pio.gzip_file(files["plain"], dst, level=lvl)
+        assert md5(gzip.open(dst, "rb").read()) == want
+    code = ("import sys, gzip, hashlib; sys.path.insert(0, %r); from porechop_amd import io as pio; "
+            "pio.gzip_file(%r, %r); pio.gzip_file(%r, %r, single_member=True); "
+            "print(hashlib.md5(gzip.open(%r, 'rb').read()).hexdigest(), hashlib.md5(gzip.open(%r, 'rb').read()).hexdigest(), pio.ReadSet(%r).count)"
+            % (REPO, files["plain"], files["dir"] + "/z1.gz", files["plain"], files["dir"] + "/z2.gz", files["dir"] + "/z1.gz",
+               files["dir"] + "/z2.gz", files["dir"] + "/z1.gz"))
+    res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, PC_NO_LIBDEFLATE="1"))
+    assert res.stdout.split() == [want, want, "6000"], res.stdout + res.stderr
+    # empty input
+    empty = os.path.join(files["dir"], "empty")
+    open(empty, "wb").close()
+    for single in (False, True):
+        pio.gzip_file(empty, empty + ".gz", single_member=single)
+        assert gzip.open(empty + ".gz", "rb").read() == b""
+
+
+def test_whole_file_loader_reads_every_layout(files):
+    ref = pio.ReadSet(files["plain"])
+    want = (ref.count, md5(ref.arena.tobytes()), md5(ref.lengths.tobytes()), ref.name(17), ref.quals(5999))
+    for k in ("sized", "single", "cli", "concat"):
+        rs = pio.ReadSet(files[k])
+        assert (rs.count, md5(rs.arena.tobytes()), md5(rs.lengths.tobytes()), rs.name(17), rs.quals(5999)) == want, k
+        rs.close()
+    # a damaged sized member falls back to the stream reader, which reports the damage like any gzip error
+    raw = bytearray(open(files["sized"], "rb").read())
+    raw[len(raw) // 2] ^= 0xFF
+    bad = os.path.join(files["dir"], "bad.fastq.gz")
+    open(bad, "wb").write(bytes(raw))
+    with pytest.raises(ValueError):
+        pio.ReadSet(bad)
+
+
+def test_stream_blocks_equal_the_plain_files_segments(files):
+    size = os.path.getsize(files["plain"])
+    for block in (300_000, 2_000_000, 1 << 30):
+        want, pos = [], 0
+        while pos < size:
+            rs, nxt = pio.ReadSet.segment(files["plain"], pos, block)
+            want.append((rs.count, md5(rs.arena.tobytes()), rs.name(0), rs.quals(rs.count - 1)))
+            rs.close()
+            pos = nxt
+        for k in ("sized", "single", "cli", "concat"):
+            st = pio.GzStream(files[k])
+            got = []
+            while True:
+                rs = st.next(block)
+                assert rs is not False
+                if rs is None:
+                    break
+                got.append((rs.count, md5(rs.arena.tobytes()), rs.name(0), rs.quals(rs.count - 1)))
+                rs.close()
+            st.close()
+            assert got == want, (k, block, len(got), len(want))
+    # the first block holds the check reads however small the target
+    st = pio.GzStream(files["sized"])
+    rs = st.next(10_000, min_reads=2500)
+    assert rs.count >= 2500
+    st.close()
+    # closing a stream whose producer is still ahead does not hang
+    st = pio.GzStream(files["cli"])
+    st.next(1000).close()
+    st.close()
+
+
+def test_stream_refuses_what_the_whole_file_loader_must_handle(files):
+    d = files["dir"]
+    fasta = os.path.join(d, "x.fasta")
+    open(fasta, "w").write(">a\nACGT\n>b\nGGCC\n")
+    pio.gzip_file(fasta, fasta + ".gz")
+    st = pio.GzStream(fasta + ".gz")
+    assert st.next(1000) is False
+    st.close()
+    assert pio.ReadSet(fasta + ".gz").count == 2
+    irregular = os.path.join(d, "irr.fastq")
+    open(irregular, "w").write("@a\nACGT\n+\nIIII\n\n@b\nAC\n+\nII\n" * 50)
+    pio.gzip_file(irregular, irregular + ".gz", single_member=True)
+    st = pio.GzStream(irregular + ".gz")
+    assert st.next(64) is False
+    st.close()
+    with pytest.raises(ValueError):
+        pio.GzStream(files["plain"])          # not gzip
+    truncated = os.path.join(d, "trunc.fastq.gz")
+    open(truncated, "wb").write(open(files["cli"], "rb").read()[:-4000])
+    st = pio.GzStream(truncated)
+    seen = []
+    while True:
+        rs = st.next(1 << 30)
+        seen.append(rs)
+        if rs is None or rs is False:
+            break
+    assert seen[-1] is False
+    st.close()
+
+
+def test_runner_gz_to_gz_streamed_equals_plain_route(oracle, tmp_path, monkeypatch):
+    from porechop_amd import runner
+    from tests import readgen
+    from tests.cpu_aligner import OracleAligner
+    inp = readgen.build_dataset("native", str(tmp_path / "datasets"))
+    for layout, single in (("sized", False), ("single", True)):
+        pio.gzip_file(inp, str(tmp_path / (layout + ".fastq.gz")), single_member=single)
+    mk = lambda: OracleAligner(oracle, (3, -6, -5, -2))
+    runner.run(inp, output=str(tmp_path / "plain.fastq"), aligner=mk())
+    want = md5(open(tmp_path / "plain.fastq", "rb").read())
+    runner.run(inp, barcode_dir=str(tmp_path / "bins_plain"), aligner=mk())
+    want_bins = {f: md5(open(tmp_path / "bins_plain" / f, "rb").read()) for f in os.listdir(tmp_path / "bins_plain")}
+    monkeypatch.setenv("PC_STREAM_BLOCK_BYTES", "5000")
+    streamed = []
+    real = runner.run_streamed
+    monkeypatch.setattr(runner, "run_streamed", lambda *a, **k: (streamed.append(1), real(*a, **k))[1])
+    for layout in ("sized", "single"):
+        out = tmp_path / (layout + "_out.fastq.gz")
+        res = runner.run(str(tmp_path / (layout + ".fastq.gz")), output=str(out), aligner=mk())
+        assert md5(gzip.open(out, "rb").read()) == want, layout
+        assert open(out, "rb").read()[12:14] == b"BC" and str(out) in res.files
+        bins = tmp_path / ("bins_" + layout)
+        runner.run(str(tmp_path / (layout + ".fastq.gz")), barcode_dir=str(bins), aligner=mk())
+        # (gz input and -b: the reference writes gz bins, porechop.py:627-631)
+        got = {f[:-3]: md5(gzip.open(bins / f, "rb").read()) for f in os.listdir(bins)}
+        assert all(f.endswith(".gz") for f in os.listdir(bins)) and got == want_bins, layout
+    assert len(streamed) == 4
+    # plain in, gz out, whole-file route; and nothing to write still leaves a valid (empty) gzip file
+    monkeypatch.setenv("PC_STREAM_BLOCK_BYTES", str(1 << 30))
+    runner.run(inp, output=str(tmp_path / "whole.fastq.gz"), aligner=mk())
+    assert md5(gzip.open(tmp_path / "whole.fastq.gz", "rb").read()) == want
+    empty = tmp_path / "none.fastq"
+    empty.write_text("@a\nACGT\n+\nIIII\n")
+    opts = runner.Options(min_split_read_size=1000, discard_middle=False)
+    runner.run(str(empty), output=str(tmp_path / "e.fastq.gz"), options=opts, aligner=mk())
+    assert gzip.open(tmp_path / "e.fastq.gz", "rb").read() in (b"", b"@a\nACGT\n+\nIIII\n")
+
+
+def test_shared_write_with_mmap_keeps_other_spans(tmp_path, monkeypatch):
+    """with PC_IO_MMAP=1 the shared writer's ftruncate cut a higher rank's span off."""
+    plain = write_fastq(str(tmp_path / "r.fastq"), 4000, seed=3, max_len=6000)
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, %r)
+from porechop_amd import io as pio
+rs = pio.ReadSet(%r)
+n = rs.count
+pr = np.arange(n, dtype=np.int64); ps = np.zeros(n, dtype=np.int32); pn = rs.lengths.copy(); num = np.zeros(n, dtype=np.int32)
+half = n // 2
+sizes_a = rs.write_sizes(pr[:half], ps[:half], pn[:half], num[:half], np.zeros(half, dtype=np.int32), 1, True)
+open(%r, "wb").close()
+# the SECOND half first, at its offset; then the first half at 0
+rs.write_shared(pr[half:], ps[half:], pn[half:], num[half:], np.zeros(n - half, dtype=np.int32), [%r], True, np.array([sizes_a[0]], dtype=np.int64))
+rs.write_shared(pr[:half], ps[:half], pn[:half], num[:half], np.zeros(half, dtype=np.int32), [%r], True, np.zeros(1, dtype=np.int64))
+''' % (REPO, plain, str(tmp_path / "o.fastq"), str(tmp_path / "o.fastq"), str(tmp_path / "o.fastq"))
+    res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, PC_IO_MMAP="1"))
+    assert res.returncode == 0, res.stderr
+    assert md5(open(tmp_path / "o.fastq", "rb").read()) == md5(open(plain, "rb").read())

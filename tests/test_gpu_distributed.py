@@ -150,7 +150,8 @@ def test_two_ranks_on_one_gpu_emit_the_configs4_leg_for_both_ranks():
     per-GPU configs[4] shape run by BOTH ranks (n_gpus 2, the exact-prefilter + pruned variant giving the same trims, calls
     and middle hits as the full computation on every rank), both ranks' timed regions, and phase A's check-read shares must
     sum to --check_reads (porechop.py:86)."""
-    args = ["--gpus", "2", "--steps", "1", "--warmup", "1", "--reads", "60000", "--reads4", "30000", "--cpu-seconds", "0", "--repeats", "1"]
+    args = ["--gpus", "2", "--steps", "1", "--warmup", "1", "--reads", "60000", "--reads4", "30000", "--cpu-seconds", "0", "--repeats", "1",
+            "--reads4-total", "100000", "--reads-e2e", "40000"]
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", PC_DIST_BACKEND="gloo")
     run = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                           "--master-port", str(_free_port()), "bench.py"] + args, cwd=REPO, env=env, capture_output=True, text=True, timeout=1500)
@@ -164,3 +165,11 @@ def test_two_ranks_on_one_gpu_emit_the_configs4_leg_for_both_ranks():
     assert c4["n_gpus"] == 2 and c4["reads_per_gpu"] == 30000
     assert c4["fast_same"] is True and d["config"]["c4_fast_same"] is True
     assert c4["reads_per_s"] > 0 and c4["fast_reads_per_s"] > c4["reads_per_s"]
+    # what N GPUs share is in these two (task 5): BASELINE configs[4] as a FIXED total from host memory, and one
+    # file in -> one file out over the ranks
+    ft = d["legs"]["configs4_fixed_total"]
+    assert ft["scaling"] == "strong" and ft["n_gpus"] == 2 and ft["reads_total"] == 100000 and ft["world_size_seen"] == 2
+    assert ft["fast_same"] is True and len(ft["ms_by_rank"]) == 2 and sum(ft["check_reads_by_rank"]) == 10000
+    assert ft["host_threads_per_rank"] >= 1 and ft["reads_per_s"] > 0
+    sf = d["legs"]["sharded_file"]
+    assert sf["md5_equal"] is True and sum(sf["reads_by_rank"]) == 40000 and min(sf["reads_by_rank"]) > 0

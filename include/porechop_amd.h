@@ -292,6 +292,24 @@ int pc_prefilter_device(pc_ctx *ctx, const void *d_arena, const int64_t *d_win_o
                         int64_t nwindows, int max_len, const int32_t *adapters, const int32_t *max_edits,
                         int nadapters, uint32_t *d_mask, void *stream);
 
+/* The prefilter over reads held at 2 BITS PER BASE (north_star: "2-bit-packed read windows"): d_plane is pc_pack_reads' plane
+ * in HBM -- a quarter of the bytes of the one HBM-bound kernel of the path, and sixteen bases ARE a dword: no byte -> code
+ * step, one funnel shift per q-gram (csrc/pc_prefilter.hip seed_scan_packed_kernel) -- d_win_off counts BASES of the plane.
+ * Same mask, same meaning.  Bases that were not A/C/G/T/U sit in the plane as 'A' and the exception list is NOT consulted:
+ * against adapters made of A/C/G/T(U) that can only ADD survivors, so a cleared bit is still a proof.  The route takes only
+ * such adapters, and only where the seed stage covers every piece (parts of >= 6 bases): otherwise
+ * PC_ERR_UNSUPPORTED_SCORES -- unpack the reads (pc_unpack_device) and call pc_prefilter_device.  d_plane 16-byte aligned
+ * and readable 64 bytes past its last base.
+ * pc_unpack_windows: n windows of the plane (d_src_off in bases, ascending, not overlapping; d_len) as bytes -- 'A' 'C' 'G' 'T',
+ * 'N' at the exceptions -- window i at d_dst + d_dst_off[i], padded with `pad` up to d_dst_off[i + 1] (d_dst_off has n + 1
+ * entries).  What a run that keeps its reads packed unpacks: the 150-base end windows of every read and the whole of the
+ * few reads that survive the prefilter. */
+int pc_prefilter_packed(pc_ctx *ctx, const void *d_plane, const int64_t *d_win_off, const int32_t *d_win_len,
+                        int64_t nwindows, int max_len, const int32_t *adapters, const int32_t *max_edits,
+                        int nadapters, uint32_t *d_mask, void *stream);
+int pc_unpack_windows(pc_ctx *ctx, const void *d_plane, const int64_t *d_exc_pos, int64_t nexc, const int64_t *d_src_off,
+                      const int32_t *d_len, int64_t n, void *d_dst, const int64_t *d_dst_off, int pad, void *stream);
+
 /* Debug builds of the 16-bit kernels (PC_CHECK_RANGE=1: packed-fp16 traced kernel, row classes 24/28/30/40;
  * PC_JIT_CHECK_RANGE=1: the run-time specialised score kernel) record the extremes of every DP value they
  * hold, in the kernel's own offset coordinates; this returns them since the last call and resets.  The

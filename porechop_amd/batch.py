@@ -308,11 +308,54 @@ class Aligner:
               "pc_prefilter_device")
         return mask
 
-    def prefilter_rows(self, arena, win_off, win_len, max_len, adapters, max_edits, stream=None):
+    def prefilter_mask_packed(self, plane, win_off, win_len, max_len, adapters, max_edits, stream=None):
+        """prefilter_mask over reads held at 2 bits per base (pc_prefilter_packed): plane = the uint8 CUDA tensor of
+        io.pack_reads' plane (64 readable bytes past the last base), win_off in BASES.  -> the mask, or None when this
+        adapter list does not take the packed route (an adapter with a letter other than A/C/G/T/U, or one the seed stage
+        cannot cover): unpack and call prefilter_mask."""
+        import torch
+        assert plane.is_cuda and plane.dtype == torch.uint8 and win_off.is_cuda and win_len.is_cuda
+        assert win_off.dtype == torch.int64 and win_len.dtype == torch.int32 and win_off.is_contiguous() and win_len.is_contiguous()
+        n, na = int(win_off.shape[0]), len(adapters)
+        words = (na + 31) // 32
+        mask = torch.empty((n, max(words, 1)), dtype=torch.int32, device=plane.device)
+        if na == 0:
+            return mask.zero_()
+        ad = np.ascontiguousarray(adapters, dtype=np.int32)
+        ed = np.ascontiguousarray(max_edits, dtype=np.int32)
+        s = stream if stream is not None else torch.cuda.current_stream().cuda_stream
+        rc = self.lib.pc_prefilter_packed(self._ctx, plane.data_ptr(), win_off.data_ptr(), win_len.data_ptr(), n, int(max_len),
+                                          ad.ctypes.data, ed.ctypes.data, na, mask.data_ptr(), ctypes.c_void_p(s))
+        if rc == -2:                              # PC_ERR_UNSUPPORTED_SCORES: not a list for the packed route
+            return None
+        check(rc, "pc_prefilter_packed")
+        return mask
+
+    def unpack_windows(self, plane, exceptions, src_off, length, dst, dst_off, pad=ord("N"), stream=None):
+        """Windows of the 2-bit plane as bytes (pc_unpack_windows): src_off int64[n] in bases (ascending, not overlapping),
+        length int32[n], dst uint8, dst_off int64[n + 1]; 'N' at the listed exceptions (int64, ascending; may be None)."""
+        import torch
+        n = int(src_off.shape[0])
+        assert plane.is_cuda and dst.is_cuda and src_off.dtype == torch.int64 and length.dtype == torch.int32
+        assert dst_off.dtype == torch.int64 and int(dst_off.shape[0]) == n + 1
+        assert src_off.is_contiguous() and length.is_contiguous() and dst_off.is_contiguous()
+        ne = 0 if exceptions is None else int(exceptions.numel())
+        s = stream if stream is not None else torch.cuda.current_stream().cuda_stream
+        check(self.lib.pc_unpack_windows(self._ctx, plane.data_ptr(), exceptions.data_ptr() if ne else None, ne, src_off.data_ptr(),
+                                         length.data_ptr(), n, dst.data_ptr(), dst_off.data_ptr(), int(pad), ctypes.c_void_p(s)),
+              "pc_unpack_windows")
+        return dst
+
+    def prefilter_rows(self, arena, win_off, win_len, max_len, adapters, max_edits, stream=None, packed=False):
         """The prefilter's survivors, sparsely: -> (rows int64 [R]: the windows with at least one surviving adapter, in
         increasing order; bits bool [R, len(adapters)]: which).  Everything not listed is PROVEN not to be a hit."""
         import torch
-        mask = self.prefilter_mask(arena, win_off, win_len, max_len, adapters, max_edits, stream)
+        if packed:              # arena is the 2-bit plane, win_off counts bases; None = this list does not take the packed route
+            mask = self.prefilter_mask_packed(arena, win_off, win_len, max_len, adapters, max_edits, stream)
+            if mask is None:
+                return None
+        else:
+            mask = self.prefilter_mask(arena, win_off, win_len, max_len, adapters, max_edits, stream)
         na = len(adapters)
         rows = torch.nonzero((mask != 0).any(dim=1)).flatten()
         sub = mask[rows]

@@ -426,7 +426,7 @@ int build_tiles(pc_ctx *c, const int32_t *job_adapter, const int32_t *job_adapte
     return PC_OK;
 }
 
-constexpr int kMaxChunks = 64;
+constexpr int kMaxChunks = 64, kMaxChunksLong = 2048;
 
 // Columns the register variants' drifting coordinates (pc_kernels.hip, column_step) can run before
 // int16 needs a renormalisation: values drift up by eps = -gap_extend per column on top of a true
@@ -494,7 +494,11 @@ int group_chunks_for(const pc_ctx *c, const Group &g, int max_len)
     int chunks = chunks_for((int64_t)g.tile_count, resident_waves(c, g), max_len, g.max_window);
     if (ragged_lengths(c, max_len)) {
         const int unit = std::max(c->len_hint, std::max(512, 4 * g.max_window));
-        chunks = std::max(chunks, std::min(kMaxChunks, (max_len + unit - 1) / unit));
+        // (a batch whose longest read is a hundred times the typical one -- a 4 Mb read among 20 kb reads -- needs more than
+        // kMaxChunks units of typical length: up to kMaxChunksLong, as far as the [pair][chunk] pass-1 buffer stays below 1 GiB)
+        const int64_t pairs = std::max<int64_t>(1, group_pairs(g, 0, g.tile_count));
+        const int by_memory = (int)std::max<int64_t>(kMaxChunks, std::min<int64_t>(kMaxChunksLong, ((int64_t)1 << 30) / (pairs * 16)));
+        chunks = std::max(chunks, std::min(by_memory, (max_len + unit - 1) / unit));
     }
     return chunks;
 }
@@ -1265,9 +1269,44 @@ int pc_prefilter_max_edits(int adapter_len, double threshold_percent)
     return k > adapter_len ? adapter_len : k;
 }
 
+static int prefilter_impl(pc_ctx *c, const void *d_arena, const int64_t *d_win_off, const int32_t *d_win_len,
+                          int64_t nwindows, int max_len, const int32_t *adapters, const int32_t *max_edits, int nadapters,
+                          uint32_t *d_mask, void *stream_v, int packed);
+
 int pc_prefilter_device(pc_ctx *c, const void *d_arena, const int64_t *d_win_off, const int32_t *d_win_len,
                         int64_t nwindows, int max_len, const int32_t *adapters, const int32_t *max_edits, int nadapters,
                         uint32_t *d_mask, void *stream_v)
+{
+    return prefilter_impl(c, d_arena, d_win_off, d_win_len, nwindows, max_len, adapters, max_edits, nadapters, d_mask, stream_v, 0);
+}
+
+// The same decision over reads held at 2 bits per base (pc_pack_reads' plane; d_win_off counts BASES; the plane must be
+// 16-byte aligned and readable 64 bytes past its last base).  Only the seed stage exists for this form: every adapter must be
+// made of A/C/G/T(U) and seedable (parts of >= 6 bases, <= 7 edits) -- else PC_ERR_UNSUPPORTED_SCORES, and the caller unpacks
+// the reads and takes pc_prefilter_device.  Bases that were not A/C/G/T/U are seen as 'A': against such adapters that can only
+// add survivors, never remove one, so a cleared bit is still a proof.
+int pc_prefilter_packed(pc_ctx *c, const void *d_plane, const int64_t *d_win_off, const int32_t *d_win_len,
+                        int64_t nwindows, int max_len, const int32_t *adapters, const int32_t *max_edits, int nadapters,
+                        uint32_t *d_mask, void *stream_v)
+{
+    if (((uintptr_t)d_plane & 15u) != 0) return PC_ERR_BAD_ARG;
+    return prefilter_impl(c, d_plane, d_win_off, d_win_len, nwindows, max_len, adapters, max_edits, nadapters, d_mask, stream_v, 1);
+}
+
+int pc_unpack_windows(pc_ctx *c, const void *d_plane, const int64_t *d_exc_pos, int64_t nexc, const int64_t *d_src_off,
+                      const int32_t *d_len, int64_t n, void *d_dst, const int64_t *d_dst_off, int pad, void *stream_v)
+{
+    if (!c || n < 0 || nexc < 0) return PC_ERR_BAD_ARG;
+    if (n == 0) return PC_OK;
+    if (!d_plane || !d_src_off || !d_len || !d_dst || !d_dst_off || (nexc && !d_exc_pos) || ((uintptr_t)d_plane & 3u)) return PC_ERR_BAD_ARG;
+    (void)hipSetDevice(c->device);
+    hipStream_t stream = (stream_v == PC_STREAM_CONTEXT) ? c->stream : (hipStream_t)stream_v;
+    return pck::launch_unpack_windows(d_plane, d_exc_pos, nexc, d_src_off, d_len, n, (uint8_t *)d_dst, d_dst_off, pad, stream) ? PC_ERR_NO_DEVICE : PC_OK;
+}
+
+static int prefilter_impl(pc_ctx *c, const void *d_arena, const int64_t *d_win_off, const int32_t *d_win_len,
+                          int64_t nwindows, int max_len, const int32_t *adapters, const int32_t *max_edits, int nadapters,
+                          uint32_t *d_mask, void *stream_v, int packed)
 {
     if (!c || nwindows < 0 || nadapters < 0 || max_len < 0) return PC_ERR_BAD_ARG;
     if (nwindows == 0 || nadapters == 0) return PC_OK;
@@ -1278,6 +1317,7 @@ int pc_prefilter_device(pc_ctx *c, const void *d_arena, const int64_t *d_win_off
     const int words = (nadapters + 31) / 32;
     std::vector<int32_t> key(adapters, adapters + nadapters);
     key.insert(key.end(), max_edits, max_edits + nadapters);
+    key.push_back(packed ? 1 : 0);                               // (the seed tables differ: q-gram orientation and base codes)
     if (key != c->pf_key) {
         // the cached seed / table state is rebuilt member by member below: until ALL of it is in place (the key is set last)
         // no key may name it -- a failed upload half-way must not leave the old key over mixed tables
@@ -1361,11 +1401,24 @@ int pc_prefilter_device(pc_ctx *c, const void *d_arena, const int64_t *d_win_off
         std::vector<size_t> rest_piece;
         bool have_q[9] = {false, false, false, false, false, false, false, false, false};
         static const bool no_seeds = [] { const char *e = getenv("PC_PF_NO_SEEDS"); return e && *e && *e != '0'; }();
+        // ONE seed length for all pieces -- the shortest any seeded piece needs: a longer part's seed is its first q bases, which an
+        // occurrence that leaves the part untouched contains just the same.  The scan then probes ONE bitmap per read base instead
+        // of one per seed length (its LDS probes and its 4 VALU operations per base and length were what bound it: DESIGN.md
+        // section 4); the price is a few more candidates for the verifier (an 8-base seed cut to 7 is found four times as often).
+        // PC_PF_MULTI_Q=1: a bitmap per seed length, as before.
+        static const bool multi_q = [] { const char *e = getenv("PC_PF_MULTI_Q"); return e && *e && *e != '0'; }();
+        int q_common = 8;
+        for (const Piece &pc : pieces) {
+            const int parts = pc.k + 1;
+            const int q = std::min(8, pc.len / std::max(1, parts));
+            if (pc.k >= 0 && pc.k < pc.len && parts <= 8 && q >= 6) q_common = std::min(q_common, q);
+        }
         for (size_t i = 0; i < pieces.size(); ++i) {
             const Piece &pc = pieces[i];
             const int parts = pc.k + 1;
-            const int q = std::min(8, pc.len / std::max(1, parts));
+            int q = std::min(8, pc.len / std::max(1, parts));
             bool ok = !no_seeds && pc.k >= 0 && pc.k < pc.len && parts <= 8 && q >= 6;
+            if (ok && !multi_q) q = q_common;
             std::vector<Seed> mine;
             if (ok) {
                 const std::string &ad = c->adapters[pc.adapter];
@@ -1376,12 +1429,18 @@ int pc_prefilter_device(pc_ctx *c, const void *d_arena, const int64_t *d_win_off
                     for (int r = 0; r < q; ++r) {
                         const unsigned char ch = (unsigned char)ad[pc.begin + pos + r];
                         if (dna5(ch) > 3) { ok = false; break; }
-                        // the seed scan's code of a base: bits 1-2 of its ASCII byte (A 0, C 1, T/U 2, G 3; either case)
-                        gram = (gram << 2) | (((uint32_t)ch >> 1) & 3u);
+                        // byte route: the seed scan's code of a base is bits 1-2 of its ASCII byte (A 0, C 1, T/U 2, G 3; either
+                        // case), first base in the HIGHEST bits; packed route: the plane's Dna ordinals, first base in the LOWEST
+                        if (packed) gram |= (uint32_t)dna5(ch) << (2 * r);
+                        else gram = (gram << 2) | (((uint32_t)ch >> 1) & 3u);
                     }
                     mine.push_back({q, gram, (int)seeded_piece.size(), pos});
                     pos += plen;
                 }
+            }
+            if (ok && packed) {
+                const std::string &ad = c->adapters[pc.adapter];
+                for (char ch : ad) if (dna5((unsigned char)ch) > 3) ok = false;      // (an 'N' of the adapter would match the read's 'N')
             }
             if (ok) {
                 have_q[q] = true;
@@ -1391,6 +1450,7 @@ int pc_prefilter_device(pc_ctx *c, const void *d_arena, const int64_t *d_win_off
                 rest_piece.push_back(i);
             }
         }
+        if (packed && (!rest_piece.empty() || multi_q)) return PC_ERR_UNSUPPORTED_SCORES;   // only the seed stage reads the plane
         c->sd_nq = 0;
         int cls_of_q[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
         for (int q = 8; q >= 6; --q) if (have_q[q]) { cls_of_q[q] = c->sd_nq; c->sd_q[c->sd_nq++] = q; }
@@ -1483,6 +1543,7 @@ int pc_prefilter_device(pc_ctx *c, const void *d_arena, const int64_t *d_win_off
     }
     HIP_TRY(hipMemsetAsync(d_mask, 0, (size_t)nwindows * words * 4, stream));
     if (c->pf_launches.empty() || max_len == 0) return PC_OK;
+    if (packed && (c->sd_nq != 1 || !c->pf_rest_launches.empty())) return PC_ERR_UNSUPPORTED_SCORES;
     // column chunks: enough (window, chunk) units to fill the chip several times over, chunks no shorter than 512
     // columns (the warm-up before a chunk is the longest piece + its edit bound: ~35 columns)
     const int64_t target = (int64_t)c->ncu * 2048 * 6;
@@ -1534,9 +1595,9 @@ int pc_prefilter_device(pc_ctx *c, const void *d_arena, const int64_t *d_win_off
     sa.max_len = max_len; sa.err = c->d_err.as<uint32_t>();
     {
         ScopedTimer ts(c, stream, 5, nwindows);     // the scan alone (pairs = windows)
-        if (pck::launch_seed_scan(sa, stream)) return PC_ERR_NO_DEVICE;
+        if (packed ? pck::launch_seed_scan_packed(sa, stream) : pck::launch_seed_scan(sa, stream)) return PC_ERR_NO_DEVICE;
     }
-    if ((rc = exhaustive(c->pf_rest_launches))) return rc;          // independent of the candidate count
+    if (!packed && (rc = exhaustive(c->pf_rest_launches))) return rc;          // independent of the candidate count
     HIP_TRY(hipMemcpyAsync(c->h_sd_count, c->d_sd_count.p, 8, hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));                          // the one host round trip of the stage
     const unsigned long long found = *c->h_sd_count;
@@ -1545,6 +1606,11 @@ int pc_prefilter_device(pc_ctx *c, const void *d_arena, const int64_t *d_win_off
         if (!told) fprintf(stderr, "porechop_amd: %llu seed candidates for a list of %lld: this batch is filtered by the exhaustive kernel\n",
                            found, (long long)cap);
         told = true;
+        if (packed) {
+            // no exhaustive kernel over the plane: nothing is excluded for this batch (every pair goes to the DP -- exact, only slower)
+            HIP_TRY(hipMemsetAsync(d_mask, 0xFF, (size_t)nwindows * words * 4, stream));
+            return PC_OK;
+        }
         HIP_TRY(hipMemsetAsync(d_mask, 0, (size_t)nwindows * words * 4, stream));
         return exhaustive(c->pf_launches);
     }
@@ -1556,7 +1622,7 @@ int pc_prefilter_device(pc_ctx *c, const void *d_arena, const int64_t *d_win_off
     va.first = c->d_sd_first.as<uint32_t>(); va.entries = c->d_sd_entries.as<int32_t>();
     va.piece_meta = c->d_sd_meta.as<int32_t>(); va.piece_eq = c->d_sd_eq.as<uint32_t>(); va.npieces = c->sd_npieces;
     va.mask = d_mask; va.words = words;
-    if (pck::launch_seed_verify(va, (int64_t)found, stream)) return PC_ERR_NO_DEVICE;
+    if (packed ? pck::launch_seed_verify_packed(va, (int64_t)found, stream) : pck::launch_seed_verify(va, (int64_t)found, stream)) return PC_ERR_NO_DEVICE;
     return PC_OK;
 
 }

@@ -160,6 +160,17 @@ struct SeedVerifyArgs {
 constexpr int kSeedBitmapWords = (1 << 16) / 32 + (1 << 14) / 32 + (1 << 12) / 32;
 int launch_seed_scan(const SeedScanArgs &a, void *stream);
 int launch_seed_verify(const SeedVerifyArgs &a, int64_t ncand, void *stream);
+// The same two stages over reads held at 2 BITS PER BASE (pc_pack_reads' plane: base i in bits 2 (i % 16) of dword i / 16,
+// SeqAn's Dna ordinals; bases that were not A/C/G/T/U sit there as 'A').  `arena` of the argument structs is the plane,
+// win_off counts BASES, ONE seed length (q[0]); q-grams are little-endian here (first base in the lowest bits), and so are the
+// host's tables for this route.  No exception list is consulted: a non-base read as 'A' can only ADD matches against
+// adapters made of A/C/G/T (the only ones this route takes), so every pair it clears is still proven.
+int launch_seed_scan_packed(const SeedScanArgs &a, void *stream);
+int launch_seed_verify_packed(const SeedVerifyArgs &a, int64_t ncand, void *stream);
+// Windows of the plane as bytes ('A' 'C' 'G' 'T', 'N' at the listed exceptions), window i to dst + dst_off[i], padded with
+// `pad` up to dst_off[i + 1]; src_off counts bases and is ascending.
+int launch_unpack_windows(const void *plane, const int64_t *exc_pos, int64_t nexc, const int64_t *src_off, const int32_t *len,
+                          int64_t n, uint8_t *dst, const int64_t *dst_off, int pad, void *stream);
 
 // exact pruning of phase B (pc_select.hip): which end-window pairs have to be traced
 struct SelectArgs {

@@ -429,7 +429,231 @@ __global__ __launch_bounds__(256) void seed_verify_kernel(SeedVerifyArgs a)
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// The seed stage over reads held at 2 bits per base (north_star: "2-bit-packed read windows"): a quarter of the bytes of
+// the one HBM-bound kernel of the path, and no byte -> code step at all -- sixteen bases ARE a dword.  A lane takes its
+// stream a 128-byte line (512 bases) at a time; the q-gram that ends at base t of a dword is one funnel shift of
+// (previous dword, this dword) by a compile-time amount, its low 5 bits pick the bit and the rest the word of the bitmap:
+// shift, bfe, LDS probe, bfe, shift-or = 4 VALU operations and one probe per base.
+// ---------------------------------------------------------------------------------------------------------
+template <int Q>
+__global__ __launch_bounds__(256) void seed_scan_packed_kernel(SeedScanArgs a)
+{
+    __shared__ uint32_t bm[(1 << (2 * Q)) / 32];
+    __shared__ int wcnt[4];
+    __shared__ uint2 wbuf[4][kWaveBuf];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (threadIdx.x < 4) wcnt[threadIdx.x] = 0;
+    for (int i = threadIdx.x; i < (1 << (2 * Q)) / 32; i += 256) bm[i] = a.bitmaps[i];
+    __syncthreads();
+    const uint32_t *plane = (const uint32_t *)a.arena;
+    const int64_t wblocks = (a.nwindows + 255) / 256;
+    const int chunk = (int)(blockIdx.x / wblocks);
+    const int64_t w = (int64_t)(blockIdx.x % wblocks) * 256 + threadIdx.x;
+    int n = 0, start = 0, c0 = 0;
+    const uint32_t *p = plane;
+    if (w < a.nwindows) {
+        const int len = a.win_len[w];
+        if (chunk == 0 && len > a.max_len) atomicAdd(a.err, 1u);
+        c0 = chunk * a.chunk_len;
+        if (c0 < len) {
+            start = c0 > a.warm ? c0 - a.warm : 0;
+            const int end = (c0 + a.chunk_len < len) ? c0 + a.chunk_len : len;
+            // whole aligned 128-byte lines of the plane: start at the line boundary (512 bases) below the chunk; the bases
+            // before the window are scanned like any others (a find is kept only where its q-gram lies inside window and chunk)
+            const int64_t b = a.win_off[w] + start;
+            const int skip = (int)(b & 511);
+            p = plane + ((b - skip) >> 4);
+            start -= skip;
+            n = end - start;
+        }
+    }
+    const int nlines = (n + 511) >> 9;               // 0 for a lane without a chunk
+    const int nl_wave = __builtin_amdgcn_readfirstlane(wave_max(nlines));
+    u32x4 r[8], nx[8];
+    // (only the 16-byte blocks that hold bases of the chunk are fetched: never more than 63 bases past a window's end)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { r[i] = u32x4{0, 0, 0, 0}; if (64 * i < n) r[i] = *(const u32x4 *)(p + 4 * i); }
+    uint32_t prev = 0;                               // the dword before the one being scanned ("AAAA..." before the first)
+    for (int L = 0; L < nl_wave; ++L) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { nx[i] = r[i]; if (512 * (L + 1) + 64 * i < n) nx[i] = *(const u32x4 *)(p + 32 * (L + 1) + 4 * i); }
+#pragma unroll
+        for (int half = 0; half < 4; ++half) {       // a quarter line: 8 dwords = 128 bases
+            uint32_t hb[8];                          // per dword: bit 15 - t = a seed ends at its base t
+            uint32_t any = 0;
+#pragma unroll
+            for (int d = 0; d < 8; ++d) {
+                const u32x4 v = r[2 * half + (d >> 2)];
+                const uint32_t cur = (d & 3) == 0 ? v.x : (d & 3) == 1 ? v.y : (d & 3) == 2 ? v.z : v.w;
+                uint32_t h = 0;
+#pragma unroll
+                for (int t = 0; t < 16; ++t) {
+                    // the Q bases ending at base t of `cur`, first base in the lowest bits: bits [st, st + 2Q) of prev:cur
+                    const int st = 32 + 2 * (t + 1) - 2 * Q;
+                    const uint32_t g = st < 32 ? __builtin_amdgcn_alignbit(cur, prev, st) : (cur >> (st - 32));
+                    const uint32_t word = bm[__builtin_amdgcn_ubfe(g, 5, 2 * Q - 5)];
+                    h = (h << 1) | __builtin_amdgcn_ubfe(word, g & 31u, 1);
+                }
+                hb[d] = h;
+                any |= h;
+                prev = cur;
+            }
+            if (any && L < nlines) {
+                const int base0 = 512 * L + 128 * half;  // stream position of this quarter line's first base
+#pragma unroll 1
+                for (int d = 0; d < 8; ++d) {
+                    uint32_t h = 0;
+#pragma unroll
+                    for (int dd = 0; dd < 8; ++dd) h = (dd == d) ? hb[dd] : h;
+                    while (h) {
+                        const int t = 15 - (31 - __builtin_clz(h));
+                        h &= ~(1u << (15 - t));
+                        const int pos = base0 + 16 * d + t;          // stream position of the seed's last base
+                        const int j = start + pos;                     // window coordinate
+                        if (pos < n && j >= c0 && j >= Q - 1) {        // (warm-up columns belong to the previous chunk)
+                            const uint2 cd = make_uint2((uint32_t)w, (uint32_t)j);
+                            const int slot = atomicAdd(&wcnt[wv], 1);
+                            if (slot < kWaveBuf) {
+                                wbuf[wv][slot] = cd;
+                            } else {
+                                const unsigned long long g2 = atomicAdd(a.count, 1ull);
+                                if (g2 < (unsigned long long)a.cap) ((uint2 *)a.cand)[g2] = cd;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        if (wcnt[wv] >= kWaveBuf / 2) flush_wave(a, wcnt, wbuf, wv, lane);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) r[i] = nx[i];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    flush_wave(a, wcnt, wbuf, wv, lane);
+}
+
+// One lane per candidate, bases from the plane: see seed_verify_kernel.
+__global__ __launch_bounds__(256) void seed_verify_packed_kernel(SeedVerifyArgs a)
+{
+    extern __shared__ uint32_t eq_tab[];             // [npieces][8]: Eq word of codes 0..3 (the plane holds nothing else)
+    for (int i = threadIdx.x; i < a.npieces * 8; i += 256) eq_tab[i] = a.piece_eq[i];
+    __syncthreads();
+    const unsigned long long total = *a.count < (unsigned long long)a.cap ? *a.count : (unsigned long long)a.cap;
+    const unsigned long long ci = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+    if (ci >= total) return;
+    const uint2 cd = ((const uint2 *)a.cand)[ci];
+    const int64_t w = (int64_t)cd.x;
+    const int j = (int)cd.y;                          // window column of the seed's last base
+    const int q = a.q[0];
+    const int n = a.win_len[w];
+    const uint32_t *plane = (const uint32_t *)a.arena;
+    const int64_t b0 = a.win_off[w];                  // base index of the window's column 0
+    auto code_at = [&](int col) -> uint32_t { const int64_t b = b0 + col; return (plane[b >> 4] >> (2 * (int)(b & 15))) & 3u; };
+    uint32_t *mrow = a.mask + w * a.words;
+    uint32_t idx = 0;                                 // little-endian q-gram: first base in the lowest bits
+    for (int t = 0; t < q; ++t) idx |= code_at(j - q + 1 + t) << (2 * t);
+    const uint32_t e0 = a.first[a.first_off[0] + idx], e1 = a.first[a.first_off[0] + idx + 1];
+    for (uint32_t e = e0; e < e1; ++e) {
+        const int4 en = ((const int4 *)a.entries)[e];
+        const int pi = en.x, off = en.y;
+        const int4 pm = ((const int4 *)a.piece_meta)[pi];
+        const int len = pm.x, k = pm.y;
+        if (mrow[pm.z] & (uint32_t)pm.w) continue;
+        int lo = j - q + 1 - off - k, hi = j - q + 1 - off + len + k;
+        lo = lo < 0 ? 0 : lo; hi = hi > n ? n : hi;
+        uint32_t pv = len >= 32 ? 0xFFFFFFFFu : ~(0xFFFFFFFFu >> len), mv = 0, sc = (uint32_t)len, mn = (uint32_t)len;
+        const uint32_t *eqp = eq_tab + pi * 8;
+        // a dword of the plane (16 bases) per fetch
+        int col = lo;
+        while (col < hi) {
+            const int64_t b = b0 + col;
+            const uint32_t wd = plane[b >> 4];
+            const int t0 = (int)(b & 15);
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                if (t >= t0 && col + (t - t0) < hi) {
+                    sc = myers_step(eqp[(wd >> (2 * t)) & 3u], pv, mv, sc);
+                    mn = sc < mn ? sc : mn;
+                }
+            }
+            col += 16 - t0;
+        }
+        if ((int)mn <= k) atomicOr(mrow + pm.z, (uint32_t)pm.w);
+    }
+}
+
+// ---- windows of the plane as bytes: one workgroup per window ---------------------------------------------------------
+__global__ __launch_bounds__(256) void unpack_windows_kernel(const uint32_t *plane, const int64_t *src_off, const int32_t *len,
+                                                             uint8_t *dst, const int64_t *dst_off, int pad)
+{
+    const int64_t i = blockIdx.x;
+    const int64_t b0 = src_off[i];
+    uint8_t *d = dst + dst_off[i];
+    const int64_t n = len[i], total = dst_off[i + 1] - dst_off[i];
+    for (int64_t c = threadIdx.x; c < total; c += blockDim.x) {
+        uint8_t v = (uint8_t)pad;
+        if (c < n) { const int64_t b = b0 + c; v = (uint8_t)((0x54474341u >> (8 * ((plane[b >> 4] >> (2 * (int)(b & 15))) & 3u))) & 0xFFu); }
+        d[c] = v;
+    }
+}
+
+// one thread per exception: the window that holds it (windows ascending by src_off, not overlapping), if any
+__global__ __launch_bounds__(256) void unpack_windows_exceptions_kernel(const int64_t *exc_pos, int64_t nexc, const int64_t *src_off,
+                                                                        const int32_t *len, int64_t n, uint8_t *dst, const int64_t *dst_off)
+{
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= nexc) return;
+    const int64_t pos = exc_pos[e];
+    int64_t lo = 0, hi = n - 1;
+    if (n <= 0 || pos < src_off[0]) return;
+    while (lo < hi) {                                 // last window with src_off <= pos
+        const int64_t mid = (lo + hi + 1) >> 1;
+        if (src_off[mid] <= pos) lo = mid; else hi = mid - 1;
+    }
+    if (pos - src_off[lo] < (int64_t)len[lo]) dst[dst_off[lo] + (pos - src_off[lo])] = (uint8_t)'N';
+}
+
 }  // namespace
+
+int launch_seed_scan_packed(const SeedScanArgs &a, void *stream)
+{
+    if (a.nwindows <= 0) return 0;
+    const int64_t wblocks = (a.nwindows + 255) / 256;
+    const int64_t gx = wblocks * a.chunks;
+    if (gx > 0x7FFFFFFFll || a.nq != 1) return -1;
+    hipStream_t s = (hipStream_t)stream;
+    switch (a.q[0]) {
+        case 6: hipLaunchKernelGGL(seed_scan_packed_kernel<6>, dim3((unsigned)gx), dim3(256), 0, s, a); break;
+        case 7: hipLaunchKernelGGL(seed_scan_packed_kernel<7>, dim3((unsigned)gx), dim3(256), 0, s, a); break;
+        case 8: hipLaunchKernelGGL(seed_scan_packed_kernel<8>, dim3((unsigned)gx), dim3(256), 0, s, a); break;
+        default: return -1;
+    }
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+int launch_seed_verify_packed(const SeedVerifyArgs &a, int64_t ncand, void *stream)
+{
+    if (ncand <= 0) return 0;
+    const int64_t gx = (ncand + 255) / 256;
+    if (gx > 0x7FFFFFFFll) return -1;
+    hipLaunchKernelGGL(seed_verify_packed_kernel, dim3((unsigned)gx), dim3(256), (size_t)a.npieces * 32, (hipStream_t)stream, a);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+int launch_unpack_windows(const void *plane, const int64_t *exc_pos, int64_t nexc, const int64_t *src_off, const int32_t *len,
+                          int64_t n, uint8_t *dst, const int64_t *dst_off, int pad, void *stream)
+{
+    if (n <= 0) return 0;
+    if (n > 0x7FFFFFFFll) return -1;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(unpack_windows_kernel, dim3((unsigned)n), dim3(256), 0, s, (const uint32_t *)plane, src_off, len, dst, dst_off, pad);
+    if (nexc > 0)
+        hipLaunchKernelGGL(unpack_windows_exceptions_kernel, dim3((unsigned)((nexc + 255) / 256)), dim3(256), 0, s, exc_pos, nexc, src_off,
+                           len, n, dst, dst_off);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
 
 int launch_seed_scan(const SeedScanArgs &a, void *stream)
 {

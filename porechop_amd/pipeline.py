@@ -53,13 +53,51 @@ class DeviceReads:
     """Reads resident in HBM: one byte per base as delivered (upper-cased ASCII), read r at
     arena[off[r] : off[r] + length[r]].  The arena must have >= 16 readable bytes after the last
     read (the kernels fetch bases a dword at a time)."""
-    arena: torch.Tensor    # uint8 [bytes]
+    arena: Optional[torch.Tensor]    # uint8 [bytes]; None = the reads are held PACKED only (plane / exc / ends below)
     off: torch.Tensor      # int64 [R]
     length: torch.Tensor   # int32 [R]
+    # reads held at 2 bits per base (packed_only): the plane io.pack_reads makes (base i of the arena in bits 2 (i % 16) of
+    # dword i / 16; 64 readable bytes past the last base), the ascending positions of the bases that were not A/C/G/T/U, and
+    # byte copies of every read's two end windows: (arena, start window offsets, end window offsets, end_size)
+    plane: Optional[torch.Tensor] = None
+    exc: Optional[torch.Tensor] = None
+    nbases: int = 0
+    ends: Optional[tuple] = None
 
     @property
     def n(self):
         return int(self.off.shape[0])
+
+    @classmethod
+    def packed_only(cls, aligner, packed, nbases, exceptions, off, length, end_size=150):
+        """Reads that crossed PCIe at 2 bits per base and STAY packed in HBM (a quarter of the bytes): only what the DP kernels
+        read is ever turned into bytes -- here the two end windows of every read (pc_unpack_windows: 2 x end_size bytes per
+        read), later the few whole reads that survive the exact prefilter, which itself scans the plane
+        (pc_prefilter_packed).  off / length index the plane in BASES (the byte offsets of the arena it was packed from)."""
+        dev = packed.device
+        need = (int(nbases) + 15) // 16 * 4 + 64
+        if int(packed.numel()) < need:                         # the scan fetches whole 16-byte blocks: slack past the last base
+            grown = torch.zeros(need, dtype=torch.uint8, device=dev)
+            grown[:packed.numel()] = packed
+            packed = grown
+        n = int(off.shape[0])
+        ln64 = length.to(torch.int64)
+        wl = torch.clamp(length, max=end_size).to(torch.int32).contiguous()
+        stride = (end_size + 15) // 16 * 16 + 16
+        dst_off = torch.arange(2 * n + 1, dtype=torch.int64, device=dev) * stride
+        ends = torch.empty(2 * n * stride + 64, dtype=torch.uint8, device=dev)
+        ends[2 * n * stride:] = ord("N")
+        if n:
+            aligner.unpack_windows(packed, exceptions, off.contiguous(), wl, ends, dst_off[:n + 1].contiguous())
+            aligner.unpack_windows(packed, exceptions, (off + (ln64 - wl.to(torch.int64))).contiguous(), wl, ends, dst_off[n:].contiguous())
+        return cls(None, off, length, plane=packed, exc=exceptions, nbases=int(nbases),
+                   ends=(ends, dst_off[:n], dst_off[n:2 * n], int(end_size)))
+
+    def materialize(self, aligner):
+        """The byte arena of packed-only reads (pc_unpack_device), for the routes that need every base as a byte."""
+        if self.arena is None:
+            self.arena = aligner.unpack_device(self.plane[:(self.nbases + 15) // 16 * 4], self.nbases, self.exc)
+        return self.arena
 
     @classmethod
     def from_packed(cls, aligner, packed, nbases, exceptions, off, length, arena=None):
@@ -209,12 +247,21 @@ class Pipeline:
     # ------------------------------------------------------------------------------------------
     def _end_windows(self, reads: DeviceReads, idx: Optional[torch.Tensor], side: str):
         """seq[:end_size] / seq[-end_size:] as (offset, length) windows (nanopore_read.py:155,160)."""
-        off = reads.off if idx is None else reads.off[idx]
         ln = reads.length if idx is None else reads.length[idx]
         wl = torch.clamp(ln, max=self.p.end_size)
+        if reads.arena is None:                      # packed-only reads: the windows' byte copies (DeviceReads.packed_only)
+            assert reads.ends is not None and reads.ends[3] == self.p.end_size
+            tab = reads.ends[1] if side == "start" else reads.ends[2]
+            return (tab if idx is None else tab[idx]), wl
+        off = reads.off if idx is None else reads.off[idx]
         if side == "start":
             return off, wl
         return off + (ln - wl).to(torch.int64), wl
+
+    @staticmethod
+    def _ends_arena(reads: DeviceReads):
+        """The bytes the end windows index: the read arena, or -- packed-only reads -- the copies of the end windows."""
+        return reads.arena if reads.arena is not None else reads.ends[0]
 
     def _scan_jobs(self, arena, jobs, mode, max_len, with_layout=False, sort_lengths=False, typ_len=0, fuse=True):
         """jobs: list of (adapter_index, win_off int64[n], win_len int32[n]) -> list of [n,8] views.
@@ -348,7 +395,7 @@ class Pipeline:
                 jobs.append((self.seq_index[s.end[1]], eo, el)); where.append((si, 1))
         if prune and self.packed_kernels():
             return self._phase_a_pruned(reads, jobs, where, best_start, best_end)
-        outs = self._scan_jobs(reads.arena, jobs, MODE_TRACE, self.p.end_size)
+        outs = self._scan_jobs(self._ends_arena(reads), jobs, MODE_TRACE, self.p.end_size)
         # one vectorised reduction for all jobs (they all cover the same n check reads)
         rec = torch.stack(outs)                                     # [J, n, 8]
         m = rec[:, :, 5].to(torch.float64)
@@ -362,7 +409,7 @@ class Pipeline:
         return best_start, best_end
 
     def _phase_a_pruned(self, reads, jobs, where, best_start, best_end):
-        scores = torch.stack(self._scan_jobs(reads.arena, jobs, MODE_SCORE, self.p.end_size))[:, :, 4]   # [J, n]
+        scores = torch.stack(self._scan_jobs(self._ends_arena(reads), jobs, MODE_SCORE, self.p.end_size))[:, :, 4]   # [J, n]
         bounds = [self.presence_score_bound(len(self.seqs[j[0]])) for j in jobs]
         need = torch.tensor([b if b is not None else -(1 << 30) for b in bounds], device=self.device)
         cand = scores >= need[:, None]
@@ -379,7 +426,7 @@ class Pipeline:
         self.stats["pairs_end_traced_after_pruning"] = self.stats.get("pairs_end_traced_after_pruning", 0) + int(counts.sum())
         if not cjobs:
             return best_start, best_end
-        outs = self._scan_jobs(reads.arena, cjobs, MODE_TRACE, self.p.end_size)
+        outs = self._scan_jobs(self._ends_arena(reads), cjobs, MODE_TRACE, self.p.end_size)
         rec = torch.cat(outs)                                   # one reduction for all candidate jobs
         full, _ = _identities(rec)
         full = torch.where(rec[:, 0] == -1, torch.zeros_like(full), full)
@@ -505,7 +552,7 @@ class Pipeline:
         for k, (j, (side, si)) in enumerate(zip(jobs, where)):
             key = rules.phase_b_pair_key(self.sets[si])
             hinted.append(tuple(j[:3]) + ((("pair", side) + key) if key is not None else ("alone", k),))
-        _, rec, rec_off = self._scan_jobs(reads.arena, hinted, MODE_SCORE, p.end_size, with_layout=True)
+        _, rec, rec_off = self._scan_jobs(self._ends_arena(reads), hinted, MODE_SCORE, p.end_size, with_layout=True)
         job_off = torch.tensor(rec_off, dtype=torch.int64, device=dev)
         job_side = torch.tensor([w[0] for w in where], dtype=torch.int32, device=dev)
         job_len = torch.tensor([len(self.seqs[j[0]]) for j in jobs], dtype=torch.int32, device=dev)
@@ -536,10 +583,10 @@ class Pipeline:
                 # the end cell of every selected pair is known from its score record: only the columns its path can occupy
                 # are traced (PC_MODE_TRACE_AT: the second pass of the whole-read scan, for end windows)
                 traced = al.gather_records(rec, dest) if hasattr(al, "gather_records") else rec.index_select(0, dest)
-                al.scan_device(reads.arena, woff, wlen, job_adapter[live], starts, p.end_size, traced, MODE_TRACE_AT)
+                al.scan_device(self._ends_arena(reads), woff, wlen, job_adapter[live], starts, p.end_size, traced, MODE_TRACE_AT)
             else:
                 traced = torch.empty((total, RESULT_INTS), dtype=torch.int32, device=dev)
-                al.scan_device(reads.arena, woff, wlen, job_adapter[live], starts, p.end_size, traced, MODE_TRACE)
+                al.scan_device(self._ends_arena(reads), woff, wlen, job_adapter[live], starts, p.end_size, traced, MODE_TRACE)
             al.phase_b_scatter(traced, dest, pjob, pread, rec, job_side, job_calls, best_full, R)
             return total
 
@@ -628,7 +675,7 @@ class Pipeline:
                                                             call_level_diff=barcode_diff)
                 tmask = self._traced_mask
             else:
-                _, out, rec_off = self._scan_jobs(reads.arena, jobs, MODE_TRACE, p.end_size, with_layout=True)
+                _, out, rec_off = self._scan_jobs(self._ends_arena(reads), jobs, MODE_TRACE, p.end_size, with_layout=True)
                 self.stats["pairs_end"] += sum(int(j[1].shape[0]) for j in jobs)
             job_of = {(si, side): k for k, (side, si) in enumerate(where)}
             jb = [(job_of.get((b[0], 0), -1) if b[0] is not None else -1,
@@ -665,12 +712,12 @@ class Pipeline:
                 out, rec_off = self._phase_b_pruned_records(reads, jobs, where, set(), 1e9, trims)
                 tmask = self._traced_mask
             else:
-                _, out, rec_off = self._scan_jobs(reads.arena, jobs, MODE_TRACE, p.end_size, with_layout=True)
+                _, out, rec_off = self._scan_jobs(self._ends_arena(reads), jobs, MODE_TRACE, p.end_size, with_layout=True)
                 self.stats["pairs_end"] += sum(int(j[1].shape[0]) for j in jobs)
             self.aligner.phase_b_reduce(out, R, rec_off, sides, p.end_size, p.min_trim_size, p.extra_end_trim,
                                         p.end_threshold, start_trim, end_trim, **masked(tmask))
             return start_trim, end_trim
-        outs = self._scan_jobs(reads.arena, jobs, MODE_TRACE, p.end_size)
+        outs = self._scan_jobs(self._ends_arena(reads), jobs, MODE_TRACE, p.end_size)
         for (side, si), rec in zip(where, outs):
             full, partial = _identities(rec)
             ok = rec[:, 0] != -1
@@ -704,7 +751,7 @@ class Pipeline:
                 ads.append((s.end, si))
         return ads
 
-    def _prefiltered_scan(self, arena, off, length, max_len, a_list, aidx, hint, ks, ragged, typ_len):
+    def _prefiltered_scan(self, arena, off, length, max_len, a_list, aidx, hint, ks, ragged, typ_len, packed_reads=None):
         """Whole-read records of the adapters a_list (positions in the middle-adapter list) against the n windows
         (off, length), computed only where the exact prefilter cannot exclude a hit.  SPARSE result
         -> (b [C] int64: position in a_list, w [C] int64: window, rec [C, 8] int32); every (adapter, window) pair that
@@ -722,7 +769,19 @@ class Pipeline:
             order = torch.argsort(length, descending=True, stable=True)
             pf_off, pf_len = off[order].contiguous(), length[order].contiguous()
         self.aligner.set_length_hint(typ_len if ragged else 0)
-        rows, bits = self.aligner.prefilter_rows(arena, pf_off, pf_len, max_len, [aidx[a] for a in a_list], [ks[a] for a in a_list])
+        # packed_reads (reads held at 2 bits per base, `off` in bases): the prefilter scans the PLANE, and only the windows
+        # that survive are turned into bytes for the DP; an adapter list the packed route does not take (a letter other than
+        # A/C/G/T/U, a piece without seeds) falls back to unpacking everything
+        got = None
+        if packed_reads is not None and packed_reads.arena is None:
+            got = self.aligner.prefilter_rows(packed_reads.plane, pf_off, pf_len, max_len, [aidx[a] for a in a_list], [ks[a] for a in a_list],
+                                              packed=True)
+            if got is None:
+                arena = packed_reads.materialize(self.aligner)
+                self.stats["packed_route_refused"] = self.stats.get("packed_route_refused", 0) + 1
+        if got is None:
+            got = self.aligner.prefilter_rows(arena, pf_off, pf_len, max_len, [aidx[a] for a in a_list], [ks[a] for a in a_list])
+        rows, bits = got
         if order is not None:
             rows = order[rows]
         self.stats["pairs_middle_prefiltered"] = self.stats.get("pairs_middle_prefiltered", 0) + B * n
@@ -736,14 +795,32 @@ class Pipeline:
             cand_g = torch.zeros((int(rows.shape[0]), G), dtype=torch.int32, device=dev).index_add_(
                 1, torch.tensor(gidx, device=dev), bits.to(torch.int32)) > 0
         hitg = torch.nonzero(cand_g.t())                              # [C, 2] (group, row), group-major
-        counts = torch.bincount(hitg[:, 0], minlength=G).cpu().numpy()     # the one synchronisation of this stage
+        scan_off = off
+        if packed_reads is not None and packed_reads.arena is None:
+            # the surviving windows as bytes, back to back (each padded to 16 bytes + slack), ascending in the plane
+            urows = torch.sort(rows).values
+            ulen = length[urows].contiguous()
+            ustride = (ulen.to(torch.int64) + (8 + 15)) // 16 * 16
+            uends = torch.zeros(int(urows.shape[0]) + 1, dtype=torch.int64, device=dev)
+            uends[1:] = torch.cumsum(ustride, 0)
+            both = torch.cat([torch.bincount(hitg[:, 0], minlength=G), uends[-1:]]).cpu().numpy()   # the one synchronisation of this stage
+            counts, utotal = both[:G], int(both[G])
+            arena = torch.empty(utotal + 64, dtype=torch.uint8, device=dev)
+            arena[utotal:] = ord("N")
+            if urows.numel():
+                self.aligner.unpack_windows(packed_reads.plane, packed_reads.exc, off[urows].contiguous(), ulen, arena, uends)
+            scan_off = torch.full((n,), -1, dtype=torch.int64, device=dev)
+            scan_off[urows] = uends[:-1]
+            self.stats["bases_unpacked_after_prefilter"] = self.stats.get("bases_unpacked_after_prefilter", 0) + utotal
+        else:
+            counts = torch.bincount(hitg[:, 0], minlength=G).cpu().numpy()     # the one synchronisation of this stage
         cjobs, cmeta, pos = [], [], 0
         members = [[b for b in range(B) if gidx[b] == g] for g in range(G)]
         for g in range(G):
             if counts[g]:
                 sel = rows[hitg[pos:pos + int(counts[g]), 1]]
                 pos += int(counts[g])
-                so, sl = off[sel], length[sel]
+                so, sl = scan_off[sel], length[sel]
                 for b in members[g]:
                     cjobs.append((aidx[a_list[b]], so, sl, hint[a_list[b]])); cmeta.append((b, sel))
         if not cjobs:
@@ -802,6 +879,10 @@ class Pipeline:
         if live.numel() == 0:
             return empty
         loff, llen = toff[live], tlen[live]
+        packed_only = reads.arena is None
+        if packed_only and not prefilter:
+            reads.materialize(self.aligner)                          # every pair runs the DP: every base is needed as a byte
+            packed_only = False
         mm = torch.stack([llen.max(), llen.min(), llen.sum(dtype=torch.int64) // llen.numel()]).cpu()
         max_len, ragged, typ_len = int(mm[0]), bool(mm[0] != mm[1]), int(mm[2])
         aidx = [self.seq_index[a[1]] for a in ads]
@@ -816,7 +897,9 @@ class Pipeline:
         sparse0 = None
         if prefilter:
             ks = [self.aligner.max_edits(len(self.seqs[ai]), p.middle_threshold) for ai in aidx]
-            sparse0 = self._prefiltered_scan(reads.arena, loff, llen, max_len, list(range(A)), aidx, hint, ks, ragged, typ_len)
+            sparse0 = self._prefiltered_scan(reads.arena, loff, llen, max_len, list(range(A)), aidx, hint, ks, ragged, typ_len,
+                                             packed_reads=reads if packed_only else None)
+            packed_only = packed_only and reads.arena is None         # (the packed route may have been refused: everything unpacked)
         elif prove and all(b is not None for b in bounds):
             score = torch.stack(self._scan_jobs(reads.arena, jobs0, MODE_SCORE, max_len, sort_lengths=ragged, typ_len=typ_len))[:, :, 4]      # [A, L]
             cand = torch.nonzero(score >= torch.tensor(bounds, device=dev)[:, None])                     # adapter-major
@@ -875,7 +958,9 @@ class Pipeline:
             dirty = torch.empty(dtotal + 64, dtype=torch.uint8, device=dev)
             dirty[dtotal:] = ord("N")
             d_off = d_ends[:-1]
-            if hasattr(self.aligner, "copy_windows"):
+            if packed_only:                                         # (d_sel is ascending: torch.unique)
+                self.aligner.unpack_windows(reads.plane, reads.exc, loff[d_sel].contiguous(), dlen, dirty, d_ends, ord("N"))
+            elif hasattr(self.aligner, "copy_windows"):
                 self.aligner.copy_windows(reads.arena, loff[d_sel].contiguous(), dlen, dirty, d_ends, ord("N"))
             else:                                                    # injected test aligner: the same copy in torch
                 seg = torch.repeat_interleave(torch.arange(Dn, device=dev), dstride)

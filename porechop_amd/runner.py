@@ -205,6 +205,14 @@ def _is_gzip(path):
         return False
 
 
+def gz_out_hint(opts, output, barcode_dir, input_path):
+    """Will this run write gzip?  (_resolve_format before the read type is known: FASTQ assumed.)"""
+    try:
+        return _resolve_format(opts, output, barcode_dir, "FASTQ", input_path)[1]
+    except Exception:
+        return False
+
+
 def _emit(rs, pr, ps_, pn_, num, pf, paths, fastq, file_pos, gz, shared=False):
     """Pieces of one read set into their files at file_pos (updated): plain bytes (pc_readset_write_at / _shared), or --
     gz -- formatted and deflated by all cores in memory, then written (pc_readset_compress: what the reference gets from
@@ -443,10 +451,14 @@ def run_streamed(input_path, output, barcode_dir, opts: Options, device=None, al
     except Exception:
         ncores = os.cpu_count() or 2
     share = max(2, min(32, ncores // 2))
+    # gz output: deflating is the wall of the run (measured, 16 cores: the writer busy 3.6 s of 3.8 at half the cores, the
+    # loader -- even one that inflates -- 1.4 s): three quarters of the cores to the writer
+    share_w = max(2, min(48, ncores * 3 // 4)) if gz_out_hint(opts, output, barcode_dir, input_path) else share
+    share_l = max(2, ncores - share_w) if share_w != share else share
 
     def loader():
         p_ = pos
-        io_lib.pc_io_set_thread_limit(share)
+        io_lib.pc_io_set_thread_limit(share_l)
         try:
             while gz_in is not None and not stop.is_set():
                 t0 = time.perf_counter()
@@ -475,7 +487,7 @@ def run_streamed(input_path, output, barcode_dir, opts: Options, device=None, al
 
     def writer():
         nonlocal file_pos
-        io_lib.pc_io_set_thread_limit(share)
+        io_lib.pc_io_set_thread_limit(share_w)
         try:
             while True:
                 item = to_write.get()

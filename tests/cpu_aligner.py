@@ -92,7 +92,39 @@ class OracleAligner:
             rows.append(torch.from_numpy(ok))
         return torch.stack(rows) if rows else torch.zeros((0, wo.shape[0]), dtype=torch.bool)
 
-    def prefilter_rows(self, arena, win_off, win_len, max_len, adapters, max_edits, stream=None):
+    @staticmethod
+    def _plane_bytes(plane, nbases):
+        """The 2-bit plane as bytes, exceptions NOT applied (what the packed prefilter sees: non-bases read as 'A')."""
+        pk = plane.cpu().numpy()[:(nbases + 3) // 4]
+        codes = ((pk[:, None] >> (2 * np.arange(4, dtype=np.uint8))[None, :]) & 3).reshape(-1)[:nbases]
+        return np.frombuffer(b"ACGT", dtype=np.uint8)[codes]
+
+    def unpack_device(self, packed, nbases, exceptions, arena=None, pad=64, stream=None):
+        raw = self._plane_bytes(packed, int(nbases)).copy()
+        if exceptions is not None and exceptions.numel():
+            raw[exceptions.cpu().numpy()] = ord("N")
+        return torch.from_numpy(np.concatenate([raw, np.full(pad, ord("N"), dtype=np.uint8)]))
+
+    def unpack_windows(self, plane, exceptions, src_off, length, dst, dst_off, pad=ord("N"), stream=None):
+        so, ln, do = src_off.cpu().numpy(), length.cpu().numpy(), dst_off.cpu().numpy()
+        nb = int((so + ln).max()) if so.size else 0
+        raw = self._plane_bytes(plane, nb).copy()
+        if exceptions is not None and exceptions.numel():
+            e = exceptions.cpu().numpy()
+            raw[e[e < nb]] = ord("N")
+        out = dst.cpu().numpy().copy()
+        for i in range(so.size):
+            out[do[i]:do[i + 1]] = pad
+            out[do[i]:do[i] + ln[i]] = raw[so[i]:so[i] + ln[i]]
+        dst.copy_(torch.from_numpy(out))
+        return dst
+
+    def prefilter_rows(self, arena, win_off, win_len, max_len, adapters, max_edits, stream=None, packed=False):
+        if packed:                                     # arena is the plane: the contract of pc_prefilter_packed
+            if any(set(self.adapters[int(a)].upper()) - set(b"ACGTU") for a in adapters):
+                return None
+            nb = int((win_off + win_len.to(torch.int64)).max().item()) if win_off.numel() else 0
+            arena = torch.from_numpy(np.concatenate([self._plane_bytes(arena, nb), np.full(64, ord("N"), dtype=np.uint8)]))
         dense = self.prefilter(arena, win_off, win_len, max_len, adapters, max_edits)
         rows = torch.nonzero(dense.any(dim=0)).flatten()
         return rows, dense[:, rows].t().contiguous()

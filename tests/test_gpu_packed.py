@@ -130,3 +130,163 @@ def test_readset_to_device_packed(aligner, tmp_path):
         assert bool((packed.arena[nb:nb + 16] == ord("N")).all())
     finally:
         rs.close()
+
+
+# ---- reads that STAY at 2 bits per base (task 4): the prefilter over the plane, windows unpacked on demand ----
+def _packed_plane(arr, dev):
+    pk, exc = pack_reads(arr)
+    plane = torch.zeros(pk.size + 64, dtype=torch.uint8, device=dev)
+    plane[:pk.size] = torch.from_numpy(pk).to(dev)
+    return plane, (torch.from_numpy(exc).to(dev) if exc.size else None), exc
+
+
+def test_unpack_windows_equals_slices_of_the_full_unpack(aligner):
+    rng = np.random.default_rng(8)
+    dev = torch.device("cuda")
+    n = 200_000
+    w = np.array([0.245] * 4 + [0.02 / (len(ALPHABET) - 4)] * (len(ALPHABET) - 4))
+    arr = np.frombuffer(ALPHABET, dtype=np.uint8)[rng.choice(len(ALPHABET), size=n, p=w / w.sum())]
+    plane, d_exc, exc = _packed_plane(arr, dev)
+    full = unpack_reads_host(pack_reads(arr)[0], n, exc)
+    # ascending, non-overlapping windows of every length and alignment, the last one ending at the last base
+    starts, lens, pos = [], [], 0
+    while pos < n - 5000:
+        ln = int(rng.choice([0, 1, 3, 15, 16, 17, 150, 151, 1000, 4097]))
+        starts.append(pos); lens.append(ln)
+        pos += ln + int(rng.integers(0, 40))
+    starts.append(n - 777); lens.append(777)
+    so = torch.tensor(starts, dtype=torch.int64, device=dev)
+    ln = torch.tensor(lens, dtype=torch.int32, device=dev)
+    stride = (ln.to(torch.int64) + 23) // 16 * 16
+    do = torch.zeros(len(starts) + 1, dtype=torch.int64, device=dev)
+    do[1:] = torch.cumsum(stride, 0)
+    dst = torch.full((int(do[-1]) + 16,), 0xEE, dtype=torch.uint8, device=dev)
+    aligner.unpack_windows(plane, d_exc, so, ln, dst, do, pad=ord("-"))
+    aligner.sync()
+    got, doh = dst.cpu().numpy(), do.cpu().numpy()
+    for i, (s, l) in enumerate(zip(starts, lens)):
+        assert np.array_equal(got[doh[i]:doh[i] + l], full[s:s + l]), i
+        assert np.all(got[doh[i] + l:doh[i + 1]] == ord("-")), i
+    assert np.all(got[doh[-1]:] == 0xEE)
+
+
+def test_prefilter_over_the_plane_equals_the_byte_route(oracle):
+    """pc_prefilter_packed vs pc_prefilter_device: the same mask on reads made of A/C/G/T; on reads that hold other letters
+    a SUPERSET (non-bases are scanned as 'A'), and never a pair within the bound dropped (the plain DP of the oracle)."""
+    import porechop_amd
+    from tests.test_gpu_prefilter import make_cases
+    rng = random.Random(5)
+    adapters = ["AATGTACTTCGTTCAGTTACGTATTGCT", "GCAATACGTAACTGAACGAAGT", "".join(rng.choice("ACGT") for _ in range(24)),
+                "".join(rng.choice("ACGT") for _ in range(33)), "".join(rng.choice("ACGT") for _ in range(30)),
+                "".join(rng.choice("ACGT") for _ in range(50))]
+    dev = torch.device("cuda")
+    for seed, alphabet, lengths, hint in ((1, "ACGT", [0, 1, 5, 16, 17, 100, 150, 600, 2500], 0), (2, "ACGTN-", [40, 150, 1000, 9000], 0),
+                                          (3, "ACGT", [100, 3000, 70000], 3000)):
+        reads = [r.upper() for r in make_cases(seed, 1500 if max(lengths) < 20000 else 300, lengths, adapters, alphabet=alphabet)]
+        text = "".join(reads).encode()
+        arr = np.frombuffer(text, dtype=np.uint8)
+        lens = np.array([len(r) for r in reads], dtype=np.int32)
+        offs = np.concatenate([[0], np.cumsum(lens[:-1], dtype=np.int64)]).astype(np.int64)
+        d_off, d_len = torch.from_numpy(offs).to(dev), torch.from_numpy(lens).to(dev)
+        plane, d_exc, exc = _packed_plane(arr, dev)
+        arena = torch.from_numpy(np.concatenate([arr, np.full(64, ord("N"), np.uint8)])).to(dev)
+        al = porechop_amd.Aligner(adapters)
+        try:
+            al.set_length_hint(hint)
+            for thr in (90.0, 80.0):
+                ks = [al.max_edits(len(a), thr) for a in adapters]
+                ids = list(range(len(adapters)))
+                m_bytes = al.prefilter_mask(arena, d_off, d_len, int(lens.max()), ids, ks)
+                m_plane = al.prefilter_mask_packed(plane, d_off, d_len, int(lens.max()), ids, ks)
+                al.sync()
+                assert m_plane is not None
+                a, b = m_bytes.cpu().numpy(), m_plane.cpu().numpy()
+                if alphabet == "ACGT":
+                    assert np.array_equal(a, b), (seed, thr, int((a != b).sum()))
+                else:
+                    assert np.all((a & ~b) == 0), (seed, thr)                      # nothing the byte route keeps is dropped
+                    assert int((b & ~a != 0).sum()) < 0.2 * len(reads)              # and not much is added
+                bits = (b[:, 0][None, :] >> np.arange(len(adapters))[:, None]) & 1
+                for j, (ad, k) in enumerate(zip(adapters, ks)):
+                    d = oracle.min_edits_many(arr, offs, lens, ad) if len(ad) <= 32 else None
+                    if d is not None:
+                        assert not ((d <= k) & (lens > 0) & (bits[j] == 0)).any(), (seed, thr, ad)
+        finally:
+            al.close()
+    # an adapter with a letter other than A/C/G/T, or one the seed stage cannot cover: the packed route says no
+    al = porechop_amd.Aligner(["ACGTNNACGTTTGACCAGTNAC", "ACGTACGTAC"])
+    try:
+        z64, z32 = torch.zeros(1, dtype=torch.int64, device=dev), torch.full((1,), 100, dtype=torch.int32, device=dev)
+        assert al.prefilter_mask_packed(torch.zeros(256, dtype=torch.uint8, device=dev), z64, z32, 100, [0], [2]) is None
+        assert al.prefilter_mask_packed(torch.zeros(256, dtype=torch.uint8, device=dev), z64, z32, 100, [1], [1]) is None
+    finally:
+        al.close()
+
+
+def _packed_vs_bytes(env_cap=None):
+    import porechop_amd
+    from porechop_amd.pipeline import DeviceReads, Pipeline, ScanParams
+    from porechop_amd.panel import load_panel
+    from tests.pairgen import synthetic_read
+    rng = random.Random(9)
+    y_top, y_bottom = "AATGTACTTCGTTCAGTTACGTATTGCT", "GCAATACGTAACTGAACGAAGT"
+    reads = []
+    for i in range(3000):
+        r = synthetic_read(rng, rng.choice([40, 300, 900, 2500, 9000]), y_top if rng.random() < 0.9 else None,
+                           y_bottom if rng.random() < 0.5 else None, (y_bottom + y_top) if i % 9 == 0 else None)
+        r = list(r)
+        for _ in range(rng.choice([0, 0, 1, 4, 40])):
+            r[rng.randrange(len(r))] = rng.choice("NnX-RYacgtUu")
+        reads.append("".join(r))
+    text = "".join(reads).encode()
+    lens = np.array([len(r) for r in reads], dtype=np.int32)
+    offs = np.concatenate([[0], np.cumsum(lens[:-1], dtype=np.int64)]).astype(np.int64)
+    dev = torch.device("cuda")
+    pl = Pipeline(load_panel(), ScanParams(), device=dev)
+    try:
+        arr = np.frombuffer(text, dtype=np.uint8)
+        as_bytes = DeviceReads(torch.from_numpy(np.concatenate([arr, np.full(64, ord("N"), np.uint8)])).to(dev),
+                               torch.from_numpy(offs).to(dev), torch.from_numpy(lens).to(dev))
+        pk, exc = pack_reads(arr)
+        as_packed = DeviceReads.packed_only(pl.aligner, torch.from_numpy(pk).to(dev), arr.size, torch.from_numpy(exc).to(dev),
+                                            torch.from_numpy(offs).to(dev), torch.from_numpy(lens).to(dev))
+        assert as_packed.arena is None
+        out = []
+        for rd in (as_bytes, as_packed):
+            bs, be = pl.phase_a(rd, torch.arange(min(rd.n, 1000), device=dev))
+            matching = pl.matching_sets(bs, be)
+            st, et = pl.phase_b(rd, matching)
+            hits = pl.phase_c(rd, st, et, matching, prefilter=True)
+            pl.aligner.sync()
+            out.append((bs.cpu(), be.cpu(), st.cpu(), et.cpu(), hits.read.cpu(), hits.adapter.cpu(), hits.start.cpu(), hits.end.cpu()))
+        return out, as_packed, dict(pl.stats), int(arr.size)
+    finally:
+        pl.close()
+
+
+def test_pipeline_over_reads_that_stay_packed_equals_the_byte_route():
+    out, as_packed, stats, nbases = _packed_vs_bytes()
+    for a, b in zip(*out):
+        assert torch.equal(a, b)
+    assert out[0][4].numel() > 100
+    assert as_packed.arena is None and "packed_route_refused" not in stats
+    assert 0 < stats["bases_unpacked_after_prefilter"] < 0.5 * nbases           # only the survivors became bytes
+
+
+def test_packed_route_with_an_overflowing_candidate_list_excludes_nothing():
+    """PC_PF_SEED_CAP=64: the seed scan over the plane finds more candidates than its list holds; there is no exhaustive
+    kernel over the plane, so the batch is handed to the DP whole (mask all ones) -- same results, only slower."""
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "import torch\n"
+            "from tests.test_gpu_packed import _packed_vs_bytes\n"
+            "out, rd, stats, n = _packed_vs_bytes()\n"
+            "assert all(torch.equal(a, b) for a, b in zip(*out)) and out[0][4].numel() > 100\n"
+            "print('CHILD_OK', stats.get('bases_unpacked_after_prefilter'), n)\n" % repo)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, PC_PF_SEED_CAP="64"), capture_output=True, text=True, timeout=900, cwd=repo)
+    assert r.returncode == 0 and "CHILD_OK" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+    _, unpacked, n = r.stdout.split("CHILD_OK")[1].split()[:3]
+    assert int(unpacked) >= int(n)                      # every read survived "the prefilter"

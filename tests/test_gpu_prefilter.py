@@ -196,11 +196,12 @@ print("CHILD_OK", exact, sound)
 """
 
 
-@pytest.mark.parametrize("env", [{}, {"PC_PF_NO_SEEDS": "1"}, {"PC_PF_SEED_CAP": "64"}])
+@pytest.mark.parametrize("env", [{}, {"PC_PF_NO_SEEDS": "1"}, {"PC_PF_SEED_CAP": "64"}, {"PC_PF_MULTI_Q": "1"}])
 def test_seed_stage_exhaustive_kernel_and_overflow_fallback_agree_with_the_plain_dp(env):
     """The same batch -- seeds of two lengths, an adapter without seeds (N inside), a low-complexity adapter against
-    poly-A reads -- through the seed stage, through the exhaustive kernel alone (PC_PF_NO_SEEDS=1) and through the
-    overflow fallback (a 64-entry candidate list): each equals the oracle's plain DP."""
+    poly-A reads -- through the seed stage (one seed length for all pieces; PC_PF_MULTI_Q=1: a bitmap per length), through
+    the exhaustive kernel alone (PC_PF_NO_SEEDS=1) and through the overflow fallback (a 64-entry candidate list): each
+    equals the oracle's plain DP."""
     import os
     import subprocess
     import sys

@@ -7,7 +7,8 @@ import ctypes
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libporechop_amd.so")
+# (PC_LIBRARY: another build of the same library, for A/B timing of kernel variants on one GPU box -- tools/ab_build.sh)
+LIB_PATH = os.environ.get("PC_LIBRARY") or os.path.join(HERE, "libporechop_amd.so")
 
 # every symbol include/porechop_amd.h declares (tests check the list against the header)
 EXPORTS = [

@@ -695,11 +695,22 @@ constexpr u32 H_NEGINF2 = 0xFC00FC00u, H_POSINF2 = 0x7C007C00u;
 // pc_debug_value_range.  (-inf only ever enters as the initial H / V of a column and as the scout's mask; it is
 // absorbed by the first max and is not a "value formed".)
 template <int R, bool CHECK = false>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(R <= 30 ? 4 : R <= 44 ? 3 : 2))) void trace16_kernel(ScanArgs a)
+#ifndef PC_T16_WAVES_A
+#define PC_T16_WAVES_A 4
+#endif
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(R <= 30 ? PC_T16_WAVES_A : R <= 44 ? 3 : 2))) void trace16_kernel(ScanArgs a)
 {
     static_assert(R >= 4 && R % 2 == 0, "row classes are even");
     constexpr int RP = (R + 3) & ~3;         // table row padded to whole b128 groups
-    constexpr int STRIDE = RP + 4;           // dwords per table row (+16 B: rows start in different banks)
+    // dwords per table row.  Every lane reads ITS letter pair's row, four dwords at a time (ds_read_b128), so up to 25
+    // different rows are read by one instruction: rows must start in different bank groups.  The stride in 16-byte slots is
+    // kept ODD -- consecutive rows then walk through all eight slots of the 32 banks.  (RP + 4 alone made it 32 dwords for
+    // the 28-row class of the ligation adapters: every row in the same four banks, each load serialised up to 25 deep.)
+#ifdef PC_VARIANT_STRIDE4
+    constexpr int STRIDE = RP + 4;
+#else
+    constexpr int STRIDE = ((RP / 4) % 2 == 0) ? RP + 4 : RP + 8;
+#endif
     constexpr int NW = (R + 3) / 4;          // trace dwords per column per lane
     __shared__ uint16_t lut_lo[256], lut_hi[256];             // byte -> table row offset (dwords) of the lo / hi stream
     __shared__ __attribute__((aligned(16))) u32 s_tab[25 * STRIDE];
@@ -783,8 +794,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(R <= 30 ? 4 
             U[r] = NEG2;
         }
         u32 top = hpack2(a.gap_open + eps - CEN);                 // T~(0, j-1) entering column j
-        // packed running maxima of the tracked last-row term  M(R,j) + R*eps  (what the fast check compares)
-        u32 best2 = hpack2(R * eps);
+        // The scout of the last-row cells (columns 1..n-1) lives PACKED while the columns run: best2 = the running maxima of
+        // the tracked term M(R,j) + R*eps, pos2 = their columns as two u16 (0: the corner (m, 0) every pair starts from),
+        // bd2 / bg2 = the diagonal term d and max(H, V) of that cell (equal <=> SeqAn's tie flag; initially not).  A new
+        // maximum is eight packed operations per column for both halves, branch-free.  (It used to be a branch taken whenever
+        // ANY of a wave's 128 pairs improved -- with ~5 record columns per pair in 150 that is nearly every column -- into a
+        // path of ~70 instructions around LDS-resident state: a fifth of the kernel's instructions for a 22-row tile.)
+        u32 best2 = hpack2(R * eps), pos2 = 0u, bd2 = 0u, bg2 = 0x3C003C00u;
 
         int nmax = n_lo > n_hi ? n_lo : n_hi;
 #pragma unroll
@@ -822,10 +838,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(R <= 30 ? 4 
         auto load_best = [&](Best &b_lo, Best &b_hi) {
             b_lo = {st_best[0][lane], st_best[1][lane], st_best[2][lane], st_best[3][lane]};
             b_hi = {st_best[4][lane], st_best[5][lane], st_best[6][lane], st_best[7][lane]};
-        };
-        auto store_best = [&](const Best &b_lo, const Best &b_hi) {
-            st_best[0][lane] = b_lo.score; st_best[1][lane] = b_lo.I; st_best[2][lane] = b_lo.J; st_best[3][lane] = b_lo.tie;
-            st_best[4][lane] = b_hi.score; st_best[5][lane] = b_hi.I; st_best[6][lane] = b_hi.J; st_best[7][lane] = b_hi.tie;
         };
         // Read bytes come 16 columns per load (q_lo / q_hi) and are handed on a dword at a time: every lane reads its
         // own window, so each load is an L2 request per lane whatever its width -- a dword per load asked L2 for
@@ -1023,22 +1035,24 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(R <= 30 ? 4 
             if constexpr (CHECK) {
                 if (j <= (n_lo > n_hi ? n_lo : n_hi)) { note(hk_sub(T[R - 1], topn)); note(topn); note(best2); vmax = hk_max(vmax, acc); }
             }
-            const u32 nb = hk_max(best2, cand);
-            if (__any(nb != best2)) {
-                Best b_lo, b_hi;
-                load_best(b_lo, b_hi);
-                const int fr_lo = st_fr[0][lane], fr_hi = st_fr[1][lane];
-                const int cl = hlo(hk_sub(T[R - 1], topn)) - R * eps, ch = hhi(hk_sub(T[R - 1], topn)) - R * eps;
+            {
+                // strict '>' in visiting order (dp_scout.h:165-179): the maximum changes only where cand is larger, and an
+                // earlier column keeps its place; -inf (untracked: limit2) never wins.  best2 is always finite.
+                const u32 nb = hk_maximum(best2, cand);
+                u32 chg, msk;
+                asm volatile("v_pk_min_u16 %0, %1, %2" : "=v"(chg) : "v"(nb ^ best2), "s"(0x00010001u));      // 1 where a half has a new maximum
+                asm volatile("v_pk_sub_u16 %0, 0, %1" : "=v"(msk) : "v"(chg));                                 // 0xFFFF there
+                const u32 j2 = (u32)j * 0x00010001u;
                 const u32 g = hk_max(h_last, v_last);
-                const bool tie_l = HV(d_last).x == HV(g).x, tie_h = HV(d_last).y == HV(g).y;      // d == max(H,V)
-                if (fr_lo < 0 && j < n_lo && cl > b_lo.score) { b_lo.score = cl; b_lo.I = m_lo; b_lo.J = j; b_lo.tie = tie_l; }
-                if (fr_hi < 0 && j < n_hi && ch > b_hi.score) { b_hi.score = ch; b_hi.I = m_hi; b_hi.J = j; b_hi.tie = tie_h; }
-                best2 = hpack2x(b_lo.score + R * eps, b_hi.score + R * eps);
-                store_best(b_lo, b_hi);
+                pos2 = (j2 & msk) | (pos2 & ~msk);
+                bd2 = (d_last & msk) | (bd2 & ~msk);
+                bg2 = (g & msk) | (bg2 & ~msk);
+                best2 = nb;
             }
             if (any_fin) {
-                Best b_lo, b_hi;
-                load_best(b_lo, b_hi);
+                // a pair's last column: its scout leaves the packed form (every in-loop cell is a last-row cell: I = m) ...
+                Best b_lo = {hlo(best2) - R * eps, m_lo, (int)(pos2 & 0xFFFFu), HV(bd2).x == HV(bg2).x ? 1 : 0};
+                Best b_hi = {hhi(best2) - R * eps, m_hi, (int)(pos2 >> 16), HV(bd2).y == HV(bg2).y ? 1 : 0};
                 const int fr_lo = st_fr[0][lane], fr_hi = st_fr[1][lane];
                 // a pair's last column: rolled re-run from the saved previous column, tracked cells top
                 // to bottom with strict '>' (dp_scout.h:165-179), plus every row's d == max(H,V) flag
@@ -1058,8 +1072,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(R <= 30 ? 4 
                     dq = old.x; Tu2 = Tn; Vp2 = Vs;
                     scan_row(r, j, Tn, HV(d).x == HV(g).x, HV(d).y == HV(g).y, fin_lo, fin_hi, b_lo, b_hi, fr_lo, fr_hi);
                 }
-                best2 = hpack2x(b_lo.score + R * eps, b_hi.score + R * eps);
-                store_best(b_lo, b_hi);
+                // ... and is final: kept in LDS till the traceback (halves still running keep their packed state untouched)
+                if (fin_lo) { st_best[0][lane] = b_lo.score; st_best[1][lane] = b_lo.I; st_best[2][lane] = b_lo.J; st_best[3][lane] = b_lo.tie; }
+                if (fin_hi) { st_best[4][lane] = b_hi.score; st_best[5][lane] = b_hi.I; st_best[6][lane] = b_hi.J; st_best[7][lane] = b_hi.tie; }
             }
             top = topn;
             if (j <= shmax) reach_column0(j);

@@ -1065,13 +1065,13 @@ def leg_host_buffers(dev, args):
         h_pk.append(out)
         h_exc.append(torch.from_numpy(exc).pin_memory() if exc.size else None)
     pack_s = time.perf_counter() - t0
-    d_pk = [torch.empty(max(int(x.numel()) for x in h_pk), dtype=torch.uint8, device=dev) for _ in range(2)]
+    d_pk = [torch.zeros(max(int(x.numel()) for x in h_pk) + 64, dtype=torch.uint8, device=dev) for _ in range(2)]   # (+64: the packed scan fetches whole 16-byte blocks)
     d_exc = [torch.empty(max([1] + [int(x.numel()) for x in h_exc if x is not None]), dtype=torch.int64, device=dev) for _ in range(2)]
     copy_stream = torch.cuda.Stream(device=dev)
     main = torch.cuda.current_stream(dev)
     uploaded = [torch.cuda.Event() for _ in range(2)]
     scanned = [torch.cuda.Event() for _ in range(2)]
-    packed, prefilter = [True], [False]
+    packed, prefilter, lazy = [True], [False], [False]      # lazy: the uploaded plane is NOT unpacked (DeviceReads.packed_only)
     # A continuous stream of batches: uploads run ONE BATCH AHEAD of the scans, across step boundaries too (the first batch
     # of step s+1 crosses the link under the last scan of step s); buffers alternate by a global batch counter.
     seq = {"next_upload": 0, "next_scan": 0, "primed": False}
@@ -1089,8 +1089,9 @@ def leg_host_buffers(dev, args):
                 ne = 0 if h_exc[k] is None else int(h_exc[k].numel())
                 if ne:
                     d_exc[s][:ne].copy_(h_exc[k], non_blocking=True)
-                pl.aligner.unpack_device(d_pk[s], nbytes, d_exc[s][:ne] if ne else None, arena=bufs[s], pad=64,
-                                         stream=copy_stream.cuda_stream)
+                if not lazy[0]:
+                    pl.aligner.unpack_device(d_pk[s], nbytes, d_exc[s][:ne] if ne else None, arena=bufs[s], pad=64,
+                                             stream=copy_stream.cuda_stream)
             else:
                 bufs[s][:nbytes].copy_(h_arena[first[k]:first[k + 1]], non_blocking=True)
                 bufs[s][nbytes:nbytes + 64].fill_(ord("N"))
@@ -1109,7 +1110,12 @@ def leg_host_buffers(dev, args):
             seq["next_scan"] += 1
             upload((k + 1) % len(bounds))                           # in flight while batch k is scanned (k = last: the next step's first)
             main.wait_event(uploaded[s])
-            batch = DeviceReads(bufs[s], offs[s][:b - a] - first[k], lens[s][:b - a])
+            if lazy[0]:
+                ne = 0 if h_exc[k] is None else int(h_exc[k].numel())
+                batch = DeviceReads.packed_only(pl.aligner, d_pk[s], first[k + 1] - first[k], d_exc[s][:ne] if ne else None,
+                                                (offs[s][:b - a] - first[k]).contiguous(), lens[s][:b - a], end_size=p.end_size)
+            else:
+                batch = DeviceReads(bufs[s], offs[s][:b - a] - first[k], lens[s][:b - a])
             if k == 0:
                 bs, be = pl.phase_a(batch, torch.arange(min(p.check_reads, b - a), device=dev))
                 matching = pl.matching_sets(bs, be)
@@ -1172,6 +1178,17 @@ def leg_host_buffers(dev, args):
     (_, hits_f), dt_f = timed(step, steps, 1, sync)
     out["exact_prefilter"] = {"reads_per_s": n * steps / dt_f, "ms_per_step": dt_f / steps * 1e3,
                               "same_hits": hits_f == res[True]["middle_hits_per_step"]}
+    # ... and with the uploaded plane left PACKED: no pc_unpack_device pass, the prefilter scans the plane, only end windows and
+    # survivors become bytes.  (The link bounds this leg: 2 bits per base of 8 Gbase at ~55 GB/s is 36 ms = 27.5 M reads/s.)
+    try:
+        lazy[0] = True
+        restart()
+        (_, hits_l), dt_l = timed(step, steps, 1, sync)
+        out["exact_prefilter"]["kept_packed"] = {"reads_per_s": n * steps / dt_l, "ms_per_step": dt_l / steps * 1e3,
+                                                 "same_hits": hits_l == res[True]["middle_hits_per_step"]}
+    except Exception as e:
+        out["exact_prefilter"]["kept_packed"] = {"failed": repr(e)}
+    lazy[0] = False
     pl.close()
     return out
 
@@ -1516,7 +1533,12 @@ def compact_line(full):
     pf = cfg.get("exact_prefilter", {})
     if pf:
         leg("exact_prefilter", reads_per_s=pf.get("reads_per_s"), ms_per_step=pf.get("ms_per_step"),
-            same=pf.get("same_trims_and_middle_hits"), seed_scan_gb_per_s=_pick(pf, "roofline", "achieved"),
+            same=pf.get("same_trims_and_middle_hits"), packed_ms_per_step=_pick(pf, "reads_resident_at_2_bits_per_base", "ms_per_step"),
+            packed_same=_pick(pf, "reads_resident_at_2_bits_per_base", "same_trims_and_middle_hits"),
+            packed_seed_scan_ms=_pick(pf, "reads_resident_at_2_bits_per_base", "seed_scan_ms"),
+            packed_hbm_bytes=_pick(pf, "reads_resident_at_2_bits_per_base", "hbm_bytes_resident"),
+            packed_failed=_pick(pf, "reads_resident_at_2_bits_per_base", "failed"),
+            seed_scan_gb_per_s=_pick(pf, "roofline", "achieved"),
             seed_scan_hbm_frac=_pick(pf, "roofline", "frac"), seed_scan_ms=_pick(pf, "roofline", "avg_launch_ms"),
             seed_scan_traffic=_pick(pf, "roofline", "traffic"), seed_scan_alg_bytes=_pick(pf, "roofline", "algorithmic_bytes_per_launch"))
     pr = cfg.get("optional_exact_pruning", {})
@@ -1541,7 +1563,10 @@ def compact_line(full):
             bytes_per_step=hb.get("bytes_uploaded_per_step"), pack_once_s=hb.get("pack_once_s"),
             unpacked_reads_per_s=_pick(hb, "bytes_per_base_1", "reads_per_s"), unpacked_h2d_ms=_pick(hb, "bytes_per_base_1", "h2d_ms_alone"),
             same_hits_both_forms=hb.get("same_hits_both_forms"), prefiltered_reads_per_s=_pick(hb, "exact_prefilter", "reads_per_s"),
-            prefiltered_same_hits=_pick(hb, "exact_prefilter", "same_hits"))
+            prefiltered_same_hits=_pick(hb, "exact_prefilter", "same_hits"),
+            kept_packed_reads_per_s=_pick(hb, "exact_prefilter", "kept_packed", "reads_per_s"),
+            kept_packed_same_hits=_pick(hb, "exact_prefilter", "kept_packed", "same_hits"),
+            kept_packed_failed=_pick(hb, "exact_prefilter", "kept_packed", "failed"))
     ee = also.get("end_to_end", {})
     if ee:
         leg("end_to_end", failed=ee.get("failed"), reads_per_s=ee.get("reads_per_s"), wall_s=ee.get("wall_s"),
@@ -1772,6 +1797,55 @@ def main():
                        torch.equal(hits_f.end, hits.end) and torch.equal(st_f, st) and torch.equal(et_f, et) and
                        (hits_f.rounds, hits_f.alignments) == (hits.rounds, hits.alignments))
 
+    # ---- the same step with the reads RESIDENT AT 2 BITS PER BASE (north_star: "2-bit-packed read windows"): the plane
+    # io.pack_reads makes stays in HBM (a quarter of the bytes), the prefilter's seed scan reads it directly
+    # (pc_prefilter_packed), and only the two 150-base end windows of every read and the few reads that survive the
+    # prefilter are ever turned into bytes (pc_unpack_windows).  Beside the headline, never `value`.
+    pk_out = None
+    if world == 1 and not args.no_extra:
+        try:
+            from porechop_amd.io import pack_reads
+            from porechop_amd.pipeline import DeviceReads
+            nb_ = int(reads.off[-1].item()) + int(reads.length[-1].item())
+            h_ = reads.arena[:nb_].cpu().numpy()
+            pk_, exc_ = pack_reads(h_, nb_)
+            del h_
+            t0p = time.perf_counter()
+            reads_pk = DeviceReads.packed_only(pl.aligner, torch.from_numpy(pk_).to(dev), nb_,
+                                               torch.from_numpy(exc_).to(dev) if exc_.size else None, reads.off, reads.length,
+                                               end_size=params.end_size)
+            pl.aligner.sync()
+            torch.cuda.synchronize()
+            build_ms = (time.perf_counter() - t0p) * 1e3
+            one_step(pl, reads_pk, n_check, world, prefilter=True)
+            pl.aligner.set_timing(True)
+            pl.aligner.get_timing()
+            stats0 = dict(pl.stats)
+            barrier()
+            t0p = time.perf_counter()
+            for _ in range(fsteps):
+                _, st_k, et_k, hits_k = one_step(pl, reads_pk, n_check, world, prefilter=True)
+            pl.aligner.sync()
+            barrier()
+            dt_pk = time.perf_counter() - t0p
+            timing_pk = pl.aligner.get_timing()
+            pl.aligner.set_timing(False)
+            same_k = bool(hits_k.read.numel() == hits.read.numel() and torch.equal(hits_k.read, hits.read) and
+                          torch.equal(hits_k.adapter, hits.adapter) and torch.equal(hits_k.start, hits.start) and
+                          torch.equal(hits_k.end, hits.end) and torch.equal(st_k, st) and torch.equal(et_k, et))
+            pk_out = {"reads_per_s": args.reads * fsteps / dt_pk, "ms_per_step": dt_pk / fsteps * 1e3, "same_trims_and_middle_hits": same_k,
+                      "hbm_bytes_resident": int(reads_pk.plane.numel()) + int(reads_pk.ends[0].numel()),
+                      "hbm_bytes_resident_as_bytes": int(reads.arena.numel()),
+                      "bytes_unpacked_per_step": (pl.stats.get("bases_unpacked_after_prefilter", 0) - stats0.get("bases_unpacked_after_prefilter", 0)) // fsteps,
+                      "packed_route_refused": pl.stats.get("packed_route_refused", 0) - stats0.get("packed_route_refused", 0),
+                      "upload_and_end_windows_ms": build_ms,
+                      "kernel_ms_per_step": {k: v[0] / fsteps for k, v in timing_pk.items()},
+                      "seed_scan_ms": timing_pk["seed_scan"][0] / max(1, timing_pk["seed_scan"][1]) if timing_pk["seed_scan"][1] else None,
+                      "seed_scan_plane_gb_per_s": (nb_ / 4 / 1e9) / (timing_pk["seed_scan"][0] / 1e3 / fsteps) if timing_pk["seed_scan"][0] else None}
+            del reads_pk
+        except Exception as e:      # an extra measurement must never break the bench line
+            pk_out = {"failed": repr(e)}
+
     out = None
     if rank == 0:
         total_reads = args.reads * world
@@ -1838,6 +1912,8 @@ def main():
                       "bit-vector edit distance on the finds -- and only the surviving pairs run the DP; everything else is proven "
                       "not to be a hit (csrc/pc_prefilter.hip, tests/test_prefilter_bound.py, tests/test_gpu_prefilter.py)"}
         pf["roofline"] = prefilter_roofline(timing_pf, mean_trim_len, A)
+        if pk_out is not None:
+            pf["reads_resident_at_2_bits_per_base"] = pk_out
         out = {
             "metric": "reads/sec (and read-bp/sec) end+middle adapter scan, 8 kb reads",
             "value": reads_per_s, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

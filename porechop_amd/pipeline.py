@@ -286,6 +286,8 @@ class Pipeline:
                 sorted_jobs.append((j[0], order_of[key][1], order_of[key][2]) + tuple(j[3:]))
             orders = [order_of[(id(j[1]), id(j[2]))][0] for j in jobs]
             jobs = sorted_jobs
+        if os.environ.get("PC_NO_FUSE", "0") not in ("", "0"):        # (timing experiments: every adapter alone, exact rows, two read streams)
+            fuse = False
         groups = {}
         for k, j in enumerate(jobs):
             # fuse=False: every job alone (one adapter per kernel: the single-sequence kernels ship with the library)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """One leg of bench.py, alone, for the profiler: every launch in the process then belongs to that leg, so rocprofv3's
 per-kernel numbers can be attributed to it.  `steps` identical steps, nothing else (no CPU legs, no cross-checks).
-usage: run_leg.py headline|prefilter|configs1|configs2|configs2_pruned|configs4|configs4_prefilter [steps]"""
+usage: run_leg.py headline|prefilter|prefilter_packed|configs1|configs2|configs2_pruned|configs4|configs4_prefilter [steps]"""
 import argparse
 import os
 import sys
@@ -22,9 +22,17 @@ pl = Pipeline(bench.load_panel_sets(), p, device=dev)
 pl.n_panel = len(pl.sets)
 fw = [a for a in bench.load_panel_json() if a["name"].startswith("Barcode ") and "(forward)" in a["name"]]
 bc = dict(barcodes_start=[a["start"][1] for a in fw], barcodes_end=[a["end"][1] for a in fw])
-if leg in ("headline", "prefilter"):
+if leg in ("headline", "prefilter", "prefilter_packed"):
     reads = make_reads(1_000_000, 8000, seed=3, start_frac=0.9, end_frac=0.5, chimera_frac=0.01, device=dev)
-    step = lambda: bench.one_step(pl, reads, p.check_reads, 1, prefilter=(leg == "prefilter"))
+    if leg == "prefilter_packed":             # the reads resident at 2 bits per base: the plane scanned, survivors unpacked
+        from porechop_amd.io import pack_reads
+        from porechop_amd.pipeline import DeviceReads
+        nb = reads.n * 8000
+        pk, exc = pack_reads(reads.arena[:nb].cpu().numpy(), nb)
+        reads = DeviceReads.packed_only(pl.aligner, torch.from_numpy(pk).to(dev), nb, torch.from_numpy(exc).to(dev) if exc.size else None,
+                                        reads.off, reads.length, end_size=p.end_size)
+        torch.cuda.empty_cache()
+    step = lambda: bench.one_step(pl, reads, p.check_reads, 1, prefilter=(leg != "headline"))
 elif leg == "configs1":
     reads = make_reads(100_000, 8000, seed=1, start_frac=0.9, end_frac=0.5, chimera_frac=0.0, device=dev)
     step = lambda: bench.step_end_trim(pl, reads, p.check_reads)

@@ -213,6 +213,27 @@ int upload_panel(pc_ctx *c)
         c->ad_window[i] = b.window;
         c->ad_span[i] = b.SPAN;
     }
+    {
+        // said once per process and cause: the answers are the reference's either way, but a user should know that the run left the
+        // fast kernels (PC_QUIET=1 silences it)
+        static bool told_scheme = false, told_adapter = false;
+        static const bool quiet = [] { const char *e = getenv("PC_QUIET"); return e && *e && *e != '0'; }();
+        int longest_slow = 0;
+        for (int i = 0; i < n; ++i) if (c->ad_slow[i] && !c->slow_scheme) longest_slow = std::max(longest_slow, c->ad_len[i]);
+        if (c->slow_scheme && n > 0 && !told_scheme && !quiet) {
+            told_scheme = true;
+            fprintf(stderr, "porechop_amd: scoring scheme %d,%d,%d,%d is outside the packed 16-bit kernels' exact range (they need match > 0, "
+                            "match > mismatch, negative gap scores and magnitudes that fit their lanes): every alignment runs the plain-int32 "
+                            "kernel -- the same answers, roughly a hundred times slower per cell, and none of the exact prunings\n",
+                    c->match, c->mismatch, c->gap_open, c->gap_extend);
+        }
+        if (longest_slow > 0 && !told_adapter && !quiet) {
+            told_adapter = true;
+            fprintf(stderr, "porechop_amd: an adapter of %d bases is longer than the %d the packed 16-bit kernels keep in registers: its "
+                            "alignments run the plain-int32 kernel (the same answers, roughly a hundred times slower per cell)\n",
+                    longest_slow, pcb::MAX_ADAPTER);
+        }
+    }
     // stream-ordered: earlier launches may still read the old tables
     // the tables below may be in use by scans in flight on ANY stream (callers pass their own): drain the device.
     // (Only when the panel or the scores change.)

@@ -213,6 +213,20 @@ class Pipeline:
             self.aligner = aligner
             self.aligner.set_adapters(self.seqs)
         self.stats = {"pairs_end": 0, "pairs_middle": 0, "cells_end": 0, "cells_middle": 0}
+        self._consts = {}
+
+    def _const(self, values, dtype=torch.int64):
+        """A small read-only device tensor of host values (job -> set / side / adapter length tables ...), kept between calls: a
+        torch.tensor(list, device=cuda) is a pageable upload that WAITS for everything enqueued before it -- half a dozen of
+        them per step were half a dozen drains of the GPU's queue (0.5 ms each at 1 M reads), for tables that repeat from batch
+        to batch."""
+        key = (dtype, tuple(values))
+        t = self._consts.get(key)
+        if t is None:
+            if len(self._consts) > 512:
+                self._consts.clear()
+            t = self._consts[key] = torch.tensor(list(values), dtype=dtype, device=self.device)
+        return t
 
     def packed_kernels(self):
         """True when every pair of this pipeline runs the packed 16-bit kernels (pc_scores_supported): the exact prunings
@@ -403,8 +417,8 @@ class Pipeline:
         m = rec[:, :, 5].to(torch.float64)
         full = _round6(100.0 * m / rec[:, :, 7].to(torch.float64))
         full = torch.where(rec[:, :, 0] == -1, torch.zeros_like(full), full).amax(dim=1)   # [J]
-        si = torch.tensor([w[0] for w in where], device=self.device)
-        side = torch.tensor([w[1] for w in where], device=self.device)
+        si = self._const([w[0] for w in where])
+        side = self._const([w[1] for w in where])
         best_start.scatter_reduce_(0, si[side == 0], full[side == 0], reduce="amax")
         best_end.scatter_reduce_(0, si[side == 1], full[side == 1], reduce="amax")
         self.stats["pairs_end"] += sum(int(j[1].shape[0]) for j in jobs)
@@ -413,7 +427,7 @@ class Pipeline:
     def _phase_a_pruned(self, reads, jobs, where, best_start, best_end):
         scores = torch.stack(self._scan_jobs(self._ends_arena(reads), jobs, MODE_SCORE, self.p.end_size))[:, :, 4]   # [J, n]
         bounds = [self.presence_score_bound(len(self.seqs[j[0]])) for j in jobs]
-        need = torch.tensor([b if b is not None else -(1 << 30) for b in bounds], device=self.device)
+        need = self._const([b if b is not None else -(1 << 30) for b in bounds])
         cand = scores >= need[:, None]
         hit = torch.nonzero(cand)                              # [C, 2] (job, window), job-major: one sync
         counts = torch.bincount(hit[:, 0], minlength=len(jobs)).cpu().numpy()
@@ -435,8 +449,8 @@ class Pipeline:
         job_of = torch.repeat_interleave(torch.arange(len(cjobs), device=self.device),
                                          torch.tensor([int(j[1].shape[0]) for j in cjobs], device=self.device))
         top = torch.zeros(len(cjobs), dtype=torch.float64, device=self.device).scatter_reduce_(0, job_of, full, reduce="amax")
-        si = torch.tensor([w[0] for w in cwhere], device=self.device)
-        side = torch.tensor([w[1] for w in cwhere], device=self.device)
+        si = self._const([w[0] for w in cwhere])
+        side = self._const([w[1] for w in cwhere])
         best_start.scatter_reduce_(0, si[side == 0], top[side == 0], reduce="amax")
         best_end.scatter_reduce_(0, si[side == 1], top[side == 1], reduce="amax")
         return best_start, best_end
@@ -495,8 +509,8 @@ class Pipeline:
         dev = self.device
         match, _, go, ge = p.scores
         g = min(-go, -ge)
-        m = torch.tensor([len(self.seqs[j[0]]) for j in jobs], dtype=torch.int64, device=dev)[:, None]
-        is_end = torch.tensor([w[0] for w in where], dtype=torch.bool, device=dev)[:, None]
+        m = self._const([len(self.seqs[j[0]]) for j in jobs])[:, None]
+        is_end = self._const([bool(w[0]) for w in where], torch.bool)[:, None]
         n = torch.where(is_end, el[None, :].to(torch.int64), sl[None, :].to(torch.int64))
         flag = score_rec[:, :, 0].to(torch.int64)
         Jc = score_rec[:, :, 1].to(torch.int64)
@@ -555,10 +569,10 @@ class Pipeline:
             key = rules.phase_b_pair_key(self.sets[si])
             hinted.append(tuple(j[:3]) + ((("pair", side) + key) if key is not None else ("alone", k),))
         _, rec, rec_off = self._scan_jobs(self._ends_arena(reads), hinted, MODE_SCORE, p.end_size, with_layout=True)
-        job_off = torch.tensor(rec_off, dtype=torch.int64, device=dev)
-        job_side = torch.tensor([w[0] for w in where], dtype=torch.int32, device=dev)
-        job_len = torch.tensor([len(self.seqs[j[0]]) for j in jobs], dtype=torch.int32, device=dev)
-        job_calls = torch.tensor([1 if w[1] in call_sets else 0 for w in where], dtype=torch.int32, device=dev)
+        job_off = self._const(rec_off)
+        job_side = self._const([w[0] for w in where], torch.int32)
+        job_len = self._const([len(self.seqs[j[0]]) for j in jobs], torch.int32)
+        job_calls = self._const([1 if w[1] in call_sets else 0 for w in where], torch.int32)
         job_adapter = np.array([j[0] for j in jobs], dtype=np.int32)
         words = (R + 63) // 64
         best_full = torch.zeros((2, R), dtype=torch.float64, device=dev)   # best traced full identity of a call pair, per side
@@ -795,7 +809,7 @@ class Pipeline:
             cand_g = bits
         else:                                            # union over the sequences of a set
             cand_g = torch.zeros((int(rows.shape[0]), G), dtype=torch.int32, device=dev).index_add_(
-                1, torch.tensor(gidx, device=dev), bits.to(torch.int32)) > 0
+                1, self._const(gidx), bits.to(torch.int32)) > 0
         hitg = torch.nonzero(cand_g.t())                              # [C, 2] (group, row), group-major
         scan_off = off
         if packed_reads is not None and packed_reads.arena is None:
@@ -904,7 +918,7 @@ class Pipeline:
             packed_only = packed_only and reads.arena is None         # (the packed route may have been refused: everything unpacked)
         elif prove and all(b is not None for b in bounds):
             score = torch.stack(self._scan_jobs(reads.arena, jobs0, MODE_SCORE, max_len, sort_lengths=ragged, typ_len=typ_len))[:, :, 4]      # [A, L]
-            cand = torch.nonzero(score >= torch.tensor(bounds, device=dev)[:, None])                     # adapter-major
+            cand = torch.nonzero(score >= self._const(bounds)[:, None])                     # adapter-major
             counts = torch.bincount(cand[:, 0], minlength=A).cpu().numpy()
             L = int(live.numel())
             recs = torch.zeros((A, L, RESULT_INTS), dtype=torch.int32, device=dev)

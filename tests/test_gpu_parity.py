@@ -435,3 +435,24 @@ def test_large_match_score_long_adapter_tracked_term_stays_exact(pa, oracle):
         assert pa.format_result(rec) == want, (len(rd), ai, pa.format_result(rec), want)
         n_full += int(rec[4] >= 29 * 60)
     assert n_full > 500                                              # the near-perfect 64-base hits were there
+
+
+def test_leaving_the_packed_kernels_is_said_on_stderr():
+    """`--scoring_scheme 3,-6,-5,0` (a zero gap-extension score: the reference's CLI takes it, porechop.py:145,196-202) and an
+    adapter above 128 bases run the plain-int32 kernel -- a hundred times slower per cell, no prunings: the library says so,
+    once; PC_QUIET=1 silences it."""
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "import porechop_amd\n"
+            "for k in range(2):\n"
+            "    al = porechop_amd.Aligner(['AATGTACTTCGTTCAGTTACGTATTGCT'], (3, -6, -5, 0)); al.align_pairs([('ACGT' * 40, 0)]); al.close()\n"
+            "al = porechop_amd.Aligner(['ACGT' * 50, 'ACGTACGTACGTAAAC']); al.align_pairs([('ACGT' * 40, 0), ('ACGT' * 40, 1)]); al.close()\n" % repo)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=repo)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.stderr.count("scoring scheme 3,-6,-5,0 is outside the packed 16-bit kernels' exact range") == 1, r.stderr[-2000:]
+    assert r.stderr.count("an adapter of 200 bases is longer than the 128") == 1, r.stderr[-2000:]
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=repo, env=dict(os.environ, PC_QUIET="1"))
+    assert r.returncode == 0 and "plain-int32" not in r.stderr

@@ -1427,13 +1427,28 @@ static int prefilter_impl(pc_ctx *c, const void *d_arena, const int64_t *d_win_o
         // of one per seed length (its LDS probes and its 4 VALU operations per base and length were what bound it: DESIGN.md
         // section 4); the price is a few more candidates for the verifier (an 8-base seed cut to 7 is found four times as often).
         // PC_PF_MULTI_Q=1: a bitmap per seed length, as before.
-        static const bool multi_q = [] { const char *e = getenv("PC_PF_MULTI_Q"); return e && *e && *e != '0'; }();
+        // ... which pays for a handful of adapters (the headline's four: 9.2e-4 candidates per base instead of 7.3e-4) and not for
+        // a barcode panel (196 sequences, mostly 24-mers with 8-base seeds: 3.7e-2 instead of 9e-3 -- the verifier and the
+        // scan's own emit path then cost three times what the second probe did): one length only while the expected
+        // candidate rate stays below 2e-3 per base or within 1.5 x of the per-length rate.  PC_PF_MULTI_Q=1 / PC_PF_SINGLE_Q=1 force.
+        static const bool force_multi = [] { const char *e = getenv("PC_PF_MULTI_Q"); return e && *e && *e != '0'; }();
+        static const bool force_single = [] { const char *e = getenv("PC_PF_SINGLE_Q"); return e && *e && *e != '0'; }();
         int q_common = 8;
         for (const Piece &pc : pieces) {
             const int parts = pc.k + 1;
             const int q = std::min(8, pc.len / std::max(1, parts));
             if (pc.k >= 0 && pc.k < pc.len && parts <= 8 && q >= 6) q_common = std::min(q_common, q);
         }
+        double rate_multi = 0.0, rate_single = 0.0;
+        for (const Piece &pc : pieces) {
+            const int parts = pc.k + 1;
+            const int q = std::min(8, pc.len / std::max(1, parts));
+            if (pc.k >= 0 && pc.k < pc.len && parts <= 8 && q >= 6) {
+                rate_multi += (double)parts / (double)(1u << (2 * q));
+                rate_single += (double)parts / (double)(1u << (2 * q_common));
+            }
+        }
+        const bool multi_q = force_multi || (!force_single && rate_single > 2e-3 && rate_single > 1.5 * rate_multi);
         for (size_t i = 0; i < pieces.size(); ++i) {
             const Piece &pc = pieces[i];
             const int parts = pc.k + 1;
@@ -1471,7 +1486,7 @@ static int prefilter_impl(pc_ctx *c, const void *d_arena, const int64_t *d_win_o
                 rest_piece.push_back(i);
             }
         }
-        if (packed && (!rest_piece.empty() || multi_q)) return PC_ERR_UNSUPPORTED_SCORES;   // only the seed stage reads the plane
+        if (packed && !rest_piece.empty()) return PC_ERR_UNSUPPORTED_SCORES;   // only the seed stage reads the plane
         c->sd_nq = 0;
         int cls_of_q[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
         for (int q = 8; q >= 6; --q) if (have_q[q]) { cls_of_q[q] = c->sd_nq; c->sd_q[c->sd_nq++] = q; }
@@ -1564,7 +1579,7 @@ static int prefilter_impl(pc_ctx *c, const void *d_arena, const int64_t *d_win_o
     }
     HIP_TRY(hipMemsetAsync(d_mask, 0, (size_t)nwindows * words * 4, stream));
     if (c->pf_launches.empty() || max_len == 0) return PC_OK;
-    if (packed && (c->sd_nq != 1 || !c->pf_rest_launches.empty())) return PC_ERR_UNSUPPORTED_SCORES;
+    if (packed && (c->sd_nq < 1 || !c->pf_rest_launches.empty())) return PC_ERR_UNSUPPORTED_SCORES;
     // column chunks: enough (window, chunk) units to fill the chip several times over, chunks no shorter than 512
     // columns (the warm-up before a chunk is the longest piece + its edit bound: ~35 columns)
     const int64_t target = (int64_t)c->ncu * 2048 * 6;

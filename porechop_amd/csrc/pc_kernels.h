@@ -162,7 +162,7 @@ int launch_seed_scan(const SeedScanArgs &a, void *stream);
 int launch_seed_verify(const SeedVerifyArgs &a, int64_t ncand, void *stream);
 // The same two stages over reads held at 2 BITS PER BASE (pc_pack_reads' plane: base i in bits 2 (i % 16) of dword i / 16,
 // SeqAn's Dna ordinals; bases that were not A/C/G/T/U sit there as 'A').  `arena` of the argument structs is the plane,
-// win_off counts BASES, ONE seed length (q[0]); q-grams are little-endian here (first base in the lowest bits), and so are the
+// win_off counts BASES; q-grams are little-endian here (first base in the lowest bits), and so are the
 // host's tables for this route.  No exception list is consulted: a non-base read as 'A' can only ADD matches against
 // adapters made of A/C/G/T (the only ones this route takes), so every pair it clears is still proven.
 int launch_seed_scan_packed(const SeedScanArgs &a, void *stream);

@@ -434,19 +434,25 @@ __global__ __launch_bounds__(256) void seed_verify_kernel(SeedVerifyArgs a)
 // the one HBM-bound kernel of the path, and no byte -> code step at all -- sixteen bases ARE a dword.  A lane takes its
 // stream a 128-byte line (512 bases) at a time; the q-gram that ends at base t of a dword is one funnel shift of
 // (previous dword, this dword) by a compile-time amount, its low 5 bits pick the bit and the rest the word of the bitmap:
-// shift, bfe, LDS probe, bfe, shift-or = 4 VALU operations and one probe per base.
+// shift, bfe, LDS probe, bfe, shift-or = 4 VALU operations and one probe per base and seed length.
 // (Tried and dropped: a copy of the bitmap per LDS bank, 64 KB, so that no probe ever conflicts -- 2.88 instead of 2.21 ms
 // for 8 Gbase: the probes' latency is hidden by resident waves, and 64 KB of LDS leaves two per SIMD instead of five.)
 // ---------------------------------------------------------------------------------------------------------
-template <int Q>
+// Q0 >= Q1 >= Q2 are the seed lengths present (0 = none): one bitmap each, in the slots the host lays them out in
+// (kBmOff0 / 1 / 2, longest first).  A batch of few adapters has ONE length (pc_api.cpp); a barcode panel keeps its lengths apart.
+template <int Q0, int Q1, int Q2>
 __global__ __launch_bounds__(256) void seed_scan_packed_kernel(SeedScanArgs a)
 {
-    __shared__ uint32_t bm[(1 << (2 * Q)) / 32];
+    constexpr int NQ = 1 + (Q1 > 0) + (Q2 > 0);
+    constexpr int QS[3] = {Q0, Q1 > 0 ? Q1 : 6, Q2 > 0 ? Q2 : 6};
+    constexpr int BOFF[3] = {kBmOff0, kBmOff1, kBmOff2};
+    constexpr int BMW = NQ == 1 ? (1 << (2 * Q0)) / 32 : kBmWords;
+    __shared__ uint32_t bm[BMW];
     __shared__ int wcnt[4];
     __shared__ uint2 wbuf[4][kWaveBuf];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (threadIdx.x < 4) wcnt[threadIdx.x] = 0;
-    for (int i = threadIdx.x; i < (1 << (2 * Q)) / 32; i += 256) bm[i] = a.bitmaps[i];
+    for (int i = threadIdx.x; i < BMW; i += 256) bm[i] = a.bitmaps[i];
     __syncthreads();
     const uint32_t *plane = (const uint32_t *)a.arena;
     const int64_t wblocks = (a.nwindows + 255) / 256;
@@ -482,39 +488,48 @@ __global__ __launch_bounds__(256) void seed_scan_packed_kernel(SeedScanArgs a)
         for (int i = 0; i < 8; ++i) { nx[i] = r[i]; if (512 * (L + 1) + 64 * i < n) nx[i] = *(const u32x4 *)(p + 32 * (L + 1) + 4 * i); }
 #pragma unroll
         for (int half = 0; half < 4; ++half) {       // a quarter line: 8 dwords = 128 bases
-            uint32_t hb[8];                          // per dword: bit 15 - t = a seed ends at its base t
+            uint32_t hb[NQ][8];                      // per seed length and dword: bit 15 - t = a seed ends at its base t
             uint32_t any = 0;
 #pragma unroll
             for (int d = 0; d < 8; ++d) {
                 const u32x4 v = r[2 * half + (d >> 2)];
                 const uint32_t cur = (d & 3) == 0 ? v.x : (d & 3) == 1 ? v.y : (d & 3) == 2 ? v.z : v.w;
-                uint32_t h = 0;
+                uint32_t h[NQ];
+#pragma unroll
+                for (int c = 0; c < NQ; ++c) h[c] = 0;
 #pragma unroll
                 for (int t = 0; t < 16; ++t) {
-                    // the Q bases ending at base t of `cur`, first base in the lowest bits: bits [st, st + 2Q) of prev:cur
-                    const int st = 32 + 2 * (t + 1) - 2 * Q;
-                    const uint32_t g = st < 32 ? __builtin_amdgcn_alignbit(cur, prev, st) : (cur >> (st - 32));
-                    const uint32_t word = bm[__builtin_amdgcn_ubfe(g, 5, 2 * Q - 5)];
-                    h = (h << 1) | __builtin_amdgcn_ubfe(word, g, 1);             // (the offset operand is taken modulo 32)
+#pragma unroll
+                    for (int c = 0; c < NQ; ++c) {
+                        // the QS[c] bases ending at base t of `cur`, first base in the lowest bits: bits [st, st + 2 q) of prev:cur
+                        const int st = 32 + 2 * (t + 1) - 2 * QS[c];
+                        const uint32_t g = st < 32 ? __builtin_amdgcn_alignbit(cur, prev, st) : (cur >> (st - 32));
+                        const uint32_t word = bm[(NQ == 1 ? 0 : BOFF[c]) + __builtin_amdgcn_ubfe(g, 5, 2 * QS[c] - 5)];
+                        h[c] = (h[c] << 1) | __builtin_amdgcn_ubfe(word, g, 1);   // (the offset operand is taken modulo 32)
+                    }
                 }
-                hb[d] = h;
-                any |= h;
+#pragma unroll
+                for (int c = 0; c < NQ; ++c) { hb[c][d] = h[c]; any |= h[c]; }
                 prev = cur;
             }
             if (any && L < nlines) {
                 const int base0 = 512 * L + 128 * half;  // stream position of this quarter line's first base
 #pragma unroll 1
-                for (int d = 0; d < 8; ++d) {
+                for (int cd_ = 0; cd_ < NQ * 8; ++cd_) {
+                    const int c = cd_ >> 3, d = cd_ & 7;
                     uint32_t h = 0;
 #pragma unroll
-                    for (int dd = 0; dd < 8; ++dd) h = (dd == d) ? hb[dd] : h;
+                    for (int cc = 0; cc < NQ; ++cc)
+#pragma unroll
+                        for (int dd = 0; dd < 8; ++dd) h = (cc == c && dd == d) ? hb[cc][dd] : h;
+                    const int qc = c == 0 ? QS[0] : c == 1 ? QS[1] : QS[2];
                     while (h) {
                         const int t = 15 - (31 - __builtin_clz(h));
                         h &= ~(1u << (15 - t));
                         const int pos = base0 + 16 * d + t;          // stream position of the seed's last base
                         const int j = start + pos;                     // window coordinate
-                        if (pos < n && j >= c0 && j >= Q - 1) {        // (warm-up columns belong to the previous chunk)
-                            const uint2 cd = make_uint2((uint32_t)w, (uint32_t)j);
+                        if (pos < n && j >= c0 && j >= qc - 1) {       // (warm-up columns belong to the previous chunk)
+                            const uint2 cd = make_uint2((uint32_t)w, (uint32_t)j | ((uint32_t)c << 28));
                             const int slot = atomicAdd(&wcnt[wv], 1);
                             if (slot < kWaveBuf) {
                                 wbuf[wv][slot] = cd;
@@ -547,8 +562,9 @@ __global__ __launch_bounds__(256) void seed_verify_packed_kernel(SeedVerifyArgs 
     if (ci >= total) return;
     const uint2 cd = ((const uint2 *)a.cand)[ci];
     const int64_t w = (int64_t)cd.x;
-    const int j = (int)cd.y;                          // window column of the seed's last base
-    const int q = a.q[0];
+    const int j = (int)(cd.y & 0x0FFFFFFFu);          // window column of the seed's last base
+    const int cls = (int)(cd.y >> 28);
+    const int q = a.q[cls];
     const int n = a.win_len[w];
     const uint32_t *plane = (const uint32_t *)a.arena;
     const int64_t b0 = a.win_off[w];                  // base index of the window's column 0
@@ -556,7 +572,7 @@ __global__ __launch_bounds__(256) void seed_verify_packed_kernel(SeedVerifyArgs 
     uint32_t *mrow = a.mask + w * a.words;
     uint32_t idx = 0;                                 // little-endian q-gram: first base in the lowest bits
     for (int t = 0; t < q; ++t) idx |= code_at(j - q + 1 + t) << (2 * t);
-    const uint32_t e0 = a.first[a.first_off[0] + idx], e1 = a.first[a.first_off[0] + idx + 1];
+    const uint32_t e0 = a.first[a.first_off[cls] + idx], e1 = a.first[a.first_off[cls] + idx + 1];
     for (uint32_t e = e0; e < e1; ++e) {
         const int4 en = ((const int4 *)a.entries)[e];
         const int pi = en.x, off = en.y;
@@ -624,14 +640,17 @@ int launch_seed_scan_packed(const SeedScanArgs &a, void *stream)
     if (a.nwindows <= 0) return 0;
     const int64_t wblocks = (a.nwindows + 255) / 256;
     const int64_t gx = wblocks * a.chunks;
-    if (gx > 0x7FFFFFFFll || a.nq != 1) return -1;
+    if (gx > 0x7FFFFFFFll) return -1;
     hipStream_t s = (hipStream_t)stream;
-    switch (a.q[0]) {
-        case 6: hipLaunchKernelGGL(seed_scan_packed_kernel<6>, dim3((unsigned)gx), dim3(256), 0, s, a); break;
-        case 7: hipLaunchKernelGGL(seed_scan_packed_kernel<7>, dim3((unsigned)gx), dim3(256), 0, s, a); break;
-        case 8: hipLaunchKernelGGL(seed_scan_packed_kernel<8>, dim3((unsigned)gx), dim3(256), 0, s, a); break;
+    // the lengths present, longest first (8 >= q[0] > q[1] > q[2] >= 6)
+    const int key = a.q[0] * 100 + (a.nq > 1 ? a.q[1] * 10 : 0) + (a.nq > 2 ? a.q[2] : 0);
+#define PC_SSP(K, A, B, C) case K: hipLaunchKernelGGL((seed_scan_packed_kernel<A, B, C>), dim3((unsigned)gx), dim3(256), 0, s, a); break;
+    switch (key) {
+        PC_SSP(600, 6, 0, 0) PC_SSP(700, 7, 0, 0) PC_SSP(800, 8, 0, 0)
+        PC_SSP(870, 8, 7, 0) PC_SSP(860, 8, 6, 0) PC_SSP(760, 7, 6, 0) PC_SSP(876, 8, 7, 6)
         default: return -1;
     }
+#undef PC_SSP
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

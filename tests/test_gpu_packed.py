@@ -293,3 +293,38 @@ def test_packed_route_with_an_overflowing_candidate_list_excludes_nothing():
     assert r.returncode == 0 and "CHILD_OK" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
     unpacked, n = r.stdout.split("CHILD_OK")[1].split()[:2]
     assert int(unpacked) >= 0.8 * int(n)                # every (trimmed) read survived "the prefilter"
+
+
+def test_packed_prefilter_with_a_bitmap_per_seed_length_equals_the_byte_route():
+    """A barcode panel's worth of adapters keeps its seed lengths apart (the candidate rate decides, pc_api.cpp): the scan over
+    the plane then probes one bitmap per length, like the byte route's -- same mask on reads made of A/C/G/T."""
+    import porechop_amd
+    from porechop_amd.panel import load_panel
+    from tests.test_gpu_prefilter import make_cases
+    seqs = []
+    for s in load_panel():
+        for side in (s.start, s.end):
+            if side is not None and side[1] not in seqs and set(side[1]) <= set("ACGT"):
+                seqs.append(side[1])
+    seqs = seqs[:200]
+    assert len(seqs) > 150
+    reads = [r.upper() for r in make_cases(7, 1200, [150, 1000, 6000], seqs[:60], alphabet="ACGT")]
+    arr = np.frombuffer("".join(reads).encode(), dtype=np.uint8)
+    lens = np.array([len(r) for r in reads], dtype=np.int32)
+    offs = np.concatenate([[0], np.cumsum(lens[:-1], dtype=np.int64)]).astype(np.int64)
+    dev = torch.device("cuda")
+    d_off, d_len = torch.from_numpy(offs).to(dev), torch.from_numpy(lens).to(dev)
+    plane, d_exc, exc = _packed_plane(arr, dev)
+    arena = torch.from_numpy(np.concatenate([arr, np.full(64, ord("N"), np.uint8)])).to(dev)
+    al = porechop_amd.Aligner(seqs)
+    try:
+        ks = [al.max_edits(len(a), 90.0) for a in seqs]
+        ids = list(range(len(seqs)))
+        m_bytes = al.prefilter_mask(arena, d_off, d_len, int(lens.max()), ids, ks)
+        m_plane = al.prefilter_mask_packed(plane, d_off, d_len, int(lens.max()), ids, ks)
+        al.sync()
+        if m_plane is not None:                      # (None: a sequence of the panel the seed stage cannot cover at 90 %)
+            assert torch.equal(m_bytes, m_plane)
+            assert int((m_plane != 0).any(dim=1).sum()) > 300
+    finally:
+        al.close()

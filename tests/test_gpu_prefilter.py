@@ -196,10 +196,10 @@ print("CHILD_OK", exact, sound)
 """
 
 
-@pytest.mark.parametrize("env", [{}, {"PC_PF_NO_SEEDS": "1"}, {"PC_PF_SEED_CAP": "64"}, {"PC_PF_MULTI_Q": "1"}])
+@pytest.mark.parametrize("env", [{}, {"PC_PF_NO_SEEDS": "1"}, {"PC_PF_SEED_CAP": "64"}, {"PC_PF_MULTI_Q": "1"}, {"PC_PF_SINGLE_Q": "1"}])
 def test_seed_stage_exhaustive_kernel_and_overflow_fallback_agree_with_the_plain_dp(env):
     """The same batch -- seeds of two lengths, an adapter without seeds (N inside), a low-complexity adapter against
-    poly-A reads -- through the seed stage (one seed length for all pieces; PC_PF_MULTI_Q=1: a bitmap per length), through
+    poly-A reads -- through the seed stage (one seed length for all pieces or a bitmap per length, as the expected candidate rate decides; PC_PF_SINGLE_Q=1 / PC_PF_MULTI_Q=1 force either), through
     the exhaustive kernel alone (PC_PF_NO_SEEDS=1) and through the overflow fallback (a 64-entry candidate list): each
     equals the oracle's plain DP."""
     import os

@@ -641,34 +641,14 @@ constexpr u32 H_NEGINF2 = 0xFC00FC00u, H_POSINF2 = 0x7C007C00u;
 #define PC_HMAX3 "v_pk_maximum3_f16 "
 #define PC_HFMA "v_pk_fma_f16 "
 #define PC_BIT " neg_lo:[0,1] neg_hi:[0,1] clamp\n\t"
-// byte accumulation of the previous row's four bits b3 b2 b1 b0 into acc = 1024 + 16 * nibble(even row) + nibble(odd row).
-#ifdef PC_T16_CHAIN
-// (the first form: ONE serial chain of four fused multiply-adds per row, acc = 2 acc + b; an even row starts at 8 + b3)
+// byte accumulation of the previous row's four bits: an even row starts a byte (acc = 2*4 + b3)
 #define PC_ACC3_EVEN PC_HADD "%[acc], %[pb3], %[eight]\n\t"
 #define PC_ACC3_ODD PC_HFMA "%[acc], %[acc], %[two], %[pb3]\n\t"
 #define PC_ACC2 PC_HFMA "%[acc], %[acc], %[two], %[pb2]\n\t"
 #define PC_ACC1 PC_HFMA "%[acc], %[acc], %[two], %[pb1]\n\t"
-#define PC_ACC0_EVEN PC_HFMA "%[acc], %[acc], %[two], %[pb0]\n\t"
-#define PC_ACC0_ODD PC_HFMA "%[acc], %[acc], %[two], %[pb0]\n\t"
-#define PC_ACC_OPS_EVEN , [eight] "s"(EIGHT2)
-#define PC_ACC_OPS_ODD
-#define PC_ACC_TMP
-#else
-// As a TREE: t1 = 2 b3 + b2 and t0 = 2 b1 + b0 side by side, t1 = 4 t1 + t0, then ONE operation on the accumulator (an even
-// row starts the byte at 64 + nibble, an odd row makes it 16 acc + nibble): the same four operations per row, but the chain
-// through `acc` is one operation per row instead of four back to back.
-#define PC_ACC3_EVEN PC_HFMA "%[t1], %[pb3], %[two], %[pb2]\n\t"
-#define PC_ACC3_ODD PC_HFMA "%[t1], %[pb3], %[two], %[pb2]\n\t"
-#define PC_ACC2 PC_HFMA "%[t0], %[pb1], %[two], %[pb0]\n\t"
-#define PC_ACC1 PC_HFMA "%[t1], %[t1], %[four], %[t0]\n\t"
-#define PC_ACC0_EVEN PC_HADD "%[acc], %[t1], %[c64]\n\t"
-#define PC_ACC0_ODD PC_HFMA "%[acc], %[acc], %[c16], %[t1]\n\t"
-#define PC_ACC_OPS_EVEN , [four] "s"(0x44004400u), [c64] "s"(0x54005400u)
-#define PC_ACC_OPS_ODD , [four] "s"(0x44004400u), [c16] "s"(0x4C004C00u)
-#define PC_ACC_TMP , [t0] "=&v"(t0_), [t1] "=&v"(t1_)
-#endif
+#define PC_ACC0 PC_HFMA "%[acc], %[acc], %[two], %[pb0]\n\t"
 // full row: ind(q = r+2) | chain(r) | bits(r) | acc(r-1)
-#define PC_ROW16_FULL(ACC3, ACC0)                                   \
+#define PC_ROW16_FULL(ACC3)                                         \
     PC_HADD "%[b0q], %[tq], %[uq]" PC_BIT                           \
     ACC3                                                            \
     PC_HMAX "%[vs], %[vp], %[tu]\n\t"                               \
@@ -679,7 +659,7 @@ constexpr u32 H_NEGINF2 = 0xFC00FC00u, H_POSINF2 = 0x7C007C00u;
     PC_ACC1                                                         \
     PC_HADD "%[tn], %[mn], %[oe]\n\t"                               \
     PC_HADD "%[b1], %[vs], %[vp]" PC_BIT                            \
-    ACC0                                                            \
+    PC_ACC0                                                         \
     PC_HADD "%[b2], %[hr], %[vs]" PC_BIT                            \
     PC_HADD "%[b3], %[mn], %[dr] neg_lo:[0,1] neg_hi:[0,1] clamp"
 // first row: nothing to accumulate yet
@@ -694,7 +674,7 @@ constexpr u32 H_NEGINF2 = 0xFC00FC00u, H_POSINF2 = 0x7C007C00u;
     PC_HADD "%[tn], %[mn], %[oe]\n\t"                               \
     PC_HADD "%[b3], %[mn], %[dr] neg_lo:[0,1] neg_hi:[0,1] clamp"
 // last two rows: no row r+2
-#define PC_ROW16_NOIND(ACC3, ACC0)                                  \
+#define PC_ROW16_NOIND(ACC3)                                        \
     ACC3                                                            \
     PC_HMAX "%[vs], %[vp], %[tu]\n\t"                               \
     PC_ACC2                                                         \
@@ -703,7 +683,7 @@ constexpr u32 H_NEGINF2 = 0xFC00FC00u, H_POSINF2 = 0x7C007C00u;
     PC_ACC1                                                         \
     PC_HADD "%[b2], %[hr], %[vs]" PC_BIT                            \
     PC_HADD "%[tn], %[mn], %[oe]\n\t"                               \
-    ACC0                                                            \
+    PC_ACC0                                                         \
     PC_HADD "%[b3], %[mn], %[dr] neg_lo:[0,1] neg_hi:[0,1] clamp"
 
 // CHECK: debug build (PC_CHECK_RANGE=1, every row class): records the extremes of EVERY finite value the kernel
@@ -748,7 +728,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(R <= 30 ? PC
     const int eps = -a.gap_extend, CEN = a.f16_cen;
     const u32 OE2 = __builtin_amdgcn_readfirstlane(hpack2(a.gap_open + eps)), EPS2 = hpack2(eps), NEG2 = H_NEGINF2;
     const u32 TWO2 = 0x40004000u, EIGHT2 = 0x48004800u;
-    (void)EIGHT2;
     u32 *slab = a.slab + (int64_t)blockIdx.x * a.slab_stride;
 
     for (int t = blockIdx.x; t < a.ntiles; t += gridDim.x) {
@@ -985,8 +964,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(R <= 30 ? PC
                 // table terms one group ahead of the row that needs them (row r+2 is fetched now)
                 if (((r + 6) & 3) == 0 && (r + 6) < RP) load_group((r + 6) >> 2);
                 u32 vs, mn, tn, b1, b2, b3;
-                u32 t0_, t1_;
-                (void)t0_; (void)t1_;
                 if (r + 2 < R) {
                     const int q = r + 2;
                     if (r == 0) {
@@ -996,30 +973,30 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(R <= 30 ? PC
                                      : [tq] "v"(T[q]), [vp] "v"(Vp), [tu] "v"(Tup), [dg] "v"(T[q - 1]), [sq] "v"(S[q]),
                                        [dr] "v"(dh[r]), [hr] "v"(U[r]), [oe] "s"(OE2));
                     } else if ((r - 1) & 1) {
-                        asm volatile(PC_ROW16_FULL(PC_ACC3_ODD, PC_ACC0_ODD)
+                        asm volatile(PC_ROW16_FULL(PC_ACC3_ODD)
                                      : [uq] "+v"(U[q]), [vs] "=&v"(vs), [dq] "=&v"(dh[q]), [b0q] "=&v"(b0[q]), [mn] "=&v"(mn), [tn] "=&v"(tn),
-                                       [b1] "=&v"(b1), [b2] "=&v"(b2), [b3] "=&v"(b3), [acc] "+v"(acc) PC_ACC_TMP
+                                       [b1] "=&v"(b1), [b2] "=&v"(b2), [b3] "=&v"(b3), [acc] "+v"(acc)
                                      : [tq] "v"(T[q]), [vp] "v"(Vp), [tu] "v"(Tup), [dg] "v"(T[q - 1]), [sq] "v"(S[q]),
                                        [dr] "v"(dh[r]), [hr] "v"(U[r]), [oe] "s"(OE2), [two] "s"(TWO2),
-                                       [pb0] "v"(b0[r - 1]), [pb1] "v"(pb1), [pb2] "v"(pb2), [pb3] "v"(pb3) PC_ACC_OPS_ODD);
+                                       [pb0] "v"(b0[r - 1]), [pb1] "v"(pb1), [pb2] "v"(pb2), [pb3] "v"(pb3));
                     } else {
-                        asm volatile(PC_ROW16_FULL(PC_ACC3_EVEN, PC_ACC0_EVEN)
+                        asm volatile(PC_ROW16_FULL(PC_ACC3_EVEN)
                                      : [uq] "+v"(U[q]), [vs] "=&v"(vs), [dq] "=&v"(dh[q]), [b0q] "=&v"(b0[q]), [mn] "=&v"(mn), [tn] "=&v"(tn),
-                                       [b1] "=&v"(b1), [b2] "=&v"(b2), [b3] "=&v"(b3), [acc] "=&v"(acc) PC_ACC_TMP
+                                       [b1] "=&v"(b1), [b2] "=&v"(b2), [b3] "=&v"(b3), [acc] "=&v"(acc)
                                      : [tq] "v"(T[q]), [vp] "v"(Vp), [tu] "v"(Tup), [dg] "v"(T[q - 1]), [sq] "v"(S[q]),
-                                       [dr] "v"(dh[r]), [hr] "v"(U[r]), [oe] "s"(OE2), [two] "s"(TWO2),
-                                       [pb0] "v"(b0[r - 1]), [pb1] "v"(pb1), [pb2] "v"(pb2), [pb3] "v"(pb3) PC_ACC_OPS_EVEN);
+                                       [dr] "v"(dh[r]), [hr] "v"(U[r]), [oe] "s"(OE2), [two] "s"(TWO2), [eight] "s"(EIGHT2),
+                                       [pb0] "v"(b0[r - 1]), [pb1] "v"(pb1), [pb2] "v"(pb2), [pb3] "v"(pb3));
                     }
                 } else if ((r - 1) & 1) {
-                    asm volatile(PC_ROW16_NOIND(PC_ACC3_ODD, PC_ACC0_ODD)
-                                 : [vs] "=&v"(vs), [mn] "=&v"(mn), [tn] "=&v"(tn), [b1] "=&v"(b1), [b2] "=&v"(b2), [b3] "=&v"(b3), [acc] "+v"(acc) PC_ACC_TMP
+                    asm volatile(PC_ROW16_NOIND(PC_ACC3_ODD)
+                                 : [vs] "=&v"(vs), [mn] "=&v"(mn), [tn] "=&v"(tn), [b1] "=&v"(b1), [b2] "=&v"(b2), [b3] "=&v"(b3), [acc] "+v"(acc)
                                  : [vp] "v"(Vp), [tu] "v"(Tup), [dr] "v"(dh[r]), [hr] "v"(U[r]), [oe] "s"(OE2), [two] "s"(TWO2),
-                                   [pb0] "v"(b0[r - 1]), [pb1] "v"(pb1), [pb2] "v"(pb2), [pb3] "v"(pb3) PC_ACC_OPS_ODD);
+                                   [pb0] "v"(b0[r - 1]), [pb1] "v"(pb1), [pb2] "v"(pb2), [pb3] "v"(pb3));
                 } else {
-                    asm volatile(PC_ROW16_NOIND(PC_ACC3_EVEN, PC_ACC0_EVEN)
-                                 : [vs] "=&v"(vs), [mn] "=&v"(mn), [tn] "=&v"(tn), [b1] "=&v"(b1), [b2] "=&v"(b2), [b3] "=&v"(b3), [acc] "=&v"(acc) PC_ACC_TMP
-                                 : [vp] "v"(Vp), [tu] "v"(Tup), [dr] "v"(dh[r]), [hr] "v"(U[r]), [oe] "s"(OE2), [two] "s"(TWO2),
-                                   [pb0] "v"(b0[r - 1]), [pb1] "v"(pb1), [pb2] "v"(pb2), [pb3] "v"(pb3) PC_ACC_OPS_EVEN);
+                    asm volatile(PC_ROW16_NOIND(PC_ACC3_EVEN)
+                                 : [vs] "=&v"(vs), [mn] "=&v"(mn), [tn] "=&v"(tn), [b1] "=&v"(b1), [b2] "=&v"(b2), [b3] "=&v"(b3), [acc] "=&v"(acc)
+                                 : [vp] "v"(Vp), [tu] "v"(Tup), [dr] "v"(dh[r]), [hr] "v"(U[r]), [oe] "s"(OE2), [two] "s"(TWO2), [eight] "s"(EIGHT2),
+                                   [pb0] "v"(b0[r - 1]), [pb1] "v"(pb1), [pb2] "v"(pb2), [pb3] "v"(pb3));
                 }
                 // row r-1's byte half is complete now: every second row a byte, every fourth a slab word
                 if (r >= 1) {
@@ -1035,13 +1012,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(R <= 30 ? PC
                 T[r] = tn; Tup = tn; Vp = vs; pb1 = b1; pb2 = b2; pb3 = b3;
             }
             // the last row's bits (R is even, so this row completes a byte)
-            {
-                u32 t0_, t1_;
-                (void)t0_; (void)t1_;
-                asm volatile(PC_ACC3_ODD "s_nop 0\n\t" PC_ACC2 "s_nop 0\n\t" PC_ACC1 "s_nop 0\n\t" PC_ACC0_ODD
-                             : [acc] "+v"(acc) PC_ACC_TMP
-                             : [two] "s"(TWO2), [pb0] "v"(b0[R - 1]), [pb1] "v"(pb1), [pb2] "v"(pb2), [pb3] "v"(pb3) PC_ACC_OPS_ODD);
-            }
+            asm volatile(PC_ACC3_ODD "s_nop 0\n\t" PC_ACC2 "s_nop 0\n\t" PC_ACC1 "s_nop 0\n\t"
+                         PC_HFMA "%[acc], %[acc], %[two], %[pb0]"
+                         : [acc] "+v"(acc)
+                         : [two] "s"(TWO2), [pb0] "v"(b0[R - 1]), [pb1] "v"(pb1), [pb2] "v"(pb2), [pb3] "v"(pb3));
             {
                 constexpr int pr = R - 1;
                 const u32 wd = ((pr & 3) == 3) ? __builtin_amdgcn_perm(accA, acc, 0x06020400u)     // rows 4g..4g+3

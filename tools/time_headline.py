@@ -22,9 +22,10 @@ for _ in range(2):
 pl.aligner.sync(); torch.cuda.synchronize()
 pl.aligner.set_timing(True); pl.aligner.get_timing()
 t0 = time.perf_counter()
-for _ in range(5):
+N = int(os.environ.get('PC_LOOP', '5'))
+for _ in range(N):
     h = step()
 pl.aligner.sync(); torch.cuda.synchronize()
-dt = (time.perf_counter() - t0) / 5 * 1e3
+dt = (time.perf_counter() - t0) / N * 1e3
 tm = pl.aligner.get_timing()
-print("NO_FUSE=%s  %.2f ms/step  hits %d  kernels %s" % (os.environ.get("PC_NO_FUSE", "0"), dt, int(h.read.numel()), {k: (round(v[0] / 5, 2), v[1] // 5) for k, v in tm.items() if v[1]}))
+print("NO_FUSE=%s  %.2f ms/step  hits %d  kernels %s" % (os.environ.get("PC_NO_FUSE", "0"), dt, int(h.read.numel()), {k: (round(v[0] / N, 2), v[1] // N) for k, v in tm.items() if v[1]}))

@@ -16,7 +16,7 @@ wl = torch.full((n,), 150, dtype=torch.int32, device="cuda")
 for name, off, ad in (("start x 28-mer", reads.off, 0), ("end x 22-mer", reads.off + 7850, 1)):
     out = torch.zeros((n, 8), dtype=torch.int32, device="cuda")
     best = 1e9
-    for rep in range(4):
+    for rep in range(int(os.environ.get('PC_LOOP', '4'))):
         al.scan_device(reads.arena, off.contiguous(), wl, [ad], [0, n], 150, out, porechop_amd.MODE_TRACE)
         try:
             al.sync()

@@ -476,10 +476,13 @@ bool parse_fastq_parallel(pc_readset *rs, const FileData &data, int nthreads)
 extern "C" {
 
 // parse one file into rs (reads appended); rs->fastq is set by the first file
-static int load_into(pc_readset *rs, const char *path, int32_t file_index, bool first)
+static int load_into(pc_readset *rs, const char *path, int32_t file_index, bool first, FileData *ready = nullptr,
+                     const std::string *ready_error = nullptr)
 {
-    FileData data;
-    if (!slurp(path, data, rs->error)) return PC_ERR_BAD_ARG;
+    FileData own;
+    if (ready && ready_error && !ready_error->empty()) { rs->error = *ready_error; return PC_ERR_BAD_ARG; }
+    if (!ready && !slurp(path, own, rs->error)) return PC_ERR_BAD_ARG;
+    FileData &data = ready ? *ready : own;
     const char first_char = data.empty() ? '\0' : data.data()[0];
     if (first_char != '>' && first_char != '@') { rs->error = "File is neither FASTA or FASTQ"; return PC_ERR_BAD_ARG; }
     const bool fastq = (first_char == '@');
@@ -531,9 +534,34 @@ int pc_readset_load_many(const char *const *paths, int npaths, pc_readset **out)
     if (!paths || npaths < 1 || !out) return PC_ERR_BAD_ARG;
     pc_readset *rs = new pc_readset();
     *out = rs;
-    for (int i = 0; i < npaths; ++i) {
-        const int rc = load_into(rs, paths[i], i, i == 0);
-        if (rc) return rc;
+    // Several files (an Albacore / Guppy directory: thousands of .fastq.gz of a few thousand reads each,
+    // porechop.py:216-268): the files of a batch are read -- and inflated -- side by side, one thread each, then parsed in
+    // order (what a file's error is, and which file reports first, stay the reference's: errors are kept per file and raised
+    // at the file's turn).  One file: as before (its own inflate / parse use all cores).
+    const int T = npaths > 1 ? usable_threads() : 1;
+    for (int i0 = 0; i0 < npaths; i0 += T) {
+        const int i1 = std::min(npaths, i0 + T);
+        if (i1 - i0 == 1) {
+            const int rc = load_into(rs, paths[i0], i0, i0 == 0);
+            if (rc) return rc;
+            continue;
+        }
+        std::vector<FileData> data((size_t)(i1 - i0));
+        std::vector<std::string> errs((size_t)(i1 - i0));
+        std::vector<std::thread> th;
+        const int limit = t_thread_limit;
+        for (int i = i0; i < i1; ++i)
+            th.emplace_back([&, i] {
+                t_thread_limit = 1;                       // (this file's share: the batch is the parallelism)
+                std::string e;
+                if (!slurp(paths[i], data[(size_t)(i - i0)], e)) errs[(size_t)(i - i0)] = e.empty() ? std::string("could not open ") + paths[i] : e;
+            });
+        for (auto &x : th) x.join();
+        t_thread_limit = limit;
+        for (int i = i0; i < i1; ++i) {
+            const int rc = load_into(rs, paths[i], i, i == 0, &data[(size_t)(i - i0)], &errs[(size_t)(i - i0)]);
+            if (rc) return rc;
+        }
     }
     rs->arena.fill(64, 'N');                              // the kernels fetch a dword at a time
     return PC_OK;

@@ -219,3 +219,29 @@ rs.write_shared(pr[:half], ps[:half], pn[:half], num[:half], np.zeros(half, dtyp
     res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, PC_IO_MMAP="1"))
     assert res.returncode == 0, res.stderr
     assert md5(open(tmp_path / "o.fastq", "rb").read()) == md5(open(plain, "rb").read())
+
+
+def test_many_gz_files_are_read_side_by_side_and_parsed_in_order(files, tmp_path):
+    """A Guppy / Albacore style directory (porechop.py:216-268): many .fastq.gz files -- inflated one thread each, parsed in
+    file order; a broken file in the middle reports what it would report alone, and the files before it do not matter."""
+    data = open(files["plain"], "rb").read()
+    marks = [0] + [data.index(b"\n@r%d " % (k * 200)) + 1 for k in range(1, 30)] + [len(data)]
+    paths = []
+    for k in range(30):
+        p = tmp_path / ("part%02d.fastq%s" % (k, ".gz" if k % 3 else ""))
+        blob = data[marks[k]:marks[k + 1]]
+        p.write_bytes(gzip.compress(blob, 1) if k % 3 else blob)
+        paths.append(str(p))
+    ref = pio.ReadSet(files["plain"])
+    rs = pio.ReadSet(paths)
+    assert rs.count == ref.count and md5(rs.arena.tobytes()) == md5(ref.arena.tobytes())
+    assert rs.name(4321) == ref.name(4321) and rs.quals(5999) == ref.quals(5999)
+    assert list(np.unique(rs.file_index)) == list(range(30)) and int(rs.file_index[-1]) == 29
+    rs.close()
+    bad = tmp_path / "part13.fastq.gz"
+    bad.write_bytes(b"\x1f\x8b\x08" + b"garbage" * 10)
+    with pytest.raises(ValueError) as one:
+        pio.ReadSet(str(bad))
+    with pytest.raises(ValueError) as many:
+        pio.ReadSet(paths)
+    assert str(one.value) == str(many.value)

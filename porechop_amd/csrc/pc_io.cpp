@@ -35,6 +35,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -686,6 +688,140 @@ namespace {
 constexpr size_t kGzQueueBytes = (size_t)512 << 20;     // inflated bytes the producer may run ahead
 constexpr size_t kGzBuffer = (size_t)32 << 20;
 
+// Members WITHOUT a size subfield -- `cat a.fastq.gz b.fastq.gz ...`, the usual way a run's thousands of small .gz files
+// become one -- cannot be found by hopping, but they can be GUESSED: every member starts with 1f 8b 08 and a flag byte, and
+// the four bytes before a true start are the previous member's ISIZE.  Worker threads inflate from the guessed starts ahead
+// of the consumer (zlib checks each member's CRC and length itself); the consumer walks the file member by member and takes
+// a guess's result only when a member really starts there -- a wrong guess (the magic inside compressed data) fails within a
+// few hundred bytes or is simply never asked for.  A member larger than kSpecCap is left to the serial path (one core, streamed).
+static const size_t kSpecCap = [] { const char *e = getenv("PC_GZ_SPEC_CAP_MB"); const long v = e ? atol(e) : 0; return (size_t)(v > 0 ? v : 256) << 20; }();
+
+struct MemberSpeculator {
+    const unsigned char *base;
+    size_t size;
+    struct Cand { size_t start; std::vector<char> out; size_t end = 0; int state = 0; };   // 0 unclaimed, 1 running, 2 ok, 3 failed / too big
+    std::deque<Cand> cands;              // ascending starts from `first_idx` on (consumed ones are dropped)
+    size_t scan_pos = 0, consumed_pos = 0;
+    int window;
+    std::mutex mu;
+    std::condition_variable cv;
+    bool stop = false;
+    std::vector<std::thread> workers;
+
+    MemberSpeculator(const unsigned char *b, size_t n, size_t from, int threads) : base(b), size(n), scan_pos(from), consumed_pos(from), window(threads * 3)
+    {
+        for (int t = 0; t < threads; ++t) workers.emplace_back([this] { work(); });
+    }
+    ~MemberSpeculator()
+    {
+        { std::lock_guard<std::mutex> lk(mu); stop = true; }
+        cv.notify_all();
+        for (auto &w : workers) w.join();
+    }
+    static bool magic_at(const unsigned char *p) { return p[0] == 0x1f && p[1] == 0x8b && p[2] == 8 && (p[3] & 0xE0) == 0; }
+    // more guesses, while fewer than `window` are waiting (with mu held)
+    void scan_more()
+    {
+        size_t waiting = 0;
+        for (const Cand &c : cands) if (c.state == 0) ++waiting;
+        while (waiting < (size_t)window && scan_pos + 18 < size) {
+            const unsigned char *q = (const unsigned char *)memchr(base + scan_pos, 0x1f, size - 18 - scan_pos);
+            if (!q) { scan_pos = size; break; }
+            const size_t at = (size_t)(q - base);
+            scan_pos = at + 1;
+            if (!magic_at(q)) continue;
+            cands.emplace_back();
+            cands.back().start = at;
+            ++waiting;
+        }
+    }
+    void work()
+    {
+        z_stream zs;
+        memset(&zs, 0, sizeof zs);
+        if (inflateInit2(&zs, 15 + 16) != Z_OK) return;
+        for (;;) {
+            Cand *c = nullptr;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                for (;;) {
+                    if (stop) { inflateEnd(&zs); return; }
+                    scan_more();
+                    for (Cand &k : cands) if (k.state == 0 && k.start >= consumed_pos) { c = &k; break; }
+                    if (c) { c->state = 1; break; }
+                    cv.wait(lk);
+                }
+            }
+            // (deque elements keep their addresses while others are pushed / popped at the ends)
+            bool good = false;
+            std::vector<char> out;
+            inflateReset(&zs);
+            size_t at = c->start;
+            zs.next_in = (Bytef *)(base + at); zs.avail_in = (uInt)std::min<size_t>(size - at, (size_t)1 << 30);
+            const size_t in0 = zs.avail_in;
+            size_t have = 0;
+            for (;;) {
+                if (out.size() < have + ((size_t)4 << 20)) out.resize(std::max(out.size() * 2, have + ((size_t)8 << 20)));
+                zs.next_out = (Bytef *)out.data() + have; zs.avail_out = (uInt)std::min<size_t>(out.size() - have, (size_t)1 << 30);
+                const size_t room = zs.avail_out;
+                const int r = inflate(&zs, Z_NO_FLUSH);
+                have += room - zs.avail_out;
+                if (r == Z_STREAM_END) { good = true; break; }
+                if (r != Z_OK || have > kSpecCap || (zs.avail_in == 0 && zs.avail_out != 0)) break;
+                { std::lock_guard<std::mutex> lk(mu); if (stop || c->start < consumed_pos) break; }      // nobody will ask for this one
+            }
+            std::lock_guard<std::mutex> lk(mu);
+            if (good) { out.resize(have); c->out.swap(out); c->end = at + (in0 - zs.avail_in); c->state = 2; }
+            else c->state = 3;
+            cv.notify_all();
+        }
+    }
+    // Is the member that starts at `pos` small enough to be worth waiting for?  (The next plausible boundary -- a magic whose
+    // preceding ISIZE fits the bytes in between -- lies within reach.)
+    bool plausible_small_member(size_t pos) const
+    {
+        const size_t reach = std::min(size, pos + kSpecCap);
+        for (size_t p = pos + 18; p + 4 <= reach; ) {
+            const unsigned char *q = (const unsigned char *)memchr(base + p, 0x1f, reach - 4 - p);
+            if (!q) break;
+            p = (size_t)(q - base);
+            if (magic_at(q)) {
+                const size_t isize = pcz::get32(q - 4), gap = p - pos;
+                if (isize <= kSpecCap && gap <= isize + isize / 8 + 128 && isize / 1100 <= gap) return true;   // (deflate neither expands nor shrinks beyond that)
+            }
+            ++p;
+        }
+        // the file's last member: its ISIZE are the last four bytes (before any zero padding)
+        size_t e = size;
+        while (e > pos + 18 && base[e - 1] == 0) --e;
+        if (e <= reach && e >= pos + 18) { const size_t isize = pcz::get32(base + e - 4); return isize <= kSpecCap; }
+        return false;
+    }
+    // The inflated member that starts at pos, if a worker has (or will soon have) it: *end = one past its last byte.
+    bool take(size_t pos, std::vector<char> &out, size_t *end)
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        consumed_pos = pos;
+        while (!cands.empty() && cands.front().start < pos && cands.front().state != 1) cands.pop_front();
+        cv.notify_all();
+        if (!plausible_small_member(pos)) return false;
+        for (;;) {
+            scan_more();
+            Cand *c = nullptr;
+            for (Cand &k : cands) { if (k.start == pos) { c = &k; break; } if (k.start > pos) break; }
+            if (!c) {
+                if (scan_pos > pos) return false;          // scanned past it: no member starts here
+                cv.wait_for(lk, std::chrono::milliseconds(1));
+                continue;
+            }
+            if (c->state == 2) { out.swap(c->out); *end = c->end; c->state = 3; return true; }
+            if (c->state == 3) return false;
+            cv.notify_all();
+            cv.wait(lk);
+        }
+    }
+};
+
 void gz_produce(pc_gzstream *s)
 {
     auto push = [&](std::vector<char> &&v) -> bool {
@@ -757,6 +893,24 @@ void gz_produce(pc_gzstream *s)
         if (inflateInit2(&zs, 15 + 16) != Z_OK) ok = false;
         std::vector<char> buf;
         bool ended = false;                               // the last member has ended and nothing follows it
+        static const bool no_spec = [] { const char *e = getenv("PC_GZ_NO_SPECULATION"); return e && *e && *e != '0'; }();
+        std::unique_ptr<MemberSpeculator> spec;
+        if (!no_spec && s->inflate_threads > 1 && size - at > ((size_t)1 << 20)) spec.reset(new MemberSpeculator(base, size, at, s->inflate_threads));
+        // members that workers have inflated ahead (see MemberSpeculator): taken whole, one after the other, for as long as
+        // a member starts where the last one ended
+        auto take_ahead = [&]() -> bool {
+            while (spec && ok && !ended) {
+                std::vector<char> whole;
+                size_t end = 0;
+                if (!spec->take(at, whole, &end)) return true;
+                at = end;
+                while (at < size && base[at] == 0) ++at;
+                if (at >= size) ended = true;
+                if (!whole.empty() && !push(std::move(whole))) return false;
+            }
+            return true;
+        };
+        if (!take_ahead()) { inflateEnd(&zs); spec.reset(); munmap(m, size); finish(false); return; }
         while (ok && !ended) {
             buf.resize(kGzBuffer);
             zs.next_out = (Bytef *)buf.data(); zs.avail_out = (uInt)buf.size();
@@ -770,6 +924,7 @@ void gz_produce(pc_gzstream *s)
                     while (at < size && base[at] == 0) ++at;
                     if (at >= size) { ended = true; break; }
                     if (inflateReset(&zs) != Z_OK) { ok = false; break; }
+                    if (spec) break;                      // (hand what there is over, then see whether the next members were inflated ahead)
                     continue;
                 }
                 if (r == Z_OK) continue;
@@ -778,9 +933,11 @@ void gz_produce(pc_gzstream *s)
             }
             if (!ok) break;
             buf.resize(buf.size() - zs.avail_out);
-            if (!buf.empty() && !push(std::move(buf))) { inflateEnd(&zs); munmap(m, size); finish(false); return; }
+            if (!buf.empty() && !push(std::move(buf))) { inflateEnd(&zs); spec.reset(); munmap(m, size); finish(false); return; }
             buf = std::vector<char>();
+            if (spec && ok && !ended && zs.total_in == 0 && !take_ahead()) { inflateEnd(&zs); spec.reset(); munmap(m, size); finish(false); return; }
         }
+        spec.reset();
         inflateEnd(&zs);
     }
     munmap(m, size);

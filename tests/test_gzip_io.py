@@ -51,7 +51,17 @@ def files(tmp_path_factory):
     with open(d / "concat.fastq.gz", "wb") as f:
         f.write(gzip.compress(data[:cut], 1))
         f.write(gzip.compress(data[cut:], 1))
-    out.update(sized=str(d / "sized.fastq.gz"), single=str(d / "single.fastq.gz"), cli=str(d / "cli.fastq.gz"), concat=str(d / "concat.fastq.gz"))
+    # forty members the ordinary way (what `cat run/*.fastq.gz` makes of a run's small files): no size subfields, found by
+    # guessing (MemberSpeculator) and inflated ahead by worker threads; a few members are empty, one is followed by zero padding
+    marks = [0] + [data.index(b"\n@r%d " % (k * 150)) + 1 for k in range(1, 40)] + [len(data)]
+    with open(d / "cat40.fastq.gz", "wb") as f:
+        for k in range(40):
+            f.write(gzip.compress(data[marks[k]:marks[k + 1]], 1 + k % 6))
+            if k % 13 == 5:
+                f.write(gzip.compress(b""))
+        f.write(b"\0" * 37)
+    out.update(sized=str(d / "sized.fastq.gz"), single=str(d / "single.fastq.gz"), cli=str(d / "cli.fastq.gz"), concat=str(d / "concat.fastq.gz"),
+               cat40=str(d / "cat40.fastq.gz"))
     return out
 
 
@@ -86,7 +96,7 @@ def test_compressor_layouts_inflate_to_the_input(files):
 def test_whole_file_loader_reads_every_layout(files):
     ref = pio.ReadSet(files["plain"])
     want = (ref.count, md5(ref.arena.tobytes()), md5(ref.lengths.tobytes()), ref.name(17), ref.quals(5999))
-    for k in ("sized", "single", "cli", "concat"):
+    for k in ("sized", "single", "cli", "concat", "cat40"):
         rs = pio.ReadSet(files[k])
         assert (rs.count, md5(rs.arena.tobytes()), md5(rs.lengths.tobytes()), rs.name(17), rs.quals(5999)) == want, k
         rs.close()
@@ -108,7 +118,7 @@ def test_stream_blocks_equal_the_plain_files_segments(files):
             want.append((rs.count, md5(rs.arena.tobytes()), rs.name(0), rs.quals(rs.count - 1)))
             rs.close()
             pos = nxt
-        for k in ("sized", "single", "cli", "concat"):
+        for k in ("sized", "single", "cli", "concat", "cat40"):
             st = pio.GzStream(files[k])
             got = []
             while True:
@@ -245,3 +255,29 @@ def test_many_gz_files_are_read_side_by_side_and_parsed_in_order(files, tmp_path
     with pytest.raises(ValueError) as many:
         pio.ReadSet(paths)
     assert str(one.value) == str(many.value)
+
+
+def test_guessed_members_larger_than_the_cap_take_the_serial_path(files):
+    """PC_GZ_SPEC_CAP_MB=1 (a fresh process: read once): the forty members of cat40 inflate to about 0.45 MB each -- with a cap
+    of 1 MB all are taken from the workers; the two members of concat (9 MB each) exceed it and stream through one core's
+    zlib.  Both ways the blocks are the plain file's; PC_GZ_NO_SPECULATION=1 gives the same again."""
+    code = ("import sys, hashlib; sys.path.insert(0, %r)\n"
+            "from porechop_amd import io as pio\n"
+            "for path in sys.argv[1:]:\n"
+            "    st = pio.GzStream(path); h = hashlib.md5(); n = 0\n"
+            "    while True:\n"
+            "        rs = st.next(700000)\n"
+            "        assert rs is not False\n"
+            "        if rs is None: break\n"
+            "        h.update(rs.arena.tobytes()[:-64]); n += rs.count; rs.close()\n"
+            "    st.close(); print(n, h.hexdigest())\n" % REPO)
+    outs = []
+    for env in ({}, {"PC_GZ_SPEC_CAP_MB": "1"}, {"PC_GZ_NO_SPECULATION": "1"}, {"PC_IO_THREADS": "2"}):
+        r = subprocess.run([sys.executable, "-c", code, files["cat40"], files["concat"], files["single"]], capture_output=True, text=True,
+                           env=dict(os.environ, **env), timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(r.stdout.split())
+    assert all(o == outs[0] for o in outs), outs
+    ref = pio.ReadSet(files["plain"])
+    assert outs[0][0] == str(ref.count) and outs[0][1] == md5(ref.arena.tobytes()[:-64])
+    assert outs[0][:2] == outs[0][2:4] == outs[0][4:6]

@@ -1331,6 +1331,7 @@ def leg_end_to_end_gz(dev, args, workers):
         plain_out_bytes = os.path.getsize(out_plain)
         os.remove(out_plain)
         legs = {}
+        first_out = None
         for name, src, reps in (("sized_members", sized, 2), ("single_member", single, 1), ("concatenated_members", catted, 1)):
             runs = []
             out_gz = os.path.join(work, "out_%s.fastq.gz" % name)
@@ -1342,10 +1343,20 @@ def leg_end_to_end_gz(dev, args, workers):
                 dt = time.perf_counter() - t0
                 runs.append({"wall_s": dt, "reads_per_s": res.n_reads / dt, "stage_seconds": {k: round(v, 3) for k, v in res.seconds.items()}})
             best = max(runs, key=lambda r: r["reads_per_s"])
+            # (the first layout's output is gunzip-ed and hashed; a later layout's output that equals it byte for byte -- same
+            # blocks, same spans, a deterministic compressor -- needs no second 6 GB through `gzip -dc`)
+            import filecmp
+            if first_out is not None and filecmp.cmp(out_gz, first_out[0], shallow=False):
+                md5_ok = first_out[1]
+            else:
+                md5_ok = bool(gunzip_md5(out_gz) == want)
             legs[name] = {"reads_per_s": best["reads_per_s"], "wall_s": best["wall_s"], "runs": runs,
                           "input_gz_bytes": os.path.getsize(src), "output_gz_bytes": os.path.getsize(out_gz),
-                          "gunzipped_output_md5_equals_plain_route": bool(gunzip_md5(out_gz) == want)}
-            os.remove(out_gz)
+                          "gunzipped_output_md5_equals_plain_route": md5_ok}
+            if first_out is None:
+                first_out = (out_gz, md5_ok)
+            else:
+                os.remove(out_gz)
         out = {"workload": "end to end, gzip both ways: %d synthetic %d-bp reads (configs[3] shape), %.1f GB of FASTQ as .fastq.gz -> "
                            "trimmed / split .fastq.gz through porechop_amd.runner.run (streamed)" % (n, L, in_bytes / 1e9),
                "files_on": "tmpfs (/dev/shm)" if base.startswith("/dev/shm") else base + " (disk-backed, through the page cache)",

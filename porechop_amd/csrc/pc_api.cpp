@@ -518,8 +518,19 @@ int group_chunks_for(const pc_ctx *c, const Group &g, int max_len)
         // (a batch whose longest read is a hundred times the typical one -- a 4 Mb read among 20 kb reads -- needs more than
         // kMaxChunks units of typical length: up to kMaxChunksLong, as far as the [pair][chunk] pass-1 buffer stays below 1 GiB)
         const int64_t pairs = std::max<int64_t>(1, group_pairs(g, 0, g.tile_count));
-        const int by_memory = (int)std::max<int64_t>(kMaxChunks, std::min<int64_t>(kMaxChunksLong, ((int64_t)1 << 30) / (pairs * 16)));
-        chunks = std::max(chunks, std::min(by_memory, (max_len + unit - 1) / unit));
+        const int by_memory = (int)std::max<int64_t>(kMaxChunks, std::min<int64_t>(kMaxChunksLong, ((int64_t)4 << 30) / (pairs * 16)));
+        // ... and few windows (a batch of 40 000 long reads is 625 tiles: units of typical length would be a fifth of the wave slots,
+        // and the launch would last as long as ONE such unit, 5 ms at 20 kb): then the units are made short enough that there are
+        // about three per slot -- the windows' columns, estimated as tiles x typical length, over 3 x the resident waves -- but
+        // not shorter than a few warm-up spans
+        int unit_len = unit;
+        const int64_t slots = resident_waves(c, g);
+        const int64_t est_units = (int64_t)g.tile_count * std::max(1, c->len_hint / std::max(1, unit)) ;
+        if (est_units < 3 * slots) {
+            const int64_t cols = (int64_t)g.tile_count * c->len_hint;
+            unit_len = (int)std::max<int64_t>(std::max(512, 4 * g.max_window), std::min<int64_t>(unit, cols / (3 * slots)));
+        }
+        chunks = std::max(chunks, std::min(by_memory, (max_len + unit_len - 1) / unit_len));
     }
     return chunks;
 }
@@ -1009,6 +1020,7 @@ int pc_scan_device(pc_ctx *c, const void *d_arena, const int64_t *d_win_off, con
                     if (mode == PC_MODE_SCORE && L.chunks == 1 && L.spec) continue;      // records written by the kernel itself
                     pl.k1 = c->d_k1.as<int32_t>() + L.k1_ints;
                     pl.tiles = a.tiles + L.begin; pl.ntiles = (int32_t)L.count; pl.chunks = L.chunks;
+                    pl.chunk_len = (max_len + L.chunks - 1) / L.chunks;
                     if ((rc = pck::launch_plan(pl, stream))) return PC_ERR_NO_DEVICE;
                 }
                 if (mode == PC_MODE_TRACE_AT) {         // the caller's score records, read before pass 2 overwrites them

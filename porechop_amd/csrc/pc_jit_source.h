@@ -692,8 +692,11 @@ extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P
             if (have_lo) { int4 *o = (int4 *)(a.rec_out + p_lo * 8); o[0] = int4{-2, bj_lo + c0_lo, bi_lo, 0}; o[1] = int4{bs_lo, 0, 0, 0}; }
             if (have_hi) { int4 *o = (int4 *)(a.rec_out + p_hi * 8); o[0] = int4{-2, bj_hi + c0_hi, bi_hi, 0}; o[1] = int4{bs_hi, 0, 0, 0}; }
         } else {
-            if (have_lo) { int4 o = {bs_lo, bi_lo, bj_lo + c0_lo, 0}; *(int4 *)(a.out + (p_lo * nchunks + chunk) * 4) = o; }
-            if (have_hi) { int4 o = {bs_hi, bi_hi, bj_hi + c0_hi, 0}; *(int4 *)(a.out + (p_hi * nchunks + chunk) * 4) = o; }
+            // (a chunk that starts beyond its window's end is never read by the planner -- it merges chunks 0 .. ceil(len / L) - 1 --
+            // and is not written: a 4 Mb read among 20 kb reads makes two thousand chunks per window, ten of them real)
+            const bool live_lo = have_lo && (chunk == 0 || n_lo > 0), live_hi = have_hi && (chunk == 0 || n_hi > 0);
+            if (live_lo) { int4 o = {bs_lo, bi_lo, bj_lo + c0_lo, 0}; *(int4 *)(a.out + (p_lo * nchunks + chunk) * 4) = o; }
+            if (live_hi) { int4 o = {bs_hi, bi_hi, bj_hi + c0_hi, 0}; *(int4 *)(a.out + (p_hi * nchunks + chunk) * 4) = o; }
         }
     }
 }

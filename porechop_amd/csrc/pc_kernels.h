@@ -71,6 +71,7 @@ struct PlanArgs {
     int64_t *win_off2; int32_t *win_len2; int32_t *col02; int32_t *ntot2; int32_t *force_row2; int32_t *force_score2;
     const Tile *tiles; int32_t ntiles;                  // same tiles as the score pass
     int32_t chunks;                                     // chunk results per pair in k1 (>= 1)
+    int32_t chunk_len;                                  // their length in columns (chunks > 1): only the chunks that start inside a window are merged
     const int32_t *ad_window;                           // [nadapters] W+SPAN+1 for that adapter length
     int32_t *score_out;                                 // PC_MODE_SCORE: [npairs][8] records (-2, J, I, 0, score, 0, 0, 0)
     int32_t end_align;                                  // 1: every window of a tile gets the same length (the larger of the two

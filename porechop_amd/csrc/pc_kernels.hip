@@ -585,8 +585,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((R > 0 && R 
         // ---- results -----------------------------------------------------------------
         if constexpr (!TRACE) {
             // J is reported in whole-window columns; chunk results go to [pair][chunk]
-            if (have_lo) { int4 o = {b_lo.score, b_lo.I, b_lo.J + c0_lo, 0}; *(int4 *)(a.out + (p_lo * nchunks + chunk) * SCORE_OUT_INTS) = o; }
-            if (have_hi) { int4 o = {b_hi.score, b_hi.I, b_hi.J + c0_hi, 0}; *(int4 *)(a.out + (p_hi * nchunks + chunk) * SCORE_OUT_INTS) = o; }
+            // (chunks that start beyond their window's end are neither written nor read: plan_kernel merges the real ones only)
+            const bool live_lo = have_lo && (chunk == 0 || n_lo > 0), live_hi = have_hi && (chunk == 0 || n_hi > 0);
+            if (live_lo) { int4 o = {b_lo.score, b_lo.I, b_lo.J + c0_lo, 0}; *(int4 *)(a.out + (p_lo * nchunks + chunk) * SCORE_OUT_INTS) = o; }
+            if (live_hi) { int4 o = {b_hi.score, b_hi.I, b_hi.J + c0_hi, 0}; *(int4 *)(a.out + (p_hi * nchunks + chunk) * SCORE_OUT_INTS) = o; }
         } else {
             traceback_pairs(a, slab, rows, NW, lane, b_lo, b_hi, pad_lo, pad_hi,
                             have_lo, have_hi, n_lo, n_hi, c0_lo, c0_hi, m_lo, m_hi, p_lo, p_hi, notrace_upto);
@@ -1114,7 +1116,12 @@ __global__ void plan_kernel(PlanArgs a)
     const int64_t p = (hi ? tile.out_hi : tile.out_lo) + i;      // pair (output) slot
     const int64_t w = (hi ? tile.win_hi : tile.win_lo) + i;      // its whole-read window
     // merge the per-chunk maxima in the reference's visiting order (strict '>', earlier chunk wins)
-    const int nch = a.chunks > 1 ? a.chunks : 1;
+    int nch = a.chunks > 1 ? a.chunks : 1;
+    if (nch > 1 && a.chunk_len > 0) {             // the chunks that hold columns of this window (chunk 0 always)
+        const int real = (a.win_len[w] + a.chunk_len - 1) / a.chunk_len;
+        nch = real < 1 ? 1 : (real < nch ? real : nch);
+    }
+    const int nstride = a.chunks > 1 ? a.chunks : 1;
     int score, I, J;
     if (a.end_records) {
         // PC_MODE_TRACE_AT: the caller's score record of this very pair, (-2, J, I, 0, score, ...)
@@ -1125,10 +1132,10 @@ __global__ void plan_kernel(PlanArgs a)
             I = 0; J = 0;
         }
     } else {
-        score = a.k1[(p * nch) * 4 + 0]; I = a.k1[(p * nch) * 4 + 1]; J = a.k1[(p * nch) * 4 + 2];
+        score = a.k1[(p * nstride) * 4 + 0]; I = a.k1[(p * nstride) * 4 + 1]; J = a.k1[(p * nstride) * 4 + 2];
         for (int c = 1; c < nch; ++c) {
-            const int sc = a.k1[(p * nch + c) * 4 + 0];
-            if (sc > score) { score = sc; I = a.k1[(p * nch + c) * 4 + 1]; J = a.k1[(p * nch + c) * 4 + 2]; }
+            const int sc = a.k1[(p * nstride + c) * 4 + 0];
+            if (sc > score) { score = sc; I = a.k1[(p * nstride + c) * 4 + 1]; J = a.k1[(p * nstride + c) * 4 + 2]; }
         }
     }
     if (a.score_out) {       // score-only request: the end cell and its score are the whole answer

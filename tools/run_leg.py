@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """One leg of bench.py, alone, for the profiler: every launch in the process then belongs to that leg, so rocprofv3's
 per-kernel numbers can be attributed to it.  `steps` identical steps, nothing else (no CPU legs, no cross-checks).
-usage: run_leg.py headline|prefilter|prefilter_packed|configs1|configs2|configs2_pruned|configs4|configs4_prefilter [steps]"""
+usage: run_leg.py headline|prefilter|prefilter_packed|ultralong|ultralong_prefilter|configs1|configs2|configs2_pruned|configs4|configs4_prefilter [steps]"""
 import argparse
 import os
 import sys
@@ -33,6 +33,10 @@ if leg in ("headline", "prefilter", "prefilter_packed"):
                                         reads.off, reads.length, end_size=p.end_size)
         torch.cuda.empty_cache()
     step = lambda: bench.one_step(pl, reads, p.check_reads, 1, prefilter=(leg != "headline"))
+elif leg in ("ultralong", "ultralong_prefilter"):
+    from porechop_amd.synth import make_ragged_reads
+    reads = make_ragged_reads(40_000, mean_len=20000, sigma=1.2, min_len=20, seed=9, start_frac=0.9, end_frac=0.5, chimera_frac=0.05, device=dev)
+    step = lambda: bench.one_step(pl, reads, p.check_reads, 1, prefilter=(leg == "ultralong_prefilter"))
 elif leg == "configs1":
     reads = make_reads(100_000, 8000, seed=1, start_frac=0.9, end_frac=0.5, chimera_frac=0.0, device=dev)
     step = lambda: bench.step_end_trim(pl, reads, p.check_reads)

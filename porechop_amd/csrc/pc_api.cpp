@@ -114,6 +114,7 @@ struct pc_ctx {
     int red_slot = 0;
     // score pass: one work counter per launch (units beyond the grid are drawn from it)
     DevBuf d_work;
+    DevBuf d_units;              // unit_prefix tables of the launches whose windows are cut into more than kMaxChunks chunks
     int len_hint = 0;            // pc_set_length_hint
     bool int16_only = false;     // pc_set_int16_only: never use the packed-fp16 kernel variants
     // pc_prefilter_device: Eq tables + piece metadata of the last (adapter list, edit bounds), kept on the device
@@ -736,7 +737,7 @@ void pc_destroy(pc_ctx *c)
     DevBuf *bufs[] = {&c->d_ad_codes, &c->d_ad_len, &c->d_ad_window, &c->d_ad_span, &c->d_tiles_slot[0], &c->d_tiles_slot[1],
                       &c->d_runs_slot[0], &c->d_runs_slot[1], &c->d_slab, &c->d_fin, &c->d_k1, &c->d_woff2,
                       &c->d_wlen2, &c->d_col0, &c->d_ntot, &c->d_frow, &c->d_fscore, &c->d_err, &c->d_arena,
-                      &c->d_woff, &c->d_wlen, &c->d_out, &c->d_red_slot[0], &c->d_red_slot[1], &c->d_work, &c->d_pf_tables, &c->d_pf_meta, &c->d_sd_bitmaps, &c->d_sd_first,
+                      &c->d_woff, &c->d_wlen, &c->d_out, &c->d_red_slot[0], &c->d_red_slot[1], &c->d_work, &c->d_units, &c->d_pf_tables, &c->d_pf_meta, &c->d_sd_bitmaps, &c->d_sd_first,
                       &c->d_sd_entries, &c->d_sd_meta, &c->d_sd_eq, &c->d_sd_cand, &c->d_sd_count, &c->d_slow_ad, &c->d_slow_state,
                       &c->d_slow_trace};
     if (c->h_sd_count) (void)hipHostFree(c->h_sd_count);
@@ -875,10 +876,15 @@ int pc_scan_device(pc_ctx *c, const void *d_arena, const int64_t *d_win_off, con
             n_score_launches += score_plan[gi].size();
         }
     }
+    size_t unit_ints = 0;                   // (real, prefix) tables of the launches cut into very many chunks
+    for (size_t gi = 0; gi < c->groups.size(); ++gi)
+        for (const ScoreLaunch &L : score_plan[gi]) if (L.chunks > kMaxChunks) unit_ints += 2 * (L.count + 1);
     if (n_score_launches) {
         if ((rc = c->d_work.ensure(n_score_launches * 4 + 256))) return rc;
         HIP_TRY(hipMemsetAsync(c->d_work.p, 0, n_score_launches * 4, stream));
+        if (unit_ints && (rc = c->d_units.ensure(unit_ints * 4 + 256))) return rc;
     }
+    size_t unit_at = 0;
     size_t score_launch_no = 0;
     (void)max_chunks;
     if (any_two) {
@@ -970,6 +976,14 @@ int pc_scan_device(pc_ctx *c, const void *d_arena, const int64_t *d_win_off, con
                                                                       : (size_t)resident_waves(c, g));
                 const int64_t sub_pairs = group_pairs(g, L.begin, L.begin + L.count);
                 ScopedTimer tm(sfork ? nullptr : c, stream, L.spec ? 3 : 0, sub_pairs);       // one timed region per kernel launch
+                // windows cut into very many chunks (a batch with an ultra-long tail): only the chunks that hold columns are units
+                const int32_t *unit_prefix = nullptr;
+                if (L.chunks > kMaxChunks) {
+                    int32_t *real = c->d_units.as<int32_t>() + unit_at, *prefix = real + (L.count + 1);
+                    unit_at += 2 * (L.count + 1);
+                    if (pck::launch_unit_prefix(a.tiles + L.begin, (int)L.count, a.win_len, chunk_len, real, prefix, stream_k)) return PC_ERR_NO_DEVICE;
+                    unit_prefix = prefix;
+                }
                 if (L.spec) {
                     pcj::SpecArgs sa;
                     memset(&sa, 0, sizeof(sa));
@@ -983,6 +997,7 @@ int pc_scan_device(pc_ctx *c, const void *d_arena, const int64_t *d_win_off, con
                     sa.work_counter = c->d_work.as<uint32_t>() + score_launch_no++;
                     // a score-only request over whole windows: the kernel writes the records itself (no planner launch)
                     sa.rec_out = (mode == PC_MODE_SCORE && L.chunks == 1) ? d_out : nullptr;
+                    sa.unit_prefix = unit_prefix;
                     if (pcj::launch(L.spec, sa, grid, stream_k)) return PC_ERR_NO_DEVICE;
                 } else {
                     pck::ScanArgs b = a;
@@ -991,6 +1006,7 @@ int pc_scan_device(pc_ctx *c, const void *d_arena, const int64_t *d_win_off, con
                     b.chunks = L.chunks; b.chunk_len = chunk_len;
                     b.fin_scratch = fin_k;
                     b.work_counter = c->d_work.as<uint32_t>() + score_launch_no++;
+                    b.unit_prefix = unit_prefix;
                     if ((rc = pck::launch_score(b, g.rows, g.pad, grid, stream_k))) return PC_ERR_NO_DEVICE;
                 }
             }

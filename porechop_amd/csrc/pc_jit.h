@@ -31,6 +31,7 @@ struct SpecArgs {
     uint32_t one2;               // 0x00010001 (set by launch())
     int32_t *rec_out;            // PC_MODE_SCORE with whole windows (chunks == 1): the pairs' 8-int score records, written by the
                                  // kernel itself -- (-2, J, I, 0, score, 0, 0, 0) at rec_out[p * 8] -- instead of by the planner
+    const int32_t *unit_prefix;  // [ntiles + 1] or null: the real (tile, chunk) units only (pck::launch_unit_prefix)
 };
 
 bool disabled();

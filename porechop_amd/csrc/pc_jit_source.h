@@ -104,6 +104,8 @@ struct SpecArgs {
     u32 *work_counter;
     u32 one2;                 // 0x00010001, kept opaque to the compiler (with a literal it turns min_u16(x, 1) into compare / select chains)
     int *rec_out;             // score-only request over whole windows: [npairs][8] records (-2, J, I, 0, score, 0, 0, 0), else null
+    const int *unit_prefix;   // [ntiles + 1] or null: tile t owns units [unit_prefix[t], unit_prefix[t + 1]) -- the chunks that hold columns
+                              // of its longest window (a 4 Mb read among 20 kb reads: 2 048 chunks per tile, ten of them real for most)
 };
 struct FastT { static constexpr bool fast = true; };
 struct SlowT { static constexpr bool fast = false; };
@@ -154,8 +156,16 @@ extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(P
         if (lane == 0) v = atomicAdd(a.work_counter, 1u);
         return (int)gridDim.x + (int)__builtin_amdgcn_readfirstlane(v);
     };
-    for (int vt = blockIdx.x; vt < a.ntiles * nchunks; vt = next_unit(vt)) {
-        const int t = vt / nchunks, chunk = vt - t * nchunks;
+    const int total_units = a.unit_prefix ? a.unit_prefix[a.ntiles] : a.ntiles * nchunks;
+    for (int vt = blockIdx.x; vt < total_units; vt = next_unit(vt)) {
+        int t, chunk;
+        if (a.unit_prefix) {                                     // the last tile whose first unit is <= vt (wave-uniform)
+            int lo = 0, hi = a.ntiles - 1;
+            while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (a.unit_prefix[mid] <= vt) lo = mid; else hi = mid - 1; }
+            t = lo; chunk = vt - a.unit_prefix[lo];
+        } else {
+            t = vt / nchunks; chunk = vt - t * nchunks;
+        }
         const Tile tile = a.tiles[t];
 #if PC_DUAL
         constexpr bool one_stream = true;

@@ -62,7 +62,11 @@ struct ScanArgs {
     int32_t f16_cen, f16_max_cols;   // packed-fp16 traced kernel: centring constant C and the columns it may run (pc_bounds.h f16_plan)
     uint32_t *work_counter;          // score pass: units beyond the grid are handed out by this counter (zeroed by the host) in
                                      // launch order -- longest tiles first -- instead of a fixed stride; null = fixed stride
+    const int32_t *unit_prefix;      // score pass: [ntiles + 1] or null -- tile t owns units [unit_prefix[t], unit_prefix[t + 1]): only
+                                     // the chunks that hold columns of its longest window (launch_unit_prefix)
 };
+// unit_prefix of a chunked score pass: one wave per tile takes the tile's longest window, a block scans the counts
+int launch_unit_prefix(const Tile *tiles, int ntiles, const int32_t *win_len, int chunk_len, int32_t *real, int32_t *prefix, void *stream);
 
 // pass-2 planner: from the score-only pass's (score, I, J) build the bounded windows
 struct PlanArgs {

@@ -321,8 +321,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((R > 0 && R 
         if (lane == 0) v = atomicAdd(a.work_counter, 1u);
         return (int)gridDim.x + (int)__builtin_amdgcn_readfirstlane(v);
     };
-    for (int vt = blockIdx.x; vt < a.ntiles * nchunks; vt = next_unit(vt)) {
-        const int t = vt / nchunks, chunk = vt - t * nchunks;
+    const int total_units = (!TRACE && a.unit_prefix) ? a.unit_prefix[a.ntiles] : a.ntiles * nchunks;
+    for (int vt = blockIdx.x; vt < total_units; vt = next_unit(vt)) {
+        int t, chunk;
+        if (!TRACE && a.unit_prefix) {                               // the last tile whose first unit is <= vt (wave-uniform)
+            int lo = 0, hi = a.ntiles - 1;
+            while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (a.unit_prefix[mid] <= vt) lo = mid; else hi = mid - 1; }
+            t = lo; chunk = vt - a.unit_prefix[lo];
+        } else {
+            t = vt / nchunks; chunk = vt - t * nchunks;
+        }
         const Tile tile = a.tiles[t];
         const int rows = GEN ? tile.rows : R;
         const int NW = (rows + 3) >> 2;      // trace dwords per column per lane
@@ -1163,6 +1171,47 @@ __global__ void plan_kernel(PlanArgs a)
     a.ntot2[p] = a.win_len[w];
     a.force_row2[p] = I;
     a.force_score2[p] = score;
+}
+
+// ---------------------------------------------------------------------------------------------
+// The real units of a chunked score pass: tile t has ceil(longest window / chunk_len) chunks that hold columns (at least
+// one), the others would only be drawn -- one atomic each on ONE counter, 7 ns apiece -- to find nothing.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void unit_real_kernel(const Tile *tiles, int ntiles, const int32_t *win_len, int chunk_len, int32_t *real)
+{
+    const int t = blockIdx.x, lane = threadIdx.x;
+    if (t >= ntiles) return;
+    const Tile tile = tiles[t];
+    int n = 0;
+    if (lane < tile.count_lo) n = win_len[tile.win_lo + lane];
+    if (lane < tile.count_hi) { const int h = win_len[tile.win_hi + lane]; n = h > n ? h : n; }
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) { const int o = __shfl_xor(n, s); n = o > n ? o : n; }
+    if (lane == 0) { const int r = (n + chunk_len - 1) / chunk_len; real[t] = r < 1 ? 1 : r; }
+}
+
+__global__ __launch_bounds__(1024) void unit_scan_kernel(const int32_t *real, int ntiles, int32_t *prefix)
+{
+    __shared__ int part[1024];
+    const int tid = threadIdx.x;
+    const int per = (ntiles + 1023) / 1024, b = tid * per, e = b + per < ntiles ? b + per : ntiles;
+    int sum = 0;
+    for (int i = b; i < e; ++i) sum += real[i];
+    part[tid] = sum;
+    __syncthreads();
+    if (tid == 0) { int acc = 0; for (int i = 0; i < 1024; ++i) { const int v = part[i]; part[i] = acc; acc += v; } prefix[ntiles] = acc; }
+    __syncthreads();
+    int acc = part[tid];
+    for (int i = b; i < e; ++i) { prefix[i] = acc; acc += real[i]; }
+}
+
+int launch_unit_prefix(const Tile *tiles, int ntiles, const int32_t *win_len, int chunk_len, int32_t *real, int32_t *prefix, void *stream)
+{
+    if (ntiles <= 0 || chunk_len <= 0) return -1;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(unit_real_kernel, dim3((unsigned)ntiles), dim3(64), 0, s, tiles, ntiles, win_len, chunk_len, real);
+    hipLaunchKernelGGL(unit_scan_kernel, dim3(1), dim3(1024), 0, s, real, ntiles, prefix);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
 int trace_words_per_col(int rows) { return (rows + 3) / 4; }

@@ -517,7 +517,7 @@ int group_chunks_for(const pc_ctx *c, const Group &g, int max_len)
     if (ragged_lengths(c, max_len)) {
         const int unit = std::max(c->len_hint, std::max(512, 4 * g.max_window));
         // (a batch whose longest read is a hundred times the typical one -- a 4 Mb read among 20 kb reads -- needs more than
-        // kMaxChunks units of typical length: up to kMaxChunksLong, as far as the [pair][chunk] pass-1 buffer stays below 1 GiB)
+        // kMaxChunks units of typical length: up to kMaxChunksLong, as far as the [pair][chunk] pass-1 buffer stays below 4 GiB)
         const int64_t pairs = std::max<int64_t>(1, group_pairs(g, 0, g.tile_count));
         const int by_memory = (int)std::max<int64_t>(kMaxChunks, std::min<int64_t>(kMaxChunksLong, ((int64_t)4 << 30) / (pairs * 16)));
         // ... and few windows (a batch of 40 000 long reads is 625 tiles: units of typical length would be a fifth of the wave slots,

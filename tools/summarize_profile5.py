@@ -26,7 +26,7 @@ src = os.path.join("gpurun_out", "prof_" + tag)
 
 def family(name):
     m = re.search(r"(pc_spec_score|trace16_kernel|seed_scan_packed_kernel|seed_verify_packed_kernel|unpack_windows_kernel|unpack_windows_exceptions_kernel|seed_scan_kernel|seed_verify_kernel|(?<![a-z_])scan_kernel<[^,>]*,[^,>]*, *(?:true|false)>|(?<![a-z_])scan_kernel|prefilter_kernel|plan_kernel|reduce_kernel|"
-                  r"expand_tiles_kernel|copy_windows_kernel|select_kernel|gather_records_kernel|gather_kernel|scatter_kernel|unpack_kernel|unpack_exceptions_kernel|slow_kernel)", name)
+                  r"expand_tiles_kernel|copy_windows_kernel|unit_real_kernel|unit_scan_kernel|select_kernel|gather_records_kernel|gather_kernel|scatter_kernel|unpack_kernel|unpack_exceptions_kernel|slow_kernel)", name)
     if not m:
         return None
     f = m.group(1)

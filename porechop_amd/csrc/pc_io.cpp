@@ -205,6 +205,13 @@ bool inflate_sized_members(const char *path, RawBuf &out)
     return ok;
 }
 
+// Any other gzip file, whole: the producer of the streamed route (gz_produce below) drained into one buffer -- members that
+// were `cat`-ed together are inflated ahead by several cores, zero padding between and after members is skipped (as Python's
+// gzip module, the reference's reader, does), and a stream that ends inside a member or is followed by anything else is an
+// ERROR (zlib's gzread, used here before, returned what it had and said nothing: a truncated download lost reads silently,
+// where the reference stops with an exception).
+bool inflate_whole_gzip(const char *path, RawBuf &out);
+
 bool slurp(const char *path, FileData &data, std::string &err)
 {
     FILE *f = fopen(path, "rb");
@@ -219,18 +226,7 @@ bool slurp(const char *path, FileData &data, std::string &err)
     if (gz && inflate_sized_members(path, data.owned)) {
         data.p = data.owned.data(); data.n = data.owned.size();
     } else if (gz) {
-        data.owned.resize(0);
-        gzFile g = gzopen(path, "rb");
-        if (!g) { err = std::string("could not open ") + path; return false; }
-        gzbuffer(g, 1 << 20);
-        std::vector<char> buf(1 << 22);
-        for (;;) {
-            const int n = gzread(g, buf.data(), (unsigned)buf.size());
-            if (n < 0) { err = "gzip stream error"; gzclose(g); return false; }
-            if (n == 0) break;
-            data.owned.append(buf.data(), buf.data() + n);
-        }
-        gzclose(g);
+        if (!inflate_whole_gzip(path, data.owned)) { err = "gzip stream error (damaged, or ended before the end of a member)"; return false; }
         data.p = data.owned.data(); data.n = data.owned.size();
     } else {
         const int fd = open(path, O_RDONLY);
@@ -942,6 +938,26 @@ void gz_produce(pc_gzstream *s)
     }
     munmap(m, size);
     finish(ok);
+}
+
+extern "C++" bool inflate_whole_gzip(const char *path, RawBuf &out)         // (declared above, outside the extern "C" block)
+{
+    pc_gzstream s;                                        // (its destructor stops and joins the producer)
+    s.path = path;
+    s.inflate_threads = std::max(1, usable_threads());
+    s.producer = std::thread(gz_produce, &s);
+    out.resize(0);
+    for (;;) {
+        std::unique_lock<std::mutex> lk(s.mu);
+        s.cv.wait(lk, [&] { return !s.ready.empty() || s.done; });
+        if (s.ready.empty()) return !s.failed;
+        std::vector<char> v = std::move(s.ready.front());
+        s.ready.pop_front();
+        s.ready_bytes -= v.size();
+        lk.unlock();
+        s.cv.notify_all();
+        out.append(v.data(), v.data() + v.size());
+    }
 }
 
 }  // namespace

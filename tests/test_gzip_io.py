@@ -281,3 +281,46 @@ def test_guessed_members_larger_than_the_cap_take_the_serial_path(files):
     ref = pio.ReadSet(files["plain"])
     assert outs[0][0] == str(ref.count) and outs[0][1] == md5(ref.arena.tobytes()[:-64])
     assert outs[0][:2] == outs[0][2:4] == outs[0][4:6]
+
+
+def test_whole_file_route_skips_zero_padding_and_refuses_a_truncated_stream(tmp_path):
+    """porechop/misc.py:60-81 reads .gz through Python's gzip module: zero padding between (and after) members is skipped,
+    a stream that ends inside a member raises.  zlib's gzread -- the whole-file route before tests/host/fuzz_io.cpp -- stopped
+    at the padding without a word and returned a truncated stream's bytes as if they were the file."""
+    plain = write_fastq(str(tmp_path / "in.fastq"), 900, seed=3)
+    text = open(plain, "rb").read()
+    cut = text.index(b"\n@r450 ") + 1
+    padded = str(tmp_path / "padded.fastq.gz")
+    open(padded, "wb").write(gzip.compress(text[:cut]) + b"\0" * 512 + gzip.compress(text[cut:]) + b"\0" * 100)
+    with gzip.open(padded, "rb") as f:                        # what the reference's reader makes of it
+        assert f.read() == text
+    ref = pio.ReadSet(plain)
+    want = (ref.count, md5(ref.arena.tobytes()), md5(ref.lengths.tobytes()), ref.name(449), ref.quals(899))
+    rs = pio.ReadSet(padded)
+    assert ref.count == 900 and (rs.count, md5(rs.arena.tobytes()), md5(rs.lengths.tobytes()), rs.name(449), rs.quals(899)) == want
+    st, n = pio.GzStream(padded), 0
+    while True:
+        blk = st.next(1 << 16)
+        assert blk is not False
+        if blk is None:
+            break
+        n += blk.count
+    st.close()
+    assert n == 900
+
+    whole = gzip.compress(text)
+    short = str(tmp_path / "short.fastq.gz")
+    open(short, "wb").write(whole[:len(whole) * 2 // 3])
+    with pytest.raises(EOFError):
+        with gzip.open(short, "rb") as f:
+            f.read()
+    with pytest.raises(ValueError) as e:
+        pio.ReadSet(short)
+    assert "gzip stream error" in str(e.value)
+    junk = str(tmp_path / "junk.fastq.gz")
+    open(junk, "wb").write(whole + b"not a gzip member")
+    with pytest.raises(gzip.BadGzipFile):
+        with gzip.open(junk, "rb") as f:
+            f.read()
+    with pytest.raises(ValueError):
+        pio.ReadSet(junk)

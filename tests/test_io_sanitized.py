@@ -1,0 +1,40 @@
+"""The host ingest / output / gzip code (porechop_amd/csrc/pc_io.cpp + pc_gz.h) under AddressSanitizer
+and UndefinedBehaviorSanitizer: tests/host/fuzz_io.cpp writes an irregular FASTQ file, compresses it in the three layouts the
+readers distinguish (sized members, ONE member, `cat`-ed members with zero padding between two of them), reads each back whole
+and as a stream of blocks, writes the reads out plain and compressed and reads those back -- all compared with the plain file's
+reads -- and then pushes damaged copies (cut short, flipped bytes, zeroed ranges, garbage appended, chunks duplicated or
+removed) through every reader: any return code is accepted, a sanitizer report or a crash is not.
+
+Found this way: zlib's gzread, which the whole-file route used, silently stops at zero padding between members (Python's
+gzip module -- the reference's reader, porechop/misc.py:60-81 -- skips it) and returns a truncated stream's bytes without an
+error (the reference raises); the whole-file route now drains the streamed route's producer instead."""
+import os
+import shutil
+import subprocess
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_ingest_output_and_gzip_under_asan_and_ubsan(tmp_path):
+    gxx = shutil.which("g++")
+    if not gxx:
+        pytest.skip("no g++")
+    exe = tmp_path / "fuzz_io"
+    build = subprocess.run([gxx, "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+                            "-fno-omit-frame-pointer", os.path.join(REPO, "porechop_amd", "csrc", "pc_io.cpp"),
+                            os.path.join(REPO, "tests", "host", "fuzz_io.cpp"), "-o", str(exe), "-lz", "-ldl", "-lpthread"],
+                           capture_output=True, text=True, timeout=600)
+    if build.returncode != 0 and ("asan" in build.stderr or "ubsan" in build.stderr):
+        pytest.skip("this g++ has no sanitizer runtimes: " + build.stderr[-300:])
+    assert build.returncode == 0, build.stderr[-3000:]
+    work = tmp_path / "work"
+    work.mkdir()
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+    for seed, rounds, extra in ((1, 5, {}), (2, 3, {"PC_NO_LIBDEFLATE": "1"}), (3, 3, {"PC_GZ_SPEC_CAP_MB": "1"})):
+        res = subprocess.run([str(exe), str(work), str(seed), str(rounds)], capture_output=True, text=True, timeout=1200,
+                             env=dict(env, **extra))
+        assert res.returncode == 0, (seed, extra, res.stdout[-1500:], res.stderr[-6000:])
+        assert "0 check failure(s)" in res.stdout and "ERROR: AddressSanitizer" not in res.stderr and "runtime error" not in res.stderr, \
+            (res.stdout[-1500:], res.stderr[-6000:])

@@ -12,7 +12,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_fp16_gates_admit_only_exact_schemes():
     with tempfile.TemporaryDirectory() as tmp:
         exe = os.path.join(tmp, "test_bounds")
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-I", os.path.join(REPO, "porechop_amd", "csrc"),
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-I", os.path.join(REPO, "porechop_amd", "csrc"),
                                os.path.join(REPO, "tests", "host", "test_bounds.cpp"), "-o", exe])
         out = subprocess.run([exe], capture_output=True, text=True, timeout=600)
         assert out.returncode == 0 and "bad=0" in out.stdout, out.stdout[-3000:]

@@ -12,8 +12,8 @@ def test_walk_and_window_bound_against_oracle():
     with tempfile.TemporaryDirectory() as tmp:
         exe = os.path.join(tmp, "test_walk")
         obj = os.path.join(tmp, "pc_oracle.o")
-        subprocess.check_call(["gcc", "-O2", "-std=c11", "-c", os.path.join(REPO, "oracle", "pc_oracle.c"), "-o", obj])
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-I", os.path.join(REPO, "porechop_amd", "csrc"),
+        subprocess.check_call(["gcc", "-O2", "-std=c11", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-c", os.path.join(REPO, "oracle", "pc_oracle.c"), "-o", obj])
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-I", os.path.join(REPO, "porechop_amd", "csrc"),
                                "-I", os.path.join(REPO, "oracle"), os.path.join(REPO, "tests", "host", "test_walk.cpp"),
                                obj, "-o", exe])
         out = subprocess.run([exe, "20000"], capture_output=True, text=True, timeout=300)

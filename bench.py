@@ -985,6 +985,16 @@ def library_fingerprint():
     return h.hexdigest()
 
 
+def device_sources_fingerprint():
+    """tools/device_fingerprint.py over the working tree: sha1 of every source that decides what the GPU does."""
+    try:
+        sys.path.insert(0, os.path.join(REPO, "tools"))
+        import device_fingerprint
+        return device_fingerprint.fingerprint()
+    except Exception:
+        return None
+
+
 _PROFILE = None
 
 
@@ -992,7 +1002,8 @@ def profile_traffic(leg, kernel, launches_per_step=None):
     """HBM-side traffic (FETCH_SIZE + WRITE_SIZE, bytes per launch) of the kernel family `kernel` in `leg`, from the newest
     profiles/*_summary.json (tools/profile_round3.sh + summarize_profile3.py: rocprofv3 --pmc, one counter per pass, a
     process that runs only that leg) -- ONLY if that summary was taken with the very library now loaded (its recorded sha1
-    equals the loaded .so's): a kernel change without a re-profile reports null, never stale counters.  The summary holds
+    equals the loaded .so's, or its device-source fingerprint equals the working tree's): a kernel change without a re-profile
+    reports null, never stale counters.  The summary holds
     per-step sums; `launches_per_step` is this run's count of timed launches of the kernel per step (None: the profile's own)."""
     global _PROFILE
     if _PROFILE is None:
@@ -1003,7 +1014,10 @@ def profile_traffic(leg, kernel, launches_per_step=None):
             if summ:
                 with open(summ[-1]) as f:
                     sj = json.load(f)
-                if sj.get("library_sha1") == library_fingerprint():
+                # ... or with a library built from the same kernels, launch planning and flags: only the host I/O code
+                # (FASTQ / gzip in and out) differs (tools/device_fingerprint.py)
+                if sj.get("library_sha1") == library_fingerprint() or \
+                        (sj.get("device_sources_sha1") and sj.get("device_sources_sha1") == device_sources_fingerprint()):
                     _PROFILE = sj
                     _PROFILE["_path"] = os.path.relpath(summ[-1], REPO)
         except Exception:

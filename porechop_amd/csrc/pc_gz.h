@@ -76,6 +76,17 @@ inline uint32_t crc_of(const void *p, size_t n)
     return (uint32_t)crc32(crc32(0L, Z_NULL, 0), (const Bytef *)p, (uInt)n);
 }
 
+// running CRC-32 (start from 0): libdeflate's runs at >10 GB/s, zlib 1.2.11's at 0.7 -- a fifth of what its own inflate takes
+inline uint32_t crc_update(uint32_t crc, const void *p, size_t n)
+{
+    const LibDeflate &l = libdeflate();
+    if (l.ok) return l.crc32_(crc, p, n);
+    const unsigned char *q = (const unsigned char *)p;
+    uLong c = crc;
+    while (n) { const uInt k = (uInt)(n > ((size_t)1 << 30) ? ((size_t)1 << 30) : n); c = crc32(c, q, k); q += k; n -= k; }
+    return (uint32_t)c;
+}
+
 inline void put16(unsigned char *p, unsigned v) { p[0] = (unsigned char)(v & 0xff); p[1] = (unsigned char)(v >> 8); }
 inline void put32(unsigned char *p, uint32_t v) { p[0] = (unsigned char)v; p[1] = (unsigned char)(v >> 8); p[2] = (unsigned char)(v >> 16); p[3] = (unsigned char)(v >> 24); }
 inline uint32_t get32(const unsigned char *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
@@ -159,6 +170,20 @@ inline size_t sized_member(const unsigned char *p, size_t avail, size_t *payload
     if (total < 12 + xlen + kTrailer || total > avail) return 0;
     if (payload_off) *payload_off = 12 + xlen;
     return total;
+}
+
+// The header of the gzip member at p (RFC 1952): -> where its deflate data starts, 0 = no member header here (or cut off).
+// The readers below inflate members RAW and check CRC-32 and ISIZE themselves (crc_update): zlib's own gzip wrapper spends a
+// fifth of its time in its table-driven CRC.
+inline size_t gzip_header_len(const unsigned char *p, size_t avail)
+{
+    if (avail < 18 || p[0] != 0x1f || p[1] != 0x8b || p[2] != 8 || (p[3] & 0xE0)) return 0;
+    size_t at = 10;
+    if (p[3] & 4) { if (at + 2 > avail) return 0; at += 2 + ((size_t)p[at] | ((size_t)p[at + 1] << 8)); }
+    if (p[3] & 8) { while (at < avail && p[at]) ++at; ++at; }
+    if (p[3] & 16) { while (at < avail && p[at]) ++at; ++at; }
+    if (p[3] & 2) at += 2;
+    return at + kTrailer <= avail ? at : 0;
 }
 
 class Inflater {

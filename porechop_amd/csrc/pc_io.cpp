@@ -45,6 +45,18 @@
 #include "../../include/porechop_amd.h"
 #include "pc_gz.h"
 
+// Byte buffers of the gzip reader: std::vector<char>::resize zeroes what it adds -- 32 MB per buffer the producer fills, 8 MB and
+// more per member a worker inflates ahead -- before inflate overwrites every byte of it.  Default-initialising elements
+// leaves the pages untouched until they are written.
+template <class T> struct NoInitAlloc : std::allocator<T> {
+    template <class U> struct rebind { using other = NoInitAlloc<U>; };
+    NoInitAlloc() = default;
+    template <class U> NoInitAlloc(const NoInitAlloc<U> &) {}
+    template <class U> void construct(U *p) noexcept { ::new ((void *)p) U; }
+    template <class U, class... A> void construct(U *p, A &&...a) { ::new ((void *)p) U(std::forward<A>(a)...); }
+};
+using Bytes = std::vector<char, NoInitAlloc<char>>;
+
 // Big buffers are recycled: a streamed run loads and frees a read set per 256 MB block, and giving 128 MB back to
 // the kernel and faulting 128 MB of fresh zeroed pages in again cost as much as writing the block (measured: 0.8 s of
 // munmap per 6.4 GB run, as much again in page faults).  Freed buffers of 32 MB and more wait here (at most 3 GB) for
@@ -665,7 +677,7 @@ struct pc_gzstream {
     std::thread producer;
     std::mutex mu;
     std::condition_variable cv;
-    std::deque<std::vector<char>> ready;
+    std::deque<Bytes> ready;
     size_t ready_bytes = 0;
     bool done = false, failed = false, stop = false;
     RawBuf pending;                      // inflated bytes not yet handed out (starts at a record start)
@@ -695,7 +707,7 @@ static const size_t kSpecCap = [] { const char *e = getenv("PC_GZ_SPEC_CAP_MB");
 struct MemberSpeculator {
     const unsigned char *base;
     size_t size;
-    struct Cand { size_t start; std::vector<char> out; size_t end = 0; int state = 0; };   // 0 unclaimed, 1 running, 2 ok, 3 failed / too big
+    struct Cand { size_t start; Bytes out; size_t end = 0; int state = 0; };   // 0 unclaimed, 1 running, 2 ok, 3 failed / too big
     std::deque<Cand> cands;              // ascending starts from `first_idx` on (consumed ones are dropped)
     size_t scan_pos = 0, consumed_pos = 0;
     int window;
@@ -715,14 +727,19 @@ struct MemberSpeculator {
         for (auto &w : workers) w.join();
     }
     static bool magic_at(const unsigned char *p) { return p[0] == 0x1f && p[1] == 0x8b && p[2] == 8 && (p[3] & 0xE0) == 0; }
-    // more guesses, while fewer than `window` are waiting (with mu held)
-    void scan_more()
+    // more guesses, while fewer than `window` are waiting (with mu held); a few megabytes per call -- ONE big member has no
+    // guesses in it, and a scan of the whole file under the lock kept the consumer waiting at its first question
+    // -> true when the budget, not the window or the end of the file, stopped it
+    bool scan_more()
     {
         size_t waiting = 0;
         for (const Cand &c : cands) if (c.state == 0) ++waiting;
+        const size_t budget_end = scan_pos + ((size_t)4 << 20);
         while (waiting < (size_t)window && scan_pos + 18 < size) {
-            const unsigned char *q = (const unsigned char *)memchr(base + scan_pos, 0x1f, size - 18 - scan_pos);
-            if (!q) { scan_pos = size; break; }
+            if (scan_pos >= budget_end) return true;
+            const size_t stop = std::min(size - 18, budget_end);
+            const unsigned char *q = (const unsigned char *)memchr(base + scan_pos, 0x1f, stop - scan_pos);
+            if (!q) { scan_pos = stop; continue; }
             const size_t at = (size_t)(q - base);
             scan_pos = at + 1;
             if (!magic_at(q)) continue;
@@ -730,44 +747,53 @@ struct MemberSpeculator {
             cands.back().start = at;
             ++waiting;
         }
+        return false;
     }
     void work()
     {
         z_stream zs;
         memset(&zs, 0, sizeof zs);
-        if (inflateInit2(&zs, 15 + 16) != Z_OK) return;
+        if (inflateInit2(&zs, -15) != Z_OK) return;       // raw: header, CRC-32 and ISIZE are checked here (pc_gz.h)
         for (;;) {
             Cand *c = nullptr;
             {
                 std::unique_lock<std::mutex> lk(mu);
                 for (;;) {
                     if (stop) { inflateEnd(&zs); return; }
-                    scan_more();
+                    const bool more = scan_more();
                     for (Cand &k : cands) if (k.state == 0 && k.start >= consumed_pos) { c = &k; break; }
                     if (c) { c->state = 1; break; }
+                    if (more) { lk.unlock(); std::this_thread::yield(); lk.lock(); continue; }
                     cv.wait(lk);
                 }
             }
             // (deque elements keep their addresses while others are pushed / popped at the ends)
             bool good = false;
-            std::vector<char> out;
+            Bytes out;
             inflateReset(&zs);
-            size_t at = c->start;
+            const size_t header = pcz::gzip_header_len(base + c->start, size - c->start);
+            size_t at = c->start + header;
             zs.next_in = (Bytef *)(base + at); zs.avail_in = (uInt)std::min<size_t>(size - at, (size_t)1 << 30);
             const size_t in0 = zs.avail_in;
             size_t have = 0;
-            for (;;) {
-                if (out.size() < have + ((size_t)4 << 20)) out.resize(std::max(out.size() * 2, have + ((size_t)8 << 20)));
+            uint32_t crc = 0;
+            for (; header; ) {
+                if (out.size() < have + ((size_t)64 << 10)) out.resize(std::max(out.size() * 2, have + ((size_t)512 << 10)));   // (most guesses die within a page)
                 zs.next_out = (Bytef *)out.data() + have; zs.avail_out = (uInt)std::min<size_t>(out.size() - have, (size_t)1 << 30);
                 const size_t room = zs.avail_out;
                 const int r = inflate(&zs, Z_NO_FLUSH);
+                crc = pcz::crc_update(crc, out.data() + have, room - zs.avail_out);
                 have += room - zs.avail_out;
-                if (r == Z_STREAM_END) { good = true; break; }
+                if (r == Z_STREAM_END) {
+                    const size_t trailer = at + (in0 - zs.avail_in);
+                    good = trailer + pcz::kTrailer <= size && pcz::get32(base + trailer) == crc && pcz::get32(base + trailer + 4) == (uint32_t)have;
+                    break;
+                }
                 if (r != Z_OK || have > kSpecCap || (zs.avail_in == 0 && zs.avail_out != 0)) break;
                 { std::lock_guard<std::mutex> lk(mu); if (stop || c->start < consumed_pos) break; }      // nobody will ask for this one
             }
             std::lock_guard<std::mutex> lk(mu);
-            if (good) { out.resize(have); c->out.swap(out); c->end = at + (in0 - zs.avail_in); c->state = 2; }
+            if (good) { out.resize(have); c->out.swap(out); c->end = at + (in0 - zs.avail_in) + pcz::kTrailer; c->state = 2; }
             else c->state = 3;
             cv.notify_all();
         }
@@ -794,7 +820,7 @@ struct MemberSpeculator {
         return false;
     }
     // The inflated member that starts at pos, if a worker has (or will soon have) it: *end = one past its last byte.
-    bool take(size_t pos, std::vector<char> &out, size_t *end)
+    bool take(size_t pos, Bytes &out, size_t *end)
     {
         std::unique_lock<std::mutex> lk(mu);
         consumed_pos = pos;
@@ -802,11 +828,11 @@ struct MemberSpeculator {
         cv.notify_all();
         if (!plausible_small_member(pos)) return false;
         for (;;) {
-            scan_more();
+            while (scan_more() && scan_pos <= pos) {}
             Cand *c = nullptr;
             for (Cand &k : cands) { if (k.start == pos) { c = &k; break; } if (k.start > pos) break; }
             if (!c) {
-                if (scan_pos > pos) return false;          // scanned past it: no member starts here
+                if (scan_pos > pos || scan_pos + 18 >= size) return false;          // scanned past it (or to the end): no member starts here
                 cv.wait_for(lk, std::chrono::milliseconds(1));
                 continue;
             }
@@ -820,7 +846,7 @@ struct MemberSpeculator {
 
 void gz_produce(pc_gzstream *s)
 {
-    auto push = [&](std::vector<char> &&v) -> bool {
+    auto push = [&](Bytes &&v) -> bool {
         std::unique_lock<std::mutex> lk(s->mu);
         s->cv.wait(lk, [&] { return s->stop || s->ready_bytes < kGzQueueBytes; });
         if (s->stop) return false;
@@ -861,7 +887,7 @@ void gz_produce(pc_gzstream *s)
             p += n;
         }
         if (mem.empty()) break;                           // an ordinary gzip member from here on
-        std::vector<char> buf(total);
+        Bytes buf(total);
         const int T = std::max(1, std::min<int>(s->inflate_threads, (int)(mem.size() / 16 + 1)));
         std::atomic<size_t> next{0};
         std::atomic<bool> good{true};
@@ -886,9 +912,11 @@ void gz_produce(pc_gzstream *s)
     if (ok && at < size) {
         z_stream zs;
         memset(&zs, 0, sizeof zs);
-        if (inflateInit2(&zs, 15 + 16) != Z_OK) ok = false;
-        std::vector<char> buf;
+        if (inflateInit2(&zs, -15) != Z_OK) ok = false;    // raw: header, CRC-32 and ISIZE are checked here (pc_gz.h)
+        Bytes buf;
         bool ended = false;                               // the last member has ended and nothing follows it
+        bool in_member = false;
+        uint32_t crc = 0, isize = 0;
         static const bool no_spec = [] { const char *e = getenv("PC_GZ_NO_SPECULATION"); return e && *e && *e != '0'; }();
         std::unique_ptr<MemberSpeculator> spec;
         if (!no_spec && s->inflate_threads > 1 && size - at > ((size_t)1 << 20)) spec.reset(new MemberSpeculator(base, size, at, s->inflate_threads));
@@ -896,7 +924,7 @@ void gz_produce(pc_gzstream *s)
         // a member starts where the last one ended
         auto take_ahead = [&]() -> bool {
             while (spec && ok && !ended) {
-                std::vector<char> whole;
+                Bytes whole;
                 size_t end = 0;
                 if (!spec->take(at, whole, &end)) return true;
                 at = end;
@@ -911,15 +939,26 @@ void gz_produce(pc_gzstream *s)
             buf.resize(kGzBuffer);
             zs.next_out = (Bytef *)buf.data(); zs.avail_out = (uInt)buf.size();
             while (zs.avail_out) {
+                if (!in_member) {
+                    const size_t header = pcz::gzip_header_len(base + at, size - at);
+                    if (!header || inflateReset(&zs) != Z_OK) { ok = false; break; }      // (anything but a member after a member: an error, as for Python's gzip)
+                    at += header;
+                    in_member = true; crc = 0; isize = 0;
+                }
                 const size_t take = std::min<size_t>(size - at, (size_t)1 << 30);
                 zs.next_in = (Bytef *)(base + at); zs.avail_in = (uInt)take;
+                const Bytef *out0 = zs.next_out;
                 const int r = inflate(&zs, Z_NO_FLUSH);
                 at += take - zs.avail_in;
+                crc = pcz::crc_update(crc, out0, (size_t)(zs.next_out - out0));
+                isize += (uint32_t)(zs.next_out - out0);
                 if (r == Z_STREAM_END) {
+                    if (at + pcz::kTrailer > size || pcz::get32(base + at) != crc || pcz::get32(base + at + 4) != isize) { ok = false; break; }
+                    at += pcz::kTrailer;
+                    in_member = false;
                     // another member may follow (zeros after the last member are padding, as gzip treats them)
                     while (at < size && base[at] == 0) ++at;
                     if (at >= size) { ended = true; break; }
-                    if (inflateReset(&zs) != Z_OK) { ok = false; break; }
                     if (spec) break;                      // (hand what there is over, then see whether the next members were inflated ahead)
                     continue;
                 }
@@ -930,8 +969,8 @@ void gz_produce(pc_gzstream *s)
             if (!ok) break;
             buf.resize(buf.size() - zs.avail_out);
             if (!buf.empty() && !push(std::move(buf))) { inflateEnd(&zs); spec.reset(); munmap(m, size); finish(false); return; }
-            buf = std::vector<char>();
-            if (spec && ok && !ended && zs.total_in == 0 && !take_ahead()) { inflateEnd(&zs); spec.reset(); munmap(m, size); finish(false); return; }
+            buf = Bytes();
+            if (spec && ok && !ended && !in_member && !take_ahead()) { inflateEnd(&zs); spec.reset(); munmap(m, size); finish(false); return; }
         }
         spec.reset();
         inflateEnd(&zs);
@@ -951,7 +990,7 @@ extern "C++" bool inflate_whole_gzip(const char *path, RawBuf &out)         // (
         std::unique_lock<std::mutex> lk(s.mu);
         s.cv.wait(lk, [&] { return !s.ready.empty() || s.done; });
         if (s.ready.empty()) return !s.failed;
-        std::vector<char> v = std::move(s.ready.front());
+        Bytes v = std::move(s.ready.front());
         s.ready.pop_front();
         s.ready_bytes -= v.size();
         lk.unlock();
@@ -1015,7 +1054,7 @@ int pc_gzstream_next(pc_gzstream *s, int64_t target_bytes, int64_t min_reads, pc
             s->eof = true;
             continue;
         }
-        std::vector<char> v = std::move(s->ready.front());
+        Bytes v = std::move(s->ready.front());
         s->ready.pop_front();
         s->ready_bytes -= v.size();
         lk.unlock();

@@ -181,12 +181,12 @@ int main(int argc, char **argv)
 
     // ---- 1. one file, four layouts, every reader ------------------------------------------------------------------
     std::vector<size_t> starts;
-    const std::string fastq = make_fastq(2500, &starts);
+    const std::string fastq = make_fastq(1200, &starts);
     const std::string plain = dir + "/in.fastq";
     spit(plain, fastq);
     Reads want;
     CHECK(load_whole(plain, &want) == PC_OK, "plain load");
-    CHECK(want.name.size() == 2500, "reads %zu", want.name.size());
+    CHECK(want.name.size() == 1200, "reads %zu", want.name.size());
 
     const std::string sized = dir + "/sized.fastq.gz", single = dir + "/single.fastq.gz", cat = dir + "/cat.fastq.gz";
     CHECK(pc_gzip_file(plain.c_str(), sized.c_str(), 0, 0) == PC_OK, "gzip sized");
@@ -276,9 +276,15 @@ int main(int argc, char **argv)
             const std::string bad = dir + (l < 3 ? "/bad.fastq.gz" : "/bad.fastq");
             spit(bad, damage(originals[l]));
             Reads a;
-            (load_whole(bad, &a) == PC_OK ? accepted : refused) += 1;
+            const bool whole_ok = load_whole(bad, &a) == PC_OK;
+            (whole_ok ? accepted : refused) += 1;
+            // ONE member has one CRC-32 over everything: whatever is read from a damaged copy without complaint is the original
+            // (a flipped bit in the header's time stamp, say) -- anything else got past the checks
+            if (l == 1 && whole_ok) CHECK(a == want, "damaged single-member file accepted with other reads (round %d)", r);
             if (l < 3) {
-                (load_stream(bad, (int64_t)1 << (12 + rng() % 12), (int64_t)(rng() % 200), &a) == PC_OK ? accepted : refused) += 1;
+                const bool stream_ok = load_stream(bad, (int64_t)1 << (12 + rng() % 12), (int64_t)(rng() % 200), &a) == PC_OK;
+                (stream_ok ? accepted : refused) += 1;
+                if (l == 1 && stream_ok) CHECK(a == want, "damaged single-member file streamed with other reads (round %d)", r);
             } else {
                 (load_segments(bad, (int64_t)1 << (12 + rng() % 10), &a) == PC_OK ? accepted : refused) += 1;
                 int64_t rec = 0;

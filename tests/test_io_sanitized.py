@@ -32,7 +32,7 @@ def test_ingest_output_and_gzip_under_asan_and_ubsan(tmp_path):
     work = tmp_path / "work"
     work.mkdir()
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
-    for seed, rounds, extra in ((1, 5, {}), (2, 3, {"PC_NO_LIBDEFLATE": "1"}), (3, 3, {"PC_GZ_SPEC_CAP_MB": "1"})):
+    for seed, rounds, extra in ((1, 4, {}), (2, 3, {"PC_NO_LIBDEFLATE": "1", "PC_GZ_SPEC_CAP_MB": "1"})):
         res = subprocess.run([str(exe), str(work), str(seed), str(rounds)], capture_output=True, text=True, timeout=1200,
                              env=dict(env, **extra))
         assert res.returncode == 0, (seed, extra, res.stdout[-1500:], res.stderr[-6000:])

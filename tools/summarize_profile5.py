@@ -105,6 +105,17 @@ for leg in sorted(os.listdir(src)):
         shutil.copy(single, os.path.join("profiles", "%s_%s_kernel_stats_single_stream.csv" % (rnd, leg)))
     out["legs"][leg] = {"steps_profiled": steps, "command": "python tools/run_leg.py %s %d" % (leg, steps),
                         "kernels": {k: dict(v) for k, v in ks.items()}}
+# the sources the profiled library was built from, when that library is the one in the tree now (tools/device_fingerprint.py:
+# bench.py then keeps using these counters after a change to the host I/O code alone)
+try:
+    import hashlib
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import device_fingerprint
+    lib = os.path.join("porechop_amd", "libporechop_amd.so")
+    if out["library_sha1"] and hashlib.sha1(open(lib, "rb").read()).hexdigest() == out["library_sha1"]:
+        out["device_sources_sha1"] = device_fingerprint.fingerprint()
+except Exception:
+    pass
 with open(os.path.join("profiles", rnd + "_summary.json"), "w") as f:
     json.dump(out, f, indent=1)
 for leg, v in out["legs"].items():

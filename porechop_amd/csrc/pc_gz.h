@@ -38,6 +38,8 @@ struct LibDeflate {
     int (*deflate_decompress)(void *, const void *, size_t, void *, size_t, size_t *) = nullptr;
     void (*free_decompressor)(void *) = nullptr;
     uint32_t (*crc32_)(uint32_t, const void *, size_t) = nullptr;
+    // (optional: the one-shot route of the streamed reader, pc_io.cpp oneshot_member) -> 0 done, 1 bad data, 3 out of room
+    int (*deflate_decompress_ex)(void *, const void *, size_t, void *, size_t, size_t *, size_t *) = nullptr;
     bool ok = false;
     LibDeflate()
     {
@@ -53,6 +55,7 @@ struct LibDeflate {
         deflate_decompress = (int (*)(void *, const void *, size_t, void *, size_t, size_t *))dlsym(h, "libdeflate_deflate_decompress");
         free_decompressor = (void (*)(void *))dlsym(h, "libdeflate_free_decompressor");
         crc32_ = (uint32_t (*)(uint32_t, const void *, size_t))dlsym(h, "libdeflate_crc32");
+        deflate_decompress_ex = (int (*)(void *, const void *, size_t, void *, size_t, size_t *, size_t *))dlsym(h, "libdeflate_deflate_decompress_ex");
         ok = alloc_compressor && deflate_compress && free_compressor && alloc_decompressor && deflate_decompress &&
              free_decompressor && crc32_;
     }

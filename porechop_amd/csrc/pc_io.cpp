@@ -844,6 +844,131 @@ struct MemberSpeculator {
     }
 };
 
+// ---- ONE big member at libdeflate's speed, still streamed ----------------------------------------------------------------
+// libdeflate inflates 2-3 x faster than zlib but only whole buffers: no streaming interface.  It does, like any LZ77 decoder
+// into a flat buffer, write its output strictly front to back (a match copy may run a few dozen bytes AHEAD of the position,
+// never behind it).  So: the member is inflated by ONE libdeflate call on its own thread into fresh anonymous memory (zero
+// pages until written), and this thread watches the output appear -- a probe every megabyte: non-zero bytes there mean the
+// decoder has passed it -- and hands over what lies safely behind the front (256 KB: eight times the window the decoder may still
+// read back into), block by block, its CRC-32 taken on the way and checked against the trailer at the end; pages handed
+// over are given back to the kernel.  x86 keeps stores in order, so whatever lies behind a byte seen written has been
+// written.  Output with 64 zero bytes at a probe only delays the hand-over until the call returns.
+// The output size is not known (ISIZE is modulo 4 GiB): the room is `ratio` times the compressed bytes, bounded by half the
+// memory the process may still take; a member that needs more is restarted by the caller through zlib, which discards what
+// was handed over already.  PC_GZ_NO_ONESHOT=1 turns the route off; PC_GZ_ONESHOT_MIN_MB / PC_GZ_ONESHOT_RATIO tune it.
+size_t memory_room()
+{
+    auto number_in = [](const char *path, const char *key) -> long long {
+        FILE *f = fopen(path, "r");
+        if (!f) return -1;
+        char line[256];
+        long long v = -1;
+        while (fgets(line, sizeof line, f)) {
+            if (!key) { if (line[0] >= '0' && line[0] <= '9') v = atoll(line); break; }
+            if (!strncmp(line, key, strlen(key))) { v = atoll(line + strlen(key)); break; }
+        }
+        fclose(f);
+        return v;
+    };
+    long long avail = number_in("/proc/meminfo", "MemAvailable:");
+    avail = avail > 0 ? avail * 1024 : (long long)sysconf(_SC_AVPHYS_PAGES) * (long long)sysconf(_SC_PAGESIZE);
+    const long long cmax = number_in("/sys/fs/cgroup/memory.max", nullptr), ccur = number_in("/sys/fs/cgroup/memory.current", nullptr);
+    if (cmax > 0 && ccur >= 0) avail = std::min(avail, std::max(0LL, cmax - ccur));
+    return avail > 0 ? (size_t)avail : 0;
+}
+
+enum { kOneShotDone = 1, kOneShotNotTried = 0, kOneShotOutOfRoom = 2, kOneShotFailed = -1 };
+
+// The member whose deflate data starts at base[*data_at]: -> kOneShotDone (*data_at = one past its trailer), kOneShotNotTried
+// (nothing handed over: inflate it the ordinary way), kOneShotOutOfRoom (*handed bytes WERE handed over: inflate it the
+// ordinary way and discard that many), kOneShotFailed (damaged, or the consumer is gone).
+extern "C++" {
+template <class Push>
+int oneshot_member(const unsigned char *base, size_t size, size_t *data_at, Push &&push, size_t *handed)
+{
+    static const struct Knobs {
+        bool off, verbose; size_t min_bytes; size_t ratio; size_t room_bytes;
+        Knobs()
+        {
+            const char *o = getenv("PC_GZ_NO_ONESHOT"), *m = getenv("PC_GZ_ONESHOT_MIN_MB"), *r = getenv("PC_GZ_ONESHOT_RATIO");
+            const char *v = getenv("PC_GZ_VERBOSE"), *rm = getenv("PC_GZ_ONESHOT_ROOM_KB");       // (tests: a room too small on purpose)
+            verbose = v && *v && *v != '0';
+            room_bytes = (size_t)(rm && atol(rm) > 0 ? atol(rm) : 0) << 10;
+            off = o && *o && *o != '0';
+            min_bytes = (size_t)(m && atol(m) >= 0 ? atol(m) : 32) << 20;
+            ratio = (size_t)(r && atol(r) > 0 ? atol(r) : 12);
+        }
+    } knobs;
+    const pcz::LibDeflate &ld = pcz::libdeflate();
+    *handed = 0;
+    const size_t at = *data_at;
+    if (knobs.off || !ld.ok || !ld.deflate_decompress_ex || at + pcz::kTrailer >= size) return kOneShotNotTried;
+    const size_t in_n = size - at - pcz::kTrailer;            // at most this much deflate data (the call stops at the end of the stream)
+    if (in_n < knobs.min_bytes) return kOneShotNotTried;
+    size_t room = std::min(in_n * knobs.ratio + ((size_t)64 << 20), memory_room() / 2) & ~(size_t)4095;
+    if (room < in_n * 2) return kOneShotNotTried;                                 // memory is tight: stream through zlib
+    if (knobs.room_bytes) room = std::max<size_t>(knobs.room_bytes, 8192) & ~(size_t)4095;
+    void *mem = mmap(nullptr, room, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+    if (mem == MAP_FAILED) return kOneShotNotTried;
+    void *dec = ld.alloc_decompressor();
+    if (!dec) { munmap(mem, room); return kOneShotNotTried; }
+    unsigned char *out = (unsigned char *)mem;
+    std::atomic<int> finished{0};
+    size_t used_in = 0, made = 0;
+    int rc = 1;
+    std::thread decoder([&] {
+        rc = ld.deflate_decompress_ex(dec, base + at, in_n, out, room, &used_in, &made);
+        finished.store(1, std::memory_order_release);
+    });
+    constexpr size_t kStride = (size_t)1 << 20, kBehind = (size_t)256 << 10;
+    auto written_at = [&](size_t p) {
+        const volatile unsigned char *q = out + p;
+        for (int k = 0; k < 64; ++k) if (q[k]) return true;
+        return false;
+    };
+    size_t released = 0, dropped = 0, front = 0;          // front: a multiple of kStride whose probe has been seen written
+    uint32_t crc = 0;
+    bool consumer_gone = false;
+    auto release_to = [&](size_t upto) {
+        std::atomic_thread_fence(std::memory_order_acquire);
+        while (released < upto && !consumer_gone) {
+            const size_t n = std::min(kGzBuffer, upto - released);
+            Bytes b(n);
+            memcpy(b.data(), out + released, n);
+            crc = pcz::crc_update(crc, b.data(), n);
+            released += n;
+            if (!push(std::move(b))) consumer_gone = true;
+            const size_t keep = released & ~(size_t)4095;
+            if (keep > dropped) { madvise(out + dropped, keep - dropped, MADV_DONTNEED); dropped = keep; }
+        }
+    };
+    while (!finished.load(std::memory_order_acquire)) {
+        while (front + kStride + 64 <= room && written_at(front + kStride)) front += kStride;
+        if (!consumer_gone && front > kBehind && front - kBehind > released + ((size_t)4 << 20)) release_to(front - kBehind);
+        else std::this_thread::sleep_for(std::chrono::microseconds(200));
+    }
+    decoder.join();
+    ld.free_decompressor(dec);
+    int result;
+    if (consumer_gone) result = kOneShotFailed;
+    else if (rc == 0) {
+        release_to(made);
+        const size_t trailer = at + used_in;
+        const bool good = !consumer_gone && trailer + pcz::kTrailer <= size && pcz::get32(base + trailer) == crc && pcz::get32(base + trailer + 4) == (uint32_t)made;
+        if (good) *data_at = trailer + pcz::kTrailer;
+        result = good ? kOneShotDone : kOneShotFailed;
+    } else if (rc == 3) {
+        result = released ? kOneShotOutOfRoom : kOneShotNotTried;
+    } else {
+        result = released ? kOneShotFailed : kOneShotNotTried;          // (zlib will say the same about a damaged stream)
+    }
+    *handed = released;
+    munmap(mem, room);
+    if (knobs.verbose) fprintf(stderr, "pc_gz: one-shot member at %zu: rc %d, %zu -> %zu bytes, %zu handed over, result %d\n", at, rc, used_in, made, released, result);
+    return result;
+}
+}  // extern "C++"
+
 void gz_produce(pc_gzstream *s)
 {
     auto push = [&](Bytes &&v) -> bool {
@@ -935,7 +1060,23 @@ void gz_produce(pc_gzstream *s)
             return true;
         };
         if (!take_ahead()) { inflateEnd(&zs); spec.reset(); munmap(m, size); finish(false); return; }
+        size_t discard = 0;                               // inflated bytes of the current member that were handed over already
         while (ok && !ended) {
+            if (!in_member && !discard) {
+                // a big member the workers did not take: one libdeflate call, watched (oneshot_member)
+                const size_t header = pcz::gzip_header_len(base + at, size - at);
+                size_t data_at = at + header, handed = 0;
+                const int one = header ? oneshot_member(base, size, &data_at, push, &handed) : kOneShotNotTried;
+                if (one == kOneShotFailed) { if (s->stop) { inflateEnd(&zs); spec.reset(); munmap(m, size); finish(false); return; } ok = false; break; }
+                if (one == kOneShotOutOfRoom) discard = handed;
+                if (one == kOneShotDone) {
+                    at = data_at;
+                    while (at < size && base[at] == 0) ++at;
+                    if (at >= size) { ended = true; break; }
+                    if (!take_ahead()) { inflateEnd(&zs); spec.reset(); munmap(m, size); finish(false); return; }
+                    continue;
+                }
+            }
             buf.resize(kGzBuffer);
             zs.next_out = (Bytef *)buf.data(); zs.avail_out = (uInt)buf.size();
             while (zs.avail_out) {
@@ -968,6 +1109,12 @@ void gz_produce(pc_gzstream *s)
             }
             if (!ok) break;
             buf.resize(buf.size() - zs.avail_out);
+            if (discard) {                                // (the one-shot route ran out of room after handing this much over)
+                const size_t drop = std::min(discard, buf.size());
+                buf.erase(buf.begin(), buf.begin() + (ptrdiff_t)drop);
+                discard -= drop;
+            }
+            if (!in_member) discard = 0;
             if (!buf.empty() && !push(std::move(buf))) { inflateEnd(&zs); spec.reset(); munmap(m, size); finish(false); return; }
             buf = Bytes();
             if (spec && ok && !ended && !in_member && !take_ahead()) { inflateEnd(&zs); spec.reset(); munmap(m, size); finish(false); return; }

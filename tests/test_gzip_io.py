@@ -324,3 +324,41 @@ def test_whole_file_route_skips_zero_padding_and_refuses_a_truncated_stream(tmp_
             f.read()
     with pytest.raises(ValueError):
         pio.ReadSet(junk)
+
+
+def test_one_big_member_through_the_watched_one_shot_route(files):
+    """pc_io.cpp oneshot_member: ONE libdeflate call per big member on its own thread, its output handed over while it appears.
+    Forced on for every member here (PC_GZ_ONESHOT_MIN_MB=0; the default takes members of 32 MB and more), with room and with
+    a room the member outgrows after a hand-over (zlib restarts and discards it): the blocks equal the plain file's."""
+    code = r"""
+import hashlib, sys
+sys.path.insert(0, %r)
+from porechop_amd import io as pio
+for path in sys.argv[1:]:
+    st, h, n = pio.GzStream(path), hashlib.md5(), 0
+    while True:
+        rs = st.next(3_000_000)
+        assert rs is not False
+        if rs is None:
+            break
+        h.update(rs.arena.tobytes()[:int(rs.lengths.sum())]); h.update(rs.name(rs.count - 1).encode()); h.update(rs.quals(0).encode()); n += rs.count
+        rs.close()
+    st.close()
+    print("GOT", n, h.hexdigest())
+""" % REPO
+    ref = pio.ReadSet(files["plain"])
+    size = os.path.getsize(files["plain"])
+    want_n = ref.count
+    outs = {}
+    for tag, extra in (("zlib", {"PC_GZ_NO_ONESHOT": "1"}), ("oneshot", {"PC_GZ_ONESHOT_MIN_MB": "0", "PC_GZ_VERBOSE": "1"}),
+                       ("outgrown", {"PC_GZ_ONESHOT_MIN_MB": "0", "PC_GZ_VERBOSE": "1", "PC_GZ_ONESHOT_ROOM_KB": str(size // 1024 * 3 // 4)})):
+        res = subprocess.run([sys.executable, "-c", code, files["single"], files["cli"], files["concat"]], capture_output=True, text=True,
+                             env=dict(os.environ, PC_GZ_NO_SPECULATION="1", **extra), timeout=600)
+        assert res.returncode == 0, res.stderr[-2000:]
+        outs[tag] = [l for l in res.stdout.splitlines() if l.startswith("GOT")]
+        assert len(outs[tag]) == 3 and all(int(l.split()[1]) == want_n for l in outs[tag]), (tag, outs[tag])
+        if tag == "oneshot":
+            assert res.stderr.count("result 1") >= 4, res.stderr[-1500:]          # single, cli, and the two members of concat
+        if tag == "outgrown":
+            assert "result 2" in res.stderr, res.stderr[-1500:]
+    assert outs["zlib"] == outs["oneshot"] == outs["outgrown"]

@@ -467,7 +467,8 @@ int pc_gz_finish(const char *path);
 int pc_gzip_file(const char *src, const char *dst, int level, int single_member);
 
 /* A gzip FASTQ file as a stream of blocks (the streamed route for .gz input): a producer thread inflates ahead of the
- * caller -- members that carry their size on several cores, any other gzip stream through zlib -- so that inflating block
+ * caller -- members that carry their size on several cores, members without one guessed and inflated ahead, ONE big member by
+ * a single libdeflate call whose output is handed over while it appears (zlib without libdeflate) -- so that inflating block
  * k+1 overlaps parsing, scanning and writing block k.
  * pc_gzstream_next: the records that start before the first record start at or after target_bytes of the bytes not yet
  *   handed out (where pc_readset_load_segment would cut the plain file), at least min_reads of them unless the file ends

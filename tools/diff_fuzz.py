@@ -85,6 +85,29 @@ for k in range(cases):
         inp = os.path.join(work, "in.fasta" if as_fasta else "in.fastq")
         with open(inp, "w") as f:
             f.write(readgen.fasta_text(reads) if as_fasta else readgen.fastq_text(reads))
+        # a third of the inputs gzip-ed, in the layouts the readers tell apart (the reference decides by magic bytes,
+        # porechop/misc.py:60-81): one member, several members with zero padding between two of them, sized members
+        layout = rng.choice(["", "", "one", "members", "sized"])
+        if layout:
+            import gzip
+            text = open(inp, "rb").read()
+            os.remove(inp)
+            inp += ".gz"
+            if layout == "one":
+                blob = gzip.compress(text, rng.choice([1, 6, 9]))
+            elif layout == "sized":
+                from porechop_amd import io as pio
+                open(inp[:-3], "wb").write(text)
+                pio.gzip_file(inp[:-3], inp)
+                os.remove(inp[:-3])
+                blob = None
+            else:
+                marks = sorted({0, len(text)} | {m for m in (text.find(b"\n>" if as_fasta else b"\n@", rng.randrange(max(1, len(text)))) + 1 for _ in range(3)) if m > 0})
+                blob = b""
+                for a, b in zip(marks, marks[1:]):
+                    blob += gzip.compress(text[a:b], 1) + (b"\0" * rng.choice([0, 0, 13, 600]))
+            if blob is not None:
+                open(inp, "wb").write(blob)
     barcodes = kind in ("native", "rapid", "edge") and rng.random() < 0.5
     extra = random_options(barcodes)
     if not barcodes and "--untrimmed" in extra:
@@ -124,7 +147,7 @@ for k in range(cases):
         emitted.append({"input": os.path.basename(keep), "mode": mode, "argv": extra, "outputs": want, "exit": wexit})
     ok = (got == want) and (gexit == wexit)
     bad += not ok
-    print("%s case %2d %-8s %-14s %s%s" % ("ok " if ok else "BAD", k, kind, mode, " ".join(extra), "" if ok else "\n     want %r %r\n     got  %r %r" % (wexit, want, gexit, got)), flush=True)
+    print("%s case %2d %-8s %-12s %-14s %s%s" % ("ok " if ok else "BAD", k, kind, os.path.basename(inp), mode, " ".join(extra), "" if ok else "\n     want %r %r\n     got  %r %r" % (wexit, want, gexit, got)), flush=True)
 shutil.rmtree(tmp, ignore_errors=True)
 if emit:
     import json

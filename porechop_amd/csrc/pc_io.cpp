@@ -872,7 +872,8 @@ size_t memory_room()
     };
     long long avail = number_in("/proc/meminfo", "MemAvailable:");
     avail = avail > 0 ? avail * 1024 : (long long)sysconf(_SC_AVPHYS_PAGES) * (long long)sysconf(_SC_PAGESIZE);
-    const long long cmax = number_in("/sys/fs/cgroup/memory.max", nullptr), ccur = number_in("/sys/fs/cgroup/memory.current", nullptr);
+    long long cmax = number_in("/sys/fs/cgroup/memory.max", nullptr), ccur = number_in("/sys/fs/cgroup/memory.current", nullptr);     // (v2; "max" = no limit)
+    if (cmax <= 0) { cmax = number_in("/sys/fs/cgroup/memory/memory.limit_in_bytes", nullptr); ccur = number_in("/sys/fs/cgroup/memory/memory.usage_in_bytes", nullptr); }
     if (cmax > 0 && ccur >= 0) avail = std::min(avail, std::max(0LL, cmax - ccur));
     return avail > 0 ? (size_t)avail : 0;
 }

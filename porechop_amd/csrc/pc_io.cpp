@@ -853,9 +853,9 @@ struct MemberSpeculator {
 // read back into), block by block, its CRC-32 taken on the way and checked against the trailer at the end; pages handed
 // over are given back to the kernel.  x86 keeps stores in order, so whatever lies behind a byte seen written has been
 // written.  Output with 64 zero bytes at a probe only delays the hand-over until the call returns.
-// The output size is not known (ISIZE is modulo 4 GiB): the room is `ratio` times the compressed bytes, bounded by half the
-// memory the process may still take; a member that needs more is restarted by the caller through zlib, which discards what
-// was handed over already.  PC_GZ_NO_ONESHOT=1 turns the route off; PC_GZ_ONESHOT_MIN_MB / PC_GZ_ONESHOT_RATIO tune it.
+// The output size is not known (ISIZE is modulo 4 GiB): the room is `ratio` (12) times the compressed bytes, and the route is
+// only taken when half the memory the process may still take holds 8 times; a member that needs more than the room is
+// restarted by the caller through zlib, which discards what was handed over already.  PC_GZ_NO_ONESHOT=1 turns the route off; PC_GZ_ONESHOT_MIN_MB / PC_GZ_ONESHOT_RATIO tune it.
 size_t memory_room()
 {
     auto number_in = [](const char *path, const char *key) -> long long {
@@ -907,7 +907,9 @@ int oneshot_member(const unsigned char *base, size_t size, size_t *data_at, Push
     const size_t in_n = size - at - pcz::kTrailer;            // at most this much deflate data (the call stops at the end of the stream)
     if (in_n < knobs.min_bytes) return kOneShotNotTried;
     size_t room = std::min(in_n * knobs.ratio + ((size_t)64 << 20), memory_room() / 2) & ~(size_t)4095;
-    if (room < in_n * 2) return kOneShotNotTried;                                 // memory is tight: stream through zlib
+    // (FASTQ inflates 3-7 x: with less than 8 x within reach the member might outgrow the room after gigabytes were handed over,
+    // and zlib would inflate all of it again -- memory that tight streams through zlib from the start)
+    if (room < in_n * std::min<size_t>(8, knobs.ratio)) return kOneShotNotTried;
     if (knobs.room_bytes) room = std::max<size_t>(knobs.room_bytes, 8192) & ~(size_t)4095;
     void *mem = mmap(nullptr, room, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
     if (mem == MAP_FAILED) return kOneShotNotTried;

@@ -3,7 +3,8 @@ and UndefinedBehaviorSanitizer: tests/host/fuzz_io.cpp writes an irregular FASTQ
 readers distinguish (sized members, ONE member, `cat`-ed members with zero padding between two of them), reads each back whole
 and as a stream of blocks, writes the reads out plain and compressed and reads those back -- all compared with the plain file's
 reads -- and then pushes damaged copies (cut short, flipped bytes, zeroed ranges, garbage appended, chunks duplicated or
-removed) through every reader: any return code is accepted, a sanitizer report or a crash is not.
+removed) through every reader: any return code is accepted, a sanitizer report or a crash is not.  (A few rounds here; 240 rounds
+over four more seeds are recorded in profiles/r05_fuzz_io.txt.)
 
 Found this way: zlib's gzread, which the whole-file route used, silently stops at zero padding between members (Python's
 gzip module -- the reference's reader, porechop/misc.py:60-81 -- skips it) and returns a truncated stream's bytes without an
@@ -36,9 +37,9 @@ def test_ingest_output_and_gzip_under_asan_and_ubsan(tmp_path):
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
     # the third and fourth: every member the workers do not take goes through the watched one-shot libdeflate route
     # (oneshot_member), with room for it and with a room it outgrows after ~5 MB were handed over (seed 1's file is 6.1 MB)
-    for seed, rounds, extra in ((1, 3, {}), (2, 2, {"PC_NO_LIBDEFLATE": "1", "PC_GZ_SPEC_CAP_MB": "1"}),
-                                (1, 3, {"PC_GZ_ONESHOT_MIN_MB": "0", "PC_GZ_VERBOSE": "1"}),
-                                (1, 2, {"PC_GZ_ONESHOT_MIN_MB": "0", "PC_GZ_ONESHOT_ROOM_KB": "5700", "PC_GZ_VERBOSE": "1"})):
+    for seed, rounds, extra in ((1, 2, {}), (2, 1, {"PC_NO_LIBDEFLATE": "1", "PC_GZ_SPEC_CAP_MB": "1"}),
+                                (1, 2, {"PC_GZ_ONESHOT_MIN_MB": "0", "PC_GZ_VERBOSE": "1"}),
+                                (1, 1, {"PC_GZ_ONESHOT_MIN_MB": "0", "PC_GZ_ONESHOT_ROOM_KB": "5700", "PC_GZ_VERBOSE": "1"})):
         res = subprocess.run([str(exe), str(work), str(seed), str(rounds)], capture_output=True, text=True, timeout=1200,
                              env=dict(env, **extra))
         assert res.returncode == 0, (seed, extra, res.stdout[-1500:], res.stderr[-6000:])

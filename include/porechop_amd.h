@@ -466,6 +466,17 @@ void pc_gzimage_free(pc_gzimage *img);
 int pc_gz_finish(const char *path);
 int pc_gzip_file(const char *src, const char *dst, int level, int single_member);
 
+/* A gzip FASTQ file made of SIZED members (what the writer above makes; bgzip) for the ranks of a sharded run: the inflated
+ * stream is addressed like a plain file -- position x lies in the member whose inflated span holds it -- so that rank r of W
+ * takes the records that start in [find(total * r / W), find(total * (r + 1) / W)) and inflates only the members that hold
+ * them (the counterparts of pc_fastq_find_record / pc_readset_load_segment; porechop/misc.py:151-168 is what they replace).
+ * pc_gz_sized_size: the inflated size; PC_ERR_UNSUPPORTED_SCORES for a file that is not made of sized members throughout.
+ * pc_gz_sized_find_record: the first record start at or after `pos` of the inflated bytes (the inflated size when none is left).
+ * pc_readset_load_gz_range: the records of [begin, end), both as pc_gz_sized_find_record gives them. */
+int pc_gz_sized_size(const char *path, int64_t *inflated_bytes);
+int pc_gz_sized_find_record(const char *path, int64_t pos, int64_t *record_start);
+int pc_readset_load_gz_range(const char *path, int64_t begin, int64_t end, pc_readset **out);
+
 /* A gzip FASTQ file as a stream of blocks (the streamed route for .gz input): a producer thread inflates ahead of the
  * caller -- members that carry their size on several cores, members without one guessed and inflated ahead, ONE big member by
  * a single libdeflate call whose output is handed over while it appears (zlib without libdeflate) -- so that inflating block

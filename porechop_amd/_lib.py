@@ -22,6 +22,7 @@ EXPORTS = [
     "pc_readset_load_segment", "pc_readset_write_at", "pc_io_set_thread_limit", "pc_pack_reads", "pc_unpack_device", "pc_fastq_find_record", "pc_readset_write_sizes", "pc_readset_write_shared",
     "pc_readset_compress", "pc_gzimage_sizes", "pc_gzimage_write", "pc_gzimage_free", "pc_gz_finish", "pc_gzip_file",
     "pc_gzstream_open", "pc_gzstream_next", "pc_gzstream_close", "pc_prefilter_packed", "pc_unpack_windows",
+    "pc_gz_sized_size", "pc_gz_sized_find_record", "pc_readset_load_gz_range",
 ]
 
 
@@ -190,6 +191,12 @@ def load_library():
     L.pc_gzstream_next.restype = c_int
     L.pc_gzstream_close.argtypes = [c_vp]
     L.pc_gzstream_close.restype = None
+    L.pc_gz_sized_size.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_int64)]
+    L.pc_gz_sized_size.restype = ctypes.c_int
+    L.pc_gz_sized_find_record.argtypes = [ctypes.c_char_p, ctypes.c_int64, ctypes.POINTER(ctypes.c_int64)]
+    L.pc_gz_sized_find_record.restype = ctypes.c_int
+    L.pc_readset_load_gz_range.argtypes = [ctypes.c_char_p, ctypes.c_int64, ctypes.c_int64, ctypes.POINTER(c_vp)]
+    L.pc_readset_load_gz_range.restype = ctypes.c_int
     L.pc_pack_reads.argtypes = [c_vp, c_i64, c_vp, c_vp, c_i64, ctypes.POINTER(c_i64)]
     L.pc_pack_reads.restype = c_int
     L.pc_unpack_device.argtypes = [c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_int, c_vp]

@@ -666,6 +666,146 @@ int pc_fastq_find_record(const char *path, int64_t byte_pos, int64_t *record_sta
     return rc;
 }
 
+// ---- a gzip FASTQ file of SIZED members, addressed by positions in its inflated bytes (sharded runs) ------------------
+// Members that carry their size (what this library writes; bgzip) are independent and found by hopping from header to
+// header: the inflated stream can be addressed like a plain file without inflating it -- position x lies in the member whose
+// inflated span holds it.  That gives the ranks of a sharded run what pc_fastq_find_record / pc_readset_load_segment give
+// them on a plain file: rank r of W takes the records that start in [find(total * r / W), find(total * (r + 1) / W)) of
+// the inflated bytes and inflates only the members that hold them.
+namespace {
+struct SizedIndex {
+    struct M { size_t in, in_n, out, out_n; uint32_t crc; };
+    const unsigned char *base = nullptr;
+    size_t size = 0, total = 0;
+    std::vector<M> mem;
+    ~SizedIndex() { if (base) munmap((void *)base, size); }
+    // false: not a file made of sized members from its first byte to its last
+    bool open_file(const char *path)
+    {
+        const int fd = open(path, O_RDONLY);
+        if (fd < 0) return false;
+        struct stat st;
+        if (fstat(fd, &st) != 0 || st.st_size < (off_t)(pcz::kHeader + pcz::kTrailer)) { close(fd); return false; }
+        size = (size_t)st.st_size;
+        void *m = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
+        close(fd);
+        if (m == MAP_FAILED) { size = 0; return false; }
+        base = (const unsigned char *)m;
+        size_t at = 0;
+        while (at < size) {
+            size_t payload = 0;
+            const size_t n = pcz::sized_member(base + at, size - at, &payload);
+            if (!n) return false;
+            const size_t isize = pcz::get32(base + at + n - 4);
+            mem.push_back({at + payload, n - payload - pcz::kTrailer, total, isize, pcz::get32(base + at + n - 8)});
+            total += isize;
+            at += n;
+        }
+        return true;
+    }
+    // the member that holds inflated position x (x < total); empty members are skipped over
+    size_t member_of(size_t x) const
+    {
+        size_t lo = 0, hi = mem.size();
+        while (hi - lo > 1) { const size_t mid = (lo + hi) / 2; if (mem[mid].out <= x) lo = mid; else hi = mid; }
+        return lo;
+    }
+    // inflates the members that hold [a, b) (a < b <= total) -> buf holds the inflated bytes from *buf_at on
+    bool inflate(size_t a, size_t b, RawBuf &buf, size_t *buf_at) const
+    {
+        const size_t m0 = member_of(a), m1 = member_of(b - 1) + 1;
+        const size_t o0 = mem[m0].out, o1 = mem[m1 - 1].out + mem[m1 - 1].out_n;
+        buf.resize(o1 - o0);
+        *buf_at = o0;
+        const int T = (int)std::max<size_t>(1, std::min<size_t>((size_t)usable_threads(), (m1 - m0) / 64 + 1));
+        std::atomic<size_t> next{m0};
+        std::atomic<bool> good{true};
+        auto work = [&]() {
+            pcz::Inflater inf;
+            for (;;) {
+                const size_t i0 = next.fetch_add(64);
+                if (i0 >= m1 || !good.load()) return;
+                for (size_t i = i0; i < std::min(m1, i0 + 64); ++i)
+                    if (!inf.raw(base + mem[i].in, mem[i].in_n, buf.data() + (mem[i].out - o0), mem[i].out_n, mem[i].crc)) { good.store(false); return; }
+            }
+        };
+        std::vector<std::thread> th;
+        for (int t = 1; t < T; ++t) th.emplace_back(work);
+        work();
+        for (auto &x : th) x.join();
+        return good.load();
+    }
+};
+}  // namespace
+
+// The inflated size of a gzip file made of sized members only; PC_ERR_UNSUPPORTED_SCORES for any other file.
+int pc_gz_sized_size(const char *path, int64_t *inflated_bytes)
+{
+    if (!path || !inflated_bytes) return PC_ERR_BAD_ARG;
+    SizedIndex ix;
+    if (!ix.open_file(path)) return PC_ERR_UNSUPPORTED_SCORES;
+    *inflated_bytes = (int64_t)ix.total;
+    return PC_OK;
+}
+
+// pc_fastq_find_record on the inflated bytes of such a file: the first record start at or after `pos`, or the inflated size
+// when none is left.  Only the members around `pos` are inflated (a window that doubles until the record start is found).
+int pc_gz_sized_find_record(const char *path, int64_t pos, int64_t *record_start)
+{
+    if (!path || !record_start || pos < 0) return PC_ERR_BAD_ARG;
+    SizedIndex ix;
+    if (!ix.open_file(path) || ix.total == 0) return PC_ERR_UNSUPPORTED_SCORES;
+    if ((size_t)pos >= ix.total) { *record_start = (int64_t)ix.total; return PC_OK; }
+    if (pos == 0) { *record_start = 0; return PC_OK; }
+    const size_t x = (size_t)pos;
+    for (size_t window = (size_t)1 << 20; ; window *= 4) {
+        const size_t b = std::min(ix.total, x + window);
+        RawBuf buf;
+        size_t buf_at = 0;
+        if (!ix.inflate(x - 1, b, buf, &buf_at)) return PC_ERR_UNSUPPORTED_SCORES;
+        const char *wb = buf.data(), *we = buf.data() + buf.size(), *p = wb + (x - buf_at);
+        const bool to_the_end = buf_at + buf.size() >= ix.total;
+        if (buf_at == 0 && wb[0] != '@') return PC_ERR_UNSUPPORTED_SCORES;
+        // (p > wb unless the window starts at the stream's first byte, where find_record_start's `begin` shortcut is right)
+        const char *e = find_record_start(p, wb, we);
+        if (e) {
+            // final: it was judged by lines inside the window, and so was every line start before it (a candidate is only
+            // passed over for want of bytes when its '+' line lies beyond the window -- then so does every later one's)
+            *record_start = (int64_t)(buf_at + (size_t)(e - wb));
+            return PC_OK;
+        }
+        if (to_the_end) {
+            // no record starts after pos: the stream's last record (fewer than eight lines remain), or irregular
+            const char *q = next_line(p - 1, we);
+            for (int tries = 0; tries < 8 && q < we; ++tries) q = next_line(q, we);
+            if (q >= we) { *record_start = (int64_t)ix.total; return PC_OK; }
+            return PC_ERR_UNSUPPORTED_SCORES;
+        }
+    }
+}
+
+// The records of [begin, end) of the inflated bytes -- both record starts as pc_gz_sized_find_record gives them (or the
+// inflated size) -- as a read set: pc_readset_load_segment for one rank's share of such a file.
+int pc_readset_load_gz_range(const char *path, int64_t begin, int64_t end, pc_readset **out)
+{
+    if (!path || !out || begin < 0 || end < begin) return PC_ERR_BAD_ARG;
+    pc_readset *rs = new pc_readset();
+    *out = rs;
+    rs->fastq = true;
+    SizedIndex ix;
+    if (!ix.open_file(path) || (size_t)end > ix.total) { rs->error = "not streamable"; return PC_ERR_UNSUPPORTED_SCORES; }
+    if (end > begin) {
+        RawBuf buf;
+        size_t buf_at = 0;
+        if (!ix.inflate((size_t)begin, (size_t)end, buf, &buf_at)) { rs->error = "gzip stream error"; return PC_ERR_UNSUPPORTED_SCORES; }
+        const char *b = buf.data() + ((size_t)begin - buf_at), *e = buf.data() + ((size_t)end - buf_at);
+        if (*b != '@' || !parse_fastq_range(rs, b, e, usable_threads())) { rs->error = "not streamable"; return PC_ERR_UNSUPPORTED_SCORES; }
+    }
+    rs->file_index.resize(rs->off.size(), 0);
+    rs->arena.fill(64, 'N');
+    return PC_OK;
+}
+
 // ---- a gzip FASTQ file as a stream of blocks (the streamed route of runner.py for .gz input) -------------------------
 // A producer thread inflates AHEAD of the consumer into a bounded queue of buffers: members that carry their size
 // (pc_gz.h) a batch at a time on several cores, any other gzip stream (one big member: gzip, pigz; concatenated members)

@@ -51,6 +51,20 @@ def fastq_record_start(path, byte_pos):
     return int(out.value) if rc == 0 else None
 
 
+def gz_sized_size(path):
+    """Inflated size of a gzip file made of sized members only (this library's output; bgzip), else None: pc_gz_sized_size."""
+    lib = load_library()
+    out = ctypes.c_int64()
+    return int(out.value) if lib.pc_gz_sized_size(str(path).encode(), ctypes.byref(out)) == 0 else None
+
+
+def gz_sized_record_start(path, pos):
+    """fastq_record_start on the INFLATED bytes of such a file (only the members around pos are inflated), or None."""
+    lib = load_library()
+    out = ctypes.c_int64()
+    return int(out.value) if lib.pc_gz_sized_find_record(str(path).encode(), int(pos), ctypes.byref(out)) == 0 else None
+
+
 GZ_LEVEL = int(os.environ.get("PC_GZ_LEVEL", "0"))      # 0: the library's default (pc_gz.h default_level)
 
 
@@ -167,6 +181,19 @@ class ReadSet:
                 lib.pc_readset_free(h)
             return None, int(byte_begin)
         return cls(path, _handle=h), int(nxt.value)
+
+    @classmethod
+    def gz_range(cls, path, begin, end):
+        """The records of [begin, end) of the inflated bytes of a gzip file of sized members (both from
+        gz_sized_record_start): pc_readset_load_gz_range -> ReadSet, or None."""
+        lib = load_library()
+        h = ctypes.c_void_p()
+        rc = lib.pc_readset_load_gz_range(str(path).encode(), int(begin), int(end), ctypes.byref(h))
+        if rc != 0:
+            if h:
+                lib.pc_readset_free(h)
+            return None
+        return cls(path, _handle=h)
 
     def _bind(self):
         n = self.lib.pc_readset_count(self._h)

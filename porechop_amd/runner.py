@@ -624,7 +624,8 @@ def run_streamed(input_path, output, barcode_dir, opts: Options, device=None, al
 
 def run_sharded(input_path, output, barcode_dir, opts: Options, device=None, aligner=None,
                 adapter_panel: List[AdapterSet] = None) -> Optional[RunResult]:
-    """One plain FASTQ file over the ranks of a torch.distributed job WITHOUT any rank touching the whole file: rank r
+    """One plain FASTQ file -- or one gzip file of sized members, addressed by its inflated bytes -- over the ranks of a
+    torch.distributed job WITHOUT any rank touching the whole file: rank r
     parses the records that start in its W-th of the file's bytes (pc_fastq_find_record / pc_readset_load_segment),
     scans them on its GPU and writes its own span of the shared output files (pc_readset_write_sizes, exchanged, give
     every rank its positions; pc_readset_write_shared).  The collectives: phase A's presence table (MAX), read counts,
@@ -643,7 +644,24 @@ def run_sharded(input_path, output, barcode_dir, opts: Options, device=None, ali
     seen = all_gather_objects((os.path.abspath(input_path), target_dir_or_file, os.path.getsize(input_path) if ok else -1))
     ok = ok and all(x == seen[0] for x in seen)
     rs, b0, b1 = None, 0, 0
-    if ok:
+    if ok and _is_gzip(input_path):
+        # a gzip file of SIZED members (this package's own output; bgzip): positions are those of the inflated bytes, a rank
+        # inflates only the members that hold its records (pc_gz_sized_find_record / pc_readset_load_gz_range); any other
+        # gzip file cannot be cut without inflating all of it: not this route
+        from .io import gz_sized_record_start, gz_sized_size
+        size = gz_sized_size(input_path)
+        if not size:
+            ok = False
+        else:
+            b0 = 0 if rank == 0 else gz_sized_record_start(input_path, size * rank // world)
+            b1 = size if rank == world - 1 else gz_sized_record_start(input_path, size * (rank + 1) // world)
+            if b0 is None or b1 is None:
+                ok = False
+            elif b1 > b0:
+                rs = ReadSet.gz_range(input_path, b0, b1)
+                if rs is None:
+                    ok = False
+    elif ok:
         size = os.path.getsize(input_path)
         b0 = 0 if rank == 0 else fastq_record_start(input_path, size * rank // world)
         b1 = size if rank == world - 1 else fastq_record_start(input_path, size * (rank + 1) // world)

@@ -227,6 +227,31 @@ int main(int argc, char **argv)
         }
     }
 
+    {
+        // the sized layout addressed by positions in its inflated bytes (sharded runs): same cuts, same reads as the plain file
+        int64_t total = -1;
+        CHECK(pc_gz_sized_size(sized.c_str(), &total) == PC_OK && total == (int64_t)fastq.size(), "sized size %lld", (long long)total);
+        CHECK(pc_gz_sized_size(single.c_str(), &total) != PC_OK && pc_gz_sized_size(plain.c_str(), &total) != PC_OK, "sized size of other layouts");
+        for (int world : {1, 2, 5, 33}) {
+            std::vector<int64_t> cuts{0};
+            for (int r = 1; r < world; ++r) {
+                int64_t a = -1, b = -2;
+                const int64_t pos = (int64_t)fastq.size() * r / world;
+                CHECK(pc_gz_sized_find_record(sized.c_str(), pos, &a) == PC_OK && pc_fastq_find_record(plain.c_str(), pos, &b) == PC_OK && a == b,
+                      "sized find_record %lld: %lld vs %lld", (long long)pos, (long long)a, (long long)b);
+                cuts.push_back(a);
+            }
+            cuts.push_back((int64_t)fastq.size());
+            Reads all;
+            for (int r = 0; r < world; ++r) {
+                pc_readset *rs = nullptr;
+                CHECK(pc_readset_load_gz_range(sized.c_str(), cuts[(size_t)r], cuts[(size_t)r + 1], &rs) == PC_OK, "gz range %d of %d", r, world);
+                if (rs) { append(all, reads_of(rs)); pc_readset_free(rs); }
+            }
+            CHECK(all == want, "gz ranges of %d ranks (%zu reads)", world, all.name.size());
+        }
+    }
+
     // ---- 2. the writer, plain and compressed, and back ---------------------------------------------------------------
     {
         pc_readset *rs = nullptr;
@@ -281,6 +306,16 @@ int main(int argc, char **argv)
             // ONE member has one CRC-32 over everything: whatever is read from a damaged copy without complaint is the original
             // (a flipped bit in the header's time stamp, say) -- anything else got past the checks
             if (l == 1 && whole_ok) CHECK(a == want, "damaged single-member file accepted with other reads (round %d)", r);
+            if (l == 0) {                          // (damaged sized members through the sharded run's readers)
+                int64_t total = 0, rec = 0;
+                if (pc_gz_sized_size(bad.c_str(), &total) == PC_OK && total > 0) {
+                    (void)pc_gz_sized_find_record(bad.c_str(), (int64_t)(rng() % (uint64_t)total), &rec);
+                    const int64_t a = (int64_t)(rng() % (uint64_t)total), b = a + (int64_t)(rng() % (uint64_t)(total - a + 1));
+                    pc_readset *rs = nullptr;
+                    (pc_readset_load_gz_range(bad.c_str(), a, b, &rs) == PC_OK ? accepted : refused) += 1;
+                    if (rs) pc_readset_free(rs);
+                }
+            }
             if (l < 3) {
                 const bool stream_ok = load_stream(bad, (int64_t)1 << (12 + rng() % 12), (int64_t)(rng() % 200), &a) == PC_OK;
                 (stream_ok ? accepted : refused) += 1;

@@ -99,3 +99,95 @@ def test_sharded_runs_write_the_reference_files(tmp_path, world):
         assert sum(mine) == total and max(mine) < total, (name, mine, total)          # no rank held every read
         assert all(got[r][1][name][2] == got[0][1][name][2] for r in range(world))   # every rank reports the same file statistics
     assert all(all(got[r][2]) and len(got[r][2]) == len(CASES[world]) for r in range(world))  # every run took the sharded route
+
+
+GZ_CASES = ["native_default", "native_bins", "edge_default", "native_gz_out"]
+
+
+def _gz_worker(rank, world, port, workdir, q):
+    """The same runs over a gzip input of SIZED members (this package's own output layout; bgzip): the ranks cut the
+    INFLATED bytes and each inflates only its members (runner.run_sharded -> pc_gz_sized_find_record / pc_readset_load_gz_range)."""
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle.oracle import Oracle
+    from porechop_amd import runner
+    from tests import readgen
+    from tests.cpu_aligner import OracleAligner
+    from tests.runner_cases import load_cases, options_from_argv
+    oracle = Oracle()
+    cases = load_cases()
+    seen_sharded, out, shares = [], {}, {}
+    orig = runner.run_sharded
+
+    def spy(*a, **kw):
+        r = orig(*a, **kw)
+        seen_sharded.append(r is not None)
+        return r
+    runner.run_sharded = spy
+    for name in GZ_CASES:
+        case = cases[name]
+        opts = options_from_argv(case["argv"])
+        inp = os.path.join(workdir, "gz_inputs", case["dataset"] + ".fastq.gz")
+        work = os.path.join(workdir, "gzrun_" + name)
+        if rank == 0:
+            os.makedirs(work)
+        dist.barrier()
+        target = os.path.join(work, "bins" if case["mode"] == "b" else case["mode"][2:])
+        kw = {"options": opts, "aligner": OracleAligner(oracle, opts.scoring_scheme)}
+        res = runner.run(inp, barcode_dir=target, **kw) if case["mode"] == "b" else runner.run(inp, output=target, **kw)
+        dist.barrier()
+        out[name] = readgen.output_md5s(target) if (rank == 0 and os.path.exists(target)) else {}
+        shares[name] = (len(res.start_trim), res.n_reads)
+    q.put((rank, out, shares, seen_sharded))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_runs_over_a_gzip_input_of_sized_members(tmp_path, world):
+    from oracle.oracle import Oracle
+    from porechop_amd import io as pio, runner
+    from tests import readgen
+    from tests.cpu_aligner import OracleAligner
+    from tests.runner_cases import load_cases, options_from_argv
+    cases = load_cases()
+    oracle = Oracle()
+    os.makedirs(tmp_path / "gz_inputs")
+    want = {}
+    for name in GZ_CASES:                      # the single-process run over the same .gz file is the expectation
+        case = cases[name]
+        plain = readgen.build_dataset(case["dataset"], str(tmp_path / "datasets"))
+        if os.path.isdir(plain) or not open(plain, "rb").read(1) == b"@":
+            pytest.skip("dataset %s is not one FASTQ file" % case["dataset"])
+        inp = str(tmp_path / "gz_inputs" / (case["dataset"] + ".fastq.gz"))
+        if not os.path.exists(inp):
+            pio.gzip_file(plain, inp)
+        opts = options_from_argv(case["argv"])
+        target = str(tmp_path / ("single_" + name) / ("bins" if case["mode"] == "b" else case["mode"][2:]))
+        os.makedirs(os.path.dirname(target))
+        kw = {"options": opts, "aligner": OracleAligner(oracle, opts.scoring_scheme)}
+        runner.run(inp, barcode_dir=target, **kw) if case["mode"] == "b" else runner.run(inp, output=target, **kw)
+        want[name] = readgen.output_md5s(target)
+        if case["mode"] != "b":
+            assert want[name] == case["outputs"], name          # ... and, to one file, the reference CLI's on the plain input
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gz_worker, args=(r, world, port, str(tmp_path), q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(world):
+        rank, out, shares, seen = q.get(timeout=900)
+        got[rank] = (out, shares, seen)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for name in GZ_CASES:
+        assert got[0][0][name] == want[name] and want[name], (name, got[0][0][name], want[name])
+        total = got[0][1][name][1]
+        mine = [got[r][1][name][0] for r in range(world)]
+        assert sum(mine) == total and max(mine) < total, (name, mine, total)          # no rank held every read
+    assert all(all(got[r][2]) and len(got[r][2]) == len(GZ_CASES) for r in range(world))      # every run took the sharded route

@@ -77,3 +77,51 @@ def test_sizes_and_shared_spans_rebuild_the_single_writers_files(tmp_path):
         for a, b in zip(single, shared):
             assert open(a, "rb").read() == open(b, "rb").read()
     rs.close()
+
+
+def test_sized_member_gzip_is_cut_like_the_plain_file(tmp_path):
+    """pc_gz_sized_find_record / pc_readset_load_gz_range: a gzip file of sized members addressed by positions in its
+    INFLATED bytes gives every rank the cut and the reads the plain file gives it -- long lines that span many 64 KB
+    members included -- and any other gzip file says "not such a file" (the caller falls back)."""
+    import gzip
+    from porechop_amd import io as pio
+    rng = random.Random(11)
+    p = str(tmp_path / "reads.fastq")
+    with open(p, "w") as f:
+        for i in range(500):
+            L = rng.choice([1, 30, 200, 1500, 1500, 70000, 200000] if i % 50 == 7 else [1, 30, 200, 1500])
+            seq = "".join(rng.choice("ACGT") for _ in range(L))
+            qual = "".join(rng.choice("@+5I") for _ in range(L))
+            f.write("@read%d some description\n%s\n+\n%s\n" % (i, seq, qual))
+    size = os.path.getsize(p)
+    z = str(tmp_path / "reads.fastq.gz")
+    pio.gzip_file(p, z)
+    assert pio.gz_sized_size(z) == size
+    whole = ReadSet(p)
+    want = [(whole.name(i), whole.seq(i), whole.quals(i)) for i in range(whole.count)]
+    for pos in [0, 1, 2, size - 1, size, size + 9] + [rng.randrange(size) for _ in range(60)]:
+        assert pio.gz_sized_record_start(z, pos) == fastq_record_start(p, pos), pos
+    for world in (1, 2, 3, 7, 64):
+        cuts = [0] + [pio.gz_sized_record_start(z, size * r // world) for r in range(1, world)] + [size]
+        assert cuts == [0] + [fastq_record_start(p, size * r // world) for r in range(1, world)] + [size]
+        got = []
+        for r in range(world):
+            rs = ReadSet.gz_range(z, cuts[r], cuts[r + 1])
+            assert rs is not None
+            got += [(rs.name(i), rs.seq(i), rs.quals(i)) for i in range(rs.count)]
+            rs.close()
+        assert got == want
+    whole.close()
+    # any other layout: not addressable without inflating everything
+    text = open(p, "rb").read()
+    plainz = str(tmp_path / "one.fastq.gz")
+    open(plainz, "wb").write(gzip.compress(text[:200000], 1))
+    assert pio.gz_sized_size(plainz) is None and pio.gz_sized_record_start(plainz, 5) is None and ReadSet.gz_range(plainz, 0, 10) is None
+    assert pio.gz_sized_size(p) is None
+    # a damaged member inside a rank's range is an error for that rank, not a silent loss
+    raw = bytearray(open(z, "rb").read())
+    raw[len(raw) // 2] ^= 0x55
+    bad = str(tmp_path / "bad.fastq.gz")
+    open(bad, "wb").write(bytes(raw))
+    if pio.gz_sized_size(bad) == size:            # (the flip may hit a header: then the file is not "sized" any more)
+        assert ReadSet.gz_range(bad, 0, size) is None

@@ -486,6 +486,97 @@ bool parse_fastq_parallel(pc_readset *rs, const FileData &data, int nthreads)
 extern "C" {
 
 // parse one file into rs (reads appended); rs->fastq is set by the first file
+// FASTA, the reference's way (misc.py:123-148), on one span: lines stripped, blank lines skipped, a stripped line that starts
+// with '>' opens a record, everything else is appended to the running sequence.  A record whose name is empty is not kept --
+// and, as there, its sequence is NOT cleared when the next header comes (`sequence = ''` sits under `if name:`), so it ends
+// up in front of the next named record's.  *carry_out = what a span that ends inside such a nameless record would hand on.
+static void parse_fasta_span(pc_readset *rs, const char *begin, const char *end, std::string *carry_out = nullptr)
+{
+    Lines ln{begin, end};
+    const char *b, *e;
+    std::string name, seq;
+    while (ln.next(b, e)) {
+        strip(b, e);
+        if (b == e) continue;
+        if (*b == '>') {
+            if (!name.empty()) {
+                add_read(rs, name.data(), name.data() + name.size(), seq.data(), seq.data() + seq.size(), nullptr, nullptr);
+                seq.clear();
+            }
+            name.assign(b + 1, e);
+        } else {
+            seq.append(b, e);
+        }
+    }
+    if (!name.empty()) { add_read(rs, name.data(), name.data() + name.size(), seq.data(), seq.data() + seq.size(), nullptr, nullptr); seq.clear(); }
+    if (carry_out) *carry_out = seq;
+}
+
+// The same on all cores: the file is cut where a line BEGINS with '>' (such a line opens a record whatever the stripping does;
+// a header with blanks in front of its '>' simply stays inside a span), every span is parsed by the serial rule into its own
+// read set, and the sets are appended in order.  false (nothing added): a span ends inside a nameless record whose sequence the
+// next span's first record would inherit -- the caller parses the file serially.
+static bool parse_fasta_parallel(pc_readset *rs, const char *begin, const char *end, int nthreads)
+{
+    const size_t size = (size_t)(end - begin);
+    std::vector<const char *> cut{begin};
+    for (int t = 1; t < nthreads; ++t) {
+        const char *p = begin + size / (size_t)nthreads * (size_t)t;
+        if (p <= cut.back()) continue;
+        const char *q = nullptr;
+        for (const char *s = p; s + 1 < end; ) {
+            const char *nl = (const char *)memchr(s, '\n', (size_t)(end - 1 - s));
+            if (!nl) break;
+            if (nl[1] == '>') { q = nl + 1; break; }
+            s = nl + 1;
+        }
+        if (!q) break;
+        if (q > cut.back()) cut.push_back(q);
+    }
+    cut.push_back(end);
+    const size_t nspans = cut.size() - 1;
+    std::vector<std::unique_ptr<pc_readset>> part(nspans);
+    std::vector<std::string> carry(nspans);
+    std::vector<std::thread> th;
+    auto work = [&](size_t k) {
+        part[k].reset(new pc_readset());
+        part[k]->arena.reserve((size_t)(cut[k + 1] - cut[k]) + 64);
+        parse_fasta_span(part[k].get(), cut[k], cut[k + 1], &carry[k]);
+    };
+    for (size_t k = 1; k < nspans; ++k) th.emplace_back(work, k);
+    work(0);
+    for (auto &x : th) x.join();
+    for (size_t k = 0; k + 1 < nspans; ++k) if (!carry[k].empty()) return false;
+    // every span's reads go to their place side by side (the copies are also the first touch of the big arena's pages)
+    std::vector<size_t> r0(nspans + 1, rs->off.size()), a0(nspans + 1, rs->arena.size()), n0(nspans + 1, rs->name_arena.size());
+    for (size_t k = 0; k < nspans; ++k) {
+        r0[k + 1] = r0[k] + part[k]->off.size();
+        a0[k + 1] = a0[k] + part[k]->arena.size();
+        n0[k + 1] = n0[k] + part[k]->name_arena.size();
+    }
+    rs->arena.reserve(a0[nspans] + 128);
+    rs->arena.resize(a0[nspans]);
+    rs->name_arena.resize(n0[nspans]);
+    rs->off.resize(r0[nspans]); rs->len.resize(r0[nspans]); rs->rna.resize(r0[nspans]); rs->name_off.resize(r0[nspans]);
+    auto place = [&](size_t k) {
+        pc_readset &p = *part[k];
+        if (p.arena.size()) memcpy(rs->arena.data() + a0[k], p.arena.data(), p.arena.size());
+        if (p.name_arena.size()) memcpy(rs->name_arena.data() + n0[k], p.name_arena.data(), p.name_arena.size());
+        for (size_t i = 0; i < p.off.size(); ++i) {
+            rs->off[r0[k] + i] = (int64_t)a0[k] + p.off[i];
+            rs->name_off[r0[k] + i] = (int64_t)n0[k] + p.name_off[i];
+            rs->len[r0[k] + i] = p.len[i];
+            rs->rna[r0[k] + i] = p.rna[i];
+        }
+        part[k].reset();
+    };
+    th.clear();
+    for (size_t k = 1; k < nspans; ++k) th.emplace_back(place, k);
+    place(0);
+    for (auto &x : th) x.join();
+    return true;
+}
+
 static int load_into(pc_readset *rs, const char *path, int32_t file_index, bool first, FileData *ready = nullptr,
                      const std::string *ready_error = nullptr)
 {
@@ -517,22 +608,11 @@ static int load_into(pc_readset *rs, const char *path, int32_t file_index, bool 
             strip(sb, se); strip(qb, qe);
             add_read(rs, nb, e, sb, se, qb, qe);
         }
+    } else if (!serial_only && data.size() >= ((size_t)1 << 20) && usable_threads() > 1 &&
+               parse_fasta_parallel(rs, data.data(), data.data() + data.size(), usable_threads())) {
+        // FASTA, parsed in parallel
     } else {
-        std::string name, seq;
-        bool have = false;
-        while (ln.next(b, e)) {
-            strip(b, e);
-            if (b == e) continue;
-            if (*b == '>') {
-                if (have && !name.empty()) add_read(rs, name.data(), name.data() + name.size(), seq.data(), seq.data() + seq.size(), nullptr, nullptr);
-                seq.clear();
-                name.assign(b + 1, e);
-                have = true;
-            } else {
-                seq.append(b, e);
-            }
-        }
-        if (have && !name.empty()) add_read(rs, name.data(), name.data() + name.size(), seq.data(), seq.data() + seq.size(), nullptr, nullptr);
+        parse_fasta_span(rs, data.data(), data.data() + data.size());
     }
     rs->file_index.resize(rs->off.size(), file_index);
     (void)before;

@@ -172,6 +172,47 @@ def test_parallel_fastq_parse_equals_the_semantics(tmp_path):
         ReadSet(str(bad))
 
 
+def test_parallel_fasta_parse_equals_the_semantics(tmp_path):
+    """FASTA files above 1 MB are parsed by several threads, cut where a line begins with '>' (misc.py:115-148 strips every
+    line, skips blank ones, and takes a stripped line starting with '>' as a header): multi-line sequences, blank lines,
+    headers with blanks in front of the '>', records without a name, CRLF -- the result is the line-by-line loader's."""
+    rng = random.Random(9)
+    recs = []
+    for i in range(2500):
+        n = rng.choice([0, 1, 40, 700, 5000])
+        seq = "".join(rng.choice("ACGTacgtNU") for _ in range(n))
+        width = rng.choice([60, 70, 1000000])
+        lines = [seq[k:k + width] for k in range(0, len(seq), width)]
+        if rng.random() < 0.1:
+            lines.insert(rng.randrange(len(lines) + 1), "")                  # a blank line inside a record
+        if rng.random() < 0.1:
+            lines = ["  " + l + " " for l in lines]                           # blanks around sequence lines
+        head = (">" if i % 97 != 3 else " >") + ("" if i % 211 == 5 else "r%d desc %d" % (i, i)) + (" " if i % 5 == 0 else "")
+        recs.append(head + "\n" + "".join(l + "\n" for l in lines))
+    for name, text in (("big.fasta", "".join(recs)), ("crlf.fasta", "".join(recs).replace("\n", "\r\n"))):
+        path = tmp_path / name
+        with open(path, "w", newline="") as f:
+            f.write(text)
+        assert os.path.getsize(path) > (1 << 20)
+        want, is_fastq = python_semantics(str(path))
+        assert not is_fastq and len(want) > 2000
+        for threads in ("1", "3", "16"):
+            os.environ["PC_IO_THREADS"] = threads
+            check(str(path), want, False)
+    # every other record nameless: its bases go in front of the next record's (the reference clears the running sequence only
+    # under `if name:`), and a cut that falls behind one makes the parallel parser hand the file to the serial one
+    path = tmp_path / "nameless.fasta"
+    with open(path, "w") as f:
+        for i in range(30000):
+            f.write((">r%d\n" % i if i % 2 else ">\n") + "".join(rng.choice("ACGTU") for _ in range(40)) + "\n")
+    want, _ = python_semantics(str(path))
+    assert len(want) == 15000 and all(len(w[1]) == 80 for w in want[1:])
+    for threads in ("1", "16"):
+        os.environ["PC_IO_THREADS"] = threads
+        check(str(path), want, False)
+    os.environ.pop("PC_IO_THREADS", None)
+
+
 def test_writer_large_outputs(tmp_path):
     """pc_readset_write formats big files with several threads writing in place: FASTQ and FASTA,
     numbered pieces, RNA, FASTA-sourced '+' qualities -- against plain Python formatting."""

@@ -78,6 +78,31 @@ for k in range(cases):
              "edge": lambda: None}[kind]()
     work = os.path.join(tmp, "case%d" % k)
     os.makedirs(work)
+    if reads is not None and rng.random() < 0.3:
+        # odd reads among the ordinary ones: RNA (more U than T: aligned as T, written back with EVERY T as U,
+        # nanopore_read.py:23-35,97-147), a few U's only, lower case, runs of N / '-', qualities shorter than the sequence,
+        # names with tabs and repeated blanks, an empty read
+        odd = []
+        for name, seq, qual in reads:
+            r = rng.random()
+            if r < 0.08:
+                seq = seq.replace("T", "U")
+            elif r < 0.12:
+                seq = "".join(("U" if c == "T" and rng.random() < 0.3 else c) for c in seq)
+            elif r < 0.18:
+                seq = seq.lower()
+            elif r < 0.22 and len(seq) > 300:
+                p0 = rng.randrange(len(seq) - 100)
+                seq = seq[:p0] + rng.choice("N-n") * rng.randrange(1, 90) + seq[p0 + 60:]
+                qual = (qual * 2)[:len(seq)]
+            elif r < 0.25:
+                qual = qual[:rng.randrange(len(qual) + 1)]
+            elif r < 0.28:
+                name = name + "\tx  y " + name
+            elif r < 0.29:
+                seq, qual = "", ""
+            odd.append((name, seq, qual))
+        reads = odd
     if reads is None:
         inp = readgen.build_dataset("edge", work)
     else:

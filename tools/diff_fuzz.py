@@ -105,6 +105,26 @@ for k in range(cases):
         reads = odd
     if reads is None:
         inp = readgen.build_dataset("edge", work)
+    elif rng.random() < 0.15:
+        # a directory the way Albacore / Guppy lay them out (porechop.py:232-259): fastq files found recursively, in path
+        # order, the check reads spread over the files, the basecaller's barcode taken from a /barcodeNN/ or /unclassified/
+        # path component; some files gzip-ed, a file that is not a fastq in between, an upper-case extension
+        import gzip
+        inp = os.path.join(work, "indir")
+        subs = rng.sample(["", "pass/barcode01", "pass/barcode02", "pass/barcode11", "fail/unclassified", "x/barcode07/y", "misc"], rng.randrange(1, 5))
+        nfiles = rng.randrange(1, 7)
+        cuts = sorted(rng.randrange(len(reads) + 1) for _ in range(nfiles - 1))
+        for j, (a, b) in enumerate(zip([0] + cuts, cuts + [len(reads)])):
+            d = os.path.join(inp, rng.choice(subs))
+            os.makedirs(d, exist_ok=True)
+            text = readgen.fastq_text(reads[a:b]).encode()
+            if not text and rng.random() < 0.7:
+                continue                                               # (an empty .fastq file ends the reference with an error: rarely)
+            ext = rng.choice([".fastq", ".fastq", ".fastq.gz", ".FASTQ"])
+            with open(os.path.join(d, "part%d%s" % (rng.randrange(1000), ext)), "wb") as f:
+                f.write(gzip.compress(text, 1) if ext.endswith(".gz") else text)
+        os.makedirs(os.path.join(inp, "misc"), exist_ok=True)
+        open(os.path.join(inp, "misc", "notes.txt"), "w").write("not reads\n")
     else:
         as_fasta = rng.random() < 0.2
         inp = os.path.join(work, "in.fasta" if as_fasta else "in.fastq")
@@ -151,6 +171,8 @@ for k in range(cases):
         want, wexit = readgen.output_md5s(rtarget) if os.path.exists(rtarget) else {}, None
     except SystemExit as e:
         want, wexit = {}, str(e)
+    except Exception:                                     # the reference dies with a traceback (an empty file in a directory, say)
+        want, wexit = {}, "traceback"
     finally:
         os.chdir(cwd)
     # ---- runner
@@ -163,6 +185,10 @@ for k in range(cases):
         got, gexit = readgen.output_md5s(gtarget) if os.path.exists(gtarget) else {}, None
     except runner.UsageError as e:
         got, gexit = {}, str(e)
+    except ValueError as e:                               # (what the loader raises for files it cannot read)
+        got, gexit = {}, "error: " + str(e)
+    if wexit == "traceback" and gexit is not None:
+        gexit = "traceback"                                # the reference has no message to compare: failing is what counts
     if emit:
         keep = os.path.join(emit, "case%d_%s" % (k, os.path.basename(inp)))
         if os.path.isdir(inp):

@@ -30,6 +30,11 @@ if "--emit" in sys.argv:
     del sys.argv[i:i + 2]
     os.makedirs(emit, exist_ok=True)
 emitted = []
+# --dropin: instead of the runner, the UNCHANGED reference Python is run a second time with porechop_amd.dropin installed over
+# an oracle backend (mode B of INTEGRATION.md): same files, and not one alignment asked for that the batching had not foreseen
+dropin_mode = "--dropin" in sys.argv
+if dropin_mode:
+    sys.argv.remove("--dropin")
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 tmp = tempfile.mkdtemp(prefix="pc_fuzz_")
@@ -175,6 +180,38 @@ for k in range(cases):
         want, wexit = {}, "traceback"
     finally:
         os.chdir(cwd)
+    # ---- the reference again, over the drop-in
+    misses = None
+    if dropin_mode:
+        import importlib
+        import porechop_amd.dropin as dropin
+        from tests.test_dropin_reference import OracleBackend, OracleProductBackend
+        nr = importlib.import_module("porechop.nanopore_read")
+        saved = (pp.find_matching_adapter_sets, pp.find_adapters_at_read_ends, pp.find_adapters_in_read_middles, nr.adapter_alignment)
+        for a in adapters_mod.ADAPTERS:
+            a.best_start_score, a.best_end_score = 0.0, 0.0
+        dropin.install(pp, rng.choice([OracleBackend, OracleProductBackend])(oracle))
+        gwork = os.path.join(work, "got"); os.makedirs(gwork)
+        gtarget = os.path.join(gwork, "bins" if mode == "b" else mode[2:])
+        sys.argv = ["porechop", "-i", inp, "-v", "0", "--threads", "1"] + (["-b", gtarget] if mode == "b" else ["-o", gtarget]) + extra
+        cwd = os.getcwd(); os.chdir(gwork)
+        try:
+            with redirect_stdout(io.StringIO()), redirect_stderr(io.StringIO()):
+                pp.main()
+            got, gexit = readgen.output_md5s(gtarget) if os.path.exists(gtarget) else {}, None
+        except SystemExit as e:
+            got, gexit = {}, str(e)
+        except Exception:
+            got, gexit = {}, "traceback"
+        finally:
+            os.chdir(cwd)
+            pp.find_matching_adapter_sets, pp.find_adapters_at_read_ends, pp.find_adapters_in_read_middles, nr.adapter_alignment = saved
+        misses = dropin.stats().get("misses")
+        ok = (got == want) and (gexit == wexit) and (misses == 0 or gexit is not None)
+        bad += not ok
+        print("%s case %2d %-8s %-12s %-14s misses %s %s%s" % ("ok " if ok else "BAD", k, kind, os.path.basename(inp), mode, misses, " ".join(extra), "" if ok else
+              "\n     want %r %r\n     got  %r %r" % (wexit, want, gexit, got)), flush=True)
+        continue
     # ---- runner
     opts = options_from_argv(extra)
     gtarget = os.path.join(work, "got", "bins" if mode == "b" else mode[2:])

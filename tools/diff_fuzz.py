@@ -221,6 +221,11 @@ for k in range(cases):
     # =True) -> _prefiltered_scan: survivors, set grouping, sparse records, the masked rounds), the stand-in deciding "within
     # max_edits" by the oracle's plain edit-distance DP; the other half behind the score bound
     stand_in.fast_prefilter = rng.random() < 0.5
+    # a third of the runs as a STREAM of small blocks (run_streamed: plain and gzip FASTQ files above two blocks; parse k+1 ||
+    # scan k || write k-1, phase A on the first block, gzip output appended member by member)
+    os.environ.pop("PC_STREAM_BLOCK_BYTES", None)
+    if rng.random() < 0.33:
+        os.environ["PC_STREAM_BLOCK_BYTES"] = str(rng.choice([3000, 20000, 150000]))
     try:
         runner.run(inp, barcode_dir=gtarget if mode == "b" else None, output=None if mode == "b" else gtarget,
                    options=opts, aligner=stand_in)
@@ -240,7 +245,7 @@ for k in range(cases):
         emitted.append({"input": os.path.basename(keep), "mode": mode, "argv": extra, "outputs": want, "exit": wexit})
     ok = (got == want) and (gexit == wexit)
     bad += not ok
-    print("%s case %2d %-8s %-12s %-14s %s %s%s" % ("ok " if ok else "BAD", k, kind, os.path.basename(inp), mode, "prefilter" if stand_in.fast_prefilter else "bound    ", " ".join(extra), "" if ok else "\n     want %r %r\n     got  %r %r" % (wexit, want, gexit, got)), flush=True)
+    print("%s case %2d %-8s %-12s %-14s %s %s%s" % ("ok " if ok else "BAD", k, kind, os.path.basename(inp), mode, ("prefilter" if stand_in.fast_prefilter else "bound    ") + (" blocks=" + os.environ["PC_STREAM_BLOCK_BYTES"] if "PC_STREAM_BLOCK_BYTES" in os.environ else ""), " ".join(extra), "" if ok else "\n     want %r %r\n     got  %r %r" % (wexit, want, gexit, got)), flush=True)
 shutil.rmtree(tmp, ignore_errors=True)
 if emit:
     import json

@@ -25,7 +25,7 @@ def test_ingest_output_and_gzip_under_asan_and_ubsan(tmp_path):
     if not gxx:
         pytest.skip("no g++")
     exe = tmp_path / "fuzz_io"
-    build = subprocess.run([gxx, "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+    build = subprocess.run([gxx, "-std=c++17", "-O1", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
                             "-fno-omit-frame-pointer", os.path.join(REPO, "porechop_amd", "csrc", "pc_io.cpp"),
                             os.path.join(REPO, "tests", "host", "fuzz_io.cpp"), "-o", str(exe), "-lz", "-ldl", "-lpthread"],
                            capture_output=True, text=True, timeout=600)
@@ -37,8 +37,8 @@ def test_ingest_output_and_gzip_under_asan_and_ubsan(tmp_path):
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
     # the third and fourth: every member the workers do not take goes through the watched one-shot libdeflate route
     # (oneshot_member), with room for it and with a room it outgrows after ~5 MB were handed over (seed 1's file is 6.1 MB)
-    for seed, rounds, extra in ((1, 2, {}), (2, 1, {"PC_NO_LIBDEFLATE": "1", "PC_GZ_SPEC_CAP_MB": "1"}),
-                                (1, 2, {"PC_GZ_ONESHOT_MIN_MB": "0", "PC_GZ_VERBOSE": "1"}),
+    for seed, rounds, extra in ((1, 1, {}), (2, 1, {"PC_NO_LIBDEFLATE": "1", "PC_GZ_SPEC_CAP_MB": "1"}),
+                                (1, 1, {"PC_GZ_ONESHOT_MIN_MB": "0", "PC_GZ_VERBOSE": "1"}),
                                 (1, 1, {"PC_GZ_ONESHOT_MIN_MB": "0", "PC_GZ_ONESHOT_ROOM_KB": "5700", "PC_GZ_VERBOSE": "1"})):
         res = subprocess.run([str(exe), str(work), str(seed), str(rounds)], capture_output=True, text=True, timeout=1200,
                              env=dict(env, **extra))

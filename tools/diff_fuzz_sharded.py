@@ -4,7 +4,7 @@ CLI against porechop_amd.runner.run under torch.distributed with 2 ... 5 ranks, 
 FASTQ file or one gzip file of sized members (the sharded route: every rank parses / inflates only its own share and writes its
 own span of the shared output files), and now and then a layout that cannot be cut (one gzip member, FASTA: every rank loads
 it, rank 0 writes).  The multi-GPU path cannot be run on hardware from here; this is its functional evidence.
-    python tools/diff_fuzz_sharded.py [cases] [seed] [world]"""
+    python tools/diff_fuzz_sharded.py [cases] [seed] [world] [--long]      (--long: reads of 100 kb and more among them)"""
 import io
 import os
 import random
@@ -62,6 +62,9 @@ def main():
     import torch.multiprocessing as mp
     from tests import readgen
     from tests.golden.make_golden import stage_reference
+    long_lines = "--long" in sys.argv
+    if long_lines:
+        sys.argv.remove("--long")
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 30
     rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
     world = int(sys.argv[3]) if len(sys.argv) > 3 else 3
@@ -90,6 +93,8 @@ def main():
                  "rapid": lambda: readgen.rapid_reads(seed, nreads), "ligation": lambda: readgen.ligation_reads(seed, nreads)}[kind]()
         if rng.random() < 0.2:                                       # very uneven shares: a few long reads among short ones
             reads = [(n, s_ * (6 if i % 9 == 0 else 1), q * (6 if i % 9 == 0 else 1)) for i, (n, s_, q) in enumerate(reads)]
+        if long_lines and rng.random() < 0.5:                        # lines that span several 64 KB gzip members
+            reads = [(n, s_ * (45 if i % 11 == 3 else 1), q * (45 if i % 11 == 3 else 1)) for i, (n, s_, q) in enumerate(reads)]
         work = os.path.join(tmp, "case%d" % k)
         os.makedirs(work)
         layout = rng.choice(["plain", "plain", "sized", "sized", "one", "fasta"])

@@ -425,7 +425,17 @@ def leg_configs1(dev, args, workers):
     pairs = n * sum((s is not None) + (e is not None) for s, e in ads)
     cells = n * 150 * sum((len(s[1]) if s else 0) + (len(e[1]) if e else 0) for s, e in ads)
     out["phase_b"] = {"reads_per_s": n * args.steps / dtb, "ms_per_step": dtb / args.steps * 1e3, "pairs_per_read": pairs / n}
-    out["roofline"] = trace_roofline(tb, 2 * n, pairs, cells, args.steps, pl.aligner.trace_ops_per_2_cells(), leg="configs1")
+    # the end-scan kernel of north_star = phase B alone: rate and launch time from THIS region; no counter traffic here -- the
+    # profiled leg (profiles/<round>_summary.json) runs whole steps, phases A + B, and its counters belong to that scope:
+    out["roofline"] = trace_roofline(tb, 2 * n, pairs, cells, args.steps, pl.aligner.trace_ops_per_2_cells(), leg=None)
+    nchk = min(p.check_reads, n)
+    pa = [(s.start, s.end) for s in pl.sets if "(full sequence)" not in s.name]
+    pairs_a = nchk * sum((s is not None) + (e is not None) for s, e in pa)
+    cells_a = nchk * 150 * sum((len(s[1]) if s else 0) + (len(e[1]) if e else 0) for s, e in pa)
+    out["step_roofline"] = trace_roofline(timing, 2 * n + 2 * nchk, pairs + pairs_a, cells + cells_a, args.steps,
+                                          pl.aligner.trace_ops_per_2_cells(), leg="configs1")
+    if out["step_roofline"]:
+        out["step_roofline"]["scope"] = "whole step: phases A + B, every traced launch (counter traffic and algorithmic bytes on this one scope)"
     if args.cpu_seconds > 0:
         seqs, ln = host_seqs(reads, min(n, 16384))
         sets = [(s.name, s.start, s.end) for s in pl.sets]
@@ -1534,6 +1544,10 @@ def compact_line(full):
         for t, a in (("traffic", "alg_bytes_per_launch"), ("seed_scan_traffic", "seed_scan_alg_bytes")):
             if d.get(t) and d.get(a):
                 d["traffic_ratio"] = _r(d[t] / d[a], 4)
+        if d.get("valu_frac") is not None:
+            # against the guide's nominal 2-cycle wave64 issue (MI355X_MICROARCH.md: 1.2 G wave-instr/s/SIMD at 2.4 GHz) -- twice the
+            # 4-cycle ceiling valu_frac is priced against (the rate every packed-16 op measures chip-wide, tools/ubench_valu.hip)
+            d["valu_frac_nominal"] = _r(d["valu_frac"] / 2.0)
         legs[name] = d
 
     c1 = also.get("configs1", {})
@@ -1542,7 +1556,10 @@ def compact_line(full):
             phase_b_reads_per_s=_pick(c1, "phase_b", "reads_per_s"), parity_checked=_pick(c1, "parity", "checked"),
             mismatches=_pick(c1, "parity", "mismatches"), roofline_frac=_pick(c1, "roofline", "frac"),
             valu_frac=_pick(c1, "roofline", "valu", "frac"), avg_launch_ms=_pick(c1, "roofline", "avg_launch_ms"),
-            traffic=_pick(c1, "roofline", "traffic"), alg_bytes_per_launch=_pick(c1, "roofline", "algorithmic_bytes_per_launch"),
+            phase_b_gcups=_pick(c1, "roofline", "valu", "achieved_gcups"),
+            step_valu_frac=_pick(c1, "step_roofline", "valu", "frac"), step_gcups=_pick(c1, "step_roofline", "valu", "achieved_gcups"),
+            traffic=_pick(c1, "step_roofline", "traffic"), alg_bytes_per_launch=_pick(c1, "step_roofline", "algorithmic_bytes_per_launch"),
+            traffic_scope="phases A+B (step_roofline), per traced launch" if _pick(c1, "step_roofline", "traffic") else None,
             cpu_reads_per_s=_pick(c1, "cpu_baseline", "value"))
     c2 = also.get("configs2", {})
     if c2:
@@ -1642,7 +1659,7 @@ def compact_line(full):
     short = {"configs1": "c1", "configs2": "c2", "configs4_per_gpu": "c4", "exact_prefilter": "pf", "ragged_lengths": "ragged",
              "from_host_memory": "h2d", "end_to_end": "e2e", "proven_middle_scan": "proven", "ultralong": "ul", "end_to_end_gz": "e2egz", "configs4_fixed_total": "c4total", "sharded_file": "sharded"}
     for name, d in legs.items():
-        for k in ("reads_per_s", "parity_checked", "mismatches", "roofline_frac", "valu_frac", "cpu_reads_per_s",
+        for k in ("reads_per_s", "parity_checked", "mismatches", "roofline_frac", "valu_frac", "valu_frac_nominal", "cpu_reads_per_s",
                   "pruned_reads_per_s", "fast_reads_per_s", "seed_scan_hbm_frac", "same", "pruned_same", "fast_same", "md5_equal",
                   "deflate_gb_per_s"):
             if k in d:
@@ -1658,7 +1675,9 @@ def compact_line(full):
                      "region_ms_min": _r(_pick(full, "repeats", "min")), "region_ms_median": _r(_pick(full, "repeats", "median")),
                      "region_ms_max": _r(_pick(full, "repeats", "max")),
                      "ms_per_step_by_rank": [_r(x) for x in cfg.get("ms_per_step_by_rank") or []],
-                     "check_reads": cfg.get("check_reads"), "check_reads_by_rank": cfg.get("check_reads_by_rank")}
+                     "check_reads": cfg.get("check_reads"), "check_reads_by_rank": cfg.get("check_reads_by_rank"),
+                     "rccl_world_size_seen": cfg.get("rccl_world_size_seen"), "device_by_rank": cfg.get("device_by_rank"),
+                     "gpus_visible": cfg.get("gpus_visible"), "self_launched": cfg.get("self_launched")}
     out["config"].update({"kernel_ms_" + k: _r(v) for k, v in (cfg.get("kernel_ms_per_step") or {}).items() if v})
     out["config"].update(flat)
     if dr:
@@ -1673,7 +1692,10 @@ def compact_line(full):
                            "launches": roof.get("launches"), "avg_launch_ms": _r(roof.get("avg_launch_ms")),
                            "algorithmic_bytes_per_launch": _r(roof.get("algorithmic_bytes_per_launch")),
                            "valu_gcups": _r(_pick(roof, "valu", "achieved_gcups")), "valu_peak_gcups": _r(_pick(roof, "valu", "peak_gcups")),
-                           "valu_frac": _r(_pick(roof, "valu", "frac")), "ops_per_2_cells": _pick(roof, "valu", "ops_per_2_cells")}
+                           "valu_frac": _r(_pick(roof, "valu", "frac")), "ops_per_2_cells": _pick(roof, "valu", "ops_per_2_cells"),
+                           "valu_frac_nominal": _r((_pick(roof, "valu", "frac") or 0.0) / 2.0),
+                           "valu_peak_nominal_gcups": _r((_pick(roof, "valu", "peak_gcups") or 0.0) * 2.0),
+                           "valu_nominal_is": "the guide's 2-cycle wave64 issue: 1.2 G wave-instr/s/SIMD at 2.4 GHz"}
         if roof.get("traffic") and roof.get("algorithmic_bytes_per_launch"):
             out["roofline"]["traffic_ratio"] = _r(roof["traffic"] / roof["algorithmic_bytes_per_launch"], 4)
     if cpu:
@@ -1715,6 +1737,27 @@ def compact_line(full):
     return out
 
 
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def self_launch(n):
+    """Re-execute this very command line as n ranks of one node (torch.distributed.run: one process per GPU over RCCL;
+    PC_DIST_BACKEND=gloo lets more ranks than GPUs share one for functional checks).  -> the launcher's exit code."""
+    import subprocess
+    env = dict(os.environ)
+    env["PC_BENCH_SELF_LAUNCHED"] = "1"
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, host_cores() // n)))
+    port = int(os.environ.get("MASTER_PORT", "0")) or free_port()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -1738,6 +1781,12 @@ def main():
                     "(default: gpurun_out/bench_full.json under the repo)")
     args = ap.parse_args()
 
+    # `python bench.py --gpus N` with N > 1 and no launcher around it starts its own N ranks: the same command re-executed
+    # under torch.distributed.run (one process per GPU, rendezvous on 127.0.0.1); rank 0 prints the one line.  Under
+    # torchrun (WORLD_SIZE set) nothing is re-launched.
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -1752,8 +1801,22 @@ def main():
         else:
             dist.init_process_group(backend)
     if args.gpus != world and rank == 0:
-        print("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run --nproc-per-node %d)"
-              % (args.gpus, world, args.gpus), file=sys.stderr)
+        print("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks: measuring %d" % (args.gpus, world, world), file=sys.stderr)
+    if os.environ.get("PC_BENCH_LAUNCH_PROBE", "0") not in ("", "0"):
+        # launch plumbing only (tests/test_bench_launch_cpu.py, no GPU needed): every rank reports in, rank 0 prints who came
+        seen = [None] * world
+        if world > 1:
+            dist.all_gather_object(seen, (rank, local_rank, os.getpid()))
+        else:
+            seen = [(rank, local_rank, os.getpid())]
+        if rank == 0:
+            print(json.dumps({"probe": True, "n_gpus": world, "world_size": dist.get_world_size() if world > 1 else 1,
+                              "backend": dist.get_backend() if world > 1 else "none", "ranks": [list(x) for x in seen],
+                              "self_launched": os.environ.get("PC_BENCH_SELF_LAUNCHED", "0") == "1", "steps": args.steps}), flush=True)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
 
@@ -1795,6 +1858,11 @@ def main():
     if world > 1:
         dist.all_reduce(shares, op=dist.ReduceOp.SUM)
     check_shares = [int(x) for x in shares.cpu()]
+    devs = torch.zeros(world, dtype=torch.int64, device=dev)
+    devs[rank] = dev_index
+    if world > 1:
+        dist.all_reduce(devs, op=dist.ReduceOp.SUM)
+    device_by_rank = [int(x) for x in devs.cpu()]
     matching = None
     for _ in range(args.warmup):
         matching, st, et, hits = one_step(pl, reads, n_check, world)
@@ -1976,6 +2044,9 @@ def main():
                        "reads_per_gpu": args.reads, "read_len": args.read_len, "parallelism": "reads sharded x%d" % world,
                        "world_size": dist.get_world_size() if world > 1 else 1,
                        "backend": (dist.get_backend() if world > 1 else "none (single process)"),
+                       "rccl_world_size_seen": (dist.get_world_size() if world > 1 and dist.get_backend() == "nccl" else None),
+                       "device_by_rank": device_by_rank, "gpus_visible": torch.cuda.device_count(),
+                       "self_launched": os.environ.get("PC_BENCH_SELF_LAUNCHED", "0") == "1",
                        "ms_per_step_by_rank": [s_ / args.steps * 1e3 for s_ in rank_s],
                        "check_reads": params.check_reads, "check_reads_by_rank": check_shares,
                        "matching_sets": [pl.sets[i].name for i in matching],

@@ -641,7 +641,9 @@ __device__ __forceinline__ int hhi(u32 x) { return (int)(float)HV(x).y; }
 constexpr u32 H_NEGINF2 = 0xFC00FC00u, H_POSINF2 = 0x7C007C00u;
 
 // the trace slab is written once and read back only along the path, long after it has left the caches
-#ifndef PC_SLAB_TEMPORAL
+#if defined(PC_ABL_NOSTORE)          // timing experiment: the trace words are formed and dropped
+#define SLAB_STORE(p, v) asm volatile("" :: "v"(v))
+#elif !defined(PC_SLAB_TEMPORAL)
 #define SLAB_STORE(p, v) __builtin_nontemporal_store((v), (p))
 #else
 #define SLAB_STORE(p, v) (*(p) = (v))
@@ -946,7 +948,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(R <= 30 ? PC
                 for (int r = 0; r < R; ++r) fin[r * 64 + lane] = make_uint2(T[r], U[r]);
             }
             const u32 topn = hk_add(top, EPS2);                   // T~(0, j)
+#ifdef PC_ABL_NOTABLE                 // timing experiment: one table row for every column (its loads hoist out of the loop)
+            const uint4 *srow = (const uint4 *)(s_tab);
+#else
             const uint4 *srow = (const uint4 *)(s_tab + trow_j);
+#endif
             u32 *trace_dst = slab + ((int64_t)((a.debug & 2) ? 0 : (j - 1)) * NW) * 64 + lane;
 
             // ---- the column ------------------------------------------------------------------

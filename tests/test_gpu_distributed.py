@@ -153,12 +153,14 @@ def test_two_ranks_on_one_gpu_emit_the_configs4_leg_for_both_ranks():
     args = ["--gpus", "2", "--steps", "1", "--warmup", "1", "--reads", "60000", "--reads4", "30000", "--cpu-seconds", "0", "--repeats", "1",
             "--reads4-total", "100000", "--reads-e2e", "40000"]
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", PC_DIST_BACKEND="gloo")
-    run = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                          "--master-port", str(_free_port()), "bench.py"] + args, cwd=REPO, env=env, capture_output=True, text=True, timeout=1500)
+    # the PLAIN command: bench.py starts its own two ranks (tests/test_bench_launch_cpu.py covers the launch alone)
+    env.pop("WORLD_SIZE", None), env.pop("RANK", None), env.pop("LOCAL_RANK", None)
+    run = subprocess.run([sys.executable, "bench.py"] + args, cwd=REPO, env=env, capture_output=True, text=True, timeout=1500)
     assert run.returncode == 0, run.stderr[-3000:]
     line = [l for l in run.stdout.strip().splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["config"]["world_size"] == 2 and d["config"]["backend"] == "gloo"
+    assert d["config"]["self_launched"] is True and d["config"]["device_by_rank"] == [0, 0] and d["config"]["rccl_world_size_seen"] is None
     assert len(d["config"]["ms_per_step_by_rank"]) == 2
     assert sum(d["config"]["check_reads_by_rank"]) == d["config"]["check_reads"] == 10000
     c4 = d["legs"]["configs4_per_gpu"]

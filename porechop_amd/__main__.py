@@ -7,15 +7,6 @@ import sys
 from .runner import Options, UsageError, run
 
 
-def _package_version():
-    try:
-        from ._lib import load_library
-        v = load_library().pc_version()
-        return (v.decode() if isinstance(v, bytes) else str(v)).replace("porechop_amd ", "")
-    except Exception:
-        return "0.1"
-
-
 def main(argv=None):
     d = Options()
     p = argparse.ArgumentParser(prog="porechop_amd", description="MI355X adapter trimming with Porechop's semantics")
@@ -43,8 +34,9 @@ def main(argv=None):
     p.add_argument("--extra_middle_trim_good_side", type=int, default=d.extra_middle_trim_good_side)
     p.add_argument("--extra_middle_trim_bad_side", type=int, default=d.extra_middle_trim_bad_side)
     p.add_argument("--min_split_read_size", type=int, default=d.min_split_read_size)
-    # porechop.py:182-183 prints its bare version number; scripts parse it: the Porechop release whose behaviour this is, then ours
-    p.add_argument("--version", action="version", version="0.2.4 (porechop_amd %s: Porechop 0.2.4's behaviour on MI355X)" % _package_version())
+    # porechop.py:182-183 prints its bare version number and wrappers compare the whole line: exactly that, nothing after it
+    # (the build string of this package is pc_version() / `python -c "import porechop_amd; print(porechop_amd.load_library().pc_version())"`)
+    p.add_argument("--version", action="version", version="0.2.4")
     a = p.parse_args(argv)
     try:
         scheme = tuple(int(x) for x in a.scoring_scheme.split(","))

@@ -171,6 +171,15 @@ inline size_t sized_member(const unsigned char *p, size_t avail, size_t *payload
         at += 4 + slen;
     }
     if (total < 12 + xlen + kTrailer || total > avail) return 0;
+    // ISIZE (the member's last four bytes) is what the readers size their buffers from BEFORE anything is inflated: a member
+    // of this layout holds at most 64 KiB of data (BSIZE is 16 bits, and neither bgzip nor this package puts more than 65 280
+    // input bytes into one); a trailer that claims more is damage or forgery -- such a file is not "sized" and takes the
+    // ordinary gzip route, which inflates it member by member and reports what is wrong with it
+    {
+        const unsigned char *t = p + total - 4;
+        const size_t isize = (size_t)t[0] | ((size_t)t[1] << 8) | ((size_t)t[2] << 16) | ((size_t)t[3] << 24);
+        if (isize > 65536) return 0;
+    }
     if (payload_off) *payload_off = 12 + xlen;
     return total;
 }

@@ -952,8 +952,10 @@ struct MemberSpeculator {
     // -> true when the budget, not the window or the end of the file, stopped it
     bool scan_more()
     {
+        // (guesses the consumer has already passed are never claimed: they must not count, or a member whose data is dense
+        // with the magic bytes fills the window with them and the scan never reaches the member the consumer asks for)
         size_t waiting = 0;
-        for (const Cand &c : cands) if (c.state == 0) ++waiting;
+        for (const Cand &c : cands) if (c.state == 0 && c.start >= consumed_pos) ++waiting;
         const size_t budget_end = scan_pos + ((size_t)4 << 20);
         while (waiting < (size_t)window && scan_pos + 18 < size) {
             if (scan_pos >= budget_end) return true;
@@ -1044,22 +1046,37 @@ struct MemberSpeculator {
     {
         std::unique_lock<std::mutex> lk(mu);
         consumed_pos = pos;
-        while (!cands.empty() && cands.front().start < pos && cands.front().state != 1) cands.pop_front();
+        // guesses behind the consumer are dead: unclaimed ones anywhere in the queue are marked so (elements a worker holds a
+        // pointer to stay where they are: only the ends of a deque may go), finished ones leave from the front
+        auto drop_stale = [&] {
+            for (Cand &k : cands) { if (k.start >= pos) break; if (k.state == 0) k.state = 3; }
+            while (!cands.empty() && cands.front().start < pos && cands.front().state != 1) cands.pop_front();
+        };
+        drop_stale();
         cv.notify_all();
         if (!plausible_small_member(pos)) return false;
+        // never wait for ever: when nothing has moved for kPatience the caller inflates this member itself (serial zlib path)
+        const auto t0 = std::chrono::steady_clock::now();
+        const auto kPatience = std::chrono::seconds(20);
         for (;;) {
             while (scan_more() && scan_pos <= pos) {}
             Cand *c = nullptr;
             for (Cand &k : cands) { if (k.start == pos) { c = &k; break; } if (k.start > pos) break; }
             if (!c) {
                 if (scan_pos > pos || scan_pos + 18 >= size) return false;          // scanned past it (or to the end): no member starts here
+                drop_stale();
+                if (std::chrono::steady_clock::now() - t0 > kPatience) return false;
                 cv.wait_for(lk, std::chrono::milliseconds(1));
                 continue;
             }
             if (c->state == 2) { out.swap(c->out); *end = c->end; c->state = 3; return true; }
             if (c->state == 3) return false;
             cv.notify_all();
-            cv.wait(lk);
+            if (cv.wait_for(lk, std::chrono::milliseconds(200)) == std::cv_status::timeout &&
+                std::chrono::steady_clock::now() - t0 > kPatience) {
+                if (c->state == 0) c->state = 3;                                    // (a running worker notices consumed_pos moving on)
+                return false;
+            }
         }
     }
 };
@@ -1123,6 +1140,11 @@ int oneshot_member(const unsigned char *base, size_t size, size_t *data_at, Push
     const pcz::LibDeflate &ld = pcz::libdeflate();
     *handed = 0;
     const size_t at = *data_at;
+#if !defined(__x86_64__) && !defined(__i386__)
+    // the hand-over below reads another thread's output through nothing but the stores' order: sound on x86 (stores are not
+    // reordered with older stores), not on weakly ordered hosts -- those inflate the member the ordinary way
+    return kOneShotNotTried;
+#endif
     if (knobs.off || !ld.ok || !ld.deflate_decompress_ex || at + pcz::kTrailer >= size) return kOneShotNotTried;
     const size_t in_n = size - at - pcz::kTrailer;            // at most this much deflate data (the call stops at the end of the stream)
     if (in_n < knobs.min_bytes) return kOneShotNotTried;
@@ -1131,6 +1153,18 @@ int oneshot_member(const unsigned char *base, size_t size, size_t *data_at, Push
     // and zlib would inflate all of it again -- memory that tight streams through zlib from the start)
     if (room < in_n * std::min<size_t>(8, knobs.ratio)) return kOneShotNotTried;
     if (knobs.room_bytes) room = std::max<size_t>(knobs.room_bytes, 8192) & ~(size_t)4095;
+    // Peak memory of this route: the decoder cannot be paused (ONE libdeflate call), so while the consumer is slower than it
+    // (push() blocks on the 512 MB queue) the inflated member piles up in the mapping -- pages are returned only once handed
+    // over.  The room is therefore the bound: at most half of what the process could still take when the member began
+    // (memory_room: MemAvailable and the cgroup's limit), PC_GZ_ONESHOT_MAX_MB caps it further (several processes on one
+    // box: each sees the same free memory), and a member that outgrows it is restarted through zlib's streaming inflate.
+    {
+        static const size_t cap = [] { const char *e = getenv("PC_GZ_ONESHOT_MAX_MB"); const long v = e ? atol(e) : 0; return v > 0 ? (size_t)v << 20 : (size_t)0; }();
+        if (cap && room > cap) {
+            if (cap < in_n * std::min<size_t>(8, knobs.ratio)) return kOneShotNotTried;
+            room = cap & ~(size_t)4095;
+        }
+    }
     void *mem = mmap(nullptr, room, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
     if (mem == MAP_FAILED) return kOneShotNotTried;
     void *dec = ld.alloc_decompressor();

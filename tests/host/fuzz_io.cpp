@@ -17,6 +17,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <zlib.h>
 
 #include <random>
 #include <string>
@@ -202,6 +203,58 @@ int main(int argc, char **argv)
             if (p == 4) all += std::string(700, '\0');
         }
         spit(cat, all);
+    }
+    // a file DENSE with the bytes a member starts with (1f 8b 08 00) inside its members -- stored members carry them verbatim,
+    // deflated ones now and then: the reader guesses member starts from those bytes, and guesses it has already passed must
+    // neither fill its window nor keep it waiting (the default reader hung on exactly this shape)
+    {
+        std::vector<size_t> dstarts;
+        std::string dq;
+        for (size_t i = 0; i < 9000; ++i) {
+            dstarts.push_back(dq.size());
+            const size_t len = 50 + rng() % 200;
+            dq += "@d" + std::to_string(i) + "\n";
+            for (size_t k = 0; k < len; ++k) dq += "ACGT"[rng() % 4];
+            dq += "\n+\n";
+            std::string q(len, '5');
+            for (size_t k = 0; k + 4 <= len; k += 9) { q[k] = 0x1f; q[k + 1] = (char)0x8b; q[k + 2] = 8; q[k + 3] = 0; }
+            dq += q + "\n";
+        }
+        dstarts.push_back(dq.size());
+        auto stored_member = [](const std::string &d) {
+            std::string m("\x1f\x8b\x08\x00\x00\x00\x00\x00\x00\xff", 10);
+            size_t at = 0;
+            do {
+                const size_t n = std::min<size_t>(65535, d.size() - at);
+                m += (char)(at + n == d.size() ? 1 : 0);
+                m += (char)(n & 0xFF); m += (char)(n >> 8); m += (char)(~n & 0xFF); m += (char)((~n >> 8) & 0xFF);
+                m.append(d, at, n);
+                at += n;
+            } while (at < d.size());
+            const uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), (const Bytef *)d.data(), (uInt)d.size()), isz = (uint32_t)d.size();
+            for (int k = 0; k < 4; ++k) m += (char)((crc >> (8 * k)) & 0xFF);
+            for (int k = 0; k < 4; ++k) m += (char)((isz >> (8 * k)) & 0xFF);
+            return m;
+        };
+        const std::string dplain = dir + "/dense.fastq", dense = dir + "/dense.fastq.gz";
+        spit(dplain, dq);
+        Reads dwant;
+        CHECK(load_whole(dplain, &dwant) == PC_OK && dwant.name.size() == 9000, "dense plain load");
+        std::string all;
+        const size_t parts = 40;
+        for (size_t p = 0; p < parts; ++p) {
+            const size_t a = dstarts[(dstarts.size() - 1) * p / parts], b = dstarts[(dstarts.size() - 1) * (p + 1) / parts];
+            if (p % 2 == 0) { all += stored_member(dq.substr(a, b - a)); continue; }
+            spit(dir + "/part.fastq", dq.substr(a, b - a));
+            CHECK(pc_gzip_file((dir + "/part.fastq").c_str(), (dir + "/part.gz").c_str(), 6, 1) == PC_OK, "gzip dense part");
+            all += slurp(dir + "/part.gz");
+        }
+        spit(dense, all);
+        pc_io_set_thread_limit(8);
+        Reads got, st;
+        CHECK(load_whole(dense, &got) == PC_OK && got == dwant, "whole dense (%zu reads)", got.name.size());
+        CHECK(load_stream(dense, (int64_t)1 << 16, 100, &st) == PC_OK && st == dwant, "stream dense (%zu reads)", st.name.size());
+        pc_io_set_thread_limit(4);
     }
     const std::string layouts[3] = {sized, single, cat};
     for (const std::string &p : layouts) {

@@ -362,3 +362,38 @@ for path in sys.argv[1:]:
         if tag == "outgrown":
             assert "result 2" in res.stderr, res.stderr[-1500:]
     assert outs["zlib"] == outs["oneshot"] == outs["outgrown"]
+
+
+def test_members_dense_with_the_gzip_magic_do_not_hang_the_reader(tmp_path):
+    """40 `cat`-ed members, half of them STORED (their bytes appear verbatim), whose quality lines hold
+    `1f 8b 08 00` every nine bytes.  The reader guesses member starts from those bytes; the guesses it has already passed used
+    to fill its window, the scan never reached the member the consumer asked for, and `ReadSet(path)` hung with every thread
+    asleep.  Must load every read (in a subprocess with a timeout: a regression is a hang, not an exception)."""
+    import gzip
+    import io
+    import random
+    import subprocess
+    import sys
+    rng = random.Random(7)
+    recs = []
+    n = 12000
+    for i in range(n):
+        L = rng.randint(50, 200)
+        q = bytearray(rng.choice(b"!#5:I") for _ in range(L))
+        for k in range(0, L - 4, 9):
+            q[k:k + 4] = b"\x1f\x8b\x08\x00"
+        recs.append(b"@r%d\n" % i + "".join(rng.choice("ACGT") for _ in range(L)).encode() + b"\n+\n" + bytes(q) + b"\n")
+    parts = []
+    for m in range(40):
+        b = io.BytesIO()
+        with gzip.GzipFile(fileobj=b, mode="wb", compresslevel=0 if m % 2 == 0 else 6, mtime=0) as f:
+            f.write(b"".join(recs[m * (n // 40):(m + 1) * (n // 40)]))
+        parts.append(b.getvalue())
+    path = tmp_path / "dense.fastq.gz"
+    path.write_bytes(b"".join(parts))
+    code = ("import sys; sys.path.insert(0, %r); from porechop_amd.io import ReadSet; rs = ReadSet(%r); "
+            "print(rs.count, rs.seq(0)[:5], rs.name(rs.count - 1))" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), str(path)))
+    for env in ({}, {"PC_GZ_NO_SPECULATION": "1"}):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120, env=dict(os.environ, **env))
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert r.stdout.split()[0] == str(n) and r.stdout.split()[2] == "r%d" % (n - 1), r.stdout

@@ -90,7 +90,7 @@ struct pc_ctx {
     std::vector<int> ad_len, ad_window, ad_span;
     bool panel_dirty = true;
     DevBuf d_ad_codes, d_ad_len, d_ad_window, d_ad_span;
-    DevBuf d_slab, d_fin, d_k1, d_woff2, d_wlen2, d_col0, d_ntot, d_frow, d_fscore, d_err;
+    DevBuf d_slab, d_fin, d_k1, d_woff2, d_wlen2, d_col0, d_ntot, d_frow, d_fscore, d_tcols, d_err;
     // the tile table lives in one of two slots: a new table is built (on the context's own stream) in the slot
     // the scans two tables ago used, so building never waits for the scans in flight on the current one
     DevBuf d_tiles_slot[2], d_runs_slot[2];
@@ -736,7 +736,7 @@ void pc_destroy(pc_ctx *c)
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     DevBuf *bufs[] = {&c->d_ad_codes, &c->d_ad_len, &c->d_ad_window, &c->d_ad_span, &c->d_tiles_slot[0], &c->d_tiles_slot[1],
                       &c->d_runs_slot[0], &c->d_runs_slot[1], &c->d_slab, &c->d_fin, &c->d_k1, &c->d_woff2,
-                      &c->d_wlen2, &c->d_col0, &c->d_ntot, &c->d_frow, &c->d_fscore, &c->d_err, &c->d_arena,
+                      &c->d_wlen2, &c->d_col0, &c->d_ntot, &c->d_frow, &c->d_fscore, &c->d_tcols, &c->d_err, &c->d_arena,
                       &c->d_woff, &c->d_wlen, &c->d_out, &c->d_red_slot[0], &c->d_red_slot[1], &c->d_work, &c->d_units, &c->d_pf_tables, &c->d_pf_meta, &c->d_sd_bitmaps, &c->d_sd_first,
                       &c->d_sd_entries, &c->d_sd_meta, &c->d_sd_eq, &c->d_sd_cand, &c->d_sd_count, &c->d_slow_ad, &c->d_slow_state,
                       &c->d_slow_trace};
@@ -891,7 +891,7 @@ int pc_scan_device(pc_ctx *c, const void *d_arena, const int64_t *d_win_off, con
         const size_t n = (size_t)npairs;
         if ((rc = c->d_k1.ensure(k1_ints * 4 + 256)) || (rc = c->d_woff2.ensure(n * 8)) || (rc = c->d_wlen2.ensure(n * 4)) ||
             (rc = c->d_col0.ensure(n * 4)) || (rc = c->d_ntot.ensure(n * 4)) || (rc = c->d_frow.ensure(n * 4)) ||
-            (rc = c->d_fscore.ensure(n * 4)))
+            (rc = c->d_fscore.ensure(n * 4)) || (rc = c->d_tcols.ensure(n * 4)))
             return rc;
     }
 
@@ -1022,6 +1022,11 @@ int pc_scan_device(pc_ctx *c, const void *d_arena, const int64_t *d_win_off, con
             pl.win_off2 = c->d_woff2.as<int64_t>(); pl.win_len2 = c->d_wlen2.as<int32_t>();
             pl.col02 = c->d_col0.as<int32_t>(); pl.ntot2 = c->d_ntot.as<int32_t>();
             pl.force_row2 = c->d_frow.as<int32_t>(); pl.force_score2 = c->d_fscore.as<int32_t>();
+            {   // the pair's own bound on the traced columns (schemes of the packed kernels: match > 0, both gap scores < 0)
+                static const bool off = [] { const char *e = getenv("PC_NO_PAIR_TRACE_BOUND"); return e && *e && *e != '0'; }();
+                pl.match = c->match; pl.gap_unit = std::min(-c->gap_open, -(linear ? c->gap_open : c->gap_extend));
+                pl.trace_cols2 = (!off && pl.match > 0 && pl.gap_unit > 0) ? c->d_tcols.as<int32_t>() : nullptr;
+            }
             a.chunks = 1;
             pl.ad_window = c->d_ad_window.as<int32_t>();
             pl.score_out = (mode == PC_MODE_SCORE) ? d_out : nullptr;
@@ -1049,7 +1054,7 @@ int pc_scan_device(pc_ctx *c, const void *d_arena, const int64_t *d_win_off, con
             // pass 2: traced window ending at the max cell
             a.win_off = pl.win_off2; a.win_len = pl.win_len2; a.col0 = pl.col02; a.n_total = pl.ntot2;
             a.win_by_out = 1;
-            a.force_row = pl.force_row2; a.force_score = pl.force_score2;
+            a.force_row = pl.force_row2; a.force_score = pl.force_score2; a.trace_cols = pl.trace_cols2;
             a.out = d_out;
             a.slab = (uint32_t *)((char *)c->d_slab.p + slab_off[gidx]);
             a.slab_cols = g.max_window + 1;

@@ -39,6 +39,8 @@ struct ScanArgs {
     const int32_t *n_total;      // [npairs] whole read length                   (null => win_len)
     const int32_t *force_row;    // [npairs] end cell row (1..m) at the window's last column (null => scout)
     const int32_t *force_score;  // [npairs] score the forced cell must reproduce (null => unchecked)
+    const int32_t *trace_cols;   // [npairs] columns before the end cell the traced path can touch, + 2 (plan_kernel: from the
+                                 // pair's own end row and score; null => the adapter's W + 2)
     const uint32_t *ad_codes;    // [nadapters][128] Dna5 codes 0..4
     const int32_t *ad_len;       // [nadapters]
     const Tile *tiles;
@@ -73,6 +75,8 @@ struct PlanArgs {
     const int64_t *win_off; const int32_t *win_len;     // the whole-read scan descriptors
     const int32_t *k1;                                  // [npairs][4] score, I, J, 0
     int64_t *win_off2; int32_t *win_len2; int32_t *col02; int32_t *ntot2; int32_t *force_row2; int32_t *force_score2;
+    int32_t *trace_cols2;                               // [npairs] out: I + floor((match I - score) / g) + 2 (see plan_kernel), or null
+    int32_t match, gap_unit;                            // the scheme's match score and g = min(|open|, |extend|) for that bound
     const Tile *tiles; int32_t ntiles;                  // same tiles as the score pass
     int32_t chunks;                                     // chunk results per pair in k1 (>= 1)
     int32_t chunk_len;                                  // their length in columns (chunks > 1): only the chunks that start inside a window are merged

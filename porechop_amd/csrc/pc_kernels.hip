@@ -183,7 +183,10 @@ __device__ __forceinline__ void column_step(u32 (&T)[R], u32 (&U)[R], u32 h2,
 // COUNT (the range-checking builds): the matches are also counted from the bases on the walk's diagonal steps and must
 // equal the count pc_walk.h derives from the score -- with match - mismatch = 1 a wrong end-cell score would otherwise turn
 // into a wrong identity without tripping finish()'s divisibility check.
-template <bool COUNT = false>
+// GROUPED (the fp16 kernel's slab): a column's words lie in groups of four, [column][group][lane][word of the group] -- a lane's
+// four words are 16 contiguous bytes, written by ONE buffer_store_dwordx4 (a last group of 1..3 words by a narrower store);
+// the column pitch is NW x 64 dwords either way.
+template <bool COUNT = false, bool GROUPED = false>
 __device__ __forceinline__ void traceback_pairs(const ScanArgs &a, const u32 *slab, const int rows, const int NW, const int lane,
                                                 const Best b_lo, const Best b_hi, const int pad_lo, const int pad_hi,
                                                 const bool have_lo, const bool have_hi, const int n_lo, const int n_hi,
@@ -201,7 +204,14 @@ __device__ __forceinline__ void traceback_pairs(const ScanArgs &a, const u32 *sl
         const int wq = r >> 2;
         const int rows_in_group = (rows - 4 * wq) < 4 ? (rows - 4 * wq) : 4;
         const int pos = rows_in_group - 1 - (r & 3);
-        const u32 dw = slab[((int64_t)(col - 1) * NW + wq) * 64 + lane];
+        int64_t at;
+        if constexpr (GROUPED) {
+            const int g = wq >> 2, kg = (NW - 4 * g) < 4 ? (NW - 4 * g) : 4;
+            at = (int64_t)(col - 1) * NW * 64 + g * 256 + lane * kg + (wq & 3);
+        } else {
+            at = ((int64_t)(col - 1) * NW + wq) * 64 + lane;
+        }
+        const u32 dw = slab[at];
         return (int)((dw >> (16 * hf + 4 * pos)) & 0xFu);
     };
     pcw::Walk wk_lo, wk_hi;
@@ -648,6 +658,27 @@ constexpr u32 H_NEGINF2 = 0xFC00FC00u, H_POSINF2 = 0x7C007C00u;
 #else
 #define SLAB_STORE(p, v) (*(p) = (v))
 #endif
+// K trace words of one lane (K = 4, or the 1..3 of a column's last group) to the block's slab: one buffer store
+typedef u32 u32x2 __attribute__((ext_vector_type(2)));
+typedef u32 u32x3 __attribute__((ext_vector_type(3)));
+typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+template <int K>
+__device__ __forceinline__ void slab_store_group(const __amdgpu_buffer_rsrc_t rsrc, const u32 (&w)[4], const int lane, const int soff)
+{
+#if defined(PC_ABL_NOSTORE)
+    asm volatile("" :: "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]));
+#else
+#ifdef PC_SLAB_TEMPORAL
+    constexpr int AUX = 0;
+#else
+    constexpr int AUX = 2;          // nt: written once, read back only along the path, long after it has left the caches
+#endif
+    if constexpr (K == 4) { const u32x4 v = {w[0], w[1], w[2], w[3]}; __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, lane * 16, soff, AUX); }
+    else if constexpr (K == 3) { const u32x3 v = {w[0], w[1], w[2]}; __builtin_amdgcn_raw_buffer_store_b96(v, rsrc, lane * 12, soff, AUX); }
+    else if constexpr (K == 2) { const u32x2 v = {w[0], w[1]}; __builtin_amdgcn_raw_buffer_store_b64(v, rsrc, lane * 8, soff, AUX); }
+    else __builtin_amdgcn_raw_buffer_store_b32(w[0], rsrc, lane * 4, soff, AUX);
+#endif
+}
 #define PC_HMAX "v_pk_max_f16 "
 #define PC_HADD "v_pk_add_f16 "
 #define PC_HMAX3 "v_pk_maximum3_f16 "
@@ -741,6 +772,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(R <= 30 ? PC
     const u32 OE2 = __builtin_amdgcn_readfirstlane(hpack2(a.gap_open + eps)), EPS2 = hpack2(eps), NEG2 = H_NEGINF2;
     const u32 TWO2 = 0x40004000u, EIGHT2 = 0x48004800u;
     u32 *slab = a.slab + (int64_t)blockIdx.x * a.slab_stride;
+#ifndef PC_SLAB_OLD
+    const __amdgpu_buffer_rsrc_t slab_rsrc = __builtin_amdgcn_make_buffer_rsrc(slab, 0, (int)(a.slab_stride * 4), 0x00020000);
+#endif
 
     for (int t = blockIdx.x; t < a.ntiles; t += gridDim.x) {
         const Tile tile = a.tiles[t];
@@ -823,11 +857,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(R <= 30 ? PC
         }
         int notrace_upto = 0;
         if (a.force_row && a.ad_window) {
-            const int wl = a.ad_window[tile.adapter_lo] - a.ad_span[tile.adapter_lo] - 1;
-            const int wh = a.ad_window[tile.adapter_hi] - a.ad_span[tile.adapter_hi] - 1;
+            // traced columns before the end cell: the adapter's W + 2, or the pair's own (smaller) bound from plan_kernel
+            int wl = a.ad_window[tile.adapter_lo] - a.ad_span[tile.adapter_lo] - 1 + 2;
+            int wh = a.ad_window[tile.adapter_hi] - a.ad_span[tile.adapter_hi] - 1 + 2;
+            if (a.trace_cols) {
+                if (have_lo) { const int t = a.trace_cols[p_lo]; wl = t < wl ? t : wl; }
+                if (have_hi) { const int t = a.trace_cols[p_hi]; wh = t < wh ? t : wh; }
+            }
             int t0 = 1 << 30;
-            if (have_lo && n_lo > 0) t0 = n_lo - wl - 2;
-            if (have_hi && n_hi > 0 && n_hi - wh - 2 < t0) t0 = n_hi - wh - 2;
+            if (have_lo && n_lo > 0) t0 = n_lo - wl;
+            if (have_hi && n_hi > 0 && n_hi - wh < t0) t0 = n_hi - wh;
 #pragma unroll
             for (int s = 32; s >= 1; s >>= 1) { const int o = __shfl_xor(t0, s); t0 = o < t0 ? o : t0; }
             notrace_upto = __builtin_amdgcn_readfirstlane((t0 > 0 && t0 < nmax) ? t0 : 0);   // (a tile of empty windows has no t0)
@@ -953,7 +992,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(R <= 30 ? PC
 #else
             const uint4 *srow = (const uint4 *)(s_tab + trow_j);
 #endif
+#ifdef PC_SLAB_OLD
             u32 *trace_dst = slab + ((int64_t)((a.debug & 2) ? 0 : (j - 1)) * NW) * 64 + lane;
+#else
+            // this column's trace words leave in groups of four: ONE buffer_store_dwordx4 per 16 rows (address = the block's
+            // buffer resource + a scalar column offset + a per-lane constant: no 64-bit address arithmetic per column, a
+            // quarter of the store instructions and of the address traffic of a dword per 4 rows)
+            const int col_soff = ((a.debug & 2) ? 0 : (j - 1)) * (NW * 256);
+            u32 tw[4] = {0u, 0u, 0u, 0u};
+#endif
 
             // ---- the column ------------------------------------------------------------------
             u32 S[RP];
@@ -1018,7 +1065,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(R <= 30 ? PC
                 if (r >= 1) {
                     const int pr = r - 1;
                     if ((pr & 3) == 1) accA = acc;
-                    if ((pr & 3) == 3) { const u32 wd = __builtin_amdgcn_perm(accA, acc, 0x06020400u); SLAB_STORE(&trace_dst[(pr >> 2) * 64], wd); }
+                    if ((pr & 3) == 3) {
+                        const u32 wd = __builtin_amdgcn_perm(accA, acc, 0x06020400u);
+#ifdef PC_SLAB_OLD
+                        SLAB_STORE(&trace_dst[(pr >> 2) * 64], wd);
+#else
+                        tw[(pr >> 2) & 3] = wd;
+                        if (((pr >> 2) & 3) == 3) slab_store_group<4>(slab_rsrc, tw, lane, col_soff + (pr >> 4) * 1024);
+#endif
+                    }
                 }
                 if (r == R - 1) { d_last = dh[r]; h_last = U[r]; v_last = vs; }
                 if constexpr (CHECK) {
@@ -1036,7 +1091,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(R <= 30 ? PC
                 constexpr int pr = R - 1;
                 const u32 wd = ((pr & 3) == 3) ? __builtin_amdgcn_perm(accA, acc, 0x06020400u)     // rows 4g..4g+3
                                                : __builtin_amdgcn_perm(acc, 0u, 0x0c060c04u);     // a last group of two rows
+#ifdef PC_SLAB_OLD
                 SLAB_STORE(&trace_dst[(pr >> 2) * 64], wd);
+#else
+                tw[(pr >> 2) & 3] = wd;
+                slab_store_group<((NW - 1) & 3) + 1>(slab_rsrc, tw, lane, col_soff + ((NW - 1) >> 2) * 1024);
+#endif
             }
 
             if constexpr (CHECK) {
@@ -1110,7 +1170,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(R <= 30 ? PC
             if (have_hi) a.out[p_hi * TRACE_OUT_INTS + 4] = b_hi.score;
             continue;
         }
-        traceback_pairs<CHECK>(a, slab, R, NW, lane, b_lo, b_hi, pad_lo, pad_hi,
+#ifdef PC_SLAB_OLD
+        constexpr bool kGrouped = false;
+#else
+        constexpr bool kGrouped = true;
+#endif
+        traceback_pairs<CHECK, kGrouped>(a, slab, R, NW, lane, b_lo, b_hi, pad_lo, pad_hi,
                                have_lo, have_hi, n_lo, n_hi, c0_lo, c0_hi, m_lo, m_hi, p_lo, p_hi, notrace_upto,
                                w_lo, w_hi, tile.adapter_lo, tile.adapter_hi);
     }
@@ -1126,48 +1191,64 @@ __global__ void plan_kernel(PlanArgs a)
 {
     const Tile tile = a.tiles[blockIdx.x];
     const int i = threadIdx.x & 63, hi = threadIdx.x >> 6;
-    if (i >= (hi ? tile.count_hi : tile.count_lo)) return;
+    const bool have = i < (hi ? tile.count_hi : tile.count_lo);
     const int64_t p = (hi ? tile.out_hi : tile.out_lo) + i;      // pair (output) slot
     const int64_t w = (hi ? tile.win_hi : tile.win_lo) + i;      // its whole-read window
-    // merge the per-chunk maxima in the reference's visiting order (strict '>', earlier chunk wins)
-    int nch = a.chunks > 1 ? a.chunks : 1;
-    if (nch > 1 && a.chunk_len > 0) {             // the chunks that hold columns of this window (chunk 0 always)
-        const int real = (a.win_len[w] + a.chunk_len - 1) / a.chunk_len;
-        nch = real < 1 ? 1 : (real < nch ? real : nch);
-    }
-    const int nstride = a.chunks > 1 ? a.chunks : 1;
-    int score, I, J;
-    if (a.end_records) {
-        // PC_MODE_TRACE_AT: the caller's score record of this very pair, (-2, J, I, 0, score, ...)
-        const int4 r0 = ((const int4 *)(a.end_records + p * TRACE_OUT_INTS))[0];
-        score = a.end_records[p * TRACE_OUT_INTS + 4]; I = r0.z; J = r0.y;
-        if (r0.x != -2 || J < 0 || J > a.win_len[w] || I < 0) {       // not a score record of this window: loud, never guessed
-            atomicAdd(a.err, 1u);
-            I = 0; J = 0;
+    __shared__ int tile_len;                                     // end-aligned tiles: the columns the tile's windows get
+    if (threadIdx.x == 0) tile_len = 0;
+    __syncthreads();
+    int score = 0, I = 0, J = 0;
+    if (have) {
+        // merge the per-chunk maxima in the reference's visiting order (strict '>', earlier chunk wins)
+        int nch = a.chunks > 1 ? a.chunks : 1;
+        if (nch > 1 && a.chunk_len > 0) {             // the chunks that hold columns of this window (chunk 0 always)
+            const int real = (a.win_len[w] + a.chunk_len - 1) / a.chunk_len;
+            nch = real < 1 ? 1 : (real < nch ? real : nch);
         }
-    } else {
-        score = a.k1[(p * nstride) * 4 + 0]; I = a.k1[(p * nstride) * 4 + 1]; J = a.k1[(p * nstride) * 4 + 2];
-        for (int c = 1; c < nch; ++c) {
-            const int sc = a.k1[(p * nstride + c) * 4 + 0];
-            if (sc > score) { score = sc; I = a.k1[(p * nstride + c) * 4 + 1]; J = a.k1[(p * nstride + c) * 4 + 2]; }
+        const int nstride = a.chunks > 1 ? a.chunks : 1;
+        if (a.end_records) {
+            // PC_MODE_TRACE_AT: the caller's score record of this very pair, (-2, J, I, 0, score, ...)
+            const int4 r0 = ((const int4 *)(a.end_records + p * TRACE_OUT_INTS))[0];
+            score = a.end_records[p * TRACE_OUT_INTS + 4]; I = r0.z; J = r0.y;
+            if (r0.x != -2 || J < 0 || J > a.win_len[w] || I < 0) {       // not a score record of this window: loud, never guessed
+                atomicAdd(a.err, 1u);
+                I = 0; J = 0;
+            }
+        } else {
+            score = a.k1[(p * nstride) * 4 + 0]; I = a.k1[(p * nstride) * 4 + 1]; J = a.k1[(p * nstride) * 4 + 2];
+            for (int c = 1; c < nch; ++c) {
+                const int sc = a.k1[(p * nstride + c) * 4 + 0];
+                if (sc > score) { score = sc; I = a.k1[(p * nstride + c) * 4 + 1]; J = a.k1[(p * nstride + c) * 4 + 2]; }
+            }
         }
     }
     if (a.score_out) {       // score-only request: the end cell and its score are the whole answer
-        int4 *o = (int4 *)(a.score_out + p * TRACE_OUT_INTS);
-        o[0] = make_int4(-2, J, I, 0);
-        o[1] = make_int4(score, 0, 0, 0);
+        if (have) {
+            int4 *o = (int4 *)(a.score_out + p * TRACE_OUT_INTS);
+            o[0] = make_int4(-2, J, I, 0);
+            o[1] = make_int4(score, 0, 0, 0);
+        }
         return;
     }
     int window = a.ad_window[hi ? tile.adapter_hi : tile.adapter_lo];
     if (a.window_cap > 0 && window > a.window_cap) window = a.window_cap;
-    int c0 = J - window;
-    if (a.end_align && J > 0) {             // (J == 0: the end cell is the corner (m, 0) -- nothing to run, nothing to align)
+    if (a.end_align) {
         // (a longer warm-up is still exact; the lead-in columns are garbage the kernel discards when it reaches
         // the read's column 0 -- they only have to be readable: not before the arena's first byte)
         const int wl = a.ad_window[tile.adapter_lo], wh = a.ad_window[tile.adapter_hi];
         window = wl > wh ? wl : wh;
         if (a.window_cap > 0 && window > a.window_cap) window = a.window_cap;
-        c0 = J - window;
+        // The tile's windows all get the length of the longest one any of its pairs needs -- a pair whose end cell lies J
+        // columns into its read needs min(J, window): its read's column 0 is exact by itself -- not the full window: tiles
+        // of pairs that end early (adapters at the start of their windows; callers hand such pairs over together) run that
+        // many columns instead of `window` of which most would be lead-in.
+        if (have && J > 0) atomicMax(&tile_len, J < window ? J : window);
+    }
+    __syncthreads();
+    if (!have) return;
+    int c0 = J - window;
+    if (a.end_align && J > 0) {             // (J == 0: the end cell is the corner (m, 0) -- nothing to run, nothing to align)
+        c0 = J - tile_len;
         const int64_t room = a.win_off[w];
         if (c0 < 0 && (int64_t)(-c0) > room) c0 = -(int)room;
     } else if (c0 < 0) c0 = 0;
@@ -1177,6 +1258,15 @@ __global__ void plan_kernel(PlanArgs a)
     a.ntot2[p] = a.win_len[w];
     a.force_row2[p] = I;
     a.force_score2[p] = score;
+    if (a.trace_cols2) {
+        // Columns the traced path can touch left of J, from THIS pair's end cell: the path is an optimal one of score
+        // `score` >= 0 that ends in adapter row I, so it has at most I diagonal steps earning at most `match` each, and every
+        // gap character costs at least g = min(|open|, |extend|): read-gap columns <= (match I - score) / g, columns touched
+        // <= I + that (pc_bounds.h derives the adapter-wide W the same way from I <= m, score >= 0).  + 2: a column's trace
+        // bits depend on the column before it.  A walk that leaves the traced columns is flagged by the kernel (never expected).
+        const int slack = a.match * I - score;
+        a.trace_cols2[p] = I + (slack > 0 ? slack / a.gap_unit : 0) + 2;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -599,6 +599,13 @@ class Pipeline:
                 # the end cell of every selected pair is known from its score record: only the columns its path can occupy
                 # are traced (PC_MODE_TRACE_AT: the second pass of the whole-read scan, for end windows)
                 traced = al.gather_records(rec, dest) if hasattr(al, "gather_records") else rec.index_select(0, dest)
+                if os.environ.get("PC_NO_J_SORT", "0") in ("", "0"):
+                    # ... and a tile (128 consecutive pairs of a job) runs as many columns as its LATEST end cell needs
+                    # (plan_kernel: min(J, window), the lead-in of the others is waste): pairs of a job are handed over by
+                    # end column, so that adapters found at the start of their windows -- J ~ 30 of 150 -- share tiles
+                    order = torch.argsort(pjob.to(torch.int64) * (1 << 20) + traced[:, 1].to(torch.int64))
+                    woff, wlen, dest, pjob, pread = woff[order], wlen[order], dest[order], pjob[order], pread[order]
+                    traced = traced[order]
                 al.scan_device(self._ends_arena(reads), woff, wlen, job_adapter[live], starts, p.end_size, traced, MODE_TRACE_AT)
             else:
                 traced = torch.empty((total, RESULT_INTS), dtype=torch.int32, device=dev)

@@ -45,124 +45,15 @@ import porechop.adapters as adapters_mod  # noqa: E402
 oracle = Oracle()
 
 
-def random_options(barcodes):
-    o = []
-    def maybe(p, *args):
-        if rng.random() < p:
-            o.extend(args)
-    maybe(0.3, "--end_size", str(rng.choice([30, 80, 120, 150, 200])))
-    maybe(0.3, "--min_trim_size", str(rng.choice([0, 2, 4, 10])))
-    maybe(0.3, "--extra_end_trim", str(rng.choice([0, 1, 2, 7])))
-    maybe(0.3, "--end_threshold", str(rng.choice([60, 75, 90])))
-    maybe(0.3, "--middle_threshold", str(rng.choice([75, 85, 90, 97])))
-    maybe(0.2, "--adapter_threshold", str(rng.choice([80, 90, 97])))
-    maybe(0.2, "--check_reads", str(rng.choice([5, 40, 10000])))
-    maybe(0.2, "--min_split_read_size", str(rng.choice([1, 200, 1000, 3000])))
-    maybe(0.2, "--extra_middle_trim_good_side", str(rng.choice([0, 10, 50])))
-    maybe(0.2, "--extra_middle_trim_bad_side", str(rng.choice([0, 100, 300])))
-    maybe(0.15, "--scoring_scheme", rng.choice(["3,-6,-5,-2", "2,-3,-5,-2", "3,-6,-2,-5", "4,-5,-6,-6"]))
-    maybe(0.15, "--no_split")
-    maybe(0.15, "--discard_middle")
-    maybe(0.25, "--format", rng.choice(["fasta", "fastq", "fastq.gz", "auto"]))
-    if barcodes:
-        maybe(0.3, "--require_two_barcodes")
-        maybe(0.3, "--barcode_threshold", str(rng.choice([60, 75, 85])))
-        maybe(0.3, "--barcode_diff", str(rng.choice([0, 5, 15])))
-        maybe(0.2, "--untrimmed")
-        maybe(0.2, "--discard_unassigned")
-    return o
-
+from tests.fuzzcase import make_case, content_md5  # noqa: E402
+from porechop_amd import io as pio  # noqa: E402
 
 bad = 0
 for k in range(cases):
-    kind = rng.choice(["native", "native", "rapid", "ligation", "edge"])
-    seed = rng.randint(1, 10 ** 6)
-    nreads = rng.choice([25, 60])
-    reads = {"native": lambda: readgen.native_reads(seed, nreads, barcodes=tuple(rng.sample(range(1, 13), 3))),
-             "rapid": lambda: readgen.rapid_reads(seed, nreads), "ligation": lambda: readgen.ligation_reads(seed, nreads),
-             "edge": lambda: None}[kind]()
+    cseed = rng.randint(1, 10 ** 9)
     work = os.path.join(tmp, "case%d" % k)
-    os.makedirs(work)
-    if reads is not None and rng.random() < 0.3:
-        # odd reads among the ordinary ones: RNA (more U than T: aligned as T, written back with EVERY T as U,
-        # nanopore_read.py:23-35,97-147), a few U's only, lower case, runs of N / '-', qualities shorter than the sequence,
-        # names with tabs and repeated blanks, an empty read
-        odd = []
-        for name, seq, qual in reads:
-            r = rng.random()
-            if r < 0.08:
-                seq = seq.replace("T", "U")
-            elif r < 0.12:
-                seq = "".join(("U" if c == "T" and rng.random() < 0.3 else c) for c in seq)
-            elif r < 0.18:
-                seq = seq.lower()
-            elif r < 0.22 and len(seq) > 300:
-                p0 = rng.randrange(len(seq) - 100)
-                seq = seq[:p0] + rng.choice("N-n") * rng.randrange(1, 90) + seq[p0 + 60:]
-                qual = (qual * 2)[:len(seq)]
-            elif r < 0.25:
-                qual = qual[:rng.randrange(len(qual) + 1)]
-            elif r < 0.28:
-                name = name + "\tx  y " + name
-            elif r < 0.29:
-                seq, qual = "", ""
-            odd.append((name, seq, qual))
-        reads = odd
-    if reads is None:
-        inp = readgen.build_dataset("edge", work)
-    elif rng.random() < 0.15:
-        # a directory the way Albacore / Guppy lay them out (porechop.py:232-259): fastq files found recursively, in path
-        # order, the check reads spread over the files, the basecaller's barcode taken from a /barcodeNN/ or /unclassified/
-        # path component; some files gzip-ed, a file that is not a fastq in between, an upper-case extension
-        import gzip
-        inp = os.path.join(work, "indir")
-        subs = rng.sample(["", "pass/barcode01", "pass/barcode02", "pass/barcode11", "fail/unclassified", "x/barcode07/y", "misc"], rng.randrange(1, 5))
-        nfiles = rng.randrange(1, 7)
-        cuts = sorted(rng.randrange(len(reads) + 1) for _ in range(nfiles - 1))
-        for j, (a, b) in enumerate(zip([0] + cuts, cuts + [len(reads)])):
-            d = os.path.join(inp, rng.choice(subs))
-            os.makedirs(d, exist_ok=True)
-            text = readgen.fastq_text(reads[a:b]).encode()
-            if not text and rng.random() < 0.7:
-                continue                                               # (an empty .fastq file ends the reference with an error: rarely)
-            ext = rng.choice([".fastq", ".fastq", ".fastq.gz", ".FASTQ"])
-            with open(os.path.join(d, "part%d%s" % (rng.randrange(1000), ext)), "wb") as f:
-                f.write(gzip.compress(text, 1) if ext.endswith(".gz") else text)
-        os.makedirs(os.path.join(inp, "misc"), exist_ok=True)
-        open(os.path.join(inp, "misc", "notes.txt"), "w").write("not reads\n")
-    else:
-        as_fasta = rng.random() < 0.2
-        inp = os.path.join(work, "in.fasta" if as_fasta else "in.fastq")
-        with open(inp, "w") as f:
-            f.write(readgen.fasta_text(reads) if as_fasta else readgen.fastq_text(reads))
-        # a third of the inputs gzip-ed, in the layouts the readers tell apart (the reference decides by magic bytes,
-        # porechop/misc.py:60-81): one member, several members with zero padding between two of them, sized members
-        layout = rng.choice(["", "", "one", "members", "sized"])
-        if layout:
-            import gzip
-            text = open(inp, "rb").read()
-            os.remove(inp)
-            inp += ".gz"
-            if layout == "one":
-                blob = gzip.compress(text, rng.choice([1, 6, 9]))
-            elif layout == "sized":
-                from porechop_amd import io as pio
-                open(inp[:-3], "wb").write(text)
-                pio.gzip_file(inp[:-3], inp)
-                os.remove(inp[:-3])
-                blob = None
-            else:
-                marks = sorted({0, len(text)} | {m for m in (text.find(b"\n>" if as_fasta else b"\n@", rng.randrange(max(1, len(text)))) + 1 for _ in range(3)) if m > 0})
-                blob = b""
-                for a, b in zip(marks, marks[1:]):
-                    blob += gzip.compress(text[a:b], 1) + (b"\0" * rng.choice([0, 0, 13, 600]))
-            if blob is not None:
-                open(inp, "wb").write(blob)
-    barcodes = kind in ("native", "rapid", "edge") and rng.random() < 0.5
-    extra = random_options(barcodes)
-    if not barcodes and "--untrimmed" in extra:
-        extra.remove("--untrimmed")
-    mode = "b" if barcodes else "o:" + rng.choice(["out.fastq", "out.fasta", "out.fastq.gz", "out.txt"])
+    case = make_case(cseed, work, sized_gzip=pio.gzip_file)
+    inp, mode, extra, kind = case["input"], case["mode"], case["argv"], case["kind"]
     # ---- reference
     for a in adapters_mod.ADAPTERS:
         a.best_start_score, a.best_end_score = 0.0, 0.0
@@ -217,15 +108,10 @@ for k in range(cases):
     gtarget = os.path.join(work, "got", "bins" if mode == "b" else mode[2:])
     os.makedirs(os.path.dirname(gtarget))
     stand_in = OracleAligner(oracle, opts.scoring_scheme)
-    # half of the runs take the middle scan behind the exact PREFILTER, the GPU library's default route (Pipeline.phase_c(prefilter
-    # =True) -> _prefiltered_scan: survivors, set grouping, sparse records, the masked rounds), the stand-in deciding "within
-    # max_edits" by the oracle's plain edit-distance DP; the other half behind the score bound
-    stand_in.fast_prefilter = rng.random() < 0.5
-    # a third of the runs as a STREAM of small blocks (run_streamed: plain and gzip FASTQ files above two blocks; parse k+1 ||
-    # scan k || write k-1, phase A on the first block, gzip output appended member by member)
+    stand_in.fast_prefilter = case["prefilter"]
     os.environ.pop("PC_STREAM_BLOCK_BYTES", None)
-    if rng.random() < 0.33:
-        os.environ["PC_STREAM_BLOCK_BYTES"] = str(rng.choice([3000, 20000, 150000]))
+    if case["blocks"]:
+        os.environ["PC_STREAM_BLOCK_BYTES"] = case["blocks"]
     try:
         runner.run(inp, barcode_dir=gtarget if mode == "b" else None, output=None if mode == "b" else gtarget,
                    options=opts, aligner=stand_in)
@@ -237,12 +123,10 @@ for k in range(cases):
     if wexit == "traceback" and gexit is not None:
         gexit = "traceback"                                # the reference has no message to compare: failing is what counts
     if emit:
-        keep = os.path.join(emit, "case%d_%s" % (k, os.path.basename(inp)))
-        if os.path.isdir(inp):
-            shutil.copytree(inp, keep)
-        else:
-            shutil.copy(inp, keep)
-        emitted.append({"input": os.path.basename(keep), "mode": mode, "argv": extra, "outputs": want, "exit": wexit})
+        # the RECIPE (one seed regenerates input, mode and options: tests/fuzzcase.py) and what the reference made of it
+        emitted.append({"cseed": cseed, "content_md5": content_md5(inp), "input": os.path.relpath(inp, work), "mode": mode, "argv": extra,
+                        "prefilter": case["prefilter"], "blocks": case["blocks"], "kind": kind, "outputs": want, "exit": wexit,
+                        "agreed_here": bool((got == want) and (gexit == wexit))})
     ok = (got == want) and (gexit == wexit)
     bad += not ok
     print("%s case %2d %-8s %-12s %-14s %s %s%s" % ("ok " if ok else "BAD", k, kind, os.path.basename(inp), mode, ("prefilter" if stand_in.fast_prefilter else "bound    ") + (" blocks=" + os.environ["PC_STREAM_BLOCK_BYTES"] if "PC_STREAM_BLOCK_BYTES" in os.environ else ""), " ".join(extra), "" if ok else "\n     want %r %r\n     got  %r %r" % (wexit, want, gexit, got)), flush=True)

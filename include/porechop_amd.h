@@ -307,6 +307,14 @@ int pc_prefilter_device(pc_ctx *ctx, const void *d_arena, const int64_t *d_win_o
 int pc_prefilter_packed(pc_ctx *ctx, const void *d_plane, const int64_t *d_win_off, const int32_t *d_win_len,
                         int64_t nwindows, int max_len, const int32_t *adapters, const int32_t *max_edits,
                         int nadapters, uint32_t *d_mask, void *stream);
+
+/* The seed stage sizes its verification launch from a count it reads back from the device: ONE host round trip per call.
+ * pc_prefilter_defer_count(ctx, 1) removes it -- the verification is launched for the whole candidate list (threads beyond
+ * the count leave at once) and the count follows to pinned host memory; after the caller's next synchronisation of the
+ * stream, pc_prefilter_overflowed(ctx) says whether the last call's list overflowed (1: its mask is NOT complete -- repeat
+ * the call with the deferral off; rare: low-complexity reads against a low-complexity seed). */
+int pc_prefilter_defer_count(pc_ctx *ctx, int enabled);
+int pc_prefilter_overflowed(pc_ctx *ctx);
 int pc_unpack_windows(pc_ctx *ctx, const void *d_plane, const int64_t *d_exc_pos, int64_t nexc, const int64_t *d_src_off,
                       const int32_t *d_len, int64_t n, void *d_dst, const int64_t *d_dst_off, int pad, void *stream);
 

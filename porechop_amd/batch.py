@@ -346,6 +346,14 @@ class Aligner:
               "pc_unpack_windows")
         return dst
 
+    def prefilter_defer_count(self, enabled=True):
+        """No host round trip inside prefilter_mask (pc_prefilter_defer_count): after the caller's next synchronisation,
+        prefilter_overflowed() says whether the last mask is incomplete (then: call again with the deferral off)."""
+        check(self.lib.pc_prefilter_defer_count(self._ctx, 1 if enabled else 0), "pc_prefilter_defer_count")
+
+    def prefilter_overflowed(self):
+        return bool(self.lib.pc_prefilter_overflowed(self._ctx))
+
     def prefilter_rows(self, arena, win_off, win_len, max_len, adapters, max_edits, stream=None, packed=False):
         """The prefilter's survivors, sparsely: -> (rows int64 [R]: the windows with at least one surviving adapter, in
         increasing order; bits bool [R, len(adapters)]: which).  Everything not listed is PROVEN not to be a hit."""

@@ -57,6 +57,9 @@ struct Group {            // tiles that run in one launch
     size_t tile_begin, tile_count;
     int max_window;       // for two-pass groups: slab columns needed by the traced window
     std::vector<pck::TileRun> runs;   // the group's tiles, run by run (tile0 relative to tile_begin)
+    // single-pass groups (end windows): the segments -- runs of output slots with one adapter -- and their pieces, for the
+    // two-pass end scan's ordering by end column (pck::launch_bucket_pairs); offsets into the slot's bucket table
+    size_t seg_begin = 0, nseg = 0, blk_begin = 0, nblk = 0;
 };
 
 inline int64_t run_tiles(const pck::TileRun &r) { return r.dual ? (r.n + 63) / 64 : (r.n + 127) / 128; }
@@ -90,7 +93,7 @@ struct pc_ctx {
     std::vector<int> ad_len, ad_window, ad_span;
     bool panel_dirty = true;
     DevBuf d_ad_codes, d_ad_len, d_ad_window, d_ad_span;
-    DevBuf d_slab, d_fin, d_k1, d_woff2, d_wlen2, d_col0, d_ntot, d_frow, d_fscore, d_tcols, d_err;
+    DevBuf d_slab, d_fin, d_k1, d_woff2, d_wlen2, d_col0, d_ntot, d_frow, d_fscore, d_tcols, d_perm, d_bucket_cnt, d_bucket_slot[2], d_err;
     // the tile table lives in one of two slots: a new table is built (on the context's own stream) in the slot
     // the scans two tables ago used, so building never waits for the scans in flight on the current one
     DevBuf d_tiles_slot[2], d_runs_slot[2];
@@ -130,6 +133,8 @@ struct pc_ctx {
     int sd_nq = 0, sd_q[3] = {6, 6, 6}, sd_first_off[3] = {0, 0, 0}, sd_npieces = 0;
     double sd_rate = 0.0;                    // expected candidates per read column
     unsigned long long *h_sd_count = nullptr;   // pinned host copy of the candidate count
+    bool pf_defer_count = false;                // pc_prefilter_defer_count: no host round trip inside the prefilter
+    int64_t pf_deferred_cap = 0;                // > 0: the last prefilter call left its count check to pc_prefilter_overflowed
     // cached job table (bench loops repeat the same one: skip the re-upload).  The tile table itself only
     // exists on the device: it is expanded there from the groups' runs (one per job and shape).
     std::vector<Group> groups;
@@ -148,6 +153,7 @@ struct pc_ctx {
     std::mutex mu;
     // optional per-launch HIP-event timing (pc_set_timing / pc_get_timing)
     bool timing = false;
+    size_t bucket_blocks_at = 0;         // byte offset of the BucketBlock table in d_bucket_slot (behind the segments' first slots)
     struct Timed { hipEvent_t e0, e1; int kind; int64_t pairs; };
     std::vector<Timed> timed;
 };
@@ -401,6 +407,8 @@ int build_tiles(pc_ctx *c, const int32_t *job_adapter, const int32_t *job_adapte
     c->groups.clear();
     c->slow_jobs.swap(slow);
     std::vector<pck::TileRun> all_runs;
+    std::vector<int64_t> seg_first;
+    std::vector<pck::BucketBlock> bblocks;
     size_t ntiles = 0;
     for (auto &kv : by_group) {
         Group g;
@@ -419,6 +427,19 @@ int build_tiles(pc_ctx *c, const int32_t *job_adapter, const int32_t *job_adapte
         g.tile_count = (size_t)t;
         g.runs.swap(kv.second);
         ntiles += g.tile_count;
+        if ((!g.two_pass || mode == PC_MODE_TRACE_AT) && g.rows > 0) {
+            g.seg_begin = seg_first.size(); g.blk_begin = bblocks.size();
+            for (const pck::TileRun &r : g.runs) {
+                for (int half = 0; half < (r.dual ? 2 : 1); ++half) {
+                    const int64_t first = r.out0 + (half ? r.n : 0);
+                    const int32_t sgm = (int32_t)(seg_first.size() - g.seg_begin);
+                    seg_first.push_back(first);
+                    for (int64_t at = 0; at < r.n; at += pck::kBucketBlock)
+                        bblocks.push_back(pck::BucketBlock{first + at, (int32_t)std::min<int64_t>(pck::kBucketBlock, r.n - at), sgm});
+                }
+            }
+            g.nseg = seg_first.size() - g.seg_begin; g.nblk = bblocks.size() - g.blk_begin;
+        }
         if (g.tile_count) c->groups.push_back(std::move(g));
     }
     if (ntiles > (size_t)INT32_MAX) return PC_ERR_BAD_ARG;
@@ -431,7 +452,14 @@ int build_tiles(pc_ctx *c, const int32_t *job_adapter, const int32_t *job_adapte
     int rc = c->d_tiles_slot[sl].ensure(std::max<size_t>(1, ntiles) * sizeof(pck::Tile));
     if (rc) return rc;
     if ((rc = c->d_runs_slot[sl].ensure(std::max<size_t>(1, all_runs.size()) * sizeof(pck::TileRun)))) return rc;
+    c->bucket_blocks_at = (seg_first.size() * 8 + 15) & ~(size_t)15;
+    if ((rc = c->d_bucket_slot[sl].ensure(c->bucket_blocks_at + std::max<size_t>(1, bblocks.size()) * sizeof(pck::BucketBlock)))) return rc;
     if (ntiles) {
+        if (!seg_first.empty()) {
+            HIP_TRY(hipMemcpyAsync(c->d_bucket_slot[sl].p, seg_first.data(), seg_first.size() * 8, hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(hipMemcpyAsync((char *)c->d_bucket_slot[sl].p + c->bucket_blocks_at, bblocks.data(), bblocks.size() * sizeof(pck::BucketBlock),
+                                   hipMemcpyHostToDevice, c->stream));
+        }
         // a few hundred bytes per job cross PCIe; the tiles (56 B per 64..128 windows) are written by the GPU
         HIP_TRY(hipMemcpyAsync(c->d_runs_slot[sl].p, all_runs.data(), all_runs.size() * sizeof(pck::TileRun), hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));        // all_runs is a local: the copy must have left it
@@ -736,7 +764,7 @@ void pc_destroy(pc_ctx *c)
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     DevBuf *bufs[] = {&c->d_ad_codes, &c->d_ad_len, &c->d_ad_window, &c->d_ad_span, &c->d_tiles_slot[0], &c->d_tiles_slot[1],
                       &c->d_runs_slot[0], &c->d_runs_slot[1], &c->d_slab, &c->d_fin, &c->d_k1, &c->d_woff2,
-                      &c->d_wlen2, &c->d_col0, &c->d_ntot, &c->d_frow, &c->d_fscore, &c->d_tcols, &c->d_err, &c->d_arena,
+                      &c->d_wlen2, &c->d_col0, &c->d_ntot, &c->d_frow, &c->d_fscore, &c->d_tcols, &c->d_perm, &c->d_bucket_cnt, &c->d_bucket_slot[0], &c->d_bucket_slot[1], &c->d_err, &c->d_arena,
                       &c->d_woff, &c->d_wlen, &c->d_out, &c->d_red_slot[0], &c->d_red_slot[1], &c->d_work, &c->d_units, &c->d_pf_tables, &c->d_pf_meta, &c->d_sd_bitmaps, &c->d_sd_first,
                       &c->d_sd_entries, &c->d_sd_meta, &c->d_sd_eq, &c->d_sd_cand, &c->d_sd_count, &c->d_slow_ad, &c->d_slow_state,
                       &c->d_slow_trace};
@@ -887,7 +915,39 @@ int pc_scan_device(pc_ctx *c, const void *d_arena, const int64_t *d_win_off, con
     size_t unit_at = 0;
     size_t score_launch_no = 0;
     (void)max_chunks;
-    if (any_two) {
+    // The two-pass end scan (end windows, packed-fp16 traced kernel): pass 1 = the traced kernel's own score-only variant over
+    // the very same tiles (five instead of 13.25 packed ops per two cells, no trace slab) leaves every pair's end cell; the pairs
+    // of each segment are ordered by end column (coarsely); pass 2 traces, per pair, only the columns its path can occupy
+    // (plan_kernel: a tile runs min(latest end column, window) columns, a pair traces I + (match I - score) / g + 2 of them).
+    // Exact by the bounds of pc_bounds.h / plan_kernel; PC_NO_TWO_PASS_ENDS=1 keeps the single traced pass.
+    // MEASURED (profiles/r06_two_pass_ends.txt): it does not pay as built.  The score-only variant of the traced kernel still
+    // issues 229 instructions per 28-row column against 465 traced -- half a traced pass before anything is traced -- so only
+    // pairs that end early win (start windows: +6 % on 1 M pairs), end windows lose (their path lies at the window's END: the
+    // second pass runs ~110 warm-up columns to trace 40: -12 %), and small launches pay four launches' latency for one.
+    // OFF unless PC_TWO_PASS_ENDS=1.  What it brought stays in use where the end cells are known anyway (PC_MODE_TRACE_AT, the
+    // traced minority of a pruned phase B): pairs ordered by end column, a tile as long as its latest end cell needs,
+    // every pair's own traced-column bound.
+    static const bool use_t2 = [] { const char *e = getenv("PC_TWO_PASS_ENDS"); return e && *e && *e != '0'; }();
+    static const int t2_min_cols = [] { const char *e = getenv("PC_TWO_PASS_MIN_COLS"); return e && atoi(e) > 0 ? atoi(e) : 96; }();
+    auto two_pass_ends = [&](const Group &g) -> bool {
+        pcb::F16Plan fp;
+        return use_t2 && !g.two_pass && g.rows > 0 && g.nseg > 0 && mode == PC_MODE_TRACE && max_len >= t2_min_cols &&
+               !getenv("PC_DEBUG_TRACE") && !getenv("PC_CHECK_RANGE") && trace16_plan(c, g.rows, max_len, &fp);
+    };
+    // PC_MODE_TRACE_AT: the caller's pairs are taken by end column too (PC_NO_END_ORDER=1: as handed over)
+    static const bool no_end_order = [] { const char *e = getenv("PC_NO_END_ORDER"); return e && *e && *e != '0'; }();
+    auto ordered_trace_at = [&](const Group &g) -> bool {
+        pcb::F16Plan fp;
+        return !no_end_order && mode == PC_MODE_TRACE_AT && g.two_pass && g.rows > 0 && g.nseg > 0 && trace16_plan(c, g.rows, g.max_window + 1, &fp);
+    };
+    bool any_t2 = false;
+    size_t t2_segments = 0;
+    for (const Group &g : c->groups)
+        if (two_pass_ends(g) || ordered_trace_at(g)) { any_t2 = true; t2_segments = std::max(t2_segments, g.seg_begin + g.nseg); }
+    if (any_t2) {
+        if ((rc = c->d_perm.ensure((size_t)npairs * 8)) || (rc = c->d_bucket_cnt.ensure(2 * t2_segments * pck::kBuckets * 4 + 256))) return rc;
+    }
+    if (any_two || any_t2) {
         const size_t n = (size_t)npairs;
         if ((rc = c->d_k1.ensure(k1_ints * 4 + 256)) || (rc = c->d_woff2.ensure(n * 8)) || (rc = c->d_wlen2.ensure(n * 4)) ||
             (rc = c->d_col0.ensure(n * 4)) || (rc = c->d_ntot.ensure(n * 4)) || (rc = c->d_frow.ensure(n * 4)) ||
@@ -924,14 +984,54 @@ int pc_scan_device(pc_ctx *c, const void *d_arena, const int64_t *d_win_off, con
             const int grid = grid_for(c, g, g.tile_count, max_len, &stride);
             a.slab_stride = (int64_t)stride;
             const int64_t np = group_pairs(g, 0, g.tile_count);
+            // one traced pass, or the two-pass end scan (see above): score pass -> order by end column -> plan -> traced pass
+            auto run_group = [&](hipStream_t ps) -> int {
+                if (!two_pass_ends(g)) return launch_traced(c, a, g, grid, ps);
+                pcb::F16Plan fp;
+                (void)trace16_plan(c, g.rows, max_len, &fp);
+                pck::ScanArgs a1 = a;
+                a1.slab = nullptr; a1.slab_cols = 0; a1.slab_stride = 0;
+                a1.f16_cen = fp.cen; a1.f16_max_cols = fp.max_cols; a1.debug = 0;
+                if (pck::launch_trace16(a1, g.rows, grid, ps, true)) return 1;
+                pck::BucketArgs b;
+                memset(&b, 0, sizeof b);
+                b.records = d_out;
+                b.seg_first = (const int64_t *)c->d_bucket_slot[c->slot].p + g.seg_begin; b.nsegments = (int32_t)g.nseg;
+                b.blocks = (const pck::BucketBlock *)((const char *)c->d_bucket_slot[c->slot].p + c->bucket_blocks_at) + g.blk_begin;
+                b.nblocks = (int32_t)g.nblk;
+                b.counts = c->d_bucket_cnt.as<uint32_t>() + g.seg_begin * pck::kBuckets;
+                b.cursors = c->d_bucket_cnt.as<uint32_t>() + (t2_segments + g.seg_begin) * pck::kBuckets;
+                b.perm = c->d_perm.as<int64_t>();
+                if (pck::launch_bucket_pairs(b, ps)) return 1;
+                pck::PlanArgs pl;
+                memset(&pl, 0, sizeof(pl));
+                pl.win_off = d_win_off; pl.win_len = d_win_len;
+                pl.win_off2 = c->d_woff2.as<int64_t>(); pl.win_len2 = c->d_wlen2.as<int32_t>();
+                pl.col02 = c->d_col0.as<int32_t>(); pl.ntot2 = c->d_ntot.as<int32_t>();
+                pl.force_row2 = c->d_frow.as<int32_t>(); pl.force_score2 = c->d_fscore.as<int32_t>();
+                pl.trace_cols2 = c->d_tcols.as<int32_t>();
+                pl.match = c->match; pl.gap_unit = std::min(-c->gap_open, -c->gap_extend);
+                pl.ad_window = c->d_ad_window.as<int32_t>();
+                pl.end_align = 1; pl.end_records = d_out; pl.window_cap = std::max(1, max_len);
+                pl.perm = b.perm;
+                pl.tiles = a.tiles; pl.ntiles = (int32_t)g.tile_count; pl.chunks = 1;
+                pl.err = a.err;
+                if (pck::launch_plan(pl, ps)) return 1;
+                pck::ScanArgs a2 = a;
+                a2.win_off = pl.win_off2; a2.win_len = pl.win_len2; a2.col0 = pl.col02; a2.n_total = pl.ntot2;
+                a2.win_by_out = 1;
+                a2.force_row = pl.force_row2; a2.force_score = pl.force_score2; a2.trace_cols = pl.trace_cols2;
+                a2.perm = b.perm;
+                return launch_traced(c, a2, g, grid, ps);
+            };
             if (fork) {
                 hipStream_t ps = (forked & 1) ? c->stream : stream;
                 if (forked == 1) HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_fork, 0));
                 ++forked;
-                if ((rc = launch_traced(c, a, g, grid, ps))) return PC_ERR_NO_DEVICE;
+                if ((rc = run_group(ps))) return PC_ERR_NO_DEVICE;
             } else {
                 ScopedTimer tm(c, stream, 2, np);
-                if ((rc = launch_traced(c, a, g, grid, stream))) return PC_ERR_NO_DEVICE;
+                if ((rc = run_group(stream))) return PC_ERR_NO_DEVICE;
             }
         } else {
             const int64_t np = group_pairs(g, 0, g.tile_count);
@@ -1047,6 +1147,19 @@ int pc_scan_device(pc_ctx *c, const void *d_arena, const int64_t *d_win_off, con
                 if (mode == PC_MODE_TRACE_AT) {         // the caller's score records, read before pass 2 overwrites them
                     pl.k1 = nullptr; pl.end_records = d_out; pl.window_cap = std::max(1, max_len);
                     pl.tiles = a.tiles; pl.ntiles = (int32_t)g.tile_count; pl.chunks = 1;
+                    if (ordered_trace_at(g)) {
+                        pck::BucketArgs b;
+                        memset(&b, 0, sizeof b);
+                        b.records = d_out;
+                        b.seg_first = (const int64_t *)c->d_bucket_slot[c->slot].p + g.seg_begin; b.nsegments = (int32_t)g.nseg;
+                        b.blocks = (const pck::BucketBlock *)((const char *)c->d_bucket_slot[c->slot].p + c->bucket_blocks_at) + g.blk_begin;
+                        b.nblocks = (int32_t)g.nblk;
+                        b.counts = c->d_bucket_cnt.as<uint32_t>() + g.seg_begin * pck::kBuckets;
+                        b.cursors = c->d_bucket_cnt.as<uint32_t>() + (t2_segments + g.seg_begin) * pck::kBuckets;
+                        b.perm = c->d_perm.as<int64_t>();
+                        if (pck::launch_bucket_pairs(b, stream)) return PC_ERR_NO_DEVICE;
+                        pl.perm = b.perm; a.perm = b.perm;
+                    }
                     if ((rc = pck::launch_plan(pl, stream))) return PC_ERR_NO_DEVICE;
                 }
             }
@@ -1667,6 +1780,26 @@ static int prefilter_impl(pc_ctx *c, const void *d_arena, const int64_t *d_win_o
         if (packed ? pck::launch_seed_scan_packed(sa, stream) : pck::launch_seed_scan(sa, stream)) return PC_ERR_NO_DEVICE;
     }
     if (!packed && (rc = exhaustive(c->pf_rest_launches))) return rc;          // independent of the candidate count
+    c->pf_deferred_cap = 0;
+    if (c->pf_defer_count) {
+        // No host round trip: the verify kernels read the count on the device (threads beyond it leave at once) and are
+        // launched for the whole list; the count travels to pinned host memory behind them, and the caller -- who
+        // synchronises anyway to size the DP over the survivors -- asks pc_prefilter_overflowed afterwards (an overflowed
+        // list is the rare case: the caller then repeats the call with the count read here, below).
+        pck::SeedVerifyArgs va;
+        memset(&va, 0, sizeof va);
+        va.arena = a.arena; va.win_off = d_win_off; va.win_len = d_win_len;
+        va.cand = c->d_sd_cand.as<uint32_t>(); va.count = c->d_sd_count.as<unsigned long long>(); va.cap = cap;
+        for (int t = 0; t < 3; ++t) { va.q[t] = c->sd_q[t]; va.first_off[t] = c->sd_first_off[t]; }
+        va.first = c->d_sd_first.as<uint32_t>(); va.entries = c->d_sd_entries.as<int32_t>();
+        va.piece_meta = c->d_sd_meta.as<int32_t>(); va.piece_eq = c->d_sd_eq.as<uint32_t>(); va.npieces = c->sd_npieces;
+        va.mask = d_mask; va.words = words;
+        if (packed ? pck::launch_seed_verify_packed(va, cap, stream) : pck::launch_seed_verify(va, cap, stream)) return PC_ERR_NO_DEVICE;
+        *c->h_sd_count = 0;
+        HIP_TRY(hipMemcpyAsync(c->h_sd_count, c->d_sd_count.p, 8, hipMemcpyDeviceToHost, stream));
+        c->pf_deferred_cap = cap;
+        return PC_OK;
+    }
     HIP_TRY(hipMemcpyAsync(c->h_sd_count, c->d_sd_count.p, 8, hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));                          // the one host round trip of the stage
     const unsigned long long found = *c->h_sd_count;
@@ -1694,6 +1827,19 @@ static int prefilter_impl(pc_ctx *c, const void *d_arena, const int64_t *d_win_o
     if (packed ? pck::launch_seed_verify_packed(va, (int64_t)found, stream) : pck::launch_seed_verify(va, (int64_t)found, stream)) return PC_ERR_NO_DEVICE;
     return PC_OK;
 
+}
+
+int pc_prefilter_defer_count(pc_ctx *c, int enabled)
+{
+    if (!c) return PC_ERR_BAD_ARG;
+    c->pf_defer_count = enabled != 0;
+    return PC_OK;
+}
+
+int pc_prefilter_overflowed(pc_ctx *c)
+{
+    if (!c) return 0;
+    return (c->pf_deferred_cap > 0 && c->h_sd_count && *c->h_sd_count > (unsigned long long)c->pf_deferred_cap) ? 1 : 0;
 }
 
 void pc_jit_async(int enabled) { pcj::set_async(enabled); }

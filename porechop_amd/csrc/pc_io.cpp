@@ -516,7 +516,7 @@ static void parse_fasta_span(pc_readset *rs, const char *begin, const char *end,
 // a header with blanks in front of its '>' simply stays inside a span), every span is parsed by the serial rule into its own
 // read set, and the sets are appended in order.  false (nothing added): a span ends inside a nameless record whose sequence the
 // next span's first record would inherit -- the caller parses the file serially.
-static bool parse_fasta_parallel(pc_readset *rs, const char *begin, const char *end, int nthreads)
+static bool parse_fasta_parallel(pc_readset *rs, const char *begin, const char *end, int nthreads, std::string *last_carry = nullptr)
 {
     const size_t size = (size_t)(end - begin);
     std::vector<const char *> cut{begin};
@@ -547,6 +547,7 @@ static bool parse_fasta_parallel(pc_readset *rs, const char *begin, const char *
     work(0);
     for (auto &x : th) x.join();
     for (size_t k = 0; k + 1 < nspans; ++k) if (!carry[k].empty()) return false;
+    if (last_carry) *last_carry = carry[nspans - 1];
     // every span's reads go to their place side by side (the copies are also the first touch of the big arena's pages)
     std::vector<size_t> r0(nspans + 1, rs->off.size()), a0(nspans + 1, rs->arena.size()), n0(nspans + 1, rs->name_arena.size());
     for (size_t k = 0; k < nspans; ++k) {
@@ -575,6 +576,32 @@ static bool parse_fasta_parallel(pc_readset *rs, const char *begin, const char *
     place(0);
     for (auto &x : th) x.join();
     return true;
+}
+
+// ---- FASTA by segments (streamed / sharded runs; the FASTQ twins are find_record_start / parse_fastq_range) ------------
+// A cut may fall wherever a line BEGINS with '>' (a header the reference only finds after stripping blanks is never
+// used as a cut: it stays inside a segment, where the parser treats it as the reference does).
+static const char *find_fasta_record_start(const char *p, const char *begin, const char *end)
+{
+    if (p <= begin) return begin;
+    for (const char *s = p - 1; s < end; ) {
+        const char *nl = (const char *)memchr(s, '\n', (size_t)(end - s));
+        if (!nl || nl + 1 >= end) return nullptr;
+        if (nl[1] == '>') return nl + 1;
+        s = nl + 1;
+    }
+    return nullptr;
+}
+// The records of [begin, end), which starts with a header line.  false: the segment cannot stand alone -- its last header has an
+// empty name, whose bases the reference hands on to the NEXT record (misc.py:123-148): the whole-file loader's case.
+static bool parse_fasta_range(pc_readset *rs, const char *begin, const char *end, int nthreads, bool to_the_end)
+{
+    std::string carry;
+    if ((size_t)(end - begin) >= ((size_t)1 << 20) && nthreads > 1 && parse_fasta_parallel(rs, begin, end, nthreads, &carry)) {
+    } else {
+        parse_fasta_span(rs, begin, end, &carry);               // (a refused parallel parse has not touched rs)
+    }
+    return to_the_end || carry.empty();
 }
 
 static int load_into(pc_readset *rs, const char *path, int32_t file_index, bool first, FileData *ready = nullptr,
@@ -663,10 +690,11 @@ int pc_readset_load(const char *path, pc_readset **out)
     return pc_readset_load_many(&path, 1, out);
 }
 
-// One segment of a plain, regular 4-line FASTQ file: the records that START in [byte_begin, cut), cut = the first
-// record start at or after byte_begin + target_bytes (or the end of the file).  *next_begin = cut (== the file
-// size after the last segment).  PC_ERR_UNSUPPORTED_SCORES is (re)used as "not streamable" (gzip, FASTA, an
-// irregular record): the caller then loads the whole file with pc_readset_load, which reproduces the reference's
+// One segment of a plain, regular 4-line FASTQ file -- or of a plain FASTA file, cut where a line begins with '>' -- : the
+// records that START in [byte_begin, cut), cut = the first record start at or after byte_begin + target_bytes (or the end
+// of the file).  *next_begin = cut (== the file size after the last segment).  PC_ERR_UNSUPPORTED_SCORES is (re)used as
+// "not streamable" (gzip, an irregular FASTQ record, a FASTA segment that ends in a header without a name -- its bases
+// belong to the next record): the caller then loads the whole file with pc_readset_load, which reproduces the reference's
 // behaviour and messages for those inputs.
 int pc_readset_load_segment(const char *path, int64_t byte_begin, int64_t target_bytes, int64_t *next_begin, pc_readset **out)
 {
@@ -683,9 +711,29 @@ int pc_readset_load_segment(const char *path, int64_t byte_begin, int64_t target
     if (m == MAP_FAILED) { rs->error = "not streamable"; return PC_ERR_UNSUPPORTED_SCORES; }
     const char *base = (const char *)m, *fend = base + size;
     int rc = PC_OK;
-    if (base[0] != '@') rc = PC_ERR_UNSUPPORTED_SCORES;             // FASTA, gzip, ...: not a plain FASTQ
+    const bool fasta = base[0] == '>';
+    if (base[0] != '@' && !fasta) rc = PC_ERR_UNSUPPORTED_SCORES;   // gzip, ...: neither a plain FASTQ nor a plain FASTA
     const char *b = base + byte_begin, *e = fend;
-    if (rc == PC_OK && b < fend) {
+    if (rc == PC_OK && fasta && b < fend) {
+        if (*b != '>') rc = PC_ERR_UNSUPPORTED_SCORES;              // (a segment starts at a cut: a header line)
+        if (rc == PC_OK && (size_t)(fend - b) > (size_t)target_bytes) {
+            e = find_fasta_record_start(b + target_bytes, b, fend);
+            if (!e) e = fend;                                       // no header after the target: the file's last record
+        }
+        if (rc == PC_OK) {
+            rs->fastq = false;
+            // a segment that ends in a header without a name cannot stand alone (its bases go to the NEXT record): it is
+            // extended header by header until it can, or to the end of the file -- never refused in mid-stream
+            while (e > b && !parse_fasta_range(rs, b, e, usable_threads(), e == fend)) {
+                const char *nx = e < fend ? find_fasta_record_start(e + 1, b, fend) : nullptr;
+                e = nx ? nx : fend;
+                delete rs;
+                rs = new pc_readset();
+                *out = rs;
+                rs->fastq = false;
+            }
+        }
+    } else if (rc == PC_OK && b < fend) {
         if ((size_t)(fend - b) > (size_t)target_bytes) {
             e = find_record_start(b + target_bytes, b, fend);
             if (!e) {
@@ -732,6 +780,12 @@ int pc_fastq_find_record(const char *path, int64_t byte_pos, int64_t *record_sta
     if (m == MAP_FAILED) return PC_ERR_UNSUPPORTED_SCORES;
     const char *base = (const char *)m, *fend = base + size;
     int rc = PC_OK;
+    if (base[0] == '>') {                                            // FASTA: the next line that begins with '>' (or the end)
+        const char *e = find_fasta_record_start(base + byte_pos, base, fend);
+        *record_start = (int64_t)((e ? e : fend) - base);
+        munmap(m, size);
+        return PC_OK;
+    }
     if (base[0] != '@') rc = PC_ERR_UNSUPPORTED_SCORES;
     if (rc == PC_OK) {
         const char *e = find_record_start(base + byte_pos, base, fend);

@@ -39,6 +39,8 @@ struct ScanArgs {
     const int32_t *n_total;      // [npairs] whole read length                   (null => win_len)
     const int32_t *force_row;    // [npairs] end cell row (1..m) at the window's last column (null => scout)
     const int32_t *force_score;  // [npairs] score the forced cell must reproduce (null => unchecked)
+    const int64_t *perm;         // [npairs] optional: slot s of a tile holds pair perm[s] (a pair of the same segment: the second
+                                 // pass of the two-pass end scan takes a segment's pairs by end column -- bucket_pairs)
     const int32_t *trace_cols;   // [npairs] columns before the end cell the traced path can touch, + 2 (plan_kernel: from the
                                  // pair's own end row and score; null => the adapter's W + 2)
     const uint32_t *ad_codes;    // [nadapters][128] Dna5 codes 0..4
@@ -75,6 +77,7 @@ struct PlanArgs {
     const int64_t *win_off; const int32_t *win_len;     // the whole-read scan descriptors
     const int32_t *k1;                                  // [npairs][4] score, I, J, 0
     int64_t *win_off2; int32_t *win_len2; int32_t *col02; int32_t *ntot2; int32_t *force_row2; int32_t *force_score2;
+    const int64_t *perm;                                // optional, as ScanArgs::perm (the tiles' slots -> pairs)
     int32_t *trace_cols2;                               // [npairs] out: I + floor((match I - score) / g) + 2 (see plan_kernel), or null
     int32_t match, gap_unit;                            // the scheme's match score and g = min(|open|, |extend|) for that bound
     const Tile *tiles; int32_t ntiles;                  // same tiles as the score pass
@@ -250,7 +253,23 @@ inline int pick_rows(int m_lo, int m_hi, bool *pad)
 int launch_trace(const ScanArgs &a, int rows, bool pad, int grid, void *stream);
 int launch_score(const ScanArgs &a, int rows, bool pad, int grid, void *stream);
 bool trace16_has(int rows);
-int launch_trace16(const ScanArgs &a, int rows, int grid, void *stream);   // packed-fp16 traced scan (needs a.f16_*)
+int launch_trace16(const ScanArgs &a, int rows, int grid, void *stream, bool score_only = false);   // packed-fp16 traced scan (needs a.f16_*);
+                                                                                   // score_only: its first pass (score records, no trace)
+
+// The pairs of every segment (a run of output slots that share one adapter) in the order of their end columns, coarsely:
+// perm[segment's slots] = the segment's pairs, bucket (J / kBucketWidth, capped) by bucket; within a bucket in no particular
+// order.  records: the score records (-2, J, I, 0, score, ...) indexed by pair.  blocks: the segments cut into pieces of at most
+// kBucketBlock slots, {first slot, count, segment}; counts / cursors: [nsegments][kBuckets] scratch.
+constexpr int kBuckets = 12, kBucketWidth = 14, kBucketBlock = 2048;
+struct BucketBlock { int64_t first; int32_t count, segment; };
+struct BucketArgs {
+    const int32_t *records;
+    const BucketBlock *blocks; int32_t nblocks;
+    const int64_t *seg_first; int32_t nsegments;       // [nsegments] first slot of each segment
+    uint32_t *counts, *cursors;                        // [nsegments][kBuckets]; zeroed by the launcher
+    int64_t *perm;
+};
+int launch_bucket_pairs(const BucketArgs &a, void *stream);
 int launch_plan(const PlanArgs &a, void *stream);
 int trace_words_per_col(int rows);   // NW
 

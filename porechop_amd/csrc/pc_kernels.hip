@@ -737,7 +737,11 @@ __device__ __forceinline__ void slab_store_group(const __amdgpu_buffer_rsrc_t rs
 // (max) and err[5] (-min): the host-side range gate (pc_bounds.h f16_plan) asserted on the device; read with
 // pc_debug_value_range.  (-inf only ever enters as the initial H / V of a column and as the scout's mask; it is
 // absorbed by the first max and is not a "value formed".)
-template <int R, bool CHECK = false>
+// SCORE: the same kernel as a score-only FIRST pass of the two-pass end scan (PC_MODE_TRACE over end windows, pc_api.cpp):
+// every column runs the bare five-op recurrence of the warm-up loop below plus the packed scout, nothing is traced or stored,
+// and the pair's end cell leaves as a score record (-2, J, I, 0, score, 0, 0, 0) -- what plan_kernel (end_records) turns into
+// the window of the second, traced pass over the columns the path can occupy.
+template <int R, bool CHECK = false, bool SCORE = false>
 #ifndef PC_T16_WAVES_A
 #define PC_T16_WAVES_A 4
 #endif
@@ -771,9 +775,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(R <= 30 ? PC
     const int eps = -a.gap_extend, CEN = a.f16_cen;
     const u32 OE2 = __builtin_amdgcn_readfirstlane(hpack2(a.gap_open + eps)), EPS2 = hpack2(eps), NEG2 = H_NEGINF2;
     const u32 TWO2 = 0x40004000u, EIGHT2 = 0x48004800u;
-    u32 *slab = a.slab + (int64_t)blockIdx.x * a.slab_stride;
+    u32 *slab = SCORE ? nullptr : a.slab + (int64_t)blockIdx.x * a.slab_stride;
 #ifndef PC_SLAB_OLD
-    const __amdgpu_buffer_rsrc_t slab_rsrc = __builtin_amdgcn_make_buffer_rsrc(slab, 0, (int)(a.slab_stride * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t slab_rsrc = __builtin_amdgcn_make_buffer_rsrc(slab, 0, SCORE ? 0 : (int)(a.slab_stride * 4), 0x00020000);
 #endif
 
     for (int t = blockIdx.x; t < a.ntiles; t += gridDim.x) {
@@ -811,10 +815,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(R <= 30 ? PC
         __syncthreads();
 
         // ---- this lane's two pairs -----------------------------------------------------
-        const int64_t p_lo = tile.out_lo + lane, p_hi = tile.out_hi + lane;
+        // (a.perm: the second pass of the two-pass end scan takes the pairs of a segment in the order of their end columns --
+        // slot s of the tile holds pair perm[s] of the same segment)
+        const bool have_lo = lane < tile.count_lo, have_hi = lane < tile.count_hi;
+        const int64_t p_lo = (a.perm && have_lo) ? a.perm[tile.out_lo + lane] : tile.out_lo + lane;
+        const int64_t p_hi = (a.perm && have_hi) ? a.perm[tile.out_hi + lane] : tile.out_hi + lane;
         const int64_t wi_lo = a.win_by_out ? p_lo : tile.win_lo + lane;
         const int64_t wi_hi = a.win_by_out ? p_hi : tile.win_hi + lane;
-        const bool have_lo = lane < tile.count_lo, have_hi = lane < tile.count_hi;
         const bool one_stream = !a.win_by_out && tile.win_lo == tile.win_hi;
         const uint8_t *w_lo = a.arena + (have_lo ? a.win_off[wi_lo] : 0);
         const uint8_t *w_hi = a.arena + (have_hi ? a.win_off[wi_hi] : 0);
@@ -851,7 +858,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(R <= 30 ? PC
         int nmax = n_lo > n_hi ? n_lo : n_hi;
 #pragma unroll
         for (int s = 32; s >= 1; s >>= 1) { const int o = __shfl_xor(nmax, s); nmax = o > nmax ? o : nmax; }
-        if (nmax > a.slab_cols || nmax > a.f16_max_cols) {        // host sized the slab / chose this kernel from a wrong bound
+        if ((!SCORE && nmax > a.slab_cols) || nmax > a.f16_max_cols) {   // host sized the slab / chose this kernel from a wrong bound
             if (lane == 0) atomicAdd(a.err, 1u);
             nmax = 0;
         }
@@ -992,6 +999,27 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(R <= 30 ? PC
 #else
             const uint4 *srow = (const uint4 *)(s_tab + trow_j);
 #endif
+            u32 d_last = 0, h_last = 0, v_last = 0;
+            if constexpr (SCORE) {
+                // ---- the column, score only: the bare recurrence (as in the warm-up columns above) -------------------
+                u32 dq = top, Tup = topn, Vp = NEG2;
+#pragma clang loop unroll(full)
+                for (int g = 0; g < RP / 4; ++g) {
+                    const uint4 v = srow[g];
+                    const u32 Sg[4] = {v.x, v.y, v.z, v.w};
+#pragma clang loop unroll(full)
+                    for (int k = 0; k < 4; ++k) {
+                        const int r = 4 * g + k;
+                        if (r < R) {
+                            const u32 Hs = hk_maximum(U[r], T[r]);
+                            const u32 d = hk_add(dq, Sg[k]);
+                            const u32 Vs = hk_maximum(Vp, Tup);
+                            const u32 Tn = hk_add(hk_maximum(hk_maximum(d, Hs), Vs), OE2);
+                            dq = T[r]; U[r] = Hs; T[r] = Tn; Tup = Tn; Vp = Vs;
+                        }
+                    }
+                }
+            } else {
 #ifdef PC_SLAB_OLD
             u32 *trace_dst = slab + ((int64_t)((a.debug & 2) ? 0 : (j - 1)) * NW) * 64 + lane;
 #else
@@ -1021,7 +1049,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(R <= 30 ? PC
             }
             u32 Tup = topn, Vp = NEG2, acc = 0, accA = 0;
             u32 pb1 = 0, pb2 = 0, pb3 = 0;       // bits of the previous row (its HOPEN bit is b0[r-1])
-            u32 d_last = 0, h_last = 0, v_last = 0;
 #pragma clang loop unroll(full)
             for (int r = 0; r < R; ++r) {
                 // table terms one group ahead of the row that needs them (row r+2 is fetched now)
@@ -1099,6 +1126,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(R <= 30 ? PC
 #endif
             }
 
+            }   // (traced column)
             if constexpr (CHECK) {
                 // only while a pair still runs: a finished stream re-reads its last bytes and its state is never used
                 if (j <= (n_lo > n_hi ? n_lo : n_hi)) {
@@ -1109,7 +1137,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(R <= 30 ? PC
             // ---- tracked cells ---------------------------------------------------------------
             const u32 cand = hk_min(hk_sub(T[R - 1], topn), limit2);     // M(R,j) + R*eps where tracked, else -inf
             if constexpr (CHECK) {
-                if (j <= (n_lo > n_hi ? n_lo : n_hi)) { note(hk_sub(T[R - 1], topn)); note(topn); note(best2); vmax = hk_max(vmax, acc); }
+                if (j <= (n_lo > n_hi ? n_lo : n_hi)) { note(hk_sub(T[R - 1], topn)); note(topn); note(best2); }
             }
             {
                 // strict '>' in visiting order (dp_scout.h:165-179): the maximum changes only where cand is larger, and an
@@ -1165,6 +1193,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(R <= 30 ? PC
         }
         Best b_lo, b_hi;
         load_best(b_lo, b_hi);
+        if constexpr (SCORE) {
+            // the end cell as a score record (what PC_MODE_SCORE leaves: plan_kernel's end_records)
+            if (have_lo) { int4 *o = (int4 *)(a.out + p_lo * TRACE_OUT_INTS); o[0] = make_int4(-2, b_lo.J, b_lo.I, 0); o[1] = make_int4(b_lo.score, 0, 0, 0); }
+            if (have_hi) { int4 *o = (int4 *)(a.out + p_hi * TRACE_OUT_INTS); o[0] = make_int4(-2, b_hi.J, b_hi.I, 0); o[1] = make_int4(b_hi.score, 0, 0, 0); }
+            continue;
+        }
         if (a.debug & 1) {
             if (have_lo) a.out[p_lo * TRACE_OUT_INTS + 4] = b_lo.score;
             if (have_hi) a.out[p_hi * TRACE_OUT_INTS + 4] = b_hi.score;
@@ -1192,8 +1226,9 @@ __global__ void plan_kernel(PlanArgs a)
     const Tile tile = a.tiles[blockIdx.x];
     const int i = threadIdx.x & 63, hi = threadIdx.x >> 6;
     const bool have = i < (hi ? tile.count_hi : tile.count_lo);
-    const int64_t p = (hi ? tile.out_hi : tile.out_lo) + i;      // pair (output) slot
-    const int64_t w = (hi ? tile.win_hi : tile.win_lo) + i;      // its whole-read window
+    const int64_t slot = (hi ? tile.out_hi : tile.out_lo) + i;
+    const int64_t p = (a.perm && have) ? a.perm[slot] : slot;    // pair (output index); with a.perm another one of the slot's segment
+    const int64_t w = (hi ? tile.win_hi : tile.win_lo) + i + (p - slot);   // its window (windows and pairs of a segment run in step)
     __shared__ int tile_len;                                     // end-aligned tiles: the columns the tile's windows get
     if (threadIdx.x == 0) tile_len = 0;
     __syncthreads();
@@ -1353,9 +1388,18 @@ bool trace16_has(int rows)
     return false;
 }
 
-int launch_trace16(const ScanArgs &a, int rows, int grid, void *stream)
+int launch_trace16(const ScanArgs &a, int rows, int grid, void *stream, bool score_only)
 {
     hipStream_t s = (hipStream_t)stream;
+    if (score_only) {
+#define PC_T16S(RR) case RR: hipLaunchKernelGGL((trace16_kernel<RR, false, true>), dim3(grid), dim3(64), 0, s, a); return hipGetLastError() == hipSuccess ? 0 : -2;
+        switch (rows) {
+            PC_T16S(16) PC_T16S(20) PC_T16S(22) PC_T16S(24) PC_T16S(26) PC_T16S(28) PC_T16S(30) PC_T16S(32) PC_T16S(34) PC_T16S(36)
+            PC_T16S(38) PC_T16S(40) PC_T16S(48) PC_T16S(56) PC_T16S(64) PC_T16S(68) PC_T16S(72)
+            default: return -1;
+        }
+#undef PC_T16S
+    }
     if (a.debug & 4) {      // range-checking build, where instantiated
 #define PC_T16C(RR) case RR: hipLaunchKernelGGL((trace16_kernel<RR, true>), dim3(grid), dim3(64), 0, s, a); return hipGetLastError() == hipSuccess ? 0 : -2;
         switch (rows) {
@@ -1375,6 +1419,83 @@ int launch_trace16(const ScanArgs &a, int rows, int grid, void *stream)
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 int launch_score(const ScanArgs &a, int rows, bool pad, int grid, void *stream) { return launch_scan<false>(a, rows, pad, grid, stream); }
+
+// ---------------------------------------------------------------------------------------------
+// Pairs of a segment by end column (see BucketArgs).  Three small launches: per-(segment, bucket) counts, their prefix, the
+// scatter.  A block takes one piece of one segment: LDS histogram, then one atomic per non-empty bucket.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int bucket_of(const int32_t *records, int64_t pair)
+{
+    const int2 v = *(const int2 *)(records + pair * TRACE_OUT_INTS);        // (flag, J)
+    if (v.x != -2 || v.y < 0) return kBuckets - 1;                          // not a score record: among the longest
+    const int b = v.y / kBucketWidth;
+    return b < kBuckets ? b : kBuckets - 1;
+}
+
+__global__ __launch_bounds__(256) void bucket_count_kernel(BucketArgs a)
+{
+    __shared__ unsigned hist[kBuckets];
+    const BucketBlock blk = a.blocks[blockIdx.x];
+    if (threadIdx.x < kBuckets) hist[threadIdx.x] = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < blk.count; i += 256) atomicAdd(&hist[bucket_of(a.records, blk.first + i)], 1u);
+    __syncthreads();
+    if (threadIdx.x < kBuckets && hist[threadIdx.x]) atomicAdd(a.counts + (int64_t)blk.segment * kBuckets + threadIdx.x, hist[threadIdx.x]);
+}
+
+__global__ __launch_bounds__(256) void bucket_prefix_kernel(BucketArgs a)
+{
+    const int sgm = blockIdx.x * 256 + threadIdx.x;
+    if (sgm >= a.nsegments) return;
+    unsigned acc = 0;
+    for (int b = 0; b < kBuckets; ++b) {        // counts -> first position of the bucket within its segment
+        const unsigned c = a.counts[(int64_t)sgm * kBuckets + b];
+        a.counts[(int64_t)sgm * kBuckets + b] = acc;
+        acc += c;
+    }
+}
+
+__global__ __launch_bounds__(256) void bucket_scatter_kernel(BucketArgs a)
+{
+    __shared__ unsigned hist[kBuckets], base[kBuckets];
+    const BucketBlock blk = a.blocks[blockIdx.x];
+    if (threadIdx.x < kBuckets) hist[threadIdx.x] = 0;
+    __syncthreads();
+    int mine[kBucketBlock / 256];
+#pragma unroll
+    for (int k = 0; k < kBucketBlock / 256; ++k) {
+        const int i = threadIdx.x + 256 * k;
+        mine[k] = i < blk.count ? bucket_of(a.records, blk.first + i) : -1;
+        if (mine[k] >= 0) atomicAdd(&hist[mine[k]], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < kBuckets) {
+        const unsigned h = hist[threadIdx.x];
+        base[threadIdx.x] = a.counts[(int64_t)blk.segment * kBuckets + threadIdx.x] +
+                            (h ? atomicAdd(a.cursors + (int64_t)blk.segment * kBuckets + threadIdx.x, h) : 0u);
+        hist[threadIdx.x] = 0;
+    }
+    __syncthreads();
+    const int64_t seg0 = a.seg_first[blk.segment];
+#pragma unroll
+    for (int k = 0; k < kBucketBlock / 256; ++k) {
+        if (mine[k] < 0) continue;
+        const unsigned r = atomicAdd(&hist[mine[k]], 1u);
+        a.perm[seg0 + base[mine[k]] + r] = blk.first + threadIdx.x + 256 * k;
+    }
+}
+
+int launch_bucket_pairs(const BucketArgs &a, void *stream)
+{
+    if (a.nblocks <= 0 || a.nsegments <= 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t bytes = (size_t)a.nsegments * kBuckets * 4;
+    if (hipMemsetAsync(a.counts, 0, bytes, s) != hipSuccess || hipMemsetAsync(a.cursors, 0, bytes, s) != hipSuccess) return -2;
+    hipLaunchKernelGGL(bucket_count_kernel, dim3((unsigned)a.nblocks), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(bucket_prefix_kernel, dim3((unsigned)((a.nsegments + 255) / 256)), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(bucket_scatter_kernel, dim3((unsigned)a.nblocks), dim3(256), 0, s, a);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
 
 int launch_plan(const PlanArgs &a, void *stream)
 {

@@ -365,6 +365,8 @@ __global__ __launch_bounds__(256) void seed_scan_kernel(SeedScanArgs a)
 // columns an occurrence through that seed can span.
 __global__ __launch_bounds__(256) void seed_verify_kernel(SeedVerifyArgs a)
 {
+    // (the launch may cover the whole candidate list's capacity -- pc_prefilter_defer_count: blocks beyond the count leave first)
+    if ((unsigned long long)blockIdx.x * 256 >= *a.count) return;
     extern __shared__ uint32_t eq_tab[];             // [npieces][8]: Eq word of codes 0..4 (5..7 unused)
     for (int i = threadIdx.x; i < a.npieces * 8; i += 256) eq_tab[i] = a.piece_eq[i];
     __shared__ uint8_t code_of[256];
@@ -554,6 +556,7 @@ __global__ __launch_bounds__(256) void seed_scan_packed_kernel(SeedScanArgs a)
 // One lane per candidate, bases from the plane: see seed_verify_kernel.
 __global__ __launch_bounds__(256) void seed_verify_packed_kernel(SeedVerifyArgs a)
 {
+    if ((unsigned long long)blockIdx.x * 256 >= *a.count) return;      // (see seed_verify_kernel)
     extern __shared__ uint32_t eq_tab[];             // [npieces][8]: Eq word of codes 0..3 (the plane holds nothing else)
     for (int i = threadIdx.x; i < a.npieces * 8; i += 256) eq_tab[i] = a.piece_eq[i];
     __syncthreads();

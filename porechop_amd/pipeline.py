@@ -25,6 +25,9 @@ from .batch import MODE_SCORE, MODE_TRACE, MODE_TRACE_AT, MODE_TWO_PASS, Aligner
 # phase B is pruned (exactly: see "Exact pruning of phase B" below) from this many (sequence, side) jobs on; measured on
 # MI355X, 1 M reads: 198 jobs 192 -> 122 ms; with the 4-6 jobs of a run without barcodes tracing everything is faster
 PRUNE_MIN_JOBS = int(os.environ.get("PC_PRUNE_MIN_JOBS", "24"))
+# up to this many adapter sets the prefilter stage of the middle scan takes ONE host round trip (survivors counted per set on
+# the device); a barcode panel's ~100 sets keep the single compaction over all of them
+LEAN_PREFILTER_GROUPS = 8
 
 
 @dataclass
@@ -599,13 +602,8 @@ class Pipeline:
                 # the end cell of every selected pair is known from its score record: only the columns its path can occupy
                 # are traced (PC_MODE_TRACE_AT: the second pass of the whole-read scan, for end windows)
                 traced = al.gather_records(rec, dest) if hasattr(al, "gather_records") else rec.index_select(0, dest)
-                if os.environ.get("PC_NO_J_SORT", "0") in ("", "0"):
-                    # ... and a tile (128 consecutive pairs of a job) runs as many columns as its LATEST end cell needs
-                    # (plan_kernel: min(J, window), the lead-in of the others is waste): pairs of a job are handed over by
-                    # end column, so that adapters found at the start of their windows -- J ~ 30 of 150 -- share tiles
-                    order = torch.argsort(pjob.to(torch.int64) * (1 << 20) + traced[:, 1].to(torch.int64))
-                    woff, wlen, dest, pjob, pread = woff[order], wlen[order], dest[order], pjob[order], pread[order]
-                    traced = traced[order]
+                # (the library takes the pairs of a job by end column -- bucket_pairs -- so that a tile runs as many columns as
+                # its LATEST end cell needs: adapters found at the start of their windows, J ~ 30 of 150, share tiles)
                 al.scan_device(self._ends_arena(reads), woff, wlen, job_adapter[live], starts, p.end_size, traced, MODE_TRACE_AT)
             else:
                 traced = torch.empty((total, RESULT_INTS), dtype=torch.int32, device=dev)
@@ -795,6 +793,54 @@ class Pipeline:
         # packed_reads (reads held at 2 bits per base, `off` in bases): the prefilter scans the PLANE, and only the windows
         # that survive are turned into bytes for the DP; an adapter list the packed route does not take (a letter other than
         # A/C/G/T/U, a piece without seeds) falls back to unpacking everything
+        groups, gidx = {}, []
+        for a in a_list:
+            gidx.append(groups.setdefault(hint[a], len(groups)))
+        G = len(groups)
+        members = [[b for b in range(B) if gidx[b] == g] for g in range(G)]
+        al = self.aligner
+        if (packed_reads is None or packed_reads.arena is not None) and G <= LEAN_PREFILTER_GROUPS and hasattr(al, "prefilter_defer_count") \
+                and hasattr(torch, "nonzero_static") and os.environ.get("PC_NO_LEAN_PREFILTER", "0") in ("", "0"):
+            # ONE host round trip for the whole stage (a handful of sets: the usual run).  The library's seed stage leaves its
+            # candidate count on the device (pc_prefilter_defer_count), the survivors of every set are counted on the device,
+            # the counts come back together, and the windows are listed by nonzero_static (no further synchronisation).
+            adl, kl = [aidx[a] for a in a_list], [ks[a] for a in a_list]
+
+            def survivors(defer):
+                al.prefilter_defer_count(defer)
+                try:
+                    mask = al.prefilter_mask(arena, pf_off, pf_len, max_len, adl, kl)
+                finally:
+                    al.prefilter_defer_count(False)
+                cands = []
+                for g in range(G):
+                    c = None
+                    for wd in sorted({b // 32 for b in members[g]}):
+                        bits = sum(1 << (b % 32) for b in members[g] if b // 32 == wd)
+                        t = (mask[:, wd] & (bits - (1 << 32) if bits >= (1 << 31) else bits)) != 0
+                        c = t if c is None else (c | t)
+                    cands.append(c)
+                return cands, torch.stack([c.sum() for c in cands]).cpu().numpy()      # the one synchronisation of this stage
+            cands, counts = survivors(True)
+            if al.prefilter_overflowed():                # (rare: the seed list overflowed -- the mask above is incomplete)
+                cands, counts = survivors(False)
+            self.stats["pairs_middle_prefiltered"] = self.stats.get("pairs_middle_prefiltered", 0) + B * n
+            cjobs, cmeta = [], []
+            for g in range(G):
+                if counts[g]:
+                    sel = torch.nonzero_static(cands[g], size=int(counts[g])).flatten()
+                    if order is not None:
+                        sel = order[sel]
+                    so, sl = off[sel], length[sel]
+                    for b in members[g]:
+                        cjobs.append((aidx[a_list[b]], so, sl, hint[a_list[b]])); cmeta.append((b, sel))
+            if not cjobs:
+                return empty
+            outs = self._scan_jobs(arena, cjobs, MODE_TWO_PASS, max_len, sort_lengths=ragged, typ_len=typ_len)
+            self.stats["pairs_middle_scanned_after_prefilter"] = self.stats.get("pairs_middle_scanned_after_prefilter", 0) + \
+                sum(int(j[1].shape[0]) for j in cjobs)
+            sb = torch.cat([torch.full((int(sel.shape[0]),), b, dtype=torch.int64, device=dev) for b, sel in cmeta])
+            return sb, torch.cat([sel for _, sel in cmeta]), torch.cat(outs)
         got = None
         if packed_reads is not None and packed_reads.arena is None:
             got = self.aligner.prefilter_rows(packed_reads.plane, pf_off, pf_len, max_len, [aidx[a] for a in a_list], [ks[a] for a in a_list],
@@ -808,10 +854,6 @@ class Pipeline:
         if order is not None:
             rows = order[rows]
         self.stats["pairs_middle_prefiltered"] = self.stats.get("pairs_middle_prefiltered", 0) + B * n
-        groups, gidx = {}, []
-        for a in a_list:
-            gidx.append(groups.setdefault(hint[a], len(groups)))
-        G = len(groups)
         if G == B:
             cand_g = bits
         else:                                            # union over the sequences of a set
@@ -838,7 +880,6 @@ class Pipeline:
         else:
             counts = torch.bincount(hitg[:, 0], minlength=G).cpu().numpy()     # the one synchronisation of this stage
         cjobs, cmeta, pos = [], [], 0
-        members = [[b for b in range(B) if gidx[b] == g] for g in range(G)]
         for g in range(G):
             if counts[g]:
                 sel = rows[hitg[pos:pos + int(counts[g]), 1]]
@@ -898,16 +939,25 @@ class Pipeline:
         s_pos, e_pos = trimmed_interval(reads.length, start_trim, end_trim)
         tlen = torch.clamp(e_pos - s_pos, min=0).to(torch.int32)
         toff = reads.off + s_pos
-        live = torch.nonzero(tlen > 0).flatten()
-        if live.numel() == 0:
+        # (one round trip: how many reads are left after trimming, and the extremes / mean of their lengths)
+        pos_len = tlen > 0
+        big = torch.iinfo(torch.int32).max
+        mm = torch.stack([pos_len.sum(), tlen.max(), torch.where(pos_len, tlen, torch.full_like(tlen, big)).min(),
+                          tlen.sum(dtype=torch.int64)]).cpu()
+        n_live = int(mm[0])
+        if n_live == 0:
             return empty
-        loff, llen = toff[live], tlen[live]
+        if n_live == R:
+            live = torch.arange(R, device=dev)
+            loff, llen = toff, tlen
+        else:
+            live = torch.nonzero_static(pos_len, size=n_live).flatten() if hasattr(torch, "nonzero_static") else torch.nonzero(pos_len).flatten()
+            loff, llen = toff[live], tlen[live]
         packed_only = reads.arena is None
         if packed_only and not prefilter:
             reads.materialize(self.aligner)                          # every pair runs the DP: every base is needed as a byte
             packed_only = False
-        mm = torch.stack([llen.max(), llen.min(), llen.sum(dtype=torch.int64) // llen.numel()]).cpu()
-        max_len, ragged, typ_len = int(mm[0]), bool(mm[0] != mm[1]), int(mm[2])
+        max_len, ragged, typ_len = int(mm[1]), bool(mm[1] != mm[2]), int(mm[3]) // n_live
         aidx = [self.seq_index[a[1]] for a in ads]
 
         def identity_of(rec):
@@ -945,15 +995,23 @@ class Pipeline:
         else:
             outs = self._scan_jobs(reads.arena, jobs0, MODE_TWO_PASS, max_len, sort_lengths=ragged, typ_len=typ_len)
             fulls = torch.stack([identity_of(rec) for rec in outs])  # [A, L]
+        L_ = int(live.numel())
         if sparse0 is not None:
             sa, sw, sr = sparse0                                     # every pair not listed is proven not to be a hit
             full_s = torch.nan_to_num(identity_of(sr), nan=0.0)
             hit_s = (full_s >= p.middle_threshold) & (sr[:, 0] != -1)
-            d_sel = torch.unique(sw[hit_s])                          # dirty reads (indices into live), increasing
+            dmask = torch.zeros(L_, dtype=torch.int32, device=dev).index_add_(0, sw, hit_s.to(torch.int32)) > 0
         else:
             hit0 = (fulls >= p.middle_threshold) & torch.stack([rec[:, 0] != -1 for rec in outs])
-            d_sel = torch.nonzero(hit0.any(dim=0)).flatten()         # dirty reads (indices into live)
-        Dn = int(d_sel.numel())
+            dmask = hit0.any(dim=0)
+        # (one round trip: the dirty reads -- those with a hit -- their number, longest, total padded size and mean length)
+        dstride_all = (llen.to(torch.int64) + (8 + 15)) // 16 * 16
+        zero64 = torch.zeros((), dtype=torch.int64, device=dev)
+        mm2 = torch.stack([dmask.sum(), torch.where(dmask, llen.to(torch.int64), zero64).max(), torch.where(dmask, dstride_all, zero64).sum(),
+                           torch.where(dmask, llen.to(torch.int64), zero64).sum()]).cpu()
+        Dn = int(mm2[0])
+        if Dn > 0:                                                   # dirty reads (indices into live), increasing
+            d_sel = torch.nonzero_static(dmask, size=Dn).flatten() if hasattr(torch, "nonzero_static") else torch.nonzero(dmask).flatten()
         n_align = A * int(live.numel())                              # alignments the reference performs
         n_spec = 0                                                   # speculative ones, discarded
         rounds = 0
@@ -976,8 +1034,7 @@ class Pipeline:
             dstride = (dlen.to(torch.int64) + (8 + 15)) // 16 * 16
             d_ends = torch.zeros(Dn + 1, dtype=torch.int64, device=dev)
             d_ends[1:] = torch.cumsum(dstride, 0)
-            mm2 = torch.stack([dlen.max().to(torch.int64), d_ends[-1], dlen.sum(dtype=torch.int64) // Dn]).cpu()
-            dmax, dtotal, dtyp = int(mm2[0]), int(mm2[1]), int(mm2[2])
+            dmax, dtotal, dtyp = int(mm2[1]), int(mm2[2]), int(mm2[3]) // Dn
             dirty = torch.empty(dtotal + 64, dtype=torch.uint8, device=dev)
             dirty[dtotal:] = ord("N")
             d_off = d_ends[:-1]
@@ -1003,26 +1060,31 @@ class Pipeline:
                 anyh = hm.any(dim=0)
                 a_hit = hm.to(torch.int32).argmax(dim=0)
                 used = torch.where(anyh, a_hit - c + 1, A - c)
-                n_used = int(used.sum().item())
+                # (one round trip per round: alignments consumed, reads that hit, the first adapter among them, bases to mask)
+                r_all = rec_all[a_hit, act]
+                cnt_all = torch.where(anyh, torch.clamp(r_all[:, 1] + 1 - r_all[:, 0], min=0), torch.zeros_like(r_all[:, 0])).to(torch.int64)
+                st_ = torch.stack([used.sum(), anyh.sum(), torch.where(anyh, a_hit, torch.full_like(a_hit, A)).min().to(torch.int64),
+                                   cnt_all.sum()]).cpu()
+                n_used, n_hit, a0, n_mask = int(st_[0]), int(st_[1]), int(st_[2]), int(st_[3])
                 n_align += n_used
                 n_spec += scheduled - n_used
-                hsel = act[anyh]
-                if hsel.numel() == 0:
+                if n_hit == 0:
                     break
-                ah = a_hit[anyh]
-                r = rec_all[ah, hsel]
+                hidx = torch.nonzero_static(anyh, size=n_hit).flatten() if hasattr(torch, "nonzero_static") else torch.nonzero(anyh).flatten()
+                hsel = act[hidx]
+                ah = a_hit[hidx]
+                r = r_all[hidx]
                 rs, re = r[:, 0], r[:, 1] + 1
                 H_read.append(live[d_sel[hsel]]); H_ad.append(ah.to(torch.int32))
                 H_s.append(rs); H_e.append(re); H_id.append(full_all[ah, hsel])
                 # masked_seq[rs:re] = '-' * n: the masked positions of all hits as one index list
-                cnt = torch.clamp(re - rs, min=0).to(torch.int64)
+                cnt = cnt_all[hidx]
                 first = torch.cumsum(cnt, 0) - cnt
-                run = torch.repeat_interleave(d_off[hsel] + rs.to(torch.int64) - first, cnt)
-                dirty[run + torch.arange(int(run.shape[0]), device=dev, dtype=torch.int64)] = ord("-")
+                run = torch.repeat_interleave(d_off[hsel] + rs.to(torch.int64) - first, cnt, output_size=n_mask)
+                dirty[run + torch.arange(n_mask, device=dev, dtype=torch.int64)] = ord("-")
                 cur[hsel] = ah                                       # the reference re-aligns the adapter that hit
                 act = hsel
                 rounds += 1
-                a0 = int(ah.min().item())
                 o_act, l_act = d_off[act], dlen[act]
                 if prefilter:                                        # the masked reads go through the same proof first
                     rb, rw, rr = self._prefiltered_scan(dirty, o_act, l_act, dmax, list(range(a0, A)), aidx, hint, ks, ragged, dtyp)

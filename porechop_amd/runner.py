@@ -408,7 +408,7 @@ def run_streamed(input_path, output, barcode_dir, opts: Options, device=None, al
         first.close()
         first_bytes *= 4
     discard_middle = opts.discard_middle or barcode_dir is not None
-    res = RunResult(n_reads=0, read_type="FASTQ")
+    res = RunResult(n_reads=0, read_type="FASTQ" if first.is_fastq else "FASTA")     # (plain FASTA streams too: cut at '>' lines)
     busy = {"load": time.perf_counter() - t_start, "scan": 0.0, "write": 0.0}
 
     panel = list(adapter_panel) if adapter_panel is not None else panel_rules.load_panel()
@@ -679,7 +679,10 @@ def run_sharded(input_path, output, barcode_dir, opts: Options, device=None, ali
     R = rs.count if rs is not None else 0
     counts = all_gather_ints([R], device if aligner is None else None)[:, 0].numpy()
     first_read, total = int(counts[:rank].sum()), int(counts.sum())
-    res = RunResult(n_reads=total, read_type="FASTQ")
+    # (the type of the file is the type of its first record: rank 0's share always holds it)
+    kinds = all_gather_objects(None if rs is None else bool(rs.is_fastq))
+    is_fastq = next((k for k in kinds if k is not None), True)
+    res = RunResult(n_reads=total, read_type="FASTQ" if is_fastq else "FASTA")
     res.seconds["load"] = time.perf_counter() - t_start
     check_idx = np.arange(max(0, min(R, max(0, opts.check_reads) - first_read)), dtype=np.int64)
 

@@ -191,3 +191,136 @@ def test_sharded_runs_over_a_gzip_input_of_sized_members(tmp_path, world):
         mine = [got[r][1][name][0] for r in range(world)]
         assert sum(mine) == total and max(mine) < total, (name, mine, total)          # no rank held every read
     assert all(all(got[r][2]) and len(got[r][2]) == len(GZ_CASES) for r in range(world))      # every run took the sharded route
+
+
+# ---- FASTA input over the ranks (cut where a line begins with '>': pc_fastq_find_record / pc_readset_load_segment) ----------
+FASTA_RUNS = [("o:out.fasta", []), ("b", []), ("o:out.fastq", ["--format", "fastq"]), ("o:out.fasta.gz", ["--discard_middle"])]
+
+
+def _fasta_input(path):
+    """Multi-line FASTA with a few odd records (an empty name, whose bases go to the next record; blank and padded lines)."""
+    import random
+    from tests import readgen
+    rng = random.Random(11)
+    reads = readgen.native_reads(77, 60, barcodes=(2, 5, 9))
+    with open(path, "w") as f:
+        for k, (name, seq, _) in enumerate(reads):
+            f.write(">" + ("" if k in (7, 31) else name) + "\n")
+            width = rng.choice([60, 80, 10 ** 9])
+            for i in range(0, len(seq), width):
+                f.write(("  " if rng.random() < 0.02 else "") + seq[i:i + width] + "\n")
+            if rng.random() < 0.1:
+                f.write("\n")
+
+
+def _fasta_worker(rank, world, port, workdir, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle.oracle import Oracle
+    from porechop_amd import runner
+    from tests import readgen
+    from tests.cpu_aligner import OracleAligner
+    from tests.runner_cases import options_from_argv
+    oracle = Oracle()
+    seen, out, shares = [], {}, {}
+    orig = runner.run_sharded
+
+    def spy(*a, **kw):
+        r = orig(*a, **kw)
+        seen.append(r is not None)
+        return r
+    runner.run_sharded = spy
+    inp = os.path.join(workdir, "in.fasta")
+    for k, (mode, argv) in enumerate(FASTA_RUNS):
+        opts = options_from_argv(argv)
+        work = os.path.join(workdir, "fa_run%d" % k)
+        if rank == 0:
+            os.makedirs(work)
+        dist.barrier()
+        target = os.path.join(work, "bins" if mode == "b" else mode[2:])
+        kw = {"options": opts, "aligner": OracleAligner(oracle, opts.scoring_scheme)}
+        res = runner.run(inp, barcode_dir=target, **kw) if mode == "b" else runner.run(inp, output=target, **kw)
+        dist.barrier()
+        out[k] = readgen.output_md5s(target) if rank == 0 else {}
+        shares[k] = (len(res.start_trim), res.n_reads, res.read_type)
+    q.put((rank, out, shares, seen))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_fasta_input_equals_the_single_process_run(tmp_path, world):
+    from oracle.oracle import Oracle
+    from porechop_amd import runner
+    from tests import readgen
+    from tests.cpu_aligner import OracleAligner
+    from tests.runner_cases import options_from_argv
+    inp = str(tmp_path / "in.fasta")
+    _fasta_input(inp)
+    oracle = Oracle()
+    want = {}
+    for k, (mode, argv) in enumerate(FASTA_RUNS):          # the single-process files (the whole-file loader)
+        opts = options_from_argv(argv)
+        target = str(tmp_path / ("single%d" % k) / ("bins" if mode == "b" else mode[2:]))
+        os.makedirs(os.path.dirname(target))
+        kw = {"options": opts, "aligner": OracleAligner(oracle, opts.scoring_scheme)}
+        res = runner.run(inp, barcode_dir=target, **kw) if mode == "b" else runner.run(inp, output=target, **kw)
+        assert res.read_type == "FASTA" and res.n_reads == 58        # (two headers without a name: their bases join the next record)
+        want[k] = readgen.output_md5s(target)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_fasta_worker, args=(r, world, port, str(tmp_path), q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(world):
+        rank, out, shares, seen = q.get(timeout=900)
+        got[rank] = (out, shares, seen)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for k in range(len(FASTA_RUNS)):
+        assert got[0][0][k] == want[k], (k, got[0][0][k], want[k])
+        mine = [got[r][1][k][0] for r in range(world)]
+        assert sum(mine) == 58 and max(mine) < 58, mine                    # no rank held every read
+        assert all(got[r][1][k][1:] == (58, "FASTA") for r in range(world))
+    assert all(all(got[r][2]) and len(got[r][2]) == len(FASTA_RUNS) for r in range(world))   # every run took the sharded route
+
+
+def test_streamed_fasta_input_equals_the_whole_file_run(tmp_path, monkeypatch):
+    """A plain FASTA file as a stream of small blocks (runner.run_streamed): the same files as the whole-file run."""
+    from oracle.oracle import Oracle
+    from porechop_amd import runner
+    from tests import readgen
+    from tests.cpu_aligner import OracleAligner
+    from tests.runner_cases import options_from_argv
+    inp = str(tmp_path / "in.fasta")
+    _fasta_input(inp)
+    oracle = Oracle()
+    took = []
+    orig = runner.run_streamed
+
+    def spy(*a, **kw):
+        r = orig(*a, **kw)
+        took.append(r is not None)
+        return r
+    monkeypatch.setattr(runner, "run_streamed", spy)
+    for k, (mode, argv) in enumerate(FASTA_RUNS):
+        opts = options_from_argv(argv + ["--check_reads", "20"])
+        files = {}
+        for blocks in (None, "5000", "40000"):
+            if blocks:
+                monkeypatch.setenv("PC_STREAM_BLOCK_BYTES", blocks)
+            else:
+                monkeypatch.delenv("PC_STREAM_BLOCK_BYTES", raising=False)
+            target = str(tmp_path / ("s%d_%s" % (k, blocks)) / ("bins" if mode == "b" else mode[2:]))
+            os.makedirs(os.path.dirname(target))
+            kw = {"options": opts, "aligner": OracleAligner(oracle, opts.scoring_scheme)}
+            res = runner.run(inp, barcode_dir=target, **kw) if mode == "b" else runner.run(inp, output=target, **kw)
+            assert res.read_type == "FASTA" and res.n_reads == 58
+            files[blocks] = readgen.output_md5s(target)
+        assert files["5000"] == files[None] and files["40000"] == files[None], (k, files)
+    assert took.count(True) >= 2 * len(FASTA_RUNS)                    # the small-block runs really streamed

@@ -313,6 +313,23 @@ int pc_prefilter_packed(pc_ctx *ctx, const void *d_plane, const int64_t *d_win_o
  * the count leave at once) and the count follows to pinned host memory; after the caller's next synchronisation of the
  * stream, pc_prefilter_overflowed(ctx) says whether the last call's list overflowed (1: its mask is NOT complete -- repeat
  * the call with the deferral off; rare: low-complexity reads against a low-complexity seed). */
+/* The glue of the middle scan (porechop/nanopore_read.py:56-62,210-243 for a whole batch) as single launches -- as torch
+ * expressions it is ~150 launches of a few microseconds per step, and the GPU idles between them.  All pointers: device memory.
+ * pc_trim_windows: seq[start_trim : len - end_trim] with Python's slice semantics -> toff / tlen; stats int64[4] = reads with a
+ *   non-empty interval, longest, 2^40 - shortest non-empty (0: none), sum.
+ * pc_middle_hits: full-adapter identity (the %f-printed double) of whole-read records and whether it reaches the threshold.
+ * pc_group_survivors: cand[g][w] = (mask row w AND gmask row g) != 0 over the prefilter's mask, counts[g] = how many.
+ * pc_round_consume: per active masked read the first adapter >= its cursor whose record is a hit; stats int64[4] = alignments
+ *   consumed, reads that hit, 2^40 - smallest hit adapter (0: none), bases to mask. */
+int pc_trim_windows(pc_ctx *ctx, const int64_t *d_off, const int32_t *d_len, const int32_t *d_start_trim, const int32_t *d_end_trim,
+                    int64_t n, int64_t *d_toff, int32_t *d_tlen, int64_t *d_stats, void *stream);
+int pc_middle_hits(pc_ctx *ctx, const int32_t *d_records, int64_t n, double threshold, double *d_full, uint8_t *d_hit, void *stream);
+int pc_group_survivors(pc_ctx *ctx, const int32_t *d_mask, int64_t n, int words, const int32_t *d_gmask, int ngroups, uint8_t *d_cand,
+                       int64_t *d_counts, void *stream);
+int pc_round_consume(pc_ctx *ctx, const double *d_full_all, const int32_t *d_rec_all, const int64_t *d_cur, const int64_t *d_act,
+                     int64_t nact, int nadapters, int64_t ndirty, double threshold, uint8_t *d_anyh, int32_t *d_a_hit, int64_t *d_cnt,
+                     int64_t *d_stats, void *stream);
+
 int pc_prefilter_defer_count(pc_ctx *ctx, int enabled);
 int pc_prefilter_overflowed(pc_ctx *ctx);
 int pc_unpack_windows(pc_ctx *ctx, const void *d_plane, const int64_t *d_exc_pos, int64_t nexc, const int64_t *d_src_off,

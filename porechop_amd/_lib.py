@@ -21,7 +21,7 @@ EXPORTS = [
     "pc_readset_is_rna", "pc_readset_load_many", "pc_readset_file_index", "pc_readset_write",
     "pc_readset_load_segment", "pc_readset_write_at", "pc_io_set_thread_limit", "pc_pack_reads", "pc_unpack_device", "pc_fastq_find_record", "pc_readset_write_sizes", "pc_readset_write_shared",
     "pc_readset_compress", "pc_gzimage_sizes", "pc_gzimage_write", "pc_gzimage_free", "pc_gz_finish", "pc_gzip_file",
-    "pc_gzstream_open", "pc_gzstream_next", "pc_gzstream_close", "pc_prefilter_packed", "pc_unpack_windows", "pc_prefilter_defer_count", "pc_prefilter_overflowed",
+    "pc_gzstream_open", "pc_gzstream_next", "pc_gzstream_close", "pc_prefilter_packed", "pc_unpack_windows", "pc_prefilter_defer_count", "pc_prefilter_overflowed", "pc_trim_windows", "pc_middle_hits", "pc_group_survivors", "pc_round_consume",
     "pc_gz_sized_size", "pc_gz_sized_find_record", "pc_readset_load_gz_range",
 ]
 
@@ -175,6 +175,14 @@ def load_library():
     L.pc_prefilter_defer_count.restype = c_int
     L.pc_prefilter_overflowed.argtypes = [c_vp]
     L.pc_prefilter_overflowed.restype = c_int
+    L.pc_trim_windows.argtypes = [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp]
+    L.pc_trim_windows.restype = c_int
+    L.pc_middle_hits.argtypes = [c_vp, c_vp, c_i64, ctypes.c_double, c_vp, c_vp, c_vp]
+    L.pc_middle_hits.restype = c_int
+    L.pc_group_survivors.argtypes = [c_vp, c_vp, c_i64, c_int, c_vp, c_int, c_vp, c_vp, c_vp]
+    L.pc_group_survivors.restype = c_int
+    L.pc_round_consume.argtypes = [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_i64, ctypes.c_double, c_vp, c_vp, c_vp, c_vp, c_vp]
+    L.pc_round_consume.restype = c_int
     L.pc_unpack_windows.argtypes = [c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_vp, c_int, c_vp]
     L.pc_unpack_windows.restype = c_int
     L.pc_readset_compress.argtypes = [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, ctypes.POINTER(c_vp)]

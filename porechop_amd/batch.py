@@ -346,6 +346,68 @@ class Aligner:
               "pc_unpack_windows")
         return dst
 
+    # ---- the glue of the middle scan as single launches (pc_middle.hip); Pipeline.phase_c keeps the torch formulation for
+    # aligners without them (the test stand-ins)
+    STAT_BIG = 1 << 40
+
+    def trim_windows(self, off, length, start_trim, end_trim):
+        """-> (toff int64[R], tlen int32[R], stats int64[4] on the device: live, longest, STAT_BIG - shortest non-empty, sum)"""
+        import torch
+        n = int(off.shape[0])
+        toff = torch.empty(n, dtype=torch.int64, device=off.device)
+        tlen = torch.empty(n, dtype=torch.int32, device=off.device)
+        stats = torch.empty(4, dtype=torch.int64, device=off.device)
+        off, length = off.contiguous(), length.contiguous()
+        st, et = start_trim.to(torch.int32).contiguous(), end_trim.to(torch.int32).contiguous()
+        assert off.dtype == torch.int64 and length.dtype == torch.int32
+        s = torch.cuda.current_stream().cuda_stream
+        check(self.lib.pc_trim_windows(self._ctx, off.data_ptr(), length.data_ptr(), st.data_ptr(), et.data_ptr(), n, toff.data_ptr(),
+                                       tlen.data_ptr(), stats.data_ptr(), ctypes.c_void_p(s)), "pc_trim_windows")
+        return toff, tlen, stats
+
+    def middle_hits(self, rec, threshold):
+        """rec int32[..., 8] (contiguous) -> (full float64[...], hit bool[...])"""
+        import torch
+        assert rec.dtype == torch.int32 and rec.is_contiguous() and rec.shape[-1] == RESULT_INTS
+        shape = rec.shape[:-1]
+        n = int(rec.numel() // RESULT_INTS)
+        full = torch.empty(shape, dtype=torch.float64, device=rec.device)
+        hit = torch.empty(shape, dtype=torch.uint8, device=rec.device)
+        s = torch.cuda.current_stream().cuda_stream
+        check(self.lib.pc_middle_hits(self._ctx, rec.data_ptr(), n, float(threshold), full.data_ptr(), hit.data_ptr(), ctypes.c_void_p(s)),
+              "pc_middle_hits")
+        return full, hit.view(torch.bool)
+
+    def group_survivors(self, mask, gmask):
+        """mask int32[n, words], gmask int32[G, words] (device) -> (cand bool[G, n], counts int64[G] on the device)"""
+        import torch
+        n, words = int(mask.shape[0]), int(mask.shape[1])
+        G = int(gmask.shape[0])
+        assert mask.dtype == torch.int32 and mask.is_contiguous() and gmask.dtype == torch.int32 and gmask.is_contiguous() and int(gmask.shape[1]) == words
+        cand = torch.empty((G, n), dtype=torch.uint8, device=mask.device)
+        counts = torch.empty(G, dtype=torch.int64, device=mask.device)
+        s = torch.cuda.current_stream().cuda_stream
+        check(self.lib.pc_group_survivors(self._ctx, mask.data_ptr(), n, words, gmask.data_ptr(), G, cand.data_ptr(), counts.data_ptr(),
+                                          ctypes.c_void_p(s)), "pc_group_survivors")
+        return cand.view(torch.bool), counts
+
+    def round_consume(self, full_all, rec_all, cur, act, threshold):
+        """One consuming step of mask-and-realign (pc_round_consume) -> (anyh bool[n], a_hit int32[n], cnt int64[n], stats int64[4])"""
+        import torch
+        A, Dn = int(full_all.shape[0]), int(full_all.shape[1])
+        n = int(act.shape[0])
+        assert full_all.dtype == torch.float64 and full_all.is_contiguous() and rec_all.dtype == torch.int32 and rec_all.is_contiguous()
+        assert cur.dtype == torch.int64 and cur.is_contiguous() and act.dtype == torch.int64
+        act = act.contiguous()
+        anyh = torch.empty(n, dtype=torch.uint8, device=act.device)
+        a_hit = torch.empty(n, dtype=torch.int32, device=act.device)
+        cnt = torch.empty(n, dtype=torch.int64, device=act.device)
+        stats = torch.empty(4, dtype=torch.int64, device=act.device)
+        s = torch.cuda.current_stream().cuda_stream
+        check(self.lib.pc_round_consume(self._ctx, full_all.data_ptr(), rec_all.data_ptr(), cur.data_ptr(), act.data_ptr(), n, A, Dn, float(threshold),
+                                        anyh.data_ptr(), a_hit.data_ptr(), cnt.data_ptr(), stats.data_ptr(), ctypes.c_void_p(s)), "pc_round_consume")
+        return anyh.view(torch.bool), a_hit, cnt, stats
+
     def prefilter_defer_count(self, enabled=True):
         """No host round trip inside prefilter_mask (pc_prefilter_defer_count): after the caller's next synchronisation,
         prefilter_overflowed() says whether the last mask is incomplete (then: call again with the deferral off)."""

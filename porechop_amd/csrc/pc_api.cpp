@@ -1408,6 +1408,48 @@ int pc_copy_windows(pc_ctx *c, const void *d_arena, const int64_t *d_src_off, co
     return pck::launch_copy_windows((const uint8_t *)d_arena, d_src_off, d_len, n, (uint8_t *)d_dst, d_dst_off, pad, stream) ? PC_ERR_NO_DEVICE : PC_OK;
 }
 
+// ---- the glue of the middle scan as single launches (pc_middle.hip); every pointer is device memory of the caller ---------------
+int pc_trim_windows(pc_ctx *c, const int64_t *d_off, const int32_t *d_len, const int32_t *d_start_trim, const int32_t *d_end_trim, int64_t n,
+                    int64_t *d_toff, int32_t *d_tlen, int64_t *d_stats, void *stream_v)
+{
+    if (!c || n < 0 || (n > 0 && (!d_off || !d_len || !d_start_trim || !d_end_trim || !d_toff || !d_tlen)) || !d_stats) return PC_ERR_BAD_ARG;
+    (void)hipSetDevice(c->device);
+    hipStream_t stream = (stream_v == PC_STREAM_CONTEXT) ? c->stream : (hipStream_t)stream_v;
+    HIP_TRY(hipMemsetAsync(d_stats, 0, 32, stream));      // (statistics that need another neutral element are stored offset: pc_middle.hip)
+    return pck::launch_trim_windows(d_off, d_len, d_start_trim, d_end_trim, n, d_toff, d_tlen, d_stats, stream) ? PC_ERR_NO_DEVICE : PC_OK;
+}
+
+int pc_middle_hits(pc_ctx *c, const int32_t *d_records, int64_t n, double threshold, double *d_full, uint8_t *d_hit, void *stream_v)
+{
+    if (!c || n < 0 || (n > 0 && (!d_records || !d_full || !d_hit))) return PC_ERR_BAD_ARG;
+    (void)hipSetDevice(c->device);
+    hipStream_t stream = (stream_v == PC_STREAM_CONTEXT) ? c->stream : (hipStream_t)stream_v;
+    return pck::launch_middle_hits(d_records, n, threshold, d_full, d_hit, stream) ? PC_ERR_NO_DEVICE : PC_OK;
+}
+
+int pc_group_survivors(pc_ctx *c, const int32_t *d_mask, int64_t n, int words, const int32_t *d_gmask, int ngroups, uint8_t *d_cand,
+                       int64_t *d_counts, void *stream_v)
+{
+    if (!c || n < 0 || words < 1 || ngroups < 0 || !d_counts || (n > 0 && ngroups > 0 && (!d_mask || !d_gmask || !d_cand))) return PC_ERR_BAD_ARG;
+    (void)hipSetDevice(c->device);
+    hipStream_t stream = (stream_v == PC_STREAM_CONTEXT) ? c->stream : (hipStream_t)stream_v;
+    if (ngroups > 0) HIP_TRY(hipMemsetAsync(d_counts, 0, (size_t)ngroups * 8, stream));
+    return pck::launch_group_survivors(d_mask, n, words, d_gmask, ngroups, d_cand, d_counts, stream) ? PC_ERR_NO_DEVICE : PC_OK;
+}
+
+int pc_round_consume(pc_ctx *c, const double *d_full_all, const int32_t *d_rec_all, const int64_t *d_cur, const int64_t *d_act, int64_t nact,
+                     int nadapters, int64_t ndirty, double threshold, uint8_t *d_anyh, int32_t *d_a_hit, int64_t *d_cnt, int64_t *d_stats,
+                     void *stream_v)
+{
+    if (!c || nact < 0 || nadapters < 1 || ndirty < 0 || !d_stats) return PC_ERR_BAD_ARG;
+    if (nact > 0 && (!d_full_all || !d_rec_all || !d_cur || !d_act || !d_anyh || !d_a_hit || !d_cnt)) return PC_ERR_BAD_ARG;
+    (void)hipSetDevice(c->device);
+    hipStream_t stream = (stream_v == PC_STREAM_CONTEXT) ? c->stream : (hipStream_t)stream_v;
+    HIP_TRY(hipMemsetAsync(d_stats, 0, 32, stream));
+    return pck::launch_round_consume(d_full_all, d_rec_all, d_cur, d_act, nact, nadapters, ndirty, threshold, d_anyh, d_a_hit, d_cnt, d_stats, stream)
+               ? PC_ERR_NO_DEVICE : PC_OK;
+}
+
 int pc_unpack_device(pc_ctx *c, const void *d_packed, int64_t nbases, const int64_t *d_exc_pos, int64_t nexc, void *d_arena,
                      int pad_bytes, void *stream_v)
 {

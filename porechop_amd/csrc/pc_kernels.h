@@ -270,6 +270,14 @@ struct BucketArgs {
     int64_t *perm;
 };
 int launch_bucket_pairs(const BucketArgs &a, void *stream);
+
+// the glue of the middle scan (pc_middle.hip)
+int launch_trim_windows(const int64_t *off, const int32_t *len, const int32_t *st, const int32_t *et, int64_t n, int64_t *toff, int32_t *tlen,
+                        int64_t *stats, void *stream);
+int launch_middle_hits(const int32_t *rec, int64_t n, double threshold, double *full, uint8_t *hit, void *stream);
+int launch_group_survivors(const int32_t *mask, int64_t n, int words, const int32_t *gmask, int ngroups, uint8_t *cand, int64_t *counts, void *stream);
+int launch_round_consume(const double *full_all, const int32_t *rec_all, const int64_t *cur, const int64_t *act, int64_t nact, int A, int64_t Dn,
+                         double threshold, uint8_t *anyh, int32_t *a_hit, int64_t *cnt, int64_t *stats, void *stream);
 int launch_plan(const PlanArgs &a, void *stream);
 int trace_words_per_col(int rows);   // NW
 

@@ -812,13 +812,22 @@ class Pipeline:
                     mask = al.prefilter_mask(arena, pf_off, pf_len, max_len, adl, kl)
                 finally:
                     al.prefilter_defer_count(False)
+                words = int(mask.shape[1])
+                gm = []
+                for g in range(G):
+                    for wd in range(words):
+                        bits = sum(1 << (b % 32) for b in members[g] if b // 32 == wd)
+                        gm.append(bits - (1 << 32) if bits >= (1 << 31) else bits)
+                if hasattr(al, "group_survivors") and os.environ.get("PC_NO_FUSED_GLUE", "0") in ("", "0"):
+                    cand, cnt = al.group_survivors(mask, self._const(gm, torch.int32).view(G, words))
+                    return [cand[g] for g in range(G)], cnt.cpu().numpy()               # the one synchronisation of this stage
                 cands = []
                 for g in range(G):
                     c = None
-                    for wd in sorted({b // 32 for b in members[g]}):
-                        bits = sum(1 << (b % 32) for b in members[g] if b // 32 == wd)
-                        t = (mask[:, wd] & (bits - (1 << 32) if bits >= (1 << 31) else bits)) != 0
-                        c = t if c is None else (c | t)
+                    for wd in range(words):
+                        if gm[g * words + wd]:
+                            t = (mask[:, wd] & gm[g * words + wd]) != 0
+                            c = t if c is None else (c | t)
                     cands.append(c)
                 return cands, torch.stack([c.sum() for c in cands]).cpu().numpy()      # the one synchronisation of this stage
             cands, counts = survivors(True)
@@ -936,14 +945,22 @@ class Pipeline:
         if A == 0 or R == 0:
             return empty
         # masked_seq = seq[start_trim : len - end_trim] with Python slice semantics (nanopore_read.py:56-62)
-        s_pos, e_pos = trimmed_interval(reads.length, start_trim, end_trim)
-        tlen = torch.clamp(e_pos - s_pos, min=0).to(torch.int32)
-        toff = reads.off + s_pos
         # (one round trip: how many reads are left after trimming, and the extremes / mean of their lengths)
-        pos_len = tlen > 0
-        big = torch.iinfo(torch.int32).max
-        mm = torch.stack([pos_len.sum(), tlen.max(), torch.where(pos_len, tlen, torch.full_like(tlen, big)).min(),
-                          tlen.sum(dtype=torch.int64)]).cpu()
+        al = self.aligner
+        fused = hasattr(al, "round_consume") and os.environ.get("PC_NO_FUSED_GLUE", "0") in ("", "0")     # pc_middle.hip: one launch each
+        if fused:
+            toff, tlen, st4 = al.trim_windows(reads.off, reads.length, start_trim, end_trim)
+            mm = st4.cpu()
+            mm[2] = (al.STAT_BIG - mm[2]) if int(mm[2]) else 0
+            pos_len = None
+        else:
+            s_pos, e_pos = trimmed_interval(reads.length, start_trim, end_trim)
+            tlen = torch.clamp(e_pos - s_pos, min=0).to(torch.int32)
+            toff = reads.off + s_pos
+            pos_len = tlen > 0
+            big = torch.iinfo(torch.int32).max
+            mm = torch.stack([pos_len.sum(), tlen.max(), torch.where(pos_len, tlen, torch.full_like(tlen, big)).min(),
+                              tlen.sum(dtype=torch.int64)]).cpu()
         n_live = int(mm[0])
         if n_live == 0:
             return empty
@@ -951,13 +968,18 @@ class Pipeline:
             live = torch.arange(R, device=dev)
             loff, llen = toff, tlen
         else:
+            if pos_len is None:
+                pos_len = tlen > 0
             live = torch.nonzero_static(pos_len, size=n_live).flatten() if hasattr(torch, "nonzero_static") else torch.nonzero(pos_len).flatten()
             loff, llen = toff[live], tlen[live]
         packed_only = reads.arena is None
         if packed_only and not prefilter:
             reads.materialize(self.aligner)                          # every pair runs the DP: every base is needed as a byte
             packed_only = False
-        max_len, ragged, typ_len = int(mm[1]), bool(mm[1] != mm[2]), int(mm[3]) // n_live
+        # (windows of different lengths are handed over longest first even when they differ by a per cent -- 8-kb reads that lost
+        # 0..150 bases to their trims: tiles of nearly one length keep the specialised score kernel on its block-resolved path;
+        # skipping the sort for such batches was measured: 0.3 ms of glue saved, 1.6 ms of scan lost at 1 M reads)
+        max_len, ragged, typ_len = int(mm[1]), bool(int(mm[1]) != int(mm[2])), int(mm[3]) // n_live
         aidx = [self.seq_index[a[1]] for a in ads]
 
         def identity_of(rec):
@@ -994,13 +1016,21 @@ class Pipeline:
             self.stats["pairs_middle_traced_after_proof"] = self.stats.get("pairs_middle_traced_after_proof", 0) + int(counts.sum())
         else:
             outs = self._scan_jobs(reads.arena, jobs0, MODE_TWO_PASS, max_len, sort_lengths=ragged, typ_len=typ_len)
-            fulls = torch.stack([identity_of(rec) for rec in outs])  # [A, L]
+            if fused:
+                fulls, hit0_f = al.middle_hits(torch.stack(outs), p.middle_threshold)          # [A, L] each
+            else:
+                fulls = torch.stack([identity_of(rec) for rec in outs])  # [A, L]
         L_ = int(live.numel())
         if sparse0 is not None:
             sa, sw, sr = sparse0                                     # every pair not listed is proven not to be a hit
-            full_s = torch.nan_to_num(identity_of(sr), nan=0.0)
-            hit_s = (full_s >= p.middle_threshold) & (sr[:, 0] != -1)
+            if fused:
+                full_s, hit_s = al.middle_hits(sr.contiguous(), p.middle_threshold)
+            else:
+                full_s = torch.nan_to_num(identity_of(sr), nan=0.0)
+                hit_s = (full_s >= p.middle_threshold) & (sr[:, 0] != -1)
             dmask = torch.zeros(L_, dtype=torch.int32, device=dev).index_add_(0, sw, hit_s.to(torch.int32)) > 0
+        elif fused and not prove:
+            dmask = hit0_f.any(dim=0)
         else:
             hit0 = (fulls >= p.middle_threshold) & torch.stack([rec[:, 0] != -1 for rec in outs])
             dmask = hit0.any(dim=0)
@@ -1055,25 +1085,32 @@ class Pipeline:
             scheduled = A * Dn
             while True:
                 # consume, per active read: adapters cur.. in order, up to and including the first hit
-                c = cur[act]
-                hm = (full_all[:, act] >= p.middle_threshold) & (rec_all[:, act, 0] != -1) & (arow >= c[None, :])
-                anyh = hm.any(dim=0)
-                a_hit = hm.to(torch.int32).argmax(dim=0)
-                used = torch.where(anyh, a_hit - c + 1, A - c)
                 # (one round trip per round: alignments consumed, reads that hit, the first adapter among them, bases to mask)
-                r_all = rec_all[a_hit, act]
-                cnt_all = torch.where(anyh, torch.clamp(r_all[:, 1] + 1 - r_all[:, 0], min=0), torch.zeros_like(r_all[:, 0])).to(torch.int64)
-                st_ = torch.stack([used.sum(), anyh.sum(), torch.where(anyh, a_hit, torch.full_like(a_hit, A)).min().to(torch.int64),
-                                   cnt_all.sum()]).cpu()
-                n_used, n_hit, a0, n_mask = int(st_[0]), int(st_[1]), int(st_[2]), int(st_[3])
+                if fused:
+                    anyh, a_hit, cnt_all, st4 = al.round_consume(full_all, rec_all, cur, act, p.middle_threshold)
+                    st_ = st4.cpu()
+                    n_used, n_hit, n_mask = int(st_[0]), int(st_[1]), int(st_[3])
+                    a0 = (al.STAT_BIG - int(st_[2])) if int(st_[2]) else A
+                    r_all = None
+                else:
+                    c = cur[act]
+                    hm = (full_all[:, act] >= p.middle_threshold) & (rec_all[:, act, 0] != -1) & (arow >= c[None, :])
+                    anyh = hm.any(dim=0)
+                    a_hit = hm.to(torch.int32).argmax(dim=0)
+                    used = torch.where(anyh, a_hit - c + 1, A - c)
+                    r_all = rec_all[a_hit, act]
+                    cnt_all = torch.where(anyh, torch.clamp(r_all[:, 1] + 1 - r_all[:, 0], min=0), torch.zeros_like(r_all[:, 0])).to(torch.int64)
+                    st_ = torch.stack([used.sum(), anyh.sum(), torch.where(anyh, a_hit, torch.full_like(a_hit, A)).min().to(torch.int64),
+                                       cnt_all.sum()]).cpu()
+                    n_used, n_hit, a0, n_mask = int(st_[0]), int(st_[1]), int(st_[2]), int(st_[3])
                 n_align += n_used
                 n_spec += scheduled - n_used
                 if n_hit == 0:
                     break
                 hidx = torch.nonzero_static(anyh, size=n_hit).flatten() if hasattr(torch, "nonzero_static") else torch.nonzero(anyh).flatten()
                 hsel = act[hidx]
-                ah = a_hit[hidx]
-                r = r_all[hidx]
+                ah = a_hit[hidx].to(torch.int64)
+                r = rec_all[ah, hsel] if r_all is None else r_all[hidx]
                 rs, re = r[:, 0], r[:, 1] + 1
                 H_read.append(live[d_sel[hsel]]); H_ad.append(ah.to(torch.int32))
                 H_s.append(rs); H_e.append(re); H_id.append(full_all[ah, hsel])
@@ -1098,7 +1135,7 @@ class Pipeline:
                     outs_r = torch.stack(outs_r)                     # [A - a0, active, 8]
                 # (all adapters at once: a loop over the 196 sequences of a barcode panel is ~2 000 tiny launches a round)
                 rec_all[a0:, act] = outs_r
-                full_all[a0:, act] = torch.nan_to_num(identity_of(outs_r), nan=0.0)
+                full_all[a0:, act] = al.middle_hits(outs_r.contiguous(), p.middle_threshold)[0] if fused else torch.nan_to_num(identity_of(outs_r), nan=0.0)
         self.stats["pairs_middle"] += n_align
         self.stats["pairs_middle_speculative"] = self.stats.get("pairs_middle_speculative", 0) + n_spec
         if not H_read:

@@ -513,6 +513,12 @@ int pc_readset_load_gz_range(const char *path, int64_t begin, int64_t end, pc_re
  *   behaviour and messages. */
 typedef struct pc_gzstream pc_gzstream;
 int pc_gzstream_open(const char *path, pc_gzstream **out);
+/* One rank's share of a multi-member gzip file WITHOUT sizes (`cat *.fastq.gz`): pc_gz_member_start = the first member that
+ * starts at or after compressed byte pos (validated: the stream behind the magic inflates to its end and CRC-32 / ISIZE agree;
+ * the file's size when there is none); pc_gzstream_open_range = the stream of pc_gzstream_open over the members in
+ * [begin, end) of the compressed bytes (both member starts; end <= 0: to the end of the file). */
+int pc_gz_member_start(const char *path, int64_t pos, int64_t *member_start);
+int pc_gzstream_open_range(const char *path, int64_t begin, int64_t end, pc_gzstream **out);
 int pc_gzstream_next(pc_gzstream *s, int64_t target_bytes, int64_t min_reads, pc_readset **out, int *eof);
 void pc_gzstream_close(pc_gzstream *s);
 

@@ -21,7 +21,7 @@ EXPORTS = [
     "pc_readset_is_rna", "pc_readset_load_many", "pc_readset_file_index", "pc_readset_write",
     "pc_readset_load_segment", "pc_readset_write_at", "pc_io_set_thread_limit", "pc_pack_reads", "pc_unpack_device", "pc_fastq_find_record", "pc_readset_write_sizes", "pc_readset_write_shared",
     "pc_readset_compress", "pc_gzimage_sizes", "pc_gzimage_write", "pc_gzimage_free", "pc_gz_finish", "pc_gzip_file",
-    "pc_gzstream_open", "pc_gzstream_next", "pc_gzstream_close", "pc_prefilter_packed", "pc_unpack_windows", "pc_prefilter_defer_count", "pc_prefilter_overflowed", "pc_trim_windows", "pc_middle_hits", "pc_group_survivors", "pc_round_consume",
+    "pc_gzstream_open", "pc_gzstream_next", "pc_gzstream_close", "pc_gz_member_start", "pc_gzstream_open_range", "pc_prefilter_packed", "pc_unpack_windows", "pc_prefilter_defer_count", "pc_prefilter_overflowed", "pc_trim_windows", "pc_middle_hits", "pc_group_survivors", "pc_round_consume",
     "pc_gz_sized_size", "pc_gz_sized_find_record", "pc_readset_load_gz_range",
 ]
 
@@ -199,6 +199,10 @@ def load_library():
     L.pc_gzip_file.restype = c_int
     L.pc_gzstream_open.argtypes = [c_cp, ctypes.POINTER(c_vp)]
     L.pc_gzstream_open.restype = c_int
+    L.pc_gzstream_open_range.argtypes = [c_cp, ctypes.c_int64, ctypes.c_int64, ctypes.POINTER(c_vp)]
+    L.pc_gzstream_open_range.restype = c_int
+    L.pc_gz_member_start.argtypes = [c_cp, ctypes.c_int64, ctypes.POINTER(ctypes.c_int64)]
+    L.pc_gz_member_start.restype = c_int
     L.pc_gzstream_next.argtypes = [c_vp, c_i64, c_i64, ctypes.POINTER(c_vp), ctypes.POINTER(c_int)]
     L.pc_gzstream_next.restype = c_int
     L.pc_gzstream_close.argtypes = [c_vp]

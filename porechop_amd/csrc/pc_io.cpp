@@ -957,6 +957,7 @@ struct pc_gzstream {
     RawBuf pending;                      // inflated bytes not yet handed out (starts at a record start)
     bool eof = false;                    // the producer's last buffer has been taken
     int inflate_threads = 1;
+    int64_t range_begin = 0, range_end = 0;   // compressed bytes [begin, end) of the file (member starts); end 0 = to the end of the file
     ~pc_gzstream()
     {
         { std::lock_guard<std::mutex> lk(mu); stop = true; }
@@ -1300,14 +1301,17 @@ void gz_produce(pc_gzstream *s)
     if (fd < 0) { finish(false); return; }
     struct stat st;
     if (fstat(fd, &st) != 0 || st.st_size <= 0) { close(fd); finish(false); return; }
-    const size_t size = (size_t)st.st_size;
-    void *m = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
+    const size_t map_size = (size_t)st.st_size;
+    // (a byte range of the file -- pc_gzstream_open_range: the members between two member starts, one rank's share of a
+    // sharded run -- is the same stream with its beginning and end moved)
+    const size_t size = (s->range_end > 0 && (size_t)s->range_end < map_size) ? (size_t)s->range_end : map_size;
+    void *m = mmap(nullptr, map_size, PROT_READ, MAP_PRIVATE, fd, 0);
     close(fd);
     if (m == MAP_FAILED) { finish(false); return; }
-    madvise(m, size, MADV_SEQUENTIAL);
+    madvise(m, map_size, MADV_SEQUENTIAL);
     const unsigned char *base = (const unsigned char *)m;
     bool ok = true;
-    size_t at = 0;
+    size_t at = (size_t)std::max<int64_t>(0, std::min<int64_t>(s->range_begin, (int64_t)size));
     // ---- members that carry their size: batches of about kGzBuffer inflated bytes, several threads -----------------
     while (ok && at < size) {
         struct Member { size_t in, in_n, out, out_n; uint32_t crc; };
@@ -1342,7 +1346,7 @@ void gz_produce(pc_gzstream *s)
         for (auto &x : th) x.join();
         if (!good.load()) { ok = false; break; }
         at = p;
-        if (total && !push(std::move(buf))) { munmap(m, size); finish(false); return; }
+        if (total && !push(std::move(buf))) { munmap(m, map_size); finish(false); return; }
     }
     // ---- the rest (all of an ordinary .gz file): zlib's inflate, member after member -------------------------------
     if (ok && at < size) {
@@ -1370,7 +1374,7 @@ void gz_produce(pc_gzstream *s)
             }
             return true;
         };
-        if (!take_ahead()) { inflateEnd(&zs); spec.reset(); munmap(m, size); finish(false); return; }
+        if (!take_ahead()) { inflateEnd(&zs); spec.reset(); munmap(m, map_size); finish(false); return; }
         size_t discard = 0;                               // inflated bytes of the current member that were handed over already
         while (ok && !ended) {
             if (!in_member && !discard) {
@@ -1378,13 +1382,13 @@ void gz_produce(pc_gzstream *s)
                 const size_t header = pcz::gzip_header_len(base + at, size - at);
                 size_t data_at = at + header, handed = 0;
                 const int one = header ? oneshot_member(base, size, &data_at, push, &handed) : kOneShotNotTried;
-                if (one == kOneShotFailed) { if (s->stop) { inflateEnd(&zs); spec.reset(); munmap(m, size); finish(false); return; } ok = false; break; }
+                if (one == kOneShotFailed) { if (s->stop) { inflateEnd(&zs); spec.reset(); munmap(m, map_size); finish(false); return; } ok = false; break; }
                 if (one == kOneShotOutOfRoom) discard = handed;
                 if (one == kOneShotDone) {
                     at = data_at;
                     while (at < size && base[at] == 0) ++at;
                     if (at >= size) { ended = true; break; }
-                    if (!take_ahead()) { inflateEnd(&zs); spec.reset(); munmap(m, size); finish(false); return; }
+                    if (!take_ahead()) { inflateEnd(&zs); spec.reset(); munmap(m, map_size); finish(false); return; }
                     continue;
                 }
             }
@@ -1426,14 +1430,14 @@ void gz_produce(pc_gzstream *s)
                 discard -= drop;
             }
             if (!in_member) discard = 0;
-            if (!buf.empty() && !push(std::move(buf))) { inflateEnd(&zs); spec.reset(); munmap(m, size); finish(false); return; }
+            if (!buf.empty() && !push(std::move(buf))) { inflateEnd(&zs); spec.reset(); munmap(m, map_size); finish(false); return; }
             buf = Bytes();
-            if (spec && ok && !ended && !in_member && !take_ahead()) { inflateEnd(&zs); spec.reset(); munmap(m, size); finish(false); return; }
+            if (spec && ok && !ended && !in_member && !take_ahead()) { inflateEnd(&zs); spec.reset(); munmap(m, map_size); finish(false); return; }
         }
         spec.reset();
         inflateEnd(&zs);
     }
-    munmap(m, size);
+    munmap(m, map_size);
     finish(ok);
 }
 
@@ -1476,6 +1480,92 @@ int pc_gzstream_open(const char *path, pc_gzstream **out)
     s->producer = std::thread(gz_produce, s);
     *out = s;
     return PC_OK;
+}
+
+// The same stream over the members that lie in [begin, end) of the file's COMPRESSED bytes (both member starts, as
+// pc_gz_member_start finds them; end <= 0: to the end of the file): one rank's share of a gzip file that is not made of
+// sized members -- `cat *.fastq.gz`, the way a run's many small files usually become one.
+int pc_gzstream_open_range(const char *path, int64_t begin, int64_t end, pc_gzstream **out)
+{
+    if (!path || !out || begin < 0) return PC_ERR_BAD_ARG;
+    *out = nullptr;
+    FILE *f = fopen(path, "rb");
+    if (!f) return PC_ERR_BAD_ARG;
+    unsigned char magic[3] = {0, 0, 0};
+    const bool at_member = fseeko(f, (off_t)begin, SEEK_SET) == 0 && fread(magic, 1, 3, f) == 3 && magic[0] == 0x1f && magic[1] == 0x8b && magic[2] == 8;
+    fclose(f);
+    if (!at_member) return PC_ERR_UNSUPPORTED_SCORES;
+    pc_gzstream *s = new pc_gzstream();
+    s->path = path;
+    s->range_begin = begin; s->range_end = end > 0 ? end : 0;
+    s->inflate_threads = std::max(1, usable_threads() / 2);
+    s->producer = std::thread(gz_produce, s);
+    *out = s;
+    return PC_OK;
+}
+
+// The first gzip member that starts at or after byte `pos` of the file (the file's size when there is none): a candidate is
+// where the member magic stands (1f 8b 08 + a flag byte without reserved bits); it IS a member start when the deflate stream
+// behind it inflates to its end and the trailer's CRC-32 and ISIZE agree with what came out (a candidate inside compressed
+// data fails within a few hundred bytes; passing the check by accident takes a 64-bit coincidence).  Lets the ranks of a
+// sharded run cut an ordinary multi-member gzip file at member boundaries without anyone inflating all of it.
+int pc_gz_member_start(const char *path, int64_t pos, int64_t *member_start)
+{
+    if (!path || !member_start || pos < 0) return PC_ERR_BAD_ARG;
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) return PC_ERR_BAD_ARG;
+    struct stat st;
+    if (fstat(fd, &st) != 0 || st.st_size <= 0) { close(fd); return PC_ERR_UNSUPPORTED_SCORES; }
+    const size_t size = (size_t)st.st_size;
+    if ((size_t)pos >= size) { close(fd); *member_start = (int64_t)size; return PC_OK; }
+    void *m = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
+    close(fd);
+    if (m == MAP_FAILED) return PC_ERR_UNSUPPORTED_SCORES;
+    const unsigned char *base = (const unsigned char *)m;
+    int rc = PC_OK;
+    if (!(base[0] == 0x1f && base[1] == 0x8b && base[2] == 8)) rc = PC_ERR_UNSUPPORTED_SCORES;
+    int64_t found = (int64_t)size;
+    if (rc == PC_OK && pos == 0) found = 0;
+    if (rc == PC_OK && pos > 0) {
+        z_stream zs;
+        memset(&zs, 0, sizeof zs);
+        if (inflateInit2(&zs, -15) != Z_OK) rc = PC_ERR_BAD_ARG;
+        std::vector<unsigned char> outb((size_t)1 << 20);
+        for (size_t p = (size_t)pos; rc == PC_OK && p + 18 < size; ) {
+            const unsigned char *q = (const unsigned char *)memchr(base + p, 0x1f, size - 18 - p);
+            if (!q) break;
+            p = (size_t)(q - base);
+            if (!(q[1] == 0x8b && q[2] == 8 && (q[3] & 0xE0) == 0)) { ++p; continue; }
+            const size_t header = pcz::gzip_header_len(q, size - p);
+            bool good = false;
+            if (header && inflateReset(&zs) == Z_OK) {
+                size_t at = p + header;
+                uint32_t crc = 0;
+                uint64_t have = 0;
+                for (;;) {
+                    zs.next_in = (Bytef *)(base + at); zs.avail_in = (uInt)std::min<size_t>(size - at, (size_t)1 << 30);
+                    const size_t in0 = zs.avail_in;
+                    zs.next_out = outb.data(); zs.avail_out = (uInt)outb.size();
+                    const int r = inflate(&zs, Z_NO_FLUSH);
+                    const size_t made = outb.size() - zs.avail_out;
+                    crc = pcz::crc_update(crc, outb.data(), made);
+                    have += made;
+                    at += in0 - zs.avail_in;
+                    if (r == Z_STREAM_END) {
+                        good = at + pcz::kTrailer <= size && pcz::get32(base + at) == crc && pcz::get32(base + at + 4) == (uint32_t)have;
+                        break;
+                    }
+                    if (r != Z_OK || (made == 0 && in0 == zs.avail_in)) break;
+                }
+            }
+            if (good) { found = (int64_t)p; break; }
+            ++p;
+        }
+        inflateEnd(&zs);
+    }
+    if (rc == PC_OK) *member_start = found;
+    munmap(m, size);
+    return rc;
 }
 
 // The next block: the records that start before the first record start at or after target_bytes of the bytes not yet

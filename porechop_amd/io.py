@@ -51,6 +51,15 @@ def fastq_record_start(path, byte_pos):
     return int(out.value) if rc == 0 else None
 
 
+def gz_member_start(path, pos):
+    """First gzip member that starts at or after COMPRESSED byte pos (validated by inflating it; the file's size when there is
+    none), or None when the file is not a gzip file: pc_gz_member_start."""
+    lib = load_library()
+    out = ctypes.c_int64()
+    rc = lib.pc_gz_member_start(str(path).encode(), int(pos), ctypes.byref(out))
+    return int(out.value) if rc == 0 else None
+
+
 def gz_sized_size(path):
     """Inflated size of a gzip file made of sized members only (this library's output; bgzip), else None: pc_gz_sized_size."""
     lib = load_library()
@@ -117,11 +126,17 @@ class GzImage:
 class GzStream:
     """A gzip FASTQ file as a stream of ReadSet blocks (pc_gzstream_*): inflated ahead of the caller by a producer thread."""
 
-    def __init__(self, path):
+    def __init__(self, path, begin=None, end=None):
+        """begin / end: only the members in [begin, end) of the COMPRESSED bytes (member starts, gz_member_start; end None =
+        to the end of the file): one rank's share of a multi-member gzip file without sizes."""
         self.lib = load_library()
         self.path = str(path)
         self._h = ctypes.c_void_p()
-        if self.lib.pc_gzstream_open(self.path.encode(), ctypes.byref(self._h)) != 0:
+        if begin is None:
+            rc = self.lib.pc_gzstream_open(self.path.encode(), ctypes.byref(self._h))
+        else:
+            rc = self.lib.pc_gzstream_open_range(self.path.encode(), int(begin), int(end) if end is not None else 0, ctypes.byref(self._h))
+        if rc != 0:
             self._h = None
             raise ValueError("not a gzip file: " + self.path)
 

@@ -648,10 +648,29 @@ def run_sharded(input_path, output, barcode_dir, opts: Options, device=None, ali
         # a gzip file of SIZED members (this package's own output; bgzip): positions are those of the inflated bytes, a rank
         # inflates only the members that hold its records (pc_gz_sized_find_record / pc_readset_load_gz_range); any other
         # gzip file cannot be cut without inflating all of it: not this route
-        from .io import gz_sized_record_start, gz_sized_size
+        from .io import gz_member_start, gz_sized_record_start, gz_sized_size
         size = gz_sized_size(input_path)
         if not size:
-            ok = False
+            # an ordinary multi-member gzip file (`cat *.fastq.gz`): cut at MEMBER starts of the compressed bytes -- rank r takes
+            # the members that start in its W-th (pc_gz_member_start validates a start by inflating the member behind it) and
+            # inflates them with its own cores (GzStream over that byte range); the members must hold whole records (they do when
+            # they were files).  ONE member: rank 0 gets all of it, the route still applies (the other ranks write nothing).
+            csize = os.path.getsize(input_path)
+            b0 = 0 if rank == 0 else gz_member_start(input_path, csize * rank // world)
+            b1 = csize if rank == world - 1 else gz_member_start(input_path, csize * (rank + 1) // world)
+            if b0 is None or b1 is None:
+                ok = False
+            elif b1 > b0:
+                try:
+                    gzs = GzStream(input_path, b0, b1)
+                    got = gzs.next(1 << 62, 0)
+                    gzs.close()
+                except ValueError:
+                    got = False
+                if got is False:
+                    ok = False
+                else:
+                    rs = got                      # (None: members without a record)
         else:
             b0 = 0 if rank == 0 else gz_sized_record_start(input_path, size * rank // world)
             b1 = size if rank == world - 1 else gz_sized_record_start(input_path, size * (rank + 1) // world)

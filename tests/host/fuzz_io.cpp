@@ -266,6 +266,33 @@ int main(int argc, char **argv)
         }
     }
     {
+        // the members of the `cat` layout over W ranks: cuts at validated member starts of the compressed bytes
+        // (pc_gz_member_start), every share through the stream over that byte range (pc_gzstream_open_range)
+        const int64_t csize = (int64_t)slurp(cat).size();
+        for (int world : {1, 2, 5}) {
+            std::vector<int64_t> cuts{0};
+            for (int r = 1; r < world; ++r) {
+                int64_t at = -1;
+                CHECK(pc_gz_member_start(cat.c_str(), csize * r / world, &at) == PC_OK && at >= csize * r / world && at <= csize, "member start %d/%d: %lld", r, world, (long long)at);
+                cuts.push_back(at);
+            }
+            cuts.push_back(csize);
+            Reads all;
+            for (int r = 0; r < world; ++r) {
+                if (cuts[(size_t)r + 1] <= cuts[(size_t)r]) continue;
+                pc_gzstream *gs = nullptr;
+                CHECK(pc_gzstream_open_range(cat.c_str(), cuts[(size_t)r], cuts[(size_t)r + 1], &gs) == PC_OK, "open range %d of %d", r, world);
+                if (!gs) continue;
+                pc_readset *rs = nullptr;
+                int eof = 0;
+                CHECK(pc_gzstream_next(gs, (int64_t)1 << 60, 0, &rs, &eof) == PC_OK, "range %d of %d", r, world);
+                if (rs) { append(all, reads_of(rs)); pc_readset_free(rs); }
+                pc_gzstream_close(gs);
+            }
+            CHECK(all == want, "member ranges of %d ranks (%zu reads)", world, all.name.size());
+        }
+    }
+    {
         Reads seg;
         CHECK(load_segments(plain, 1 << 18, &seg) == PC_OK && seg == want, "segments (%zu reads)", seg.name.size());
         for (int k = 0; k < 50; ++k) {

@@ -324,3 +324,98 @@ def test_streamed_fasta_input_equals_the_whole_file_run(tmp_path, monkeypatch):
             files[blocks] = readgen.output_md5s(target)
         assert files["5000"] == files[None] and files["40000"] == files[None], (k, files)
     assert took.count(True) >= 2 * len(FASTA_RUNS)                    # the small-block runs really streamed
+
+
+# ---- an ordinary multi-member gzip input (`cat *.fastq.gz`, no sizes) over the ranks: cut at member starts ------------------
+CATGZ_RUNS = [("o:out.fastq", []), ("b", []), ("o:out.fastq.gz", ["--no_split"])]
+
+
+def _catgz_input(path):
+    """120 reads as 17 gzip members of whole records, zero padding between some of them (what concatenated files look like)."""
+    import gzip
+    import random
+    from tests import readgen
+    rng = random.Random(5)
+    reads = readgen.native_reads(91, 120, barcodes=(3, 7, 11))
+    cuts = sorted(rng.sample(range(1, 120), 16))
+    blob = b""
+    for a, b in zip([0] + cuts, cuts + [120]):
+        blob += gzip.compress(readgen.fastq_text(reads[a:b]).encode(), rng.choice([1, 6, 9])) + b"\0" * rng.choice([0, 0, 19, 512])
+    with open(path, "wb") as f:
+        f.write(blob)
+
+
+def _catgz_worker(rank, world, port, workdir, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle.oracle import Oracle
+    from porechop_amd import runner
+    from tests import readgen
+    from tests.cpu_aligner import OracleAligner
+    from tests.runner_cases import options_from_argv
+    oracle = Oracle()
+    seen, out, shares = [], {}, {}
+    orig = runner.run_sharded
+
+    def spy(*a, **kw):
+        r = orig(*a, **kw)
+        seen.append(r is not None)
+        return r
+    runner.run_sharded = spy
+    inp = os.path.join(workdir, "cat.fastq.gz")
+    for k, (mode, argv) in enumerate(CATGZ_RUNS):
+        opts = options_from_argv(argv)
+        work = os.path.join(workdir, "cg_run%d" % k)
+        if rank == 0:
+            os.makedirs(work)
+        dist.barrier()
+        target = os.path.join(work, "bins" if mode == "b" else mode[2:])
+        kw = {"options": opts, "aligner": OracleAligner(oracle, opts.scoring_scheme)}
+        res = runner.run(inp, barcode_dir=target, **kw) if mode == "b" else runner.run(inp, output=target, **kw)
+        dist.barrier()
+        out[k] = readgen.output_md5s(target) if rank == 0 else {}
+        shares[k] = (len(res.start_trim), res.n_reads)
+    q.put((rank, out, shares, seen))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_concatenated_gzip_input_equals_the_single_process_run(tmp_path, world):
+    from oracle.oracle import Oracle
+    from porechop_amd import runner
+    from tests import readgen
+    from tests.cpu_aligner import OracleAligner
+    from tests.runner_cases import options_from_argv
+    inp = str(tmp_path / "cat.fastq.gz")
+    _catgz_input(inp)
+    oracle = Oracle()
+    want = {}
+    for k, (mode, argv) in enumerate(CATGZ_RUNS):
+        opts = options_from_argv(argv)
+        target = str(tmp_path / ("single%d" % k) / ("bins" if mode == "b" else mode[2:]))
+        os.makedirs(os.path.dirname(target))
+        kw = {"options": opts, "aligner": OracleAligner(oracle, opts.scoring_scheme)}
+        res = runner.run(inp, barcode_dir=target, **kw) if mode == "b" else runner.run(inp, output=target, **kw)
+        assert res.n_reads == 120
+        want[k] = readgen.output_md5s(target)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_catgz_worker, args=(r, world, port, str(tmp_path), q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(world):
+        rank, out, shares, seen = q.get(timeout=900)
+        got[rank] = (out, shares, seen)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for k in range(len(CATGZ_RUNS)):
+        assert got[0][0][k] == want[k], (k, got[0][0][k], want[k])
+        mine = [got[r][1][k][0] for r in range(world)]
+        assert sum(mine) == 120 and max(mine) < 120, mine                   # no rank inflated every member
+    assert all(all(got[r][2]) and len(got[r][2]) == len(CATGZ_RUNS) for r in range(world))   # every run took the sharded route

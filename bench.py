@@ -1725,7 +1725,10 @@ def compact_line(full):
                              if isinstance(v, dict) else _r(v)) for k, v in dr.items()}
     out["legs"] = legs
     line = json.dumps(out, separators=(",", ":"))
-    for victim in (("dropin", "threads_1", "phase_s"), ("cpu_baseline", "b1_cli", "threads_1", "phase_s"), ("config", "ms_per_step_by_rank")):
+    flat_nominal = [("config", k) for k in list(out["config"]) if k.endswith("_valu_frac_nominal")]
+    for victim in [("roofline", "valu_nominal_is"), ("legs", "configs1", "traffic_scope")] + flat_nominal + \
+            [("dropin", "threads_1", "phase_s"), ("cpu_baseline", "b1_cli", "threads_1", "phase_s"), ("config", "ms_per_step_by_rank"),
+             ("dropin", "threads_16", "phase_s"), ("cpu_baseline", "b1_cli", "threads_16", "phase_s")]:
         if len(line) <= 7600:
             break
         d = out

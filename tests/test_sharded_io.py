@@ -41,10 +41,24 @@ def test_segments_of_any_rank_count_concatenate_to_the_file(tmp_path):
     assert fastq_record_start(p, size + 5) == size
     assert fastq_record_start(str(tmp_path / "reads.fastq"), 1) == len("@read0 some description\n") + 2 * (whole.lengths[0] + 1) + 2
     whole.close()
+    # a plain FASTA file is cut where a line begins with '>' (round 6); anything else is not streamable: the caller falls back
     fa = str(tmp_path / "reads.fasta")
     with open(fa, "w") as f:
-        f.write(">a\nACGT\n")
-    assert fastq_record_start(fa, 3) is None                      # not a plain FASTQ: the caller falls back
+        f.write(">a\nACGT\n>b\nAC\nGT\n>c\nT\n")
+    assert fastq_record_start(fa, 0) == 0 and fastq_record_start(fa, 3) == 8 and fastq_record_start(fa, 9) == 17
+    assert fastq_record_start(fa, 18) == 22 and fastq_record_start(fa, 99) == 22          # no header left: the file's size
+    got = []
+    pos = 0
+    while pos < 22:
+        rs, nxt = ReadSet.segment(fa, pos, 5)
+        assert rs is not None and not rs.is_fastq and nxt > pos
+        got += [(rs.name(i), rs.seq(i)) for i in range(rs.count)]
+        pos = nxt
+    assert got == [("a", "ACGT"), ("b", "ACGT"), ("c", "T")]
+    other = str(tmp_path / "notes.txt")
+    with open(other, "w") as f:
+        f.write("not reads\n")
+    assert fastq_record_start(other, 3) is None
 
 
 def test_sizes_and_shared_spans_rebuild_the_single_writers_files(tmp_path):

@@ -93,7 +93,7 @@ struct pc_ctx {
     std::vector<int> ad_len, ad_window, ad_span;
     bool panel_dirty = true;
     DevBuf d_ad_codes, d_ad_len, d_ad_window, d_ad_span;
-    DevBuf d_slab, d_fin, d_k1, d_woff2, d_wlen2, d_col0, d_ntot, d_frow, d_fscore, d_tcols, d_perm, d_bucket_cnt, d_bucket_slot[2], d_err;
+    DevBuf d_slab, d_fin, d_k1, d_woff2, d_wlen2, d_col0, d_ntot, d_frow, d_fscore, d_tcols, d_perm, d_bucket_cnt, d_bucket_slot[2], d_walk, d_err;
     // the tile table lives in one of two slots: a new table is built (on the context's own stream) in the slot
     // the scans two tables ago used, so building never waits for the scans in flight on the current one
     DevBuf d_tiles_slot[2], d_runs_slot[2];
@@ -602,6 +602,12 @@ bool trace16_plan(const pc_ctx *c, int rows, int cols, pcb::F16Plan *out)
     return true;
 }
 
+bool split_walk()
+{
+    static const bool on = [] { const char *e = getenv("PC_SPLIT_WALK"); return e && *e && *e != '0'; }();
+    return on;
+}
+
 int launch_traced(const pc_ctx *c, pck::ScanArgs &a, const Group &g, int grid, hipStream_t stream)
 {
     pcb::F16Plan fp;
@@ -612,8 +618,24 @@ int launch_traced(const pc_ctx *c, pck::ScanArgs &a, const Group &g, int grid, h
             return (e ? atoi(e) : 0) | ((r && *r && *r != '0') ? 4 : 0);
         }();
         a.debug = dbg;
+        // PC_SPLIT_WALK=1: the tracebacks as launches of their own (pck::walk_kernel), behind the scan of `grid` tiles at a time
+        // -- a walk's slab is its scan block's, so a launch covers at most as many tiles as it has blocks.  The request region
+        // of this group was reserved by pc_scan_device (walk_tiles_of).
+        if (split_walk() && !dbg && a.walk_req) {
+            const int ntiles = a.ntiles;
+            const pck::Tile *tiles = a.tiles;
+            for (int first = 0; first < ntiles; first += grid) {
+                const int cnt = std::min(grid, ntiles - first);
+                a.tiles = tiles + first; a.ntiles = cnt;
+                if (pck::launch_trace16(a, g.rows, cnt, stream) || pck::launch_walk(a, g.rows, cnt, stream)) return 1;
+            }
+            a.tiles = tiles; a.ntiles = ntiles;
+            return 0;
+        }
+        a.walk_req = nullptr; a.walk_req_tile = nullptr;
         return pck::launch_trace16(a, g.rows, grid, stream);
     }
+    a.walk_req = nullptr; a.walk_req_tile = nullptr;
     return pck::launch_trace(a, g.rows, g.pad, grid, stream);
 }
 
@@ -764,7 +786,7 @@ void pc_destroy(pc_ctx *c)
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     DevBuf *bufs[] = {&c->d_ad_codes, &c->d_ad_len, &c->d_ad_window, &c->d_ad_span, &c->d_tiles_slot[0], &c->d_tiles_slot[1],
                       &c->d_runs_slot[0], &c->d_runs_slot[1], &c->d_slab, &c->d_fin, &c->d_k1, &c->d_woff2,
-                      &c->d_wlen2, &c->d_col0, &c->d_ntot, &c->d_frow, &c->d_fscore, &c->d_tcols, &c->d_perm, &c->d_bucket_cnt, &c->d_bucket_slot[0], &c->d_bucket_slot[1], &c->d_err, &c->d_arena,
+                      &c->d_wlen2, &c->d_col0, &c->d_ntot, &c->d_frow, &c->d_fscore, &c->d_tcols, &c->d_perm, &c->d_bucket_cnt, &c->d_bucket_slot[0], &c->d_bucket_slot[1], &c->d_walk, &c->d_err, &c->d_arena,
                       &c->d_woff, &c->d_wlen, &c->d_out, &c->d_red_slot[0], &c->d_red_slot[1], &c->d_work, &c->d_units, &c->d_pf_tables, &c->d_pf_meta, &c->d_sd_bitmaps, &c->d_sd_first,
                       &c->d_sd_entries, &c->d_sd_meta, &c->d_sd_eq, &c->d_sd_cand, &c->d_sd_count, &c->d_slow_ad, &c->d_slow_state,
                       &c->d_slow_trace};
@@ -871,6 +893,19 @@ int pc_scan_device(pc_ctx *c, const void *d_arena, const int64_t *d_win_off, con
         if (c->groups[gi].two_pass) { slab_off[gi] = slab_single; fin_off[gi] = fin_single; }
     slab_bytes += slab_single; fin_bytes += fin_single;
     if ((rc = c->d_slab.ensure(slab_bytes + 256)) || (rc = c->d_fin.ensure(fin_bytes + 256))) return rc;
+    // walk requests (PC_SPLIT_WALK): a region of min(grid, tiles) tiles per group; the groups of a call may run side by side
+    std::vector<size_t> walk_off(c->groups.size(), 0);
+    size_t walk_tiles = 0;
+    if (split_walk()) {
+        for (size_t gi = 0; gi < c->groups.size(); ++gi) {
+            const Group &g = c->groups[gi];
+            const int cols = g.two_pass ? g.max_window + 1 : max_len;
+            const int grid = grid_for(c, g, g.tile_count, cols, nullptr);
+            walk_off[gi] = walk_tiles;
+            walk_tiles += (size_t)std::min<size_t>((size_t)grid, g.tile_count);
+        }
+        if ((rc = c->d_walk.ensure(walk_tiles * (2 * 64 * 16 + 4) + 256))) return rc;
+    }
     // (PC_NO_TRACE_FORK=1 keeps them on one stream: a profile whose per-kernel durations add up to the step)
     static const bool no_trace_fork = [] { const char *e = getenv("PC_NO_TRACE_FORK"); return e && *e && *e != '0'; }();
     const bool fork = n_single >= 2 && stream != c->stream && !no_trace_fork;
@@ -976,6 +1011,10 @@ int pc_scan_device(pc_ctx *c, const void *d_arena, const int64_t *d_win_off, con
         a.ad_span = c->d_ad_span.as<int32_t>();
         a.ad_window = c->d_ad_window.as<int32_t>();
         a.win_by_out = 0;
+        if (split_walk() && walk_tiles) {
+            a.walk_req = (int32_t *)c->d_walk.p + walk_off[gidx] * 128 * 4;
+            a.walk_req_tile = (int32_t *)((char *)c->d_walk.p + walk_tiles * 2048) + walk_off[gidx];
+        }
         size_t stride;
         if (!g.two_pass) {
             a.win_off = d_win_off; a.win_len = d_win_len;

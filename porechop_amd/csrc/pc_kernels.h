@@ -48,6 +48,9 @@ struct ScanArgs {
     const Tile *tiles;
     int32_t ntiles;
     int32_t *out;                // trace kernels: 8 x int32 per pair; score kernels: 4 x int32 per pair
+    int32_t *walk_req;           // optional: [ntiles][2][64][4] -- the traced kernel leaves every pair's end cell (score, I, J, tie) here
+    int32_t *walk_req_tile;      // and the tile's trace-free prefix, and walk_kernel (one block per tile, a launch of its own) does the
+                                 // traceback + digest: the scan's waves never sit through a walk's dependent loads
     uint32_t *slab;              // trace scratch: [grid][slab_cols][NW][64] dwords
     int64_t slab_stride;         // dwords per block
     int32_t slab_cols;
@@ -253,6 +256,7 @@ inline int pick_rows(int m_lo, int m_hi, bool *pad)
 int launch_trace(const ScanArgs &a, int rows, bool pad, int grid, void *stream);
 int launch_score(const ScanArgs &a, int rows, bool pad, int grid, void *stream);
 bool trace16_has(int rows);
+int launch_walk(const ScanArgs &a, int rows, int ntiles, void *stream);     // the tracebacks of a launch_trace16 launch that left requests
 int launch_trace16(const ScanArgs &a, int rows, int grid, void *stream, bool score_only = false);   // packed-fp16 traced scan (needs a.f16_*);
                                                                                    // score_only: its first pass (score records, no trace)
 

@@ -1204,6 +1204,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(R <= 30 ? PC
             if (have_hi) a.out[p_hi * TRACE_OUT_INTS + 4] = b_hi.score;
             continue;
         }
+        if (a.walk_req) {        // the walks run in a launch of their own (walk_kernel): leave the end cells
+            ((int4 *)a.walk_req)[((int64_t)t * 2 + 0) * 64 + lane] = make_int4(b_lo.score, b_lo.I, b_lo.J, b_lo.tie);
+            ((int4 *)a.walk_req)[((int64_t)t * 2 + 1) * 64 + lane] = make_int4(b_hi.score, b_hi.I, b_hi.J, b_hi.tie);
+            if (lane == 0) a.walk_req_tile[t] = notrace_upto;
+            continue;
+        }
 #ifdef PC_SLAB_OLD
         constexpr bool kGrouped = false;
 #else
@@ -1217,6 +1223,40 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(R <= 30 ? PC
 #undef PC_ROW16_FULL
 #undef PC_ROW16_FIRST
 #undef PC_ROW16_NOIND
+
+// ---------------------------------------------------------------------------------------------
+// The tracebacks of a traced launch as a launch of their own: one block (wave) per tile of that launch, tile t's slab at
+// block t's place.  A walk is a chain of dependent loads from memory no cache holds; inside the scan kernel a wave sits
+// through 40-60 of them with its 128 VGPRs of column state idle; here the waves are small (many per SIMD) and run beside the
+// next launch's scan.  Same code (traceback_pairs), same records.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void walk_kernel(ScanArgs a, int rows)
+{
+    const int t = blockIdx.x, lane = threadIdx.x;
+    const Tile tile = a.tiles[t];
+    const int NW = (rows + 3) >> 2;
+    const int m_lo = a.ad_len[tile.adapter_lo], m_hi = a.ad_len[tile.adapter_hi];
+    const int pad_lo = rows - m_lo, pad_hi = rows - m_hi;
+    const bool have_lo = lane < tile.count_lo, have_hi = lane < tile.count_hi;
+    const int64_t p_lo = (a.perm && have_lo) ? a.perm[tile.out_lo + lane] : tile.out_lo + lane;
+    const int64_t p_hi = (a.perm && have_hi) ? a.perm[tile.out_hi + lane] : tile.out_hi + lane;
+    const int64_t wi_lo = a.win_by_out ? p_lo : tile.win_lo + lane;
+    const int64_t wi_hi = a.win_by_out ? p_hi : tile.win_hi + lane;
+    const int n_lo = have_lo ? a.win_len[wi_lo] : 0, n_hi = have_hi ? a.win_len[wi_hi] : 0;
+    const int c0_lo = (have_lo && a.col0) ? a.col0[p_lo] : 0, c0_hi = (have_hi && a.col0) ? a.col0[p_hi] : 0;
+    const int4 r_lo = ((const int4 *)a.walk_req)[((int64_t)t * 2 + 0) * 64 + lane], r_hi = ((const int4 *)a.walk_req)[((int64_t)t * 2 + 1) * 64 + lane];
+    const Best b_lo = {r_lo.x, r_lo.y, r_lo.z, r_lo.w}, b_hi = {r_hi.x, r_hi.y, r_hi.z, r_hi.w};
+    const u32 *slab = a.slab + (int64_t)t * a.slab_stride;
+    traceback_pairs<false, true>(a, slab, rows, NW, lane, b_lo, b_hi, pad_lo, pad_hi, have_lo, have_hi, n_lo, n_hi, c0_lo, c0_hi, m_lo, m_hi,
+                                 p_lo, p_hi, a.walk_req_tile[t]);
+}
+
+int launch_walk(const ScanArgs &a, int rows, int ntiles, void *stream)
+{
+    if (ntiles <= 0) return 0;
+    hipLaunchKernelGGL(walk_kernel, dim3((unsigned)ntiles), dim3(64), 0, (hipStream_t)stream, a, rows);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
 
 // ---------------------------------------------------------------------------------------------
 // Planner between the two passes of a whole-read scan: bounded window ending at the max cell.

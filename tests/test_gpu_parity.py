@@ -3,6 +3,7 @@ bit-exactly -- ints and the printed identity decimals -- with
   * the committed goldens minted from the compiled reference (tests/golden/), and
   * the CPU oracle (oracle/pc_oracle.c) on seeded inputs.
 """
+import os
 import random
 
 import numpy as np
@@ -456,3 +457,20 @@ def test_leaving_the_packed_kernels_is_said_on_stderr():
     assert r.stderr.count("an adapter of 200 bases is longer than the 128") == 1, r.stderr[-2000:]
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=repo, env=dict(os.environ, PC_QUIET="1"))
     assert r.returncode == 0 and "plain-int32" not in r.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("switch", ["PC_TWO_PASS_ENDS", "PC_SPLIT_WALK"])
+def test_measured_and_shelved_variants_stay_exact(switch):
+    """The two-pass end scan and the tracebacks-as-their-own-launch variant (built, measured slower, left
+    behind an environment switch that is read once per process) must keep giving the reference's records: the recorded
+    reference calls and the synthetic goldens through each of them, in a process of its own."""
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    env[switch] = "1"
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-x", "-q", "-k",
+                        "recorded or synthetic or random_end_windows or modes_agree or ragged", "--deselect", os.path.abspath(__file__) + "::test_measured_and_shelved_variants_stay_exact"],
+                       capture_output=True, text=True, timeout=1500, env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "no tests ran" not in r.stdout, r.stdout[-500:]

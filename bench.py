@@ -1266,12 +1266,14 @@ def leg_end_to_end(dev, args):
             else:
                 os.environ["PC_STREAM_BLOCK_BYTES"] = old
         same = filecmp.cmp(out_s, out_w, shallow=False)
-        best = max(runs, key=lambda r: r["reads_per_s"])
+        # the MEDIAN of the three runs is the leg's number (the first run pays the page cache's first touch, the best one is luck)
+        best = sorted(runs, key=lambda r: r["reads_per_s"])[len(runs) // 2]
         return {"workload": "end to end: %d synthetic %d-bp reads (configs[3] shape) as a %.1f GB plain FASTQ file -> trimmed / split FASTQ "
                             "(%.1f GB) through porechop_amd.runner.run (streamed: ingest, scan and writing of successive 256 MB blocks overlap)"
                             % (n, L, in_bytes / 1e9, os.path.getsize(out_s) / 1e9),
                 "files_on": "tmpfs (/dev/shm)" if base.startswith("/dev/shm") else base + " (disk-backed, through the page cache)",
-                "reads_per_s": best["reads_per_s"], "wall_s": best["wall_s"], "runs": runs,
+                "reads_per_s": best["reads_per_s"], "wall_s": best["wall_s"], "runs": runs, "reads_per_s_is": "median of the runs",
+                "best_reads_per_s": max(r["reads_per_s"] for r in runs),
                 "whole_file_path": {"wall_s": dt_w, "reads_per_s": res_w.n_reads / dt_w,
                                     "stage_seconds": {k: round(v, 3) for k, v in res_w.seconds.items()}},
                 "streamed_output_identical_to_whole_file_output": bool(same),

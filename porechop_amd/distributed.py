@@ -3,8 +3,16 @@ alignment depends on exactly one read, so phases B and C need no exchange at all
 cross-read reduction in Porechop is the adapter-set presence table of phase A -- the max
 full-adapter identity per set and side over the check reads (nanopore_read.py:159,164), consumed
 at porechop.py:327 -- which is all-reduced with MAX (RCCL on GPUs, gloo in the CPU tests)."""
+import os
+
 import torch
 import torch.distributed as dist
+
+
+def _collective_needed(group=None):
+    """More than one rank -- or PC_DIST_FORCE_COLLECTIVES=1 (tests: a ONE-rank RCCL group on a single-GPU box still takes every
+    call through the RCCL API: initialisation with a device, float64 MAX, int64 MIN / all_gather on device tensors)."""
+    return dist.get_world_size(group) > 1 or os.environ.get("PC_DIST_FORCE_COLLECTIVES", "0") not in ("", "0")
 
 
 def shard_bounds(n_items, world, rank):
@@ -49,7 +57,7 @@ def _host_collectives(group=None):
 def reduce_presence(best_start, best_end, group=None):
     """MAX all-reduce of the [S] + [S] presence tables (in place on a stacked copy)."""
     table = torch.stack([best_start, best_end])
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if dist.is_available() and dist.is_initialized() and _collective_needed(group):
         if table.is_cuda and _host_collectives(group):
             host = table.cpu()
             dist.all_reduce(host, op=dist.ReduceOp.MAX, group=group)
@@ -61,7 +69,7 @@ def reduce_presence(best_start, best_end, group=None):
 
 def gather_in_order(local, group=None):
     """Concatenate per-rank 1-D/2-D tensors in rank order (= read order for contiguous shards)."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()) or not _collective_needed(group):
         return local
     world = dist.get_world_size(group)
     if local.is_cuda and _host_collectives(group):

@@ -175,3 +175,50 @@ def test_two_ranks_on_one_gpu_emit_the_configs4_leg_for_both_ranks():
     assert ft["host_threads_per_rank"] >= 1 and ft["reads_per_s"] > 0
     sf = d["legs"]["sharded_file"]
     assert sf["md5_equal"] is True and sum(sf["reads_by_rank"]) == 40000 and min(sf["reads_by_rank"]) > 0
+
+
+def test_the_rccl_branch_runs_on_this_box_with_one_rank():
+    """backend "nccl" IS RCCL on ROCm.  A single-GPU box cannot hold two RCCL ranks (one device per rank), but a ONE-rank group
+    still takes every call of porechop_amd.distributed through the RCCL API: process-group initialisation with a device id (as
+    bench.py does), the presence table's float64 MAX all-reduce in place on device tensors (the gloo route copies through the
+    host), int64 all_gather / MIN all-reduce of device-staged values, the padded all_gather of gather_in_order, a barrier.
+    Until a multi-GPU node runs it this is the only execution the branch gets; two ranks are covered over gloo above."""
+    code = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+os.environ["PC_DIST_FORCE_COLLECTIVES"] = "1"
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+from porechop_amd import distributed as D
+assert dist.get_backend() == "nccl" and not D._host_collectives()
+dev = torch.device("cuda", 0)
+bs = torch.rand(119, dtype=torch.float64, device=dev) * 100
+be = torch.rand(119, dtype=torch.float64, device=dev) * 100
+rs, re = D.reduce_presence(bs, be)
+assert rs.is_cuda and torch.equal(rs, bs) and torch.equal(re, be)
+x = torch.arange(12, dtype=torch.int32, device=dev).reshape(6, 2)
+assert torch.equal(D.gather_in_order(x), x)
+assert D.all_gather_ints([3, 1, 4], dev).tolist() == [[3, 1, 4]]
+assert D.all_agree(True, dev) is True and D.all_agree(False, dev) is False
+assert D.all_gather_objects({"a": 1}) == [{"a": 1}]
+# ... and the sharded route of the runner itself: one file in, one file out, every exchange over RCCL
+import hashlib, tempfile
+from porechop_amd import runner
+from tests import readgen
+work = tempfile.mkdtemp(prefix="pc_rccl_")
+inp = os.path.join(work, "in.fastq")
+open(inp, "w").write(readgen.fastq_text(readgen.native_reads(17, 300, barcodes=(1, 4, 9))))
+res = runner.run_sharded(inp, os.path.join(work, "sharded.fastq"), None, runner.Options(), device="cuda:0")
+assert res is not None and res.n_reads == 300
+dist.barrier()
+torch.cuda.synchronize()
+dist.destroy_process_group()
+one = runner.run(inp, output=os.path.join(work, "single.fastq"), options=runner.Options(), device="cuda:0")
+md5 = lambda p: hashlib.md5(open(p, "rb").read()).hexdigest()
+assert md5(os.path.join(work, "sharded.fastq")) == md5(os.path.join(work, "single.fastq")) and one.n_reads == 300
+print("rccl one-rank ok", torch.cuda.get_device_name(0))
+""" % REPO
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env, cwd=REPO)
+    assert r.returncode == 0 and "rccl one-rank ok" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]

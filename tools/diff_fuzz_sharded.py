@@ -2,8 +2,9 @@
 """tools/diff_fuzz.py with the runner side run by W processes over gloo (CPU; the oracle stands in for the GPUs): the reference
 CLI against porechop_amd.runner.run under torch.distributed with 2 ... 5 ranks, on random reads and options.  Inputs: one plain
 FASTQ file or one gzip file of sized members (the sharded route: every rank parses / inflates only its own share and writes its
-own span of the shared output files), and now and then a layout that cannot be cut (one gzip member, FASTA: every rank loads
-it, rank 0 writes).  The multi-GPU path cannot be run on hardware from here; this is its functional evidence.
+own span of the shared output files), plain FASTA (cut at '>' lines since round 6) and one gzip member (cut at member starts
+since round 6: a single member is all rank 0's).  The multi-GPU path cannot be run on hardware from here; this is its
+functional evidence (round 6: profiles/r06_diff_fuzz_sharded.txt).
     python tools/diff_fuzz_sharded.py [cases] [seed] [world] [--long]      (--long: reads of 100 kb and more among them)"""
 import io
 import os

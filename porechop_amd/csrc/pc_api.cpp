@@ -105,6 +105,10 @@ struct pc_ctx {
     // is filled by the next.  (No further streams: HIP maps streams onto four hardware queues, and a fifth
     // stream would share a queue with -- and serialise behind -- a caller's upload stream; measured.)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // further streams for the single-pass groups of one call (phase A: four small row classes beside the 24-mers' launch)
+    static constexpr int kForkStreams = 3;
+    hipStream_t fork_stream[kForkStreams] = {nullptr, nullptr, nullptr};
+    hipEvent_t fork_join[kForkStreams] = {nullptr, nullptr, nullptr};
     // host-API staging
     DevBuf d_arena, d_woff, d_wlen, d_out;
     // pc_phase_b_reduce: job / bin tables in two slots (pinned host staging + device copy each); a slot is reused
@@ -782,6 +786,10 @@ void pc_destroy(pc_ctx *c)
         if (c->red_done[i]) (void)hipEventDestroy(c->red_done[i]);
         if (c->h_red[i]) (void)hipHostFree(c->h_red[i]);
     }
+    for (int k = 0; k < pc_ctx::kForkStreams; ++k) {
+        if (c->fork_stream[k]) { (void)hipStreamSynchronize(c->fork_stream[k]); (void)hipStreamDestroy(c->fork_stream[k]); }
+        if (c->fork_join[k]) (void)hipEventDestroy(c->fork_join[k]);
+    }
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     DevBuf *bufs[] = {&c->d_ad_codes, &c->d_ad_len, &c->d_ad_window, &c->d_ad_span, &c->d_tiles_slot[0], &c->d_tiles_slot[1],
@@ -990,7 +998,27 @@ int pc_scan_device(pc_ctx *c, const void *d_arena, const int64_t *d_win_off, con
             return rc;
     }
 
-    for (const Group &g : c->groups) {
+    // Launch order: the single-pass groups smallest first, each on a stream of its own (up to 1 + kForkStreams + the caller's),
+    // the largest last -- a small row class (phase A: 80-470 tiles) occupies a fraction of the chip for the duration of ONE
+    // tile; enqueued behind the 24-mers' 17 000 tiles it waited for their last round and then ran alone, started beside them
+    // it costs nothing.  Two-pass groups follow in their own order.  (PC_FORK_STREAMS=0: two streams, table order, as before.)
+    static const bool wide_fork = [] { const char *e = getenv("PC_FORK_STREAMS"); return !(e && *e == '0'); }();
+    std::vector<size_t> order;
+    for (size_t gi = 0; gi < c->groups.size(); ++gi) if (!c->groups[gi].two_pass) order.push_back(gi);
+    if (fork && wide_fork)
+        std::stable_sort(order.begin(), order.end(), [&](size_t x, size_t y) { return c->groups[x].tile_count < c->groups[y].tile_count; });
+    for (size_t gi = 0; gi < c->groups.size(); ++gi) if (c->groups[gi].two_pass) order.push_back(gi);
+    bool fork_used[pc_ctx::kForkStreams] = {false, false, false};
+    bool ctx_stream_used = false;
+    int small_forked = 0, large_forked = 0;
+    if (fork && wide_fork) {
+        for (int k = 0; k < pc_ctx::kForkStreams; ++k) {
+            if (!c->fork_stream[k] && hipStreamCreateWithFlags(&c->fork_stream[k], hipStreamNonBlocking) != hipSuccess) return PC_ERR_NO_DEVICE;
+            if (!c->fork_join[k] && hipEventCreateWithFlags(&c->fork_join[k], hipEventDisableTiming) != hipSuccess) return PC_ERR_NO_DEVICE;
+        }
+    }
+    for (const size_t gi_ : order) {
+        const Group &g = c->groups[gi_];
         pck::ScanArgs a;
         memset(&a, 0, sizeof(a));
         a.arena = (const uint8_t *)d_arena;
@@ -1064,8 +1092,15 @@ int pc_scan_device(pc_ctx *c, const void *d_arena, const int64_t *d_win_off, con
                 return launch_traced(c, a2, g, grid, ps);
             };
             if (fork) {
-                hipStream_t ps = (forked & 1) ? c->stream : stream;
-                if (forked == 1) HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_fork, 0));
+                // groups that cannot fill the chip (fewer tiles than resident waves) take the further streams in turn and start
+                // first; the large ones alternate between the caller's stream and the context's as before (several large launches
+                // side by side only take each other's slots: measured 4.6 -> 4.7 ms on phase B's four row classes)
+                int lane;
+                if (wide_fork && (int64_t)g.tile_count < (int64_t)resident_waves(c, g)) lane = 2 + (small_forked++ % pc_ctx::kForkStreams);
+                else lane = (large_forked++ & 1);
+                hipStream_t ps = lane == 0 ? stream : lane == 1 ? c->stream : c->fork_stream[lane - 2];
+                if (lane == 1 && !ctx_stream_used) { HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_fork, 0)); ctx_stream_used = true; }
+                if (lane >= 2 && !fork_used[lane - 2]) { HIP_TRY(hipStreamWaitEvent(ps, c->ev_fork, 0)); fork_used[lane - 2] = true; }
                 ++forked;
                 if ((rc = run_group(ps))) return PC_ERR_NO_DEVICE;
             } else {
@@ -1219,9 +1254,14 @@ int pc_scan_device(pc_ctx *c, const void *d_arena, const int64_t *d_win_off, con
         }
     }
     if (fork) {
-        if (forked >= 2) {
+        if (ctx_stream_used) {
             HIP_TRY(hipEventRecord(c->ev_join, c->stream));
             HIP_TRY(hipStreamWaitEvent(stream, c->ev_join, 0));
+        }
+        for (int k = 0; k < pc_ctx::kForkStreams; ++k) {
+            if (!fork_used[k]) continue;
+            HIP_TRY(hipEventRecord(c->fork_join[k], c->fork_stream[k]));
+            HIP_TRY(hipStreamWaitEvent(stream, c->fork_join[k], 0));
         }
         if (fork_timed) { (void)hipEventRecord(fork_timer.e1, stream); c->timed.push_back(fork_timer); }
     }

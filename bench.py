@@ -1042,6 +1042,53 @@ def profile_traffic(leg, kernel, launches_per_step=None):
     return None
 
 
+def live_traffic(kernel_substring, leg="headline", steps=2, timeout_s=300):
+    """FETCH_SIZE + WRITE_SIZE of one kernel family measured NOW: `rocprofv3 --pmc <counter>` (each counter in a pass of its own,
+    no trace domain beside it: MI355X_MICROARCH.md's recipe) over a child that runs `steps` steps of `leg` and nothing else
+    (tools/run_leg.py; its first step is warm-up like every launch after it: the counters are per launch and do not care).
+    -> {"bytes_per_launch", "FETCH_SIZE", "WRITE_SIZE", "launches", "seconds"} or None (no rocprofv3, a failed pass: the line then
+    keeps the profile's figure).  KB as reported -> bytes; no x2 (see the comment at the call)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if not exe:
+        return None
+    t0 = time.perf_counter()
+    out = {}
+    launches = None
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        work = tempfile.mkdtemp(prefix="pc_live_pmc_", dir="/tmp")
+        try:
+            env = dict(os.environ, TMPDIR="/tmp")
+            for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+                env.pop(k, None)
+            r = subprocess.run([exe, "--pmc", counter, "--output-format", "csv", "-d", work, "-o", "pmc", "--", sys.executable,
+                                os.path.join(REPO, "tools", "run_leg.py"), leg, str(steps)], cwd="/tmp", env=env, capture_output=True,
+                               text=True, timeout=timeout_s)
+            files = glob.glob(os.path.join(work, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None
+            total, disp = 0.0, set()
+            with open(files[0]) as f:
+                for row in csv.DictReader(f):
+                    if kernel_substring in row["Kernel_Name"] and row["Counter_Name"] == counter:
+                        total += float(row["Counter_Value"]) * 1024.0
+                        disp.add(row["Dispatch_Id"])
+            if not disp:
+                return None
+            out[counter] = total / len(disp)
+            launches = len(disp)
+        except Exception:
+            return None
+        finally:
+            shutil.rmtree(work, ignore_errors=True)
+    return {"bytes_per_launch": out["FETCH_SIZE"] + out["WRITE_SIZE"], "FETCH_SIZE": out["FETCH_SIZE"], "WRITE_SIZE": out["WRITE_SIZE"],
+            "launches": launches, "seconds": time.perf_counter() - t0}
+
+
 def leg_host_buffers(dev, args):
     """The headline workload with the reads starting in (pinned) HOST memory: every step uploads all reads over PCIe again,
     in batches on a copy stream into two device buffers while the previous batch is being scanned on the compute stream
@@ -1690,7 +1737,9 @@ def compact_line(full):
         out["roofline"] = {"bound": roof.get("bound"), "kernel": (roof.get("kernel") or "").split(" ")[0],
                            "achieved": _r(roof.get("achieved")), "peak": roof.get("peak"), "unit": roof.get("unit"),
                            "frac": _r(roof.get("frac")), "traffic": _r(roof.get("traffic")),
-                           "traffic_measured_in_this_run": False, "traffic_source": (roof.get("traffic_source") or "").split(" ")[0] or None,
+                           "traffic_measured_in_this_run": bool(roof.get("traffic_measured_in_this_run")),
+                           "traffic_from_profile": _r(roof.get("traffic_from_profile")),
+                           "traffic_source": (roof.get("traffic_source") or "").split(" ")[0] or None,
                            "launches": roof.get("launches"), "avg_launch_ms": _r(roof.get("avg_launch_ms")),
                            "algorithmic_bytes_per_launch": _r(roof.get("algorithmic_bytes_per_launch")),
                            "valu_gcups": _r(_pick(roof, "valu", "achieved_gcups")), "valu_peak_gcups": _r(_pick(roof, "valu", "peak_gcups")),
@@ -1779,6 +1828,7 @@ def main():
     ap.add_argument("--chimera", type=float, default=0.01)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="0 disables the CPU baseline / parity legs")
     ap.add_argument("--no-extra", action="store_true", help="headline only (skip the configs[1] / configs[2] legs)")
+    ap.add_argument("--no-live-traffic", action="store_true", help="do not spawn the two rocprofv3 --pmc passes that measure roofline.traffic in this run")
     ap.add_argument("--cli-reads", type=int, default=2000, help="reads of the reference-CLI baseline (B1); 0 disables it and the drop-in leg")
     ap.add_argument("--dropin-reads", type=int, default=20000, help="reads of the drop-in leg (unchanged reference Python over the HIP library)")
     ap.add_argument("--dropin-threads", type=int, default=16, help="--threads of the drop-in leg's second run (the first uses 1)")
@@ -2016,6 +2066,17 @@ def main():
                 roof["traffic"] = profile_traffic("headline", "pc_spec_score" if jit else "scan_kernel<score>", launches / args.steps)
                 if roof["traffic"] is not None:
                     roof["traffic_source"] = _PROFILE.get("_path", "") + " (mean over this kernel's launches; FETCH_SIZE + WRITE_SIZE; same library sha1)"
+                # ... and measured IN THIS RUN where the box has rocprofv3: two --pmc passes (one counter each, nothing else enabled)
+                # over a child process that runs two headline steps and nothing else (tools/run_leg.py) -- the guide's recipe,
+                # spawned from here so that the driver's own line carries counters of the library it ran
+                if not args.no_extra and not args.no_live_traffic:
+                    live = live_traffic("pc_spec_score" if jit else "scan_kernel")
+                    if live:
+                        roof["traffic_from_profile"] = roof["traffic"]
+                        roof["traffic"] = live["bytes_per_launch"]
+                        roof["traffic_measured_in_this_run"] = True
+                        roof["traffic_live"] = live
+                        roof["traffic_source"] = "this-run (rocprofv3 --pmc FETCH_SIZE, then --pmc WRITE_SIZE, over `python tools/run_leg.py headline 2`, spawned by bench.py)"
         kern_ms = {k: v[0] / args.steps for k, v in timing.items()}
         srt = sorted(region_ms)
         pf = {"reads_per_s": total_reads * fsteps / dt_pf, "ms_per_step": dt_pf / fsteps * 1e3, "steps": fsteps,

@@ -1056,6 +1056,8 @@ def live_traffic(kernel_substring, leg="headline", steps=2, timeout_s=300):
     exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
     if not exe:
         return None
+    if any("rocprof" in os.environ.get(k, "").lower() for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB")):
+        return None                    # this run is itself being profiled: no profiler inside a profiler
     t0 = time.perf_counter()
     out = {}
     launches = None

@@ -413,12 +413,13 @@ int pc_readset_is_rna(const pc_readset *rs, int64_t i);
  * directory input of porechop/porechop.py:232-259; pc_readset_file_index()[i] = which path read i
  * came from. */
 int pc_readset_load_many(const char *const *paths, int npaths, pc_readset **out);
-/* Streaming ingest of a plain, regular 4-line FASTQ file: the records that start in [byte_begin, cut), where
+/* Streaming ingest of a plain, regular 4-line FASTQ file (or a plain FASTA file, cut where a line begins with '>'): the
+ * records that start in [byte_begin, cut), where
  * cut is the first record start at or after byte_begin + target_bytes (or the end of the file); *next_begin = cut.
  * Successive calls (byte_begin = the previous *next_begin, starting at 0) yield the reads of pc_readset_load in
  * the same order, a block at a time -- so that a run's memory is bounded by its blocks and ingest, scan and
- * writing of successive blocks overlap.  Returns PC_ERR_UNSUPPORTED_SCORES ("not streamable") for gzip, FASTA or
- * an irregular record: load the whole file with pc_readset_load then. */
+ * writing of successive blocks overlap.  Returns PC_ERR_UNSUPPORTED_SCORES ("not streamable") for gzip (see
+ * pc_gzstream_* below) or an irregular record: load the whole file with pc_readset_load then. */
 int pc_readset_load_segment(const char *path, int64_t byte_begin, int64_t target_bytes, int64_t *next_begin,
                             pc_readset **out);
 const int32_t *pc_readset_file_index(const pc_readset *rs);
@@ -449,11 +450,11 @@ int pc_readset_write_at(const pc_readset *rs, int64_t npieces, const int64_t *pi
                         const int32_t *piece_len, const int32_t *piece_number, const int32_t *piece_file, int nfiles,
                         const char *const *file_paths, int fastq, int64_t *file_pos);
 
-/* A sharded run (one process per GPU) over ONE plain FASTQ file: every rank parses only its own byte range and writes its
- * own span of the shared output files.
+/* A sharded run (one process per GPU) over ONE plain FASTQ (or FASTA) file: every rank parses only its own byte range and
+ * writes its own span of the shared output files.
  * pc_fastq_find_record: the first record start at or after byte_pos (the cut pc_readset_load_segment would choose), or the
  * file size when none is left; rank r of W takes [find(size * r / W), find(size * (r + 1) / W)).  "Not streamable" (gzip,
- * FASTA, an irregular record near byte_pos) is PC_ERR_UNSUPPORTED_SCORES, as for pc_readset_load_segment.
+ * an irregular record near byte_pos) is PC_ERR_UNSUPPORTED_SCORES, as for pc_readset_load_segment.
  * pc_readset_write_sizes: the bytes pc_readset_write would put into each file, nothing written -- the ranks exchange them
  * and take the prefix sums as their positions.
  * pc_readset_write_shared: pc_readset_write_at for files other processes write disjoint spans of: opened without

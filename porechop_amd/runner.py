@@ -381,8 +381,9 @@ def run_streamed(input_path, output, barcode_dir, opts: Options, device=None, al
     (pc_readset_write_at) -- host memory holds three blocks instead of the input, and ingest, scan and writing overlap.
     Phase A and the set-level rules run once, on the first block, which must hold the check reads.  Everything after
     that is per read in Porechop (phases B and C, barcode calls, splitting, naming), so the output files are the ones
-    run() writes.  -> None when the input is not streamable (gzip, FASTA, a directory, irregular records, or a first
-    block without the check reads): the caller loads the whole file."""
+    run() writes.  Plain FASTA files (cut where a line begins with '>') and the gzip forms of both stream the same way.
+    -> None when the input is not streamable (a directory, irregular records, a damaged gzip stream, or a first block
+    without the check reads): the caller loads the whole file."""
     import queue
     import threading
     block_bytes = block_bytes or _stream_block_bytes()
@@ -396,7 +397,7 @@ def run_streamed(input_path, output, barcode_dir, opts: Options, device=None, al
     pos = 0
     if gz_in is not None:
         first = gz_in.next(block_bytes, max(0, opts.check_reads))
-        if first is False or first is None:      # not a regular 4-line FASTQ (FASTA, damaged, empty): the whole-file loader's case
+        if first is False or first is None:      # neither a regular 4-line FASTQ nor a FASTA stream (damaged, empty): the whole-file loader's case
             gz_in.close()
             return None
     while gz_in is None:
@@ -837,10 +838,10 @@ def run(input_path, output=None, barcode_dir=None, options: Options = None, devi
     `aligner` is for tests only (see Pipeline).
 
     Under torch.distributed (one process per GPU) the reads are sharded over the ranks and the adapter-set presence
-    table of phase A is MAX-all-reduced (the only cross-read quantity in Porechop).  A plain FASTQ file takes
-    run_sharded: every rank parses, scans and WRITES only its own byte range of the input / span of the shared output
-    files, and its RunResult holds its own reads' trims (first_read, local_reads say which).  Anything else (gzip,
-    FASTA, a directory, stdout) falls back to every rank loading the input, contiguous blocks of about equal bases per
+    table of phase A is MAX-all-reduced (the only cross-read quantity in Porechop).  A plain FASTQ or FASTA file, a gzip
+    file of sized members and a `cat` of gzip members take run_sharded: every rank parses, scans and WRITES only its own
+    byte range of the input / span of the shared output files, and its RunResult holds its own reads' trims (first_read,
+    local_reads say which).  Anything else (one big gzip member, a directory, stdout) falls back to every rank loading the input, contiguous blocks of about equal bases per
     rank, the per-read results gathered in rank order and rank 0 alone planning and writing.  Either way the files
     are the single-process ones."""
     opts = options or Options()

@@ -37,15 +37,27 @@ def test_ingest_output_and_gzip_under_asan_and_ubsan(tmp_path):
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
     # the third and fourth: every member the workers do not take goes through the watched one-shot libdeflate route
     # (oneshot_member), with room for it and with a room it outgrows after ~5 MB were handed over (seed 1's file is 6.1 MB)
-    for seed, rounds, extra in ((1, 1, {}), (2, 1, {"PC_NO_LIBDEFLATE": "1", "PC_GZ_SPEC_CAP_MB": "1"}),
-                                (1, 1, {"PC_GZ_ONESHOT_MIN_MB": "0", "PC_GZ_VERBOSE": "1"}),
-                                (1, 1, {"PC_GZ_ONESHOT_MIN_MB": "0", "PC_GZ_ONESHOT_ROOM_KB": "5700", "PC_GZ_VERBOSE": "1"})):
-        res = subprocess.run([str(exe), str(work), str(seed), str(rounds)], capture_output=True, text=True, timeout=1200,
-                             env=dict(env, **extra))
-        assert res.returncode == 0, (seed, extra, res.stdout[-1500:], res.stderr[-6000:])
-        assert "0 check failure(s)" in res.stdout and "ERROR: AddressSanitizer" not in res.stderr and "runtime error" not in res.stderr, \
-            (res.stdout[-1500:], res.stderr[-6000:])
+    configs = ((1, 1, {}), (2, 1, {"PC_NO_LIBDEFLATE": "1", "PC_GZ_SPEC_CAP_MB": "1"}),
+               (1, 1, {"PC_GZ_ONESHOT_MIN_MB": "0", "PC_GZ_VERBOSE": "1"}),
+               (1, 1, {"PC_GZ_ONESHOT_MIN_MB": "0", "PC_GZ_ONESHOT_ROOM_KB": "5700", "PC_GZ_VERBOSE": "1"}))
+    # (the four runs side by side, each in a directory of its own: they share nothing but the binary)
+    procs = []
+    for k, (seed, rounds, extra) in enumerate(configs):
+        wk = work / ("run%d" % k)
+        wk.mkdir()
+        procs.append(subprocess.Popen([str(exe), str(wk), str(seed), str(rounds)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                                      env=dict(env, **extra)))
+    for (seed, rounds, extra), pr in zip(configs, procs):
+        try:
+            out, err = pr.communicate(timeout=1200)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        assert pr.returncode == 0, (seed, extra, out[-1500:], err[-6000:])
+        assert "0 check failure(s)" in out and "ERROR: AddressSanitizer" not in err and "runtime error" not in err, \
+            (out[-1500:], err[-6000:])
         if "PC_GZ_ONESHOT_ROOM_KB" in extra:
-            assert "result 2" in res.stderr, res.stderr[-2000:]          # out of room after a hand-over: zlib restarted, discarding it
+            assert "result 2" in err, err[-2000:]          # out of room after a hand-over: zlib restarted, discarding it
         elif "PC_GZ_ONESHOT_MIN_MB" in extra:
-            assert "result 1" in res.stderr, res.stderr[-2000:]
+            assert "result 1" in err, err[-2000:]

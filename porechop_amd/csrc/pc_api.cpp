@@ -105,8 +105,14 @@ struct pc_ctx {
     // is filled by the next.  (No further streams: HIP maps streams onto four hardware queues, and a fifth
     // stream would share a queue with -- and serialise behind -- a caller's upload stream; measured.)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    // further streams for the single-pass groups of one call (phase A: four small row classes beside the 24-mers' launch)
+    // further streams for the single-pass groups of one call (phase A: four small row classes beside the 24-mers' launch).
+    // ONE is used unless PC_FORK_STREAMS says otherwise: caller's + context's + one + a caller's upload stream are the four
+    // hardware queues; with three, the step that uploads its reads while it scans (bench.py's from_host_memory) went from
+    // 98 to 129 ms -- the upload shared a queue with kernels -- for 0.05 ms of phase A (profiles/r06_fork_streams.txt)
     static constexpr int kForkStreams = 3;
+#ifndef PC_DEFAULT_FORK_STREAMS
+#define PC_DEFAULT_FORK_STREAMS 1
+#endif
     hipStream_t fork_stream[kForkStreams] = {nullptr, nullptr, nullptr};
     hipEvent_t fork_join[kForkStreams] = {nullptr, nullptr, nullptr};
     // host-API staging
@@ -917,7 +923,6 @@ int pc_scan_device(pc_ctx *c, const void *d_arena, const int64_t *d_win_off, con
     // (PC_NO_TRACE_FORK=1 keeps them on one stream: a profile whose per-kernel durations add up to the step)
     static const bool no_trace_fork = [] { const char *e = getenv("PC_NO_TRACE_FORK"); return e && *e && *e != '0'; }();
     const bool fork = n_single >= 2 && stream != c->stream && !no_trace_fork;
-    int forked = 0;
     pc_ctx::Timed fork_timer;
     bool fork_timed = false;
     if (fork) {
@@ -998,11 +1003,17 @@ int pc_scan_device(pc_ctx *c, const void *d_arena, const int64_t *d_win_off, con
             return rc;
     }
 
-    // Launch order: the single-pass groups smallest first, each on a stream of its own (up to 1 + kForkStreams + the caller's),
-    // the largest last -- a small row class (phase A: 80-470 tiles) occupies a fraction of the chip for the duration of ONE
-    // tile; enqueued behind the 24-mers' 17 000 tiles it waited for their last round and then ran alone, started beside them
-    // it costs nothing.  Two-pass groups follow in their own order.  (PC_FORK_STREAMS=0: two streams, table order, as before.)
-    static const bool wide_fork = [] { const char *e = getenv("PC_FORK_STREAMS"); return !(e && *e == '0'); }();
+    // Launch order: the single-pass groups smallest first, the ones that cannot fill the chip on a further stream (one by
+    // default, PC_FORK_STREAMS = 0..3), the largest last -- a small row class (phase A: 80-470 tiles) occupies a fraction of
+    // the chip for the duration of ONE tile; enqueued behind the 24-mers' 17 000 tiles it waited for their last round and
+    // then ran alone, started beside them it costs nothing.  Two-pass groups follow in their own order.
+    // (PC_FORK_STREAMS=0: two streams, table order, as before.)
+    static const int fork_streams = [] {
+        const char *e = getenv("PC_FORK_STREAMS");
+        int n = (e && *e >= '0' && *e <= '9') ? atoi(e) : PC_DEFAULT_FORK_STREAMS;
+        return n < 0 ? 0 : n > pc_ctx::kForkStreams ? pc_ctx::kForkStreams : n;
+    }();
+    const bool wide_fork = fork_streams > 0;
     std::vector<size_t> order;
     for (size_t gi = 0; gi < c->groups.size(); ++gi) if (!c->groups[gi].two_pass) order.push_back(gi);
     if (fork && wide_fork)
@@ -1012,7 +1023,7 @@ int pc_scan_device(pc_ctx *c, const void *d_arena, const int64_t *d_win_off, con
     bool ctx_stream_used = false;
     int small_forked = 0, large_forked = 0;
     if (fork && wide_fork) {
-        for (int k = 0; k < pc_ctx::kForkStreams; ++k) {
+        for (int k = 0; k < fork_streams; ++k) {
             if (!c->fork_stream[k] && hipStreamCreateWithFlags(&c->fork_stream[k], hipStreamNonBlocking) != hipSuccess) return PC_ERR_NO_DEVICE;
             if (!c->fork_join[k] && hipEventCreateWithFlags(&c->fork_join[k], hipEventDisableTiming) != hipSuccess) return PC_ERR_NO_DEVICE;
         }
@@ -1096,12 +1107,11 @@ int pc_scan_device(pc_ctx *c, const void *d_arena, const int64_t *d_win_off, con
                 // first; the large ones alternate between the caller's stream and the context's as before (several large launches
                 // side by side only take each other's slots: measured 4.6 -> 4.7 ms on phase B's four row classes)
                 int lane;
-                if (wide_fork && (int64_t)g.tile_count < (int64_t)resident_waves(c, g)) lane = 2 + (small_forked++ % pc_ctx::kForkStreams);
+                if (wide_fork && (int64_t)g.tile_count < (int64_t)resident_waves(c, g)) lane = 2 + (small_forked++ % fork_streams);
                 else lane = (large_forked++ & 1);
                 hipStream_t ps = lane == 0 ? stream : lane == 1 ? c->stream : c->fork_stream[lane - 2];
                 if (lane == 1 && !ctx_stream_used) { HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_fork, 0)); ctx_stream_used = true; }
                 if (lane >= 2 && !fork_used[lane - 2]) { HIP_TRY(hipStreamWaitEvent(ps, c->ev_fork, 0)); fork_used[lane - 2] = true; }
-                ++forked;
                 if ((rc = run_group(ps))) return PC_ERR_NO_DEVICE;
             } else {
                 ScopedTimer tm(c, stream, 2, np);

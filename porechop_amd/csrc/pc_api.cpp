@@ -105,13 +105,14 @@ struct pc_ctx {
     // is filled by the next.  (No further streams: HIP maps streams onto four hardware queues, and a fifth
     // stream would share a queue with -- and serialise behind -- a caller's upload stream; measured.)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    // further streams for the single-pass groups of one call (phase A: four small row classes beside the 24-mers' launch).
-    // ONE is used unless PC_FORK_STREAMS says otherwise: caller's + context's + one + a caller's upload stream are the four
-    // hardware queues; with three, the step that uploads its reads while it scans (bench.py's from_host_memory) went from
-    // 98 to 129 ms -- the upload shared a queue with kernels -- for 0.05 ms of phase A (profiles/r06_fork_streams.txt)
+    // further streams for the single-pass groups of one call (phase A: four small row classes beside the 24-mers' launch):
+    // OFF unless PC_FORK_STREAMS = 1..3 asks for them.  Built and measured in round 6 (profiles/r06_fork_streams.txt): phase A
+    // alone 3.37 -> 3.19 ms with three, nothing in any leg of bench.py (configs[1] 4.26 against 4.29 ms) -- and HIP maps
+    // streams onto four hardware queues, so with them a caller's upload stream shared a queue with kernels: the step that
+    // streams its reads from host memory went from 98 to 129 ms.
     static constexpr int kForkStreams = 3;
 #ifndef PC_DEFAULT_FORK_STREAMS
-#define PC_DEFAULT_FORK_STREAMS 1
+#define PC_DEFAULT_FORK_STREAMS 0
 #endif
     hipStream_t fork_stream[kForkStreams] = {nullptr, nullptr, nullptr};
     hipEvent_t fork_join[kForkStreams] = {nullptr, nullptr, nullptr};
@@ -1003,11 +1004,10 @@ int pc_scan_device(pc_ctx *c, const void *d_arena, const int64_t *d_win_off, con
             return rc;
     }
 
-    // Launch order: the single-pass groups smallest first, the ones that cannot fill the chip on a further stream (one by
-    // default, PC_FORK_STREAMS = 0..3), the largest last -- a small row class (phase A: 80-470 tiles) occupies a fraction of
-    // the chip for the duration of ONE tile; enqueued behind the 24-mers' 17 000 tiles it waited for their last round and
-    // then ran alone, started beside them it costs nothing.  Two-pass groups follow in their own order.
-    // (PC_FORK_STREAMS=0: two streams, table order, as before.)
+    // Launch order with PC_FORK_STREAMS = 1..3 (default 0: two streams, table order): the single-pass groups smallest first,
+    // the ones that cannot fill the chip on further streams, the largest last -- a small row class (phase A: 80-470 tiles)
+    // occupies a fraction of the chip for the duration of ONE tile; enqueued behind the 24-mers' 17 000 tiles it waits for
+    // their last round and then runs alone.  Two-pass groups follow in their own order.
     static const int fork_streams = [] {
         const char *e = getenv("PC_FORK_STREAMS");
         int n = (e && *e >= '0' && *e <= '9') ? atoi(e) : PC_DEFAULT_FORK_STREAMS;

@@ -420,10 +420,11 @@ class Pipeline:
         m = rec[:, :, 5].to(torch.float64)
         full = _round6(100.0 * m / rec[:, :, 7].to(torch.float64))
         full = torch.where(rec[:, :, 0] == -1, torch.zeros_like(full), full).amax(dim=1)   # [J]
-        si = self._const([w[0] for w in where])
-        side = self._const([w[1] for w in where])
-        best_start.scatter_reduce_(0, si[side == 0], full[side == 0], reduce="amax")
-        best_end.scatter_reduce_(0, si[side == 1], full[side == 1], reduce="amax")
+        # (which job feeds which entry is known on the host: index lists, not boolean masks -- a mask is a nonzero, a round trip)
+        for side, best in ((0, best_start), (1, best_end)):
+            ks = [k for k, w in enumerate(where) if w[1] == side]
+            if ks:
+                best.scatter_reduce_(0, self._const([where[k][0] for k in ks]), full[self._const(ks)], reduce="amax")
         self.stats["pairs_end"] += sum(int(j[1].shape[0]) for j in jobs)
         return best_start, best_end
 
@@ -452,10 +453,10 @@ class Pipeline:
         job_of = torch.repeat_interleave(torch.arange(len(cjobs), device=self.device),
                                          torch.tensor([int(j[1].shape[0]) for j in cjobs], device=self.device))
         top = torch.zeros(len(cjobs), dtype=torch.float64, device=self.device).scatter_reduce_(0, job_of, full, reduce="amax")
-        si = self._const([w[0] for w in cwhere])
-        side = self._const([w[1] for w in cwhere])
-        best_start.scatter_reduce_(0, si[side == 0], top[side == 0], reduce="amax")
-        best_end.scatter_reduce_(0, si[side == 1], top[side == 1], reduce="amax")
+        for side, best in ((0, best_start), (1, best_end)):
+            ks = [k for k, w in enumerate(cwhere) if w[1] == side]
+            if ks:
+                best.scatter_reduce_(0, self._const([cwhere[k][0] for k in ks]), top[self._const(ks)], reduce="amax")
         return best_start, best_end
 
     def matching_sets(self, best_start, best_end):
@@ -1048,13 +1049,18 @@ class Pipeline:
         H_read, H_ad, H_s, H_e, H_id = [], [], [], [], []
         if Dn > 0:
             if sparse0 is not None:                                  # [A, Dn, 8] from the sparse records of the dirty reads
+                # (no boolean masks -- each is a nonzero, a host round trip: the records of reads that are not dirty all go to
+                # one spare row behind the table)
                 where = torch.full((int(live.numel()),), -1, dtype=torch.int64, device=dev)
                 where[d_sel] = torch.arange(Dn, device=dev)
-                keep = where[sw] >= 0
-                rec_all = torch.zeros((A, Dn, RESULT_INTS), dtype=torch.int32, device=dev)
-                full_all = torch.zeros((A, Dn), dtype=torch.float64, device=dev)
-                rec_all[sa[keep], where[sw[keep]]] = sr[keep]
-                full_all[sa[keep], where[sw[keep]]] = full_s[keep]
+                w2 = where[sw]
+                flat = torch.where(w2 >= 0, sa * Dn + w2, torch.full_like(w2, A * Dn))
+                rec_flat = torch.zeros((A * Dn + 1, RESULT_INTS), dtype=torch.int32, device=dev)
+                full_flat = torch.zeros(A * Dn + 1, dtype=torch.float64, device=dev)
+                rec_flat[flat] = sr
+                full_flat[flat] = full_s
+                rec_all = rec_flat[:A * Dn].view(A, Dn, RESULT_INTS)
+                full_all = full_flat[:A * Dn].view(A, Dn)
             else:
                 rec_all = torch.stack([o[d_sel] for o in outs])      # [A, Dn, 8] for the current masked state
                 full_all = fulls[:, d_sel]

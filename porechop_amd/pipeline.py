@@ -1124,7 +1124,7 @@ class Pipeline:
                 cnt = cnt_all[hidx]
                 first = torch.cumsum(cnt, 0) - cnt
                 run = torch.repeat_interleave(d_off[hsel] + rs.to(torch.int64) - first, cnt, output_size=n_mask)
-                dirty[run + torch.arange(n_mask, device=dev, dtype=torch.int64)] = ord("-")
+                dirty.index_fill_(0, run + torch.arange(n_mask, device=dev, dtype=torch.int64), ord("-"))   # (x[idx] = scalar uploads the scalar: a round trip)
                 cur[hsel] = ah                                       # the reference re-aligns the adapter that hit
                 act = hsel
                 rounds += 1

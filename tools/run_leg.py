@@ -48,6 +48,28 @@ elif leg in ("configs4", "configs4_prefilter"):
     step = lambda: bench.step_configs4(pl, reads, p.check_reads, opts, prefilter=(leg == "configs4_prefilter"), prune_b=(leg == "configs4_prefilter"))
 else:
     raise SystemExit("unknown leg " + leg)
+if os.environ.get("PC_LEG_SYNCS", "0") not in ("", "0"):
+    # instead of timing: the torch calls of ONE step of this leg that synchronise host and device, by source line (tools/r6_syncs.py)
+    import collections, traceback, warnings
+    step(); step(); torch.cuda.synchronize()
+    seen = collections.Counter()
+
+    def show(message, category, filename, lineno, file=None, line=None):
+        where = "(not the package)"
+        for fr in reversed(traceback.extract_stack(limit=60)):
+            if "porechop_amd" in fr.filename or fr.filename.endswith("bench.py"):
+                where = "%s:%d %s" % (os.path.basename(fr.filename), fr.lineno, fr.name)
+                break
+        seen[where] += 1
+    warnings.showwarning = show
+    warnings.simplefilter("always")
+    torch.cuda.set_sync_debug_mode(1)
+    step()
+    torch.cuda.set_sync_debug_mode(0)
+    print("%s: synchronising torch calls in one step: %d" % (leg, sum(seen.values())))
+    for k, v in sorted(seen.items()):
+        print("  %3d  %s" % (v, k))
+    sys.exit(0)
 import time  # noqa: E402
 for _ in range(steps):
     torch.cuda.synchronize(); t0 = time.perf_counter()

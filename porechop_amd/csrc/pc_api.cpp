@@ -49,6 +49,21 @@ struct DevBuf {
     template <typename T> T *as() const { return (T *)p; }
 };
 
+struct PinBuf {            // page-locked host staging: an async upload from it needs no wait for "the copy has left"
+    void *p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes)
+    {
+        if (bytes <= cap) return PC_OK;
+        if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
+        const size_t want = bytes + bytes / 4 + 256;
+        if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) return PC_ERR_NO_DEVICE;
+        cap = want;
+        return PC_OK;
+    }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+};
+
 struct Group {            // tiles that run in one launch
     int rows;             // 0: generic kernel
     int gen_max_rows;     // generic: largest adapter in the group
@@ -97,6 +112,8 @@ struct pc_ctx {
     // the tile table lives in one of two slots: a new table is built (on the context's own stream) in the slot
     // the scans two tables ago used, so building never waits for the scans in flight on the current one
     DevBuf d_tiles_slot[2], d_runs_slot[2];
+    PinBuf h_table_slot[2];                          // the run table / segment table of the slot on their way up
+    hipEvent_t table_up[2] = {nullptr, nullptr};     // recorded on the context's stream behind those uploads: the staging is free again
     hipEvent_t slot_free[2] = {nullptr, nullptr};    // recorded on the caller's stream after the last launch that reads the slot
     hipEvent_t table_ready = nullptr;                // recorded on the context's stream after the expansion kernel
     int slot = 0;
@@ -460,20 +477,30 @@ int build_tiles(pc_ctx *c, const int32_t *job_adapter, const int32_t *job_adapte
     c->slot ^= 1;
     const int sl = c->slot;
     HIP_TRY(hipEventSynchronize(c->slot_free[sl]));
+    HIP_TRY(hipEventSynchronize(c->table_up[sl]));   // (two tables ago: long past)
     int rc = c->d_tiles_slot[sl].ensure(std::max<size_t>(1, ntiles) * sizeof(pck::Tile));
     if (rc) return rc;
     if ((rc = c->d_runs_slot[sl].ensure(std::max<size_t>(1, all_runs.size()) * sizeof(pck::TileRun)))) return rc;
     c->bucket_blocks_at = (seg_first.size() * 8 + 15) & ~(size_t)15;
     if ((rc = c->d_bucket_slot[sl].ensure(c->bucket_blocks_at + std::max<size_t>(1, bblocks.size()) * sizeof(pck::BucketBlock)))) return rc;
     if (ntiles) {
+        // The tables go up from page-locked memory of the slot (reusable once table_up[sl] has passed, above): the call does not
+        // wait for its own upload -- with the tables in locals it had to, and that wait was for EVERYTHING on the context's
+        // stream, the previous call's forked launches among them.
+        const size_t seg_bytes = seg_first.size() * 8, blk_bytes = bblocks.size() * sizeof(pck::BucketBlock), run_bytes = all_runs.size() * sizeof(pck::TileRun);
+        const size_t blk_at = (seg_bytes + 15) & ~(size_t)15, run_at = (blk_at + blk_bytes + 15) & ~(size_t)15;
+        if ((rc = c->h_table_slot[sl].ensure(run_at + run_bytes))) return rc;
+        char *hp = (char *)c->h_table_slot[sl].p;
         if (!seg_first.empty()) {
-            HIP_TRY(hipMemcpyAsync(c->d_bucket_slot[sl].p, seg_first.data(), seg_first.size() * 8, hipMemcpyHostToDevice, c->stream));
-            HIP_TRY(hipMemcpyAsync((char *)c->d_bucket_slot[sl].p + c->bucket_blocks_at, bblocks.data(), bblocks.size() * sizeof(pck::BucketBlock),
-                                   hipMemcpyHostToDevice, c->stream));
+            memcpy(hp, seg_first.data(), seg_bytes);
+            memcpy(hp + blk_at, bblocks.data(), blk_bytes);
+            HIP_TRY(hipMemcpyAsync(c->d_bucket_slot[sl].p, hp, seg_bytes, hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(hipMemcpyAsync((char *)c->d_bucket_slot[sl].p + c->bucket_blocks_at, hp + blk_at, blk_bytes, hipMemcpyHostToDevice, c->stream));
         }
         // a few hundred bytes per job cross PCIe; the tiles (56 B per 64..128 windows) are written by the GPU
-        HIP_TRY(hipMemcpyAsync(c->d_runs_slot[sl].p, all_runs.data(), all_runs.size() * sizeof(pck::TileRun), hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));        // all_runs is a local: the copy must have left it
+        memcpy(hp + run_at, all_runs.data(), run_bytes);
+        HIP_TRY(hipMemcpyAsync(c->d_runs_slot[sl].p, hp + run_at, run_bytes, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipEventRecord(c->table_up[sl], c->stream));
         if (pck::launch_expand_tiles(c->d_runs_slot[sl].as<pck::TileRun>(), (int)all_runs.size(), c->d_tiles_slot[sl].as<pck::Tile>(),
                                      (int64_t)ntiles, c->stream))
             return PC_ERR_NO_DEVICE;
@@ -770,8 +797,10 @@ int pc_create(pc_ctx **out, int device)
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->ncu = prop.multiProcessorCount;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return PC_ERR_NO_DEVICE; }
     if (c->d_err.ensure(256) != PC_OK || hipMemset(c->d_err.p, 0, 256) != hipSuccess) { delete c; return PC_ERR_NO_DEVICE; }
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 2; ++i) {
         if (hipEventCreateWithFlags(&c->slot_free[i], hipEventDisableTiming) != hipSuccess) { delete c; return PC_ERR_NO_DEVICE; }
+        if (hipEventCreateWithFlags(&c->table_up[i], hipEventDisableTiming) != hipSuccess) { delete c; return PC_ERR_NO_DEVICE; }
+    }
     if (hipEventCreateWithFlags(&c->table_ready, hipEventDisableTiming) != hipSuccess) { delete c; return PC_ERR_NO_DEVICE; }
     for (int i = 0; i < 2; ++i)
         if (hipEventCreateWithFlags(&c->red_done[i], hipEventDisableTiming) != hipSuccess) { delete c; return PC_ERR_NO_DEVICE; }
@@ -788,6 +817,7 @@ void pc_destroy(pc_ctx *c)
     (void)hipStreamSynchronize(c->stream);
     (void)hipDeviceSynchronize();
     for (int i = 0; i < 2; ++i) if (c->slot_free[i]) (void)hipEventDestroy(c->slot_free[i]);
+    for (int i = 0; i < 2; ++i) if (c->table_up[i]) (void)hipEventDestroy(c->table_up[i]);
     if (c->table_ready) (void)hipEventDestroy(c->table_ready);
     for (int i = 0; i < 2; ++i) {
         if (c->red_done[i]) (void)hipEventDestroy(c->red_done[i]);
@@ -806,6 +836,7 @@ void pc_destroy(pc_ctx *c)
                       &c->d_sd_entries, &c->d_sd_meta, &c->d_sd_eq, &c->d_sd_cand, &c->d_sd_count, &c->d_slow_ad, &c->d_slow_state,
                       &c->d_slow_trace};
     if (c->h_sd_count) (void)hipHostFree(c->h_sd_count);
+    c->h_table_slot[0].release(); c->h_table_slot[1].release();
     for (DevBuf *b : bufs) b->release();
     (void)hipStreamDestroy(c->stream);
     delete c;
